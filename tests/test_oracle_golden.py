@@ -1,0 +1,195 @@
+"""Pins the CPU oracle against the reference's own golden vectors and unit-test restatements.
+
+Goldens: brisk/src/test/test_data/brisk_verification_{ast,harris}.set (copied verbatim to
+tests/golden/), checked the way brisk/src/test/test-binary-equal.cc:319-333 + bench-ds.h:311-430
+does - except that descriptors must match exactly (reference tolerates Hamming <= 5).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def _bits(a):
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_ast_golden_detect_describe(golden_ast, idx):
+    e = golden_ast[idx]
+    assert e["image"].shape == (640, 800)
+    kps = O.detect(e["image"], 70, 3)          # BriskFeatureDetector(70) -> octaves = 3
+    assert len(kps) == (778, 1000)[idx]        # SURVEY F6 probe counts before border filtering
+    k2, desc = O.Extractor().compute(e["image"], kps)
+    g = e["keypoints"]
+    assert len(k2) == len(g) == (642, 785)[idx]
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(_bits(k2[f]), _bits(g[f])), f
+    assert desc.shape == e["descriptors"].shape == (len(g), 48)
+    assert np.array_equal(desc, e["descriptors"])
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_harris_golden_descriptor_only(golden_harris, idx):
+    """Externally provided keypoints (size 12): pins orientation + descriptor without the detector."""
+    e = golden_harris[idx]
+    g = e["keypoints"]
+    k = np.zeros(len(g), O.KP)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        k[f] = g[f]
+    k["angle"] = -1
+    ext = O.Extractor()
+    k2, desc = ext.compute(e["image"], k)
+    assert len(k2) == len(g)
+    assert np.array_equal(_bits(k2["angle"]), _bits(g["angle"]))
+    assert np.array_equal(desc, e["descriptors"])
+    k["angle"] = g["angle"]                     # provided-angle path (:742-752)
+    k3, desc3 = ext.compute(e["image"], k)
+    assert np.array_equal(desc3, e["descriptors"])
+
+
+def test_extractor_tables():
+    ext = O.Extractor()
+    assert ext.strings == 48 and ext.points == 66
+    sl, sz = ext.scale_list(), ext.size_list()
+    assert sl[0] == 1.0 and np.all(np.diff(sl) > 0) and abs(sl[63] - 30.0 ** (63 / 64)) < 1e-4
+    assert sz[0] == 13 and sz[63] == 316                    # border 13...316 px
+    v1 = O.Extractor(version=1)
+    assert v1.strings == 64 and v1.points == 60             # SURVEY F2 (briskV1 -> 512 bits)
+
+
+# ---- differential unit tests mirroring the reference's own (test-downsampling.cc, test-integral-image.cc)
+
+def plain_half(src):
+    """PlainHalfSample, test-downsampling.cc:67-88."""
+    s = src.astype(np.uint32)
+    a, b, c, d = s[0::2, 0::2], s[0::2, 1::2], s[1::2, 0::2], s[1::2, 1::2]
+    h, w = src.shape[0] // 2, src.shape[1] // 2
+    a, b, c, d = a[:h, :w], b[:h, :w], c[:h, :w], d[:h, :w]
+    return np.minimum(((a + 1 + c) // 2 + (b + 1 + d) // 2 + 1) // 2, 255).astype(np.uint8)
+
+
+def plain_twothird(src):
+    """PlainTwoThirdSample, test-downsampling.cc:90-142."""
+    s = src.astype(np.uint32)
+    h3, w3 = src.shape[0] // 3, src.shape[1] // 3
+    s = s[:h3 * 3, :w3 * 3]
+    A, B, C = s[0::3], s[1::3], s[2::3]
+    D = ((A + B + 1) // 2 + A + 1) // 2
+    E = ((C + B + 1) // 2 + C + 1) // 2
+    out = np.zeros((2 * h3, 2 * w3), np.uint8)
+    for R, r0 in ((D, 0), (E, 1)):
+        p0, p1, p2 = R[:, 0::3], R[:, 1::3], R[:, 2::3]
+        out[r0::2, 0::2] = ((p0 + p1 + 1) // 2 + p0 + 1) // 2
+        out[r0::2, 1::2] = ((p2 + p1 + 1) // 2 + p2 + 1) // 2
+    return out
+
+
+def test_halfsample_vs_plain(golden_ast):
+    img = golden_ast[0]["image"]                 # 800 cols: pure SIMD class, as in the reference test
+    assert np.array_equal(O.halfsample(img), plain_half(img))
+    rng = np.random.default_rng(0)
+    for w in (32, 64, 96, 1920):                 # w % 32 == 0 -> class 1 only
+        im = rng.integers(0, 256, (38, w), dtype=np.uint8)
+        assert np.array_equal(O.halfsample(im), plain_half(im))
+
+
+def test_halfsample_column_classes():
+    """three roundings by column class (image-down-sampling.cc:296-382)."""
+    rng = np.random.default_rng(1)
+    for w in (240, 120, 426, 213, 532, 53, 17, 48, 31):
+        im = rng.integers(0, 256, (21, w), dtype=np.uint8)
+        got = O.halfsample(im)
+        s = im.astype(np.int32)
+        hs, end, half_end, left = w // 16, (w // 16) // 2, (w // 16) % 2, (w % 16) // 2
+        assert got.shape == (10, w // 2) and 16 * end + 8 * half_end + left == w // 2
+        we = (w // 2) * 2
+        t, b = s[0:20:2, :we], s[1:20:2, :we]
+        v = (t + b + 1) >> 1
+        c1 = (v[:, 0::2] + v[:, 1::2] + 1) >> 1
+        c2 = (v[:, 0::2] + v[:, 1::2]) // 2
+        c3 = (t[:, 0::2] + t[:, 1::2] + b[:, 0::2] + b[:, 1::2] + 2) // 4
+        exp = np.concatenate([c1[:, :16 * end], c2[:, 16 * end:16 * end + 8 * half_end],
+                              c3[:, 16 * end + 8 * half_end:w // 2]], axis=1)
+        assert np.array_equal(got, exp.astype(np.uint8)), w
+
+
+def test_twothird_vs_plain(golden_ast):
+    img = golden_ast[0]["image"]
+    got, exp = O.twothirdsample(img), plain_twothird(img)
+    nsimd = (800 // 15) * 10                     # SIMD columns agree with the plain restatement
+    assert np.array_equal(got[:, :nsimd], exp[:, :nsimd])
+    rng = np.random.default_rng(2)
+    for w in (1920, 3840, 45, 15):               # no tail columns
+        im = rng.integers(0, 256, (31, w), dtype=np.uint8)
+        assert np.array_equal(O.twothirdsample(im), plain_twothird(im))
+    im = rng.integers(0, 256, (9, 640), dtype=np.uint8)   # 630 SIMD + 9 tail px
+    got = O.twothirdsample(im)
+    s = im.astype(np.int32)
+    for t in range(3):
+        x = 630 + 3 * t
+        A, B, Cc = s[0::3, x:x + 3], s[1::3, x:x + 3], s[2::3, x:x + 3]
+        o = 420 + 2 * t
+        assert np.array_equal(got[0::2, o], ((4 * A[:, 0] + 2 * (A[:, 1] + B[:, 0] + 1) + B[:, 1] + 1) // 9).astype(np.uint8))
+        assert np.array_equal(got[0::2, o + 1], ((4 * A[:, 2] + 2 * (A[:, 1] + B[:, 2] + 1) + B[:, 1] + 1) // 9).astype(np.uint8))
+        assert np.array_equal(got[1::2, o], ((4 * Cc[:, 0] + 2 * (Cc[:, 1] + B[:, 0] + 1) + B[:, 1] + 1) // 9).astype(np.uint8))
+        assert np.array_equal(got[1::2, o + 1], ((4 * Cc[:, 2] + 2 * (Cc[:, 1] + B[:, 2] + 1) + B[:, 1] + 1) // 9).astype(np.uint8))
+
+
+def test_integral_vs_naive(golden_ast):
+    """test-integral-image.cc:48-99."""
+    img = golden_ast[1]["image"]
+    exp = np.zeros((641, 801), np.int64)
+    exp[1:, 1:] = img.astype(np.int64).cumsum(0).cumsum(1)
+    assert np.array_equal(O.integral(img).astype(np.int64), exp)
+    rng = np.random.default_rng(3)
+    for shape in ((1, 1), (2, 5), (7, 3), (33, 130)):
+        im = rng.integers(0, 256, shape, dtype=np.uint8)
+        exp = np.zeros((shape[0] + 1, shape[1] + 1), np.int64)
+        exp[1:, 1:] = im.astype(np.int64).cumsum(0).cumsum(1)
+        assert np.array_equal(O.integral(im).astype(np.int64), exp)
+
+
+def disc_contrast(img):
+    """max-min over the 37-px radius-3 disc, 0 on the 3-px border."""
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    if h < 7 or w < 7:
+        return out
+    offs = [(dx, dy) for dy in range(-3, 4) for dx in range(-3, 4)
+            if (abs(dx) <= 1 and abs(dy) <= 3) or (abs(dy) <= 1 and abs(dx) <= 3) or (abs(dx) == 2 and abs(dy) == 2)]
+    assert len(offs) == 37
+    st = np.stack([img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in offs])
+    out[3:h - 3, 3:w - 3] = st.max(0) - st.min(0)
+    return out
+
+
+def test_threshold_map_is_disc_contrast():
+    """The literal SIMD/scalar pass order of brisk-layer.cc:278-598 nets out to the plain disc
+    contrast for every width (what the HIP kernel computes)."""
+    rng = np.random.default_rng(4)
+    for w in list(range(7, 60)) + [106, 133, 160, 213, 266, 426, 532, 640, 800]:
+        im = rng.integers(0, 256, (19, w), dtype=np.uint8)
+        assert np.array_equal(O.threshold_map(im), disc_contrast(im)), w
+    for h in (3, 6, 7, 8):
+        im = rng.integers(0, 256, (h, 40), dtype=np.uint8)
+        assert np.array_equal(O.threshold_map(im), disc_contrast(im)), h
+
+
+def test_detected_score_is_contrast(golden_ast):
+    """every detected pixel stores the raw threshold-map value."""
+    ss = O.ScaleSpace(golden_ast[0]["image"], 70, 3)
+    assert ss.layers == 6
+    assert [ss.image(i).shape for i in range(6)] == [(640, 800), (426, 532), (320, 400), (213, 266), (160, 200), (106, 133)]
+    import ctypes as C
+    L = O.lib()
+    for i in range(6):
+        img, thr = ss.image(i), ss.thrmap(i)
+        h, w = img.shape
+        xy = np.zeros((200000, 2), np.int32)
+        n = L.bo_oast9_16_detect(img.ctypes.data_as(C.c_void_p), w, h, thr.ctypes.data_as(C.c_void_p), 70, 230, 10,
+                                 xy.ctypes.data_as(C.c_void_p), len(xy))
+        assert 0 < n < len(xy)
+        for x, y in xy[:n:7]:
+            p = img.ctypes.data + int(y) * w + int(x)
+            assert L.bo_oast9_16_corner_score(p, w, int(thr[y, x])) == thr[y, x]

@@ -1,0 +1,249 @@
+"""ethzasl_brisk_amd - MI355X-native BRISK detect+describe engine.
+
+Python-side mirror of the two reference classes over the C ABI (include/brisk_hip.h).  It exists for
+the test-suite and bench.py; the product is libbrisk_hip.so plus the C++ host classes in
+include/brisk/.  There is no CPU fallback: every compute call needs the HIP library and a GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbrisk_hip.so")
+
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+ERRORS = {1: "BRISK_HIP_ERR_ARG", 2: "BRISK_HIP_ERR_NO_DEVICE", 3: "BRISK_HIP_ERR_HIP", 4: "BRISK_HIP_ERR_CAPACITY",
+          5: "BRISK_HIP_ERR_THRESHOLD", 6: "BRISK_HIP_ERR_PATTERN", 7: "BRISK_HIP_ERR_UNSUPPORTED"}
+
+# every symbol include/brisk_hip.h declares
+ABI_SYMBOLS = [
+    "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_last_error", "brisk_hip_set_capacity",
+    "brisk_hip_device_count", "brisk_hip_pattern_create", "brisk_hip_pattern_create_from_text",
+    "brisk_hip_pattern_destroy", "brisk_hip_pattern_descriptor_size", "brisk_hip_pattern_points",
+    "brisk_hip_pattern_tables", "brisk_hip_detect", "brisk_hip_describe", "brisk_hip_detect_describe_batch",
+    "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
+    "brisk_hip_debug_layer", "brisk_hip_debug_integral",
+]
+
+
+class BriskHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERRORS.get(code, code), msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libbrisk_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libbrisk_hip.so is missing: run `python -m ethzasl_brisk_amd.build` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.brisk_hip_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.brisk_hip_destroy.argtypes = [vp]
+    L.brisk_hip_destroy.restype = None
+    L.brisk_hip_last_error.argtypes = [vp]
+    L.brisk_hip_last_error.restype = C.c_char_p
+    L.brisk_hip_set_capacity.argtypes = [vp, C.c_int, C.c_int]
+    L.brisk_hip_pattern_create.argtypes = [vp, C.c_int, C.c_float, C.POINTER(vp)]
+    L.brisk_hip_pattern_create_from_text.argtypes = [vp, C.c_char_p, C.c_float, C.POINTER(vp)]
+    L.brisk_hip_pattern_destroy.argtypes = [vp]
+    L.brisk_hip_pattern_destroy.restype = None
+    L.brisk_hip_pattern_descriptor_size.argtypes = [vp]
+    L.brisk_hip_pattern_points.argtypes = [vp]
+    L.brisk_hip_pattern_tables.argtypes = [vp, vp, vp, vp]
+    L.brisk_hip_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp,
+                                   C.c_int, ip]
+    L.brisk_hip_describe.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, C.c_int, C.c_int, C.c_int]
+    L.brisk_hip_detect_describe_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
+                                                  C.c_int, vp]
+    L.brisk_hip_detect_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, vp]
+    L.brisk_hip_batch_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), ip, C.POINTER(vp), C.POINTER(vp),
+                                          C.POINTER(vp), ip, ip]
+    L.brisk_hip_batch_download.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip, vp, C.c_int]
+    L.brisk_hip_batch_status.argtypes = [vp, C.c_int, ip]
+    L.brisk_hip_debug_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, ip]
+    L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Device workspace (one per GPU).  Shared by detector and extractor objects."""
+
+    def __init__(self, device=0, max_candidates=None, max_keypoints=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.brisk_hip_create(device, C.byref(h))
+        if rc:
+            raise BriskHipError(rc, "brisk_hip_create(device=%d) failed" % device)
+        self._h = h
+        self.device = device
+        if max_candidates or max_keypoints:
+            self.check(self._L.brisk_hip_set_capacity(h, max_candidates or 65536, max_keypoints or 16384))
+
+    def check(self, rc):
+        if rc:
+            raise BriskHipError(rc, self._L.brisk_hip_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.brisk_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- per-stage access (parity tests) --
+    def debug_layer(self, frame, layer, which=0):
+        w, h = C.c_int(), C.c_int()
+        self.check(self._L.brisk_hip_debug_layer(self._h, frame, layer, which, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.check(self._L.brisk_hip_debug_layer(self._h, frame, layer, which, _ptr(out), C.byref(w), C.byref(h)))
+        return out
+
+    def debug_integral(self, frame, w, h):
+        out = np.zeros((h + 1, w + 1), np.uint32)
+        self.check(self._L.brisk_hip_debug_integral(self._h, frame, _ptr(out)))
+        return out
+
+    # -- device-resident batch path --
+    def detect_describe_batch(self, pattern, d_frames_ptr, nframes, w, h, frame_pitch, row_pitch, threshold, octaves,
+                              stream=None):
+        self.check(self._L.brisk_hip_detect_describe_batch(self._h, pattern._h, C.c_void_p(d_frames_ptr), nframes, w, h,
+                                                           frame_pitch, row_pitch, threshold, octaves,
+                                                           C.c_void_p(stream) if stream else None))
+
+    def detect_batch(self, d_frames_ptr, nframes, w, h, frame_pitch, row_pitch, threshold, octaves, stream=None):
+        self.check(self._L.brisk_hip_detect_batch(self._h, C.c_void_p(d_frames_ptr), nframes, w, h, frame_pitch,
+                                                  row_pitch, threshold, octaves, C.c_void_p(stream) if stream else None))
+
+    def batch_status(self, nframes):
+        f = C.c_int()
+        self.check(self._L.brisk_hip_batch_status(self._h, nframes, C.byref(f)))
+        return f.value
+
+    def batch_download(self, frame, described=True, strings=48):
+        n = C.c_int()
+        self.check(self._L.brisk_hip_batch_download(self._h, frame, int(described), None, 0, C.byref(n), None, 0))
+        kps = np.zeros(max(n.value, 1), KEYPOINT)
+        desc = np.zeros((max(n.value, 1), strings), np.uint8)
+        self.check(self._L.brisk_hip_batch_download(self._h, frame, int(described), _ptr(kps), len(kps), C.byref(n),
+                                                    _ptr(desc) if described else None, strings))
+        return kps[:n.value].copy(), (desc[:n.value].copy() if described else None)
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class BriskFeatureDetector:
+    """Mirror of brisk::BriskFeatureDetector (brisk/include/brisk/brisk-feature-detector.h:51-83)."""
+
+    def __init__(self, thresh, octaves=3, suppressScaleNonmaxima=True, context=None):
+        self.threshold = int(thresh)
+        self.octaves = int(octaves)
+        self.m_suppressScaleNonmaxima = bool(suppressScaleNonmaxima)
+        self._ctx = context or default_context()
+
+    def detect(self, image, mask=None, capacity=16384):
+        """detectImpl (brisk-feature-detector.cc:77-85): returns the keypoints (KEYPOINT array)."""
+        img = np.ascontiguousarray(image)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise ValueError("image must be a 2-D uint8 array (CV_8UC1)")
+        h, w = img.shape
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, np.uint8)
+            if m.shape != img.shape:
+                raise ValueError("mask must have the image's shape")
+        out = np.zeros(capacity, KEYPOINT)
+        n = C.c_int()
+        c = self._ctx
+        c.check(c._L.brisk_hip_detect(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
+                                      int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0, _ptr(out),
+                                      capacity, C.byref(n)))
+        return out[:n.value].copy()
+
+
+class BriskDescriptorExtractor:
+    """Mirror of brisk::BriskDescriptorExtractor (brisk/include/brisk/brisk-descriptor-extractor.h:54-202)."""
+    briskV1 = 1
+    briskV2 = 2
+    kDescriptorLength = 384
+
+    def __init__(self, rotationInvariant=True, scaleInvariant=True, version=2, patternScale=1.0, fname=None,
+                 pattern_text=None, context=None):
+        self.rotationInvariance = bool(rotationInvariant)
+        self.scaleInvariance = bool(scaleInvariant)
+        self._ctx = c = context or default_context()
+        h = C.c_void_p()
+        if fname is not None:
+            pattern_text = open(fname).read()
+        if pattern_text is not None:
+            c.check(c._L.brisk_hip_pattern_create_from_text(c._h, pattern_text.encode(), patternScale, C.byref(h)))
+        else:
+            if version not in (1, 2):
+                raise RuntimeError("only Version::briskV1 or Version::briskV2 supported!")
+            c.check(c._L.brisk_hip_pattern_create(c._h, version, patternScale, C.byref(h)))
+        self._h = h
+
+    def descriptorSize(self):
+        return self._ctx._L.brisk_hip_pattern_descriptor_size(self._h)
+
+    def descriptorType(self):
+        return 0  # CV_8U
+
+    def tables(self):
+        a, b, t = np.zeros(64, np.float32), np.zeros(64, np.int32), np.zeros(64, np.float32)
+        self._ctx.check(self._ctx._L.brisk_hip_pattern_tables(self._h, _ptr(a), _ptr(b), _ptr(t)))
+        return a, b, t
+
+    def compute(self, image, keypoints):
+        """compute() (brisk-descriptor-extractor.cc:612-778): returns (filtered keypoints, descriptors)."""
+        img = np.ascontiguousarray(image)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise RuntimeError("Unsupported image format. Must be CV_16UC1 or CV_8UC1.")  # :678 (8-bit only here)
+        h, w = img.shape
+        k = np.ascontiguousarray(keypoints, KEYPOINT).copy()
+        n = C.c_int(len(k))
+        s = self.descriptorSize()
+        desc = np.zeros((max(len(k), 1), s), np.uint8)
+        if len(k) == 0:
+            k = np.zeros(1, KEYPOINT)
+        c = self._ctx
+        c.check(c._L.brisk_hip_describe(c._h, self._h, _ptr(img), w, h, w, _ptr(k), C.byref(n), _ptr(desc), s,
+                                        int(self.rotationInvariance), int(self.scaleInvariance)))
+        return k[:n.value].copy(), desc[:n.value].copy()
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
+            self._ctx._L.brisk_hip_pattern_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,511 @@
+// brisk_capi.hip - implementation of the C ABI declared in include/brisk_hip.h.
+// Host side only: context / workspace management, pyramid geometry, H2D/D2H staging, kernel launches.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/brisk_hip.h"
+#include "brisk_common.h"
+#include "brisk_kernels.h"
+#include "brisk_pattern.h"
+
+static_assert(sizeof(brisk_hip_keypoint) == 28 && sizeof(BriskKeyPoint) == 28, "cv::KeyPoint layout");
+
+struct brisk_hip_pattern {
+  brisk_hip_ctx* ctx;
+  BriskPatternHost host;
+  BriskPatternDev dev;  // device pointers
+  void* blob;           // single device allocation backing dev.*
+};
+
+struct brisk_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string err;
+  int cand_cap = 65536, kp_cap = 16384, tie_cap = 8192;
+  // current allocation
+  int slots = 0;
+  long pyr_elems_alloc = 0;
+  long iframe_elems_alloc = 0;
+  BriskDetectBuffers B{};
+  BriskDescribeBuffers D{};
+  uint8_t* d_stage = nullptr;  // staging for host-buffer calls (image + mask)
+  size_t stage_bytes = 0;
+  BriskKeyPoint* d_kp_in = nullptr;  // host-provided keypoints (describe-only)
+  int* d_n_in = nullptr;
+  // last geometry
+  BriskGeom G{};
+  BriskTileTable T{};
+  int last_nframes = 0;
+  bool last_has_desc = false;
+};
+
+#define HIPCHK(ctx, call)                                                                       \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return BRISK_HIP_ERR_HIP;                                                                 \
+    }                                                                                           \
+  } while (0)
+
+static int fail(brisk_hip_ctx* ctx, int code, const char* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+// Pyramid geometry: brisk/src/brisk-scale-space.cc:54-90, brisk/src/brisk-layer.cc:72-95
+static void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G, BriskTileTable* T) {
+  memset(G, 0, sizeof(*G));
+  G->nlayers = (octaves == 0) ? 1 : 2 * octaves;
+  G->single_layer = (octaves == 0);
+  G->w = w;
+  G->h = h;
+  G->threshold = threshold;
+  int off = 0;
+  for (int l = 0; l < G->nlayers; ++l) {
+    BriskLayerGeom& L = G->L[l];
+    if (l == 0) {
+      L.w = w; L.h = h; L.scale = 1.0f; L.offset = 0.0f;
+    } else if (l == 1) {
+      L.w = 2 * (G->L[0].w / 3); L.h = 2 * (G->L[0].h / 3);
+      L.scale = (float)(G->L[0].scale * 1.5);
+      L.offset = (float)(0.5 * L.scale - 0.5);
+    } else {
+      L.w = G->L[l - 2].w / 2; L.h = G->L[l - 2].h / 2;
+      L.scale = G->L[l - 2].scale * 2;
+      L.offset = (float)(0.5 * L.scale - 0.5);
+    }
+    L.stride = brisk_align_up(L.w > 0 ? L.w : 1, BRISK_STRIDE_ALIGN);
+    L.off = off;
+    off += brisk_align_up(L.stride * (L.h > 0 ? L.h : 1), 256);
+  }
+  G->pyr_elems = off;
+  int t = 0;
+  for (int l = 0; l < G->nlayers; ++l) {
+    T->first_tile[l] = t;
+    T->tiles_x[l] = (G->L[l].stride + BRISK_DETECT_TILE_W - 1) / BRISK_DETECT_TILE_W;
+    const int ty = (G->L[l].h + BRISK_DETECT_TILE_H - 1) / BRISK_DETECT_TILE_H;
+    t += T->tiles_x[l] * ty;
+  }
+  for (int l = G->nlayers; l <= BRISK_MAX_LAYERS; ++l) T->first_tile[l] = t;
+  T->total_tiles = t;
+}
+
+static void free_buffers(brisk_hip_ctx* c) {
+  hipFree(c->B.pyr); hipFree(c->B.smap); hipFree(c->B.cand); hipFree(c->B.tie_idx); hipFree(c->B.keys);
+  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->D.dkp); hipFree(c->D.dscale);
+  hipFree(c->D.desc); hipFree(c->d_kp_in); hipFree(c->d_n_in);
+  c->B = BriskDetectBuffers{};
+  c->D = BriskDescribeBuffers{};
+  c->d_kp_in = nullptr; c->d_n_in = nullptr;
+  c->slots = 0; c->pyr_elems_alloc = 0; c->iframe_elems_alloc = 0;
+}
+
+static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
+  const int istride = brisk_align_up(G.w + 1, 16);
+  const long iframe = (long)istride * (G.h + 1);
+  if (nframes <= c->slots && G.pyr_elems <= c->pyr_elems_alloc && iframe <= c->iframe_elems_alloc &&
+      c->B.cand_cap == c->cand_cap && c->B.kp_cap == c->kp_cap) {
+    c->D.istride = istride;
+    c->D.iframe_elems = iframe;
+    return BRISK_HIP_OK;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int slots = nframes > c->slots ? nframes : c->slots;
+  const long pyr = G.pyr_elems > c->pyr_elems_alloc ? G.pyr_elems : c->pyr_elems_alloc;
+  const long ifr = iframe > c->iframe_elems_alloc ? iframe : c->iframe_elems_alloc;
+  free_buffers(c);
+  c->B.cand_cap = c->cand_cap; c->B.kp_cap = c->kp_cap; c->B.tie_cap = c->tie_cap;
+  HIPCHK(c, hipMalloc(&c->B.pyr, (size_t)slots * pyr + 256));
+  HIPCHK(c, hipMalloc(&c->B.smap, ((size_t)slots * pyr + 256) * sizeof(uint16_t)));
+  HIPCHK(c, hipMalloc(&c->B.cand, (size_t)slots * c->cand_cap * sizeof(BriskCand)));
+  HIPCHK(c, hipMalloc(&c->B.tie_idx, (size_t)slots * BRISK_MAX_LAYERS * c->tie_cap * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->B.keys, (size_t)slots * c->cand_cap * 2 * sizeof(unsigned)));
+  HIPCHK(c, hipMalloc(&c->B.counters, (size_t)slots * sizeof(BriskFrameCounters)));
+  HIPCHK(c, hipMalloc(&c->B.kp_out, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
+  HIPCHK(c, hipMalloc(&c->D.integral, (size_t)slots * ifr * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&c->D.dkp, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
+  HIPCHK(c, hipMalloc(&c->D.dscale, (size_t)slots * c->kp_cap * sizeof(int)));
+  c->D.desc_pitch = 64;
+  HIPCHK(c, hipMalloc(&c->D.desc, (size_t)slots * c->kp_cap * c->D.desc_pitch));
+  HIPCHK(c, hipMalloc(&c->d_kp_in, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
+  HIPCHK(c, hipMalloc(&c->d_n_in, (size_t)slots * sizeof(int)));
+  HIPCHK(c, hipMemset(c->B.pyr, 0, (size_t)slots * pyr + 256));
+  c->slots = slots; c->pyr_elems_alloc = pyr; c->iframe_elems_alloc = ifr;
+  c->D.istride = istride;
+  c->D.iframe_elems = iframe;
+  return BRISK_HIP_OK;
+}
+
+static int ensure_stage(brisk_hip_ctx* c, size_t bytes) {
+  if (bytes <= c->stage_bytes) return BRISK_HIP_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(c->d_stage);
+  c->d_stage = nullptr;
+  c->stage_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->d_stage, bytes + 256));
+  c->stage_bytes = bytes;
+  return BRISK_HIP_OK;
+}
+
+static int check_detect_args(brisk_hip_ctx* ctx, int w, int h, int threshold, int octaves) {
+  if (w <= 0 || h <= 0 || w > 8191 || h > 8191) return fail(ctx, BRISK_HIP_ERR_ARG, "image size must be in [1, 8191]");
+  if (octaves < 0 || 2 * octaves > BRISK_MAX_LAYERS) return fail(ctx, BRISK_HIP_ERR_ARG, "octaves must be in [0, 8]");
+  if (threshold < 20 || threshold > 255)
+    return fail(ctx, BRISK_HIP_ERR_THRESHOLD, "AGAST threshold must be in [20, 255] on the device path");
+  return BRISK_HIP_OK;
+}
+
+extern "C" {
+
+int brisk_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int brisk_hip_create(int device, brisk_hip_ctx** out) {
+  if (!out) return BRISK_HIP_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return BRISK_HIP_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return BRISK_HIP_ERR_NO_DEVICE;
+  brisk_hip_ctx* c = new brisk_hip_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return BRISK_HIP_ERR_HIP;
+  }
+  *out = c;
+  return BRISK_HIP_OK;
+}
+
+void brisk_hip_destroy(brisk_hip_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  free_buffers(c);
+  hipFree(c->d_stage);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* brisk_hip_last_error(const brisk_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int brisk_hip_set_capacity(brisk_hip_ctx* ctx, int max_candidates, int max_keypoints) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  if (max_candidates < 256 || max_keypoints < 16) return fail(ctx, BRISK_HIP_ERR_ARG, "capacity too small");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->cand_cap = max_candidates;
+  ctx->kp_cap = max_keypoints;
+  ctx->tie_cap = max_candidates / 4 > 1024 ? max_candidates / 4 : 1024;
+  return BRISK_HIP_OK;
+}
+
+// ---- pattern -----------------------------------------------------------------------------------
+static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
+  const BriskPatternHost& H = p->host;
+  const size_t n = (size_t)H.npoints;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_mult = take(64 * n * 4), o_sigma = take(64 * n * 4), o_uv = take((size_t)BRISK_NROT * n * 16);
+  const size_t o_thr = take(64 * 4), o_size = take(64 * 4), o_sp = take((size_t)H.nshort * 4), o_lp = take((size_t)H.nlong * 16);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc(&p->blob, off));
+  char* b = (char*)p->blob;
+  HIPCHK(ctx, hipMemcpy(b + o_mult, H.mult.data(), 64 * n * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(b + o_sigma, H.sigma.data(), 64 * n * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(b + o_uv, H.uv.data(), (size_t)BRISK_NROT * n * 16, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(b + o_thr, H.size_thresh.data(), 64 * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(b + o_size, H.size_list.data(), 64 * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(b + o_sp, H.short_pairs.data(), (size_t)H.nshort * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(b + o_lp, H.long_pairs.data(), (size_t)H.nlong * 16, hipMemcpyHostToDevice));
+  BriskPatternDev& d = p->dev;
+  d.npoints = H.npoints; d.nshort = H.nshort; d.nlong = H.nlong; d.strings = H.strings;
+  d.rotation_invariant = 1; d.scale_invariant = 1; d.basicscale = H.basicscale;
+  d.mult = (const float*)(b + o_mult); d.sigma = (const float*)(b + o_sigma); d.uv = (const double*)(b + o_uv);
+  d.size_thresh = (const float*)(b + o_thr); d.size_list = (const int*)(b + o_size);
+  d.short_pairs = (const uint16_t*)(b + o_sp); d.long_pairs = (const int*)(b + o_lp);
+  return BRISK_HIP_OK;
+}
+
+static int pattern_finish(brisk_hip_ctx* ctx, brisk_hip_pattern* p, bool ok, const std::string& err,
+                          brisk_hip_pattern** out) {
+  if (!ok) {
+    ctx->err = err;
+    delete p;
+    return BRISK_HIP_ERR_PATTERN;
+  }
+  p->ctx = ctx;
+  p->blob = nullptr;
+  const int rc = upload_pattern(ctx, p);
+  if (rc != BRISK_HIP_OK) {
+    if (p->blob) hipFree(p->blob);
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_pattern_create(brisk_hip_ctx* ctx, int version, float pattern_scale, brisk_hip_pattern** out) {
+  if (!ctx || !out) return BRISK_HIP_ERR_ARG;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  brisk_hip_pattern* p = new brisk_hip_pattern();
+  std::string err;
+  const bool ok = brisk_pattern_build_default(version, pattern_scale, &p->host, &err);
+  return pattern_finish(ctx, p, ok, err, out);
+}
+
+int brisk_hip_pattern_create_from_text(brisk_hip_ctx* ctx, const char* ptn_text, float pattern_scale,
+                                       brisk_hip_pattern** out) {
+  if (!ctx || !out || !ptn_text) return BRISK_HIP_ERR_ARG;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  brisk_hip_pattern* p = new brisk_hip_pattern();
+  std::string err;
+  const bool ok = brisk_pattern_build_from_text(ptn_text, pattern_scale, &p->host, &err);
+  return pattern_finish(ctx, p, ok, err, out);
+}
+
+void brisk_hip_pattern_destroy(brisk_hip_pattern* p) {
+  if (!p) return;
+  if (p->ctx) hipSetDevice(p->ctx->device);
+  if (p->blob) hipFree(p->blob);
+  delete p;
+}
+
+int brisk_hip_pattern_descriptor_size(const brisk_hip_pattern* p) { return p ? p->host.strings : 0; }
+int brisk_hip_pattern_points(const brisk_hip_pattern* p) { return p ? p->host.npoints : 0; }
+
+int brisk_hip_pattern_tables(const brisk_hip_pattern* p, float* scale_list, int* size_list, float* size_thresh) {
+  if (!p) return BRISK_HIP_ERR_ARG;
+  if (scale_list) memcpy(scale_list, p->host.scale_list.data(), 64 * 4);
+  if (size_list) memcpy(size_list, p->host.size_list.data(), 64 * 4);
+  if (size_thresh) memcpy(size_thresh, p->host.size_thresh.data(), 64 * 4);
+  return BRISK_HIP_OK;
+}
+
+// ---- batch (device-resident) path ------------------------------------------------------------------
+static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes, int w, int h,
+                     long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* d_mask,
+                     long mask_frame_pitch, int mask_row_pitch, hipStream_t s, bool do_detect, bool do_describe) {
+  int rc = check_detect_args(ctx, w, h, threshold, octaves);
+  if (rc) return rc;
+  if (!d_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
+    return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  make_geometry(w, h, threshold, octaves, &ctx->G, &ctx->T);
+  rc = ensure_buffers(ctx, nframes, ctx->G);
+  if (rc) return rc;
+  if (do_detect) {
+    brisk_launch_detect(ctx->G, ctx->T, ctx->B, nframes, d_frames, frame_pitch, row_pitch, d_mask, mask_frame_pitch,
+                        mask_row_pitch, s);
+  }
+  if (do_describe) {
+    BriskPatternDev P = pat->dev;
+    brisk_launch_describe(ctx->G, P, ctx->B, ctx->D, nframes, ctx->B.kp_out, &ctx->B.counters[0].nkp,
+                          sizeof(BriskFrameCounters), s);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  ctx->last_nframes = nframes;
+  ctx->last_has_desc = do_describe;
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes,
+                                    int w, int h, long frame_pitch, int row_pitch, int threshold, int octaves,
+                                    void* stream) {
+  if (!ctx || !pat) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return run_batch(ctx, pat, d_frames, nframes, w, h, frame_pitch, row_pitch, threshold, octaves, nullptr, 0, 0, s, true,
+                   true);
+}
+
+int brisk_hip_detect_batch(brisk_hip_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, long frame_pitch,
+                           int row_pitch, int threshold, int octaves, void* stream) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return run_batch(ctx, nullptr, d_frames, nframes, w, h, frame_pitch, row_pitch, threshold, octaves, nullptr, 0, 0, s, true,
+                   false);
+}
+
+int brisk_hip_batch_results(brisk_hip_ctx* ctx, const int** d_detected, const int** d_described, int* count_stride,
+                            const brisk_hip_keypoint** d_detected_kps, const brisk_hip_keypoint** d_described_kps,
+                            const uint8_t** d_desc, int* kp_cap, int* desc_pitch) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->B.counters) return fail(ctx, BRISK_HIP_ERR_ARG, "no batch has run");
+  if (d_detected) *d_detected = &ctx->B.counters[0].nkp;
+  if (d_described) *d_described = &ctx->B.counters[0].ndesc;
+  if (count_stride) *count_stride = (int)sizeof(BriskFrameCounters);
+  if (d_detected_kps) *d_detected_kps = (const brisk_hip_keypoint*)ctx->B.kp_out;
+  if (d_described_kps) *d_described_kps = (const brisk_hip_keypoint*)ctx->D.dkp;
+  if (d_desc) *d_desc = ctx->D.desc;
+  if (kp_cap) *kp_cap = ctx->B.kp_cap;
+  if (desc_pitch) *desc_pitch = ctx->D.desc_pitch;
+  return BRISK_HIP_OK;
+}
+
+static int overflow_to_rc(brisk_hip_ctx* ctx, int flags) {
+  if (flags & 1) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "candidate capacity exceeded (brisk_hip_set_capacity)");
+  if (flags & 2) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "tie-candidate capacity exceeded (brisk_hip_set_capacity)");
+  if (flags & 4) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "keypoint capacity exceeded (brisk_hip_set_capacity)");
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (nframes <= 0 || nframes > ctx->slots) return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame count");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  std::vector<BriskFrameCounters> c(nframes);
+  HIPCHK(ctx, hipMemcpy(c.data(), ctx->B.counters, sizeof(BriskFrameCounters) * nframes, hipMemcpyDeviceToHost));
+  int f = 0;
+  for (auto& x : c) f |= x.overflow;
+  if (overflow_flags) *overflow_flags = f;
+  return overflow_to_rc(ctx, f);
+}
+
+static int download_locked(brisk_hip_ctx* ctx, int frame, int which, brisk_hip_keypoint* kps, int cap, int* n,
+                           uint8_t* desc, int desc_stride, int strings) {
+  if (frame < 0 || frame >= ctx->slots) return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame index");
+  HIPCHK(ctx, hipDeviceSynchronize());
+  BriskFrameCounters c;
+  HIPCHK(ctx, hipMemcpy(&c, ctx->B.counters + frame, sizeof(c), hipMemcpyDeviceToHost));
+  int rc = overflow_to_rc(ctx, c.overflow);
+  if (rc) return rc;
+  const int cnt = which ? c.ndesc : c.nkp;
+  if (n) *n = cnt;
+  if (kps) {
+    if (cnt > cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "output keypoint buffer too small");
+    const BriskKeyPoint* src = (which ? ctx->D.dkp : ctx->B.kp_out) + (size_t)frame * ctx->B.kp_cap;
+    if (cnt) HIPCHK(ctx, hipMemcpy(kps, src, sizeof(BriskKeyPoint) * (size_t)cnt, hipMemcpyDeviceToHost));
+  }
+  if (desc && which && cnt) {
+    if (cnt > cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "output descriptor buffer too small");
+    HIPCHK(ctx, hipMemcpy2D(desc, desc_stride, ctx->D.desc + (size_t)frame * ctx->B.kp_cap * ctx->D.desc_pitch,
+                            ctx->D.desc_pitch, strings, cnt, hipMemcpyDeviceToHost));
+  }
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which, brisk_hip_keypoint* kps, int cap, int* n,
+                             uint8_t* desc, int desc_stride) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // descriptor width of the last describe is not stored per call: copy the full pitch-limited row
+  return download_locked(ctx, frame, which, kps, cap, n, desc, desc_stride,
+                         desc_stride < ctx->D.desc_pitch ? desc_stride : ctx->D.desc_pitch);
+}
+
+// ---- host-buffer calls ---------------------------------------------------------------------------
+int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                     int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, brisk_hip_keypoint* out,
+                     int cap, int* n) {
+  if (!ctx || !img || !n || (cap > 0 && !out) || cap < 0) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *n = 0;
+  if (!suppress_scale_nonmaxima)
+    return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "suppressScaleNonmaxima=false is not implemented on the device path");
+  int rc = check_detect_args(ctx, w, h, threshold, octaves);
+  if (rc) return rc;
+  if (stride < w || (mask && mask_stride < w)) return fail(ctx, BRISK_HIP_ERR_ARG, "stride smaller than width");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t img_bytes = (size_t)brisk_align_up(w, 64) * h;
+  rc = ensure_stage(ctx, img_bytes * 2);
+  if (rc) return rc;
+  const int pitch = brisk_align_up(w, 64);
+  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  const uint8_t* d_mask = nullptr;
+  if (mask) {
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage + img_bytes, pitch, mask, mask_stride, w, h, hipMemcpyHostToDevice,
+                                 ctx->stream));
+    d_mask = ctx->d_stage + img_bytes;
+  }
+  rc = run_batch(ctx, nullptr, ctx->d_stage, 1, w, h, (long)img_bytes, pitch, threshold, octaves, d_mask, (long)img_bytes,
+                 pitch, ctx->stream, true, false);
+  if (rc) return rc;
+  return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
+}
+
+int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
+                       brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
+                       int scale_invariant) {
+  if (!ctx || !pat || !img || !n || *n < 0 || (*n > 0 && (!kps || !desc))) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (w <= 0 || h <= 0 || w > 8191 || h > 8191 || stride < w) return fail(ctx, BRISK_HIP_ERR_ARG, "bad image description");
+  if (*n > 0 && desc_stride < pat->host.strings) return fail(ctx, BRISK_HIP_ERR_ARG, "descriptor stride too small");
+  if (*n > ctx->kp_cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "more keypoints than the configured capacity");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int pitch = brisk_align_up(w, 64);
+  const size_t img_bytes = (size_t)pitch * h;
+  int rc = ensure_stage(ctx, img_bytes * 2);
+  if (rc) return rc;
+  make_geometry(w, h, 20, 0, &ctx->G, &ctx->T);  // only layer 0 is needed
+  rc = ensure_buffers(ctx, 1, ctx->G);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  const int n_in = *n;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, &n_in, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (n_in) HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in, kps, sizeof(BriskKeyPoint) * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->B.counters, 0, sizeof(BriskFrameCounters), ctx->stream));
+  brisk_launch_layer0_only(ctx->G, ctx->B, 1, ctx->d_stage, (long)img_bytes, pitch, ctx->stream);
+  BriskPatternDev P = pat->dev;
+  P.rotation_invariant = rotation_invariant ? 1 : 0;
+  P.scale_invariant = scale_invariant ? 1 : 0;
+  brisk_launch_describe(ctx->G, P, ctx->B, ctx->D, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  ctx->last_nframes = 1;
+  ctx->last_has_desc = true;
+  return download_locked(ctx, 0, 1, kps, n_in, n, desc, desc_stride, pat->host.strings);
+}
+
+// ---- debug / per-stage parity ------------------------------------------------------------------
+int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, uint8_t* out, int* w, int* h) {
+  if (!ctx || !w || !h) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (frame < 0 || frame >= ctx->slots || layer < 0 || layer >= ctx->G.nlayers) return fail(ctx, BRISK_HIP_ERR_ARG, "bad index");
+  const BriskLayerGeom& L = ctx->G.L[layer];
+  *w = L.w; *h = L.h;
+  if (!out) return BRISK_HIP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  const size_t base = (size_t)frame * ctx->G.pyr_elems + L.off;
+  if (which == 0) {
+    HIPCHK(ctx, hipMemcpy2D(out, L.w, ctx->B.pyr + base, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<uint16_t> tmp((size_t)L.stride * L.h);
+    HIPCHK(ctx, hipMemcpy(tmp.data(), ctx->B.smap + base, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.h; ++y)
+      for (int x = 0; x < L.w; ++x) {
+        const uint16_t v = tmp[(size_t)y * L.stride + x];
+        out[(size_t)y * L.w + x] = (which == 1) ? (uint8_t)(v & 0xFF) : (uint8_t)(v >> 8);
+      }
+  }
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out) {
+  if (!ctx || !out) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (frame < 0 || frame >= ctx->slots) return fail(ctx, BRISK_HIP_ERR_ARG, "bad index");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, hipMemcpy2D(out, (size_t)(ctx->G.w + 1) * 4, ctx->D.integral + (size_t)frame * ctx->D.iframe_elems,
+                          (size_t)ctx->D.istride * 4, (size_t)(ctx->G.w + 1) * 4, ctx->G.h + 1, hipMemcpyDeviceToHost));
+  return BRISK_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// brisk_common.h - shared types of the MI355X BRISK engine (host + device).
+//
+// Data layout in HBM (per frame slot):
+//   pyr   : u8  pyramid, layer l at byte offset L[l].off, row stride L[l].stride (multiple of 64)
+//   smap  : u16 "score-state map", same offsets/strides as pyr (in elements):
+//             bits 0-7   D   = contrast score of a detected pixel (initial scores_ value,
+//                              brisk/src/brisk-layer.cc:110-116), 0 = not a detection
+//             bits 8-11  number of IsMax2D probes the candidate issued before its early exit
+//             bits 12-13 candidate status (BRISK_ST_*)
+//             bit  14    candidate reaches its own-layer 3x3 / 4x4 patch reads (if it is a 2D max)
+//             bit  15    pixel was score-touched (threshold 1) from the layer below
+//   cand  : BriskCand[cand_cap] candidate records (unordered, atomic append)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BRISK_HD __host__ __device__ inline
+#else
+#define BRISK_HD inline
+#endif
+
+#define BRISK_MAX_LAYERS 16
+#define BRISK_STRIDE_ALIGN 64
+
+// candidate status (smap bits 12-13)
+#define BRISK_ST_REJ 0u   // failed the 8-neighbour comparison (still issued probes)
+#define BRISK_ST_PASS 1u  // 2D maximum (no tie, or tie resolved in its favour)
+#define BRISK_ST_TIE 2u   // 2D maximum with equal-score neighbours, not yet resolved
+#define BRISK_ST_FAIL 3u  // tie resolved against it
+
+#define BRISK_SM_D(v) ((v) & 0xFFu)
+#define BRISK_SM_NPROBED(v) (((v) >> 8) & 0xFu)
+#define BRISK_SM_STATUS(v) (((v) >> 12) & 0x3u)
+#define BRISK_SM_E5 0x4000u
+#define BRISK_SM_TOUCH 0x8000u
+
+// reference constants: brisk/src/brisk-scale-space.cc:45-51
+#define BRISK_BASIC_SIZE 12.0f
+#define BRISK_MAX_THRESHOLD 1
+#define BRISK_DROP_THRESHOLD 5
+#define BRISK_MIN_DROP 15
+#define BRISK_UPPER_THRESHOLD 230
+#define BRISK_LOWER_THRESHOLD 10
+
+// descriptor constants: brisk/src/brisk-descriptor-extractor.cc:57-62
+#define BRISK_SCALES 64
+#define BRISK_NROT 1024
+#define BRISK_MAX_POINTS 128
+#define BRISK_MAX_SHORT 512
+#define BRISK_MAX_LONG 2048
+
+struct BriskLayerGeom {
+  int w, h, stride;
+  int off;  // element offset of this layer inside the per-frame pyramid / smap buffers
+  float scale, offset;
+};
+
+struct BriskGeom {
+  int nlayers;
+  int w, h;            // layer-0 size
+  int pyr_elems;       // total elements per frame (sum of stride*h, 256-aligned per layer)
+  int threshold;       // AGAST threshold (20..255)
+  int single_layer;    // octaves == 0
+  BriskLayerGeom L[BRISK_MAX_LAYERS];
+};
+
+// binary-identical to cv::KeyPoint
+struct BriskKeyPoint {
+  float x, y, size, angle, response;
+  int octave, class_id;
+};
+
+struct BriskCand {
+  uint16_t x, y;
+  uint8_t layer, D, status, flags;  // flags bit0: refined keypoint valid (3-D max), bit1: e5
+  int16_t fp_x0, fp_y0;             // e3 footprint anchor on layer+1 (4x4 block)
+  uint16_t fp_mask;
+  uint16_t pad;
+  float kx, ky, ksize, kresp;       // refined keypoint
+  uint32_t key;                     // (layer << 26) | (y << 13) | x : output order
+};
+
+// per-frame counters (device)
+struct BriskFrameCounters {
+  int ncand;                        // appended candidates (may exceed cap -> overflow)
+  int ntie[BRISK_MAX_LAYERS];       // tie candidates per layer
+  int nkp;                          // final keypoints (detect order)
+  int ndesc;                        // keypoints surviving the descriptor border filter
+  int overflow;                     // bit0 cand overflow, bit1 tie overflow, bit2 keypoint overflow
+  int pad[4];
+};
+
+// descriptor pattern tables (device pointers or host pointers, same layout)
+struct BriskPatternDev {
+  int npoints, nshort, nlong, strings;   // strings = descriptor bytes (48 / 64)
+  int rotation_invariant, scale_invariant, basicscale;
+  const float* mult;      // [64][npoints]  multiplier m so that x = (float)((double)m * U)
+  const float* sigma;     // [64][npoints]  box half side
+  const double* uv;       // [1024][npoints][2] unit-scale rotated offsets (x, y)
+  const float* size_thresh;  // [64] size_thresh[s] = smallest keypoint size with scale index >= s
+  const int* size_list;   // [64] border per scale index
+  const uint16_t* short_pairs;  // [nshort][2] (i, j)
+  const int* long_pairs;        // [nlong][4]  (i, j, weighted_dx, weighted_dy)
+};
+
+BRISK_HD int brisk_align_up(int v, int a) { return (v + a - 1) / a * a; }

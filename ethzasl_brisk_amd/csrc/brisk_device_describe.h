@@ -1,0 +1,141 @@
+// brisk_device_describe.h - per-item device logic of the BRISK descriptor
+// (brisk/src/brisk-descriptor-extractor.cc).  `__host__ __device__` for the same reason as
+// brisk_device_detect.h.  Compile with -ffp-contract=off.
+#pragma once
+#include <math.h>
+
+#include "brisk_common.h"
+
+#ifndef BRISK_PI
+#define BRISK_PI 3.14159265358979323846
+#endif
+
+// Scale index of a keypoint (:636-650).  The reference evaluates
+//   max(int(64 / lb * (log(size / 7.2f) / log2f) + 0.5), 0) saturated to 63
+// with host libm; the host pre-computes, by bisection over that exact expression, the smallest
+// float size reaching each index, so the device needs no transcendental and cannot disagree.
+BRISK_HD int brisk_scale_index(const BriskPatternDev& P, float size) {
+  if (!P.scale_invariant) return P.basicscale;
+  int s = 0;
+#pragma unroll 8
+  for (int i = 1; i < BRISK_SCALES; ++i) s += (size >= P.size_thresh[i]) ? 1 : 0;
+  return s;
+}
+
+// RoiPredicate (:532-536) negated: keypoint stays iff border <= x < cols-border (same for y)
+BRISK_HD bool brisk_inside_border(const BriskPatternDev& P, int scale, float x, float y, int cols, int rows) {
+  const int border = P.size_list[scale];
+  const float minX = (float)border, minY = (float)border;
+  const float maxX = (float)(cols - border), maxY = (float)(rows - border);
+  return !((x < minX) || (x >= maxX) || (y < minY) || (y >= maxY));
+}
+
+// Pattern point (scale, rot, i): the reference tabulates
+//   x = float(scaleList[s] * (u_x cos(theta) - u_y sin(theta)))      (:231-234, V2)
+//   x = float(scaleList[s] * r * cos(alpha + theta))                 (:105-108, V1)
+// for all 64 x 1024 x points (51.9 MB).  Both are float(double(m[s][i]) * U[rot][i]) with a
+// scale-independent double U, so the engine keeps U (1 MB, L2-resident) and m, sigma (34 KB).
+BRISK_HD void brisk_pattern_point(const BriskPatternDev& P, int scale, int rot, int i, float* x, float* y,
+                                  float* sigma) {
+  const double m = (double)P.mult[scale * P.npoints + i];
+  const double* uv = P.uv + ((long)rot * P.npoints + i) * 2;
+  *x = (float)(m * uv[0]);
+  *y = (float)(m * uv[1]);
+  *sigma = P.sigma[scale * P.npoints + i];
+}
+
+// SmoothedIntensity<uchar,int> (:370-530).  Weighted box sum: 4 corner pixels (weights A..D), 4 edge
+// strips and the interior, the strips/interior taken from the integral image (12 samples).  The
+// loop branch (:497-529, dx+dy <= 2) is the same integer with the true corners.  The integral branch
+// (:445-495, dx+dy > 2) steps `ptr += dy*imagecols + 1` (:453), so its C and D weights multiply the
+// pixels (x_right+1, y_bottom-1) and (x_left+1, y_bottom-1) instead of the bottom corners; the
+// golden vectors contain this behaviour, so it is reproduced.
+// integral: exclusive prefix sums, (rows+1) x (cols+1), row stride istride (u32, wrap-around).
+BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, const uint32_t* integral, int istride,
+                                      float key_x, float key_y, float bx, float by, float sigma_half) {
+  const float xf = bx + key_x;
+  const float yf = by + key_y;
+  const float area = (float)(4.0 * sigma_half * sigma_half);
+  if (sigma_half < 0.5) {  // :391-408
+    const int x = (int)xf, y = (int)yf;
+    const int r_x = (int)((xf - x) * 1024);
+    const int r_y = (int)((yf - y) * 1024);
+    const int r_x_1 = (1024 - r_x);
+    const int r_y_1 = (1024 - r_y);
+    const uint8_t* ptr = img + x + (long)y * stride;
+    int ret_val = (r_x_1 * r_y_1 * (int)ptr[0]);
+    ret_val += (r_x * r_y_1 * (int)ptr[1]);
+    ret_val += (r_x * r_y * (int)ptr[stride + 1]);
+    ret_val += (r_x_1 * r_y * (int)ptr[stride]);
+    return (ret_val) / 1024;
+  }
+  const int scaling = (int)(4194304.0 / area);
+  const int scaling2 = (int)((float)scaling * area / 1024.0);
+  const float x_1 = xf - sigma_half;
+  const float x1 = xf + sigma_half;
+  const float y_1 = yf - sigma_half;
+  const float y1 = yf + sigma_half;
+  const int x_left = (int)(x_1 + 0.5);
+  const int y_top = (int)(y_1 + 0.5);
+  const int x_right = (int)(x1 + 0.5);
+  const int y_bottom = (int)(y1 + 0.5);
+  const float r_x_1 = (float)((float)x_left - x_1 + 0.5);
+  const float r_y_1 = (float)((float)y_top - y_1 + 0.5);
+  const float r_x1 = (float)(x1 - (float)x_right + 0.5);
+  const float r_y1 = (float)(y1 - (float)y_bottom + 0.5);
+  const int dx = x_right - x_left - 1;
+  const int dy = y_bottom - y_top - 1;
+  const unsigned A = (unsigned)(int)((r_x_1 * r_y_1) * scaling);
+  const unsigned B = (unsigned)(int)((r_x1 * r_y_1) * scaling);
+  const unsigned C = (unsigned)(int)((r_x1 * r_y1) * scaling);
+  const unsigned D = (unsigned)(int)((r_x_1 * r_y1) * scaling);
+  const unsigned r_x_1_i = (unsigned)(int)(r_x_1 * scaling);
+  const unsigned r_y_1_i = (unsigned)(int)(r_y_1 * scaling);
+  const unsigned r_x1_i = (unsigned)(int)(r_x1 * scaling);
+  const unsigned r_y1_i = (unsigned)(int)(r_y1 * scaling);
+  // corner pixels
+  const bool quirk = (dx + dy > 2);
+  const uint8_t* ptop = img + (long)y_top * stride;
+  const uint8_t* pbot = img + (long)(quirk ? y_bottom - 1 : y_bottom) * stride;
+  const unsigned tl = ptop[x_left], tr = ptop[x_right];
+  const unsigned br = pbot[quirk ? x_right + 1 : x_right], bl = pbot[quirk ? x_left + 1 : x_left];
+  // integral samples at columns {xl, xl+1, xr, xr+1} x rows {yt, yt+1, yb, yb+1} (without the 4 outer corners)
+  const uint32_t* r0 = integral + (long)y_top * istride;
+  const uint32_t* r1 = r0 + istride;
+  const uint32_t* r2 = integral + (long)y_bottom * istride;
+  const uint32_t* r3 = r2 + istride;
+  const int c0 = x_left, c1 = x_left + 1, c2 = x_right, c3 = x_right + 1;
+  const uint32_t i01 = r0[c1], i02 = r0[c2];
+  const uint32_t i10 = r1[c0], i11 = r1[c1], i12 = r1[c2], i13 = r1[c3];
+  const uint32_t i20 = r2[c0], i21 = r2[c1], i22 = r2[c2], i23 = r2[c3];
+  const uint32_t i31 = r3[c1], i32 = r3[c2];
+  const uint32_t top = i12 - i11 - i02 + i01;     // first row, interior columns
+  const uint32_t bottom = i32 - i31 - i22 + i21;  // last row, interior columns
+  const uint32_t left = i21 - i20 - i11 + i10;    // first column, interior rows
+  const uint32_t right = i23 - i22 - i13 + i12;   // last column, interior rows
+  const uint32_t middle = i22 - i21 - i12 + i11;  // interior
+  const uint32_t acc = A * tl + B * tr + C * br + D * bl + r_y_1_i * top + r_y1_i * bottom + r_x_1_i * left +
+                       r_x1_i * right + (unsigned)scaling * middle;
+  return (int)acc / scaling2;
+}
+
+// long-pair contribution (:721-730): C integer division truncates toward zero
+BRISK_HD void brisk_long_pair(const int* values, const int* lp /* i, j, wdx, wdy */, int* d0, int* d1) {
+  const int delta_t = values[lp[0]] - values[lp[1]];
+  *d0 = delta_t * lp[2] / 1024;
+  *d1 = delta_t * lp[3] / 1024;
+}
+
+// orientation (:732-739)
+BRISK_HD float brisk_angle_from_direction(int direction0, int direction1) {
+  return (float)(atan2((double)(float)direction1, (double)(float)direction0) / BRISK_PI * 180.0);
+}
+
+BRISK_HD int brisk_theta_from_angle(float angle, bool estimated) {
+  int theta;
+  if (estimated) theta = (int)((BRISK_NROT * angle) / (360.0) + 0.5);       // :734-735 (float product)
+  else theta = (int)(BRISK_NROT * (angle / (360.0)) + 0.5);                  // :746-747 (double product)
+  if (theta < 0) theta += BRISK_NROT;
+  if (theta >= BRISK_NROT) theta -= BRISK_NROT;
+  return theta;
+}

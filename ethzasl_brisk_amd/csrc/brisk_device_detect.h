@@ -1,0 +1,785 @@
+// brisk_device_detect.h - per-item device logic of the scale-space detector.
+//
+// Everything here is `__host__ __device__` so that the HIP kernels (brisk_kernels.hip) and the
+// test-only CPU emulation harness (tests/emul) run the SAME code.  No function in this file is
+// a CPU fallback of the product: the shipped library only instantiates them inside kernels.
+//
+// Float semantics follow the reference expressions literally (un-suffixed literals are double);
+// compile with -ffp-contract=off.  Reference paths are relative to /root/reference.
+#pragma once
+#include "brisk_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+BRISK_HD int brisk_min(int a, int b) { return a < b ? a : b; }
+BRISK_HD int brisk_max(int a, int b) { return a > b ? a : b; }
+BRISK_HD int brisk_min3(int a, int b, int c) { return brisk_min(brisk_min(a, b), c); }
+BRISK_HD int brisk_max3(int a, int b, int c) { return brisk_max(brisk_max(a, b), c); }
+
+struct BriskLayerView {
+  const uint8_t* img;   // layer image
+  uint16_t* smap;       // score-state map (same stride)
+  int w, h, stride;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Down-sampling (brisk/src/image-down-sampling.cc)
+// ---------------------------------------------------------------------------------------------
+BRISK_HD int brisk_avg(int a, int b) { return (a + b + 1) >> 1; }
+
+// Halfsample8 (:142-392): output pixel (c, r) of a source of width sw.  Column classes by SIMD
+// block position: [0,16*end) double rounded average, then 8 truncating columns if the number of
+// 16-blocks is odd, then (sw%16)/2 columns with the (a+b+c+d+2)/4 rule.
+BRISK_HD uint8_t brisk_half_px(const uint8_t* src, int sstride, int sw, int c, int r) {
+  const uint8_t* p1 = src + (long)(2 * r) * sstride + 2 * c;
+  const uint8_t* p2 = p1 + sstride;
+  const int hsize = sw / 16;
+  const int n1 = 16 * (hsize / 2);
+  const int n2 = n1 + 8 * (hsize % 2);
+  const int a = p1[0], b = p1[1], cc = p2[0], d = p2[1];
+  if (c < n2) {
+    const int v0 = brisk_avg(a, cc), v1 = brisk_avg(b, d);
+    return (uint8_t)(c < n1 ? brisk_avg(v0, v1) : (v0 + v1) / 2);
+  }
+  return (uint8_t)((a + b + cc + d + 2) / 4);
+}
+
+// Twothirdsample8 (:550-787): output pixel (c, r).  SIMD blocks of 15 source / 10 output columns
+// use nested rounding averages; the ((sw/3)*3)%15 tail columns use the /9 formula.
+BRISK_HD uint8_t brisk_twothird_px(const uint8_t* src, int sstride, int sw, int c, int r) {
+  const int t = c >> 1, cx = c & 1;   // source triple, left/right output of the pair
+  const int g = r >> 1, ry = r & 1;   // source row triple, upper/lower output
+  const uint8_t* pa = src + (long)(3 * g + (ry ? 2 : 0)) * sstride + 3 * t;  // outer row (A or C)
+  const uint8_t* pb = src + (long)(3 * g + 1) * sstride + 3 * t;             // middle row B
+  const int simd_cols = (sw / 15) * 10;
+  const int o = cx ? 2 : 0;  // outer column (p0 or p2)
+  if (c < simd_cols) {
+    const int uo = brisk_avg(brisk_avg(pa[o], pb[o]), pa[o]);
+    const int um = brisk_avg(brisk_avg(pa[1], pb[1]), pa[1]);
+    return (uint8_t)brisk_avg(brisk_avg(uo, um), uo);
+  }
+  const unsigned A1 = pa[o], A2 = pa[1], B1 = pb[o], B2 = pb[1];
+  return (uint8_t)(((4 * A1 + 2 * (A2 + B1 + 1) + B2 + 1) / 9) & 0xFF);
+}
+
+// ---------------------------------------------------------------------------------------------
+// AGAST scores in closed form: the generated decision trees
+// (agast/src/oast9-16.cc:100-1843, oast9-16-nms.cc:64-1962, agast5-8-nms.cc:59-336) are the
+// segment test, so "corner at b" <=> M > b with
+//   M = max( max_arcs min_arc(p_i - c), max_arcs min_arc(c - p_i) ).
+// ---------------------------------------------------------------------------------------------
+
+// M for OAST 9_16 at p (ring order agast/include/agast/oast9-16.h:99-116).
+BRISK_HD int brisk_oast9_16_M(const uint8_t* p, int s) {
+  const int c = p[0];
+  int d[16];
+  d[0] = p[-3] - c;          d[1] = p[-3 - s] - c;      d[2] = p[-2 - 2 * s] - c;  d[3] = p[-1 - 3 * s] - c;
+  d[4] = p[-3 * s] - c;      d[5] = p[1 - 3 * s] - c;   d[6] = p[2 - 2 * s] - c;   d[7] = p[3 - s] - c;
+  d[8] = p[3] - c;           d[9] = p[3 + s] - c;       d[10] = p[2 + 2 * s] - c;  d[11] = p[1 + 3 * s] - c;
+  d[12] = p[3 * s] - c;      d[13] = p[-1 + 3 * s] - c; d[14] = p[-2 + 2 * s] - c; d[15] = p[-3 + s] - c;
+  int lo3[16], hi3[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    lo3[i] = brisk_min3(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+    hi3[i] = brisk_max3(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+  }
+  int best_bright = -256, best_dark = 256;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    best_bright = brisk_max(best_bright, brisk_min3(lo3[i], lo3[(i + 3) & 15], lo3[(i + 6) & 15]));
+    best_dark = brisk_min(best_dark, brisk_max3(hi3[i], hi3[(i + 3) & 15], hi3[(i + 6) & 15]));
+  }
+  return brisk_max(best_bright, -best_dark);
+}
+
+// M for AGAST 5_8 (ring order agast/include/agast/agast5-8.h:66-75).
+BRISK_HD int brisk_agast5_8_M(const uint8_t* p, int s) {
+  const int c = p[0];
+  int d[8];
+  d[0] = p[-1] - c; d[1] = p[-1 - s] - c; d[2] = p[-s] - c; d[3] = p[1 - s] - c;
+  d[4] = p[1] - c;  d[5] = p[1 + s] - c;  d[6] = p[s] - c;  d[7] = p[-1 + s] - c;
+  int best_bright = -256, best_dark = 256;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lo = brisk_min(brisk_min3(d[i], d[(i + 1) & 7], d[(i + 2) & 7]), brisk_min(d[(i + 3) & 7], d[(i + 4) & 7]));
+    const int hi = brisk_max(brisk_max3(d[i], d[(i + 1) & 7], d[(i + 2) & 7]), brisk_max(d[(i + 3) & 7], d[(i + 4) & 7]));
+    best_bright = brisk_max(best_bright, lo);
+    best_dark = brisk_min(best_dark, hi);
+  }
+  return brisk_max(best_bright, -best_dark);
+}
+
+// K' = clamp(M - 1, 0, 254): cornerScore(b) == max(b, K') for b >= 0
+// (oast9-16-nms.cc:39-42,1964-1975: bisection on [b, 255), 255 never tested).
+BRISK_HD int brisk_Kp_from_M(int M) { return brisk_min(brisk_max(M - 1, 0), 254); }
+
+// Disc contrast = thrmap (brisk/src/brisk-layer.cc:278-598), interior pixels only.
+BRISK_HD void brisk_disc_minmax(const uint8_t* p, int s, int* mn_, int* mx_) {
+  int mn = 255, mx = 0;
+#pragma unroll
+  for (int dy = -3; dy <= 3; ++dy) {
+    const int r = (dy == -3 || dy == 3) ? 1 : (dy == -2 || dy == 2) ? 2 : 3;
+    for (int dx = -r; dx <= r; ++dx) {
+      const int v = p[dy * s + dx];
+      mn = brisk_min(mn, v);
+      mx = brisk_max(mx, v);
+    }
+  }
+  *mn_ = mn;
+  *mx_ = mx;
+}
+
+// Per-pixel detection (agast/src/oast9-16.cc:79-100 + SURVEY F5): returns D (= thrmap value) if
+// (x,y) is an AGAST point at threshold thr, else 0.  Caller guarantees 3 <= x <= w-4, 3 <= y <= h-4.
+BRISK_HD int brisk_detect_px(const uint8_t* p, int s, int thr) {
+  int mn, mx;
+  brisk_disc_minmax(p, s, &mn, &mx);
+  const int t = mx - mn;
+  const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
+  if (t < cmp) return 0;
+  const int tc = brisk_min(brisk_max(t, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
+  const int b2 = (tc * thr) / 100;
+  // necessary condition: some ring pixel must differ from the centre by more than b2
+  const int c = p[0];
+  if (mx - c <= b2 && c - mn <= b2) return 0;
+  return brisk_oast9_16_M(p, s) > b2 ? t : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// History-free score access (threshold 1): value returned by BriskLayer::GetAgastScore(x, y, 1)
+// (brisk/src/brisk-layer.cc:118-132): 0 on the 3-px border, D for detections (D > 2 for
+// threshold >= 20), else K'.
+// ---------------------------------------------------------------------------------------------
+BRISK_HD bool brisk_border3(const BriskLayerView& L, int x, int y) {
+  return x < 3 || y < 3 || x >= L.w - 3 || y >= L.h - 3;
+}
+
+BRISK_HD int brisk_Kp(const BriskLayerView& L, int x, int y) {
+  return brisk_Kp_from_M(brisk_oast9_16_M(L.img + (long)y * L.stride + x, L.stride));
+}
+
+BRISK_HD int brisk_V(const BriskLayerView& L, int x, int y) {
+  if (brisk_border3(L, x, y)) return 0;
+  const int D = BRISK_SM_D(L.smap[(long)y * L.stride + x]);
+  if (D > 2) return D;
+  return brisk_Kp(L, x, y);
+}
+
+// GetAgastScore_5_8(x, y, 1) (brisk-layer.cc:134-145)
+BRISK_HD int brisk_V58(const BriskLayerView& L, int x, int y) {
+  if (x < 2 || y < 2 || x >= L.w - 2 || y >= L.h - 2) return 0;
+  return brisk_Kp_from_M(brisk_agast5_8_M(L.img + (long)y * L.stride + x, L.stride));
+}
+
+// Touch recorder: which pixels of the layer above a GetScoreMaxAbove call score-touches
+// (4x4 block anchored at (x0, y0)); used to replay the lazy cache (event e3).
+struct BriskTouch {
+  int x0, y0;
+  unsigned mask;
+  bool on;
+};
+
+BRISK_HD void brisk_touch(BriskTouch* t, const BriskLayerView& L, int x, int y) {
+  if (!t->on || brisk_border3(L, x, y)) return;
+  const int bx = x - t->x0, by = y - t->y0;
+  if (bx >= 0 && bx < 4 && by >= 0 && by < 4) t->mask |= 1u << (by * 4 + bx);
+}
+
+BRISK_HD int brisk_Vt(const BriskLayerView& L, int x, int y, BriskTouch* t) {
+  brisk_touch(t, L, x, y);
+  return brisk_V(L, x, y);
+}
+
+// GetAgastScore(float, float, 1) (brisk-layer.cc:147-161): bilinear blend of 4 integer scores,
+// all four always evaluated (and touched), result truncated to u8.
+BRISK_HD int brisk_Vf(const BriskLayerView& L, float xf, float yf, BriskTouch* t) {
+  const int x = (int)xf;
+  const float rx1 = xf - (float)x;
+  const float rx = 1.0f - rx1;
+  const int y = (int)yf;
+  const float ry1 = yf - (float)y;
+  const float ry = 1.0f - ry1;
+  const int s00 = brisk_Vt(L, x, y, t);
+  const int s10 = brisk_Vt(L, x + 1, y, t);
+  const int s01 = brisk_Vt(L, x, y + 1, t);
+  const int s11 = brisk_Vt(L, x + 1, y + 1, t);
+  return (int)(uint8_t)(rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Subpixel2D (brisk/src/brisk-scale-space.cc:1230-1364), including delta_y = delta_x1/2 (:1351,1355)
+// ---------------------------------------------------------------------------------------------
+BRISK_HD float brisk_subpixel2d(const int s_0_0, const int s_0_1, const int s_0_2, const int s_1_0,
+                                const int s_1_1, const int s_1_2, const int s_2_0, const int s_2_1,
+                                const int s_2_2, float& delta_x, float& delta_y) {
+  const int tmp1 = s_0_0 + s_0_2 - 2 * s_1_1 + s_2_0 + s_2_2;
+  const int coeff1 = 3 * (tmp1 + s_0_1 - ((s_1_0 + s_1_2) * 2) + s_2_1);
+  const int coeff2 = 3 * (tmp1 - ((s_0_1 + s_2_1) * 2) + s_1_0 + s_1_2);
+  const int tmp2 = s_0_2 - s_2_0;
+  const int tmp3 = (s_0_0 + tmp2 - s_2_2);
+  const int tmp4 = tmp3 - 2 * tmp2;
+  const int coeff3 = -3 * (tmp3 + s_0_1 - s_2_1);
+  const int coeff4 = -3 * (tmp4 + s_1_0 - s_1_2);
+  const int coeff5 = (s_0_0 - s_0_2 - s_2_0 + s_2_2) * 4;
+  const int coeff6 = -(s_0_0 + s_0_2 - ((s_1_0 + s_0_1 + s_1_2 + s_2_1) * 2) - 5 * s_1_1 + s_2_0 + s_2_2) * 2;
+  const int H_det = 4 * coeff1 * coeff2 - coeff5 * coeff5;
+  if (H_det == 0) {
+    delta_x = 0.0f;
+    delta_y = 0.0f;
+    return (float)((float)coeff6 / 18.0);
+  }
+  if (!(H_det > 0 && coeff1 < 0)) {
+    int tmp_max = coeff3 + coeff4 + coeff5;
+    delta_x = 1.0f;
+    delta_y = 1.0f;
+    int tmp = -coeff3 + coeff4 - coeff5;
+    if (tmp > tmp_max) { tmp_max = tmp; delta_x = -1.0f; delta_y = 1.0f; }
+    tmp = coeff3 - coeff4 - coeff5;
+    if (tmp > tmp_max) { tmp_max = tmp; delta_x = 1.0f; delta_y = -1.0f; }
+    tmp = -coeff3 - coeff4 + coeff5;
+    if (tmp > tmp_max) { tmp_max = tmp; delta_x = -1.0f; delta_y = -1.0f; }
+    return (float)((float)(tmp_max + coeff1 + coeff2 + coeff6) / 18.0);
+  }
+  delta_x = (float)(2 * coeff2 * coeff3 - coeff4 * coeff5) / (float)(-H_det);
+  delta_y = (float)(2 * coeff1 * coeff4 - coeff3 * coeff5) / (float)(-H_det);
+  bool tx = false, tx_ = false, ty = false, ty_ = false;
+  if (delta_x > 1.0f) tx = true;
+  else if (delta_x < -1.0f) tx_ = true;
+  if (delta_y > 1.0f) ty = true;
+  if (delta_y < -1.0f) ty_ = true;
+  if (tx || tx_ || ty || ty_) {
+    float delta_x1 = 0.0f, delta_x2 = 0.0f, delta_y1 = 0.0f, delta_y2 = 0.0f;
+    if (tx) {
+      delta_x1 = 1.0f;
+      delta_y1 = -(float)(coeff4 + coeff5) / (float)(2 * coeff2);
+      if (delta_y1 > 1.0f) delta_y1 = 1.0f; else if (delta_y1 < -1.0f) delta_y1 = -1.0f;
+    } else if (tx_) {
+      delta_x1 = -1.0f;
+      delta_y1 = -(float)(coeff4 - coeff5) / (float)(2 * coeff2);
+      if (delta_y1 > 1.0f) delta_y1 = 1.0f; else if (delta_y1 < -1.0f) delta_y1 = -1.0f;
+    }
+    if (ty) {
+      delta_y2 = 1.0f;
+      delta_x2 = -(float)(coeff3 + coeff5) / (float)(2 * coeff1);
+      if (delta_x2 > 1.0f) delta_x2 = 1.0f; else if (delta_x2 < -1.0f) delta_x2 = -1.0f;
+    } else if (ty_) {
+      delta_y2 = -1.0f;
+      delta_x2 = -(float)(coeff3 - coeff5) / (float)(2 * coeff1);
+      if (delta_x2 > 1.0f) delta_x2 = 1.0f; else if (delta_x2 < -1.0f) delta_x2 = -1.0f;
+    }
+    const float max1 = (float)((coeff1 * delta_x1 * delta_x1 + coeff2 * delta_y1 * delta_y1 + coeff3 * delta_x1 +
+                                coeff4 * delta_y1 + coeff5 * delta_x1 * delta_y1 + coeff6) / 18.0);
+    const float max2 = (float)((coeff1 * delta_x2 * delta_x2 + coeff2 * delta_y2 * delta_y2 + coeff3 * delta_x2 +
+                                coeff4 * delta_y2 + coeff5 * delta_x2 * delta_y2 + coeff6) / 18.0);
+    if (max1 > max2) {
+      delta_x = delta_x1;
+      delta_y = delta_x1;  // sic (reference :1351)
+      return max1;
+    }
+    delta_x = delta_x2;
+    delta_y = delta_x2;  // sic (reference :1355)
+    return max2;
+  }
+  return (float)((coeff1 * delta_x * delta_x + coeff2 * delta_y * delta_y + coeff3 * delta_x + coeff4 * delta_y +
+                  coeff5 * delta_x * delta_y + coeff6) / 18.0);
+}
+
+// 3x3 patch around (x, y) with integer score access + Subpixel2D
+BRISK_HD float brisk_patch_subpixel(const BriskLayerView& L, int x, int y, BriskTouch* t, float& dx, float& dy,
+                                    int* centre) {
+  const int s_0_0 = brisk_Vt(L, x - 1, y - 1, t);
+  const int s_1_0 = brisk_Vt(L, x, y - 1, t);
+  const int s_2_0 = brisk_Vt(L, x + 1, y - 1, t);
+  const int s_2_1 = brisk_Vt(L, x + 1, y, t);
+  const int s_1_1 = brisk_Vt(L, x, y, t);
+  const int s_0_1 = brisk_Vt(L, x - 1, y, t);
+  const int s_0_2 = brisk_Vt(L, x - 1, y + 1, t);
+  const int s_1_2 = brisk_Vt(L, x, y + 1, t);
+  const int s_2_2 = brisk_Vt(L, x + 1, y + 1, t);
+  if (centre) *centre = s_1_1;
+  return brisk_subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, dx, dy);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Refine1D family (brisk-scale-space.cc:1101-1228)
+// ---------------------------------------------------------------------------------------------
+BRISK_HD float brisk_refine1d(const float s_05, const float s0, const float s05, float& max) {
+  const int i_05 = (int)(1024.0 * s_05 + 0.5);
+  const int i0 = (int)(1024.0 * s0 + 0.5);
+  const int i05 = (int)(1024.0 * s05 + 0.5);
+  const int three_a = 16 * i_05 - 24 * i0 + 8 * i05;
+  if (three_a >= 0) {
+    if (s0 >= s_05 && s0 >= s05) { max = s0; return 1.0f; }
+    if (s_05 >= s0 && s_05 >= s05) { max = s_05; return 0.75f; }
+    if (s05 >= s0 && s05 >= s_05) { max = s05; return 1.5f; }
+  }
+  const int three_b = -40 * i_05 + 54 * i0 - 14 * i05;
+  float ret_val = -(float)three_b / (float)(2 * three_a);
+  if (ret_val < 0.75) ret_val = 0.75f;
+  else if (ret_val > 1.5) ret_val = 1.5f;
+  const int three_c = +24 * i_05 - 27 * i0 + 6 * i05;
+  max = (float)three_c + (float)three_a * ret_val * ret_val + (float)three_b * ret_val;
+  max = (float)(max / 3072.0);
+  return ret_val;
+}
+
+BRISK_HD float brisk_refine1d_1(const float s_05, const float s0, const float s05, float& max) {
+  const int i_05 = (int)(1024.0 * s_05 + 0.5);
+  const int i0 = (int)(1024.0 * s0 + 0.5);
+  const int i05 = (int)(1024.0 * s05 + 0.5);
+  const int two_a = 9 * i_05 - 18 * i0 + 9 * i05;
+  if (two_a >= 0) {
+    if (s0 >= s_05 && s0 >= s05) { max = s0; return 1.0f; }
+    if (s_05 >= s0 && s_05 >= s05) { max = s_05; return (float)0.6666666666666666666666666667; }
+    if (s05 >= s0 && s05 >= s_05) { max = s05; return (float)1.3333333333333333333333333333; }
+  }
+  const int two_b = -21 * i_05 + 36 * i0 - 15 * i05;
+  float ret_val = -(float)two_b / (float)(2 * two_a);
+  if (ret_val < 0.6666666666666666666666666667) ret_val = (float)0.666666666666666666666666667;
+  else if (ret_val > 1.33333333333333333333333333) ret_val = (float)1.333333333333333333333333333;
+  const int two_c = +12 * i_05 - 16 * i0 + 6 * i05;
+  max = (float)two_c + (float)two_a * ret_val * ret_val + (float)two_b * ret_val;
+  max = (float)(max / 2048.0);
+  return ret_val;
+}
+
+BRISK_HD float brisk_refine1d_2(const float s_05, const float s0, const float s05, float& max) {
+  const int i_05 = (int)(1024.0 * s_05 + 0.5);
+  const int i0 = (int)(1024.0 * s0 + 0.5);
+  const int i05 = (int)(1024.0 * s05 + 0.5);
+  const int a = 2 * i_05 - 4 * i0 + 2 * i05;
+  if (a >= 0) {
+    if (s0 >= s_05 && s0 >= s05) { max = s0; return 1.0f; }
+    if (s_05 >= s0 && s_05 >= s05) { max = s_05; return (float)0.7; }
+    if (s05 >= s0 && s05 >= s_05) { max = s05; return 1.5f; }
+  }
+  const int b = -5 * i_05 + 8 * i0 - 3 * i05;
+  float ret_val = -(float)b / (float)(2 * a);
+  if (ret_val < 0.7) ret_val = (float)0.7;
+  else if (ret_val > 1.5) ret_val = 1.5f;
+  const int c = +3 * i_05 - 3 * i0 + 1 * i05;
+  max = (float)c + (float)a * ret_val * ret_val + (float)b * ret_val;
+  max = max / 1024;
+  return ret_val;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GetScoreMaxAbove / GetScoreMaxBelow (brisk-scale-space.cc:757-1099), history-free evaluation
+// with touch recording.  `above` selects the window mapping; `odd` = (layer % 2 == 1).
+// ---------------------------------------------------------------------------------------------
+BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above, const bool odd, const int x_layer,
+                                     const int y_layer, const int thr, bool& ismax, float& dx, float& dy,
+                                     BriskTouch* t) {
+  const int threshold = thr + BRISK_DROP_THRESHOLD;
+  ismax = false;
+  float x_1, x1, y_1, y1;
+  if (above) {
+    if (!odd) {
+      x_1 = (float)((float)(4 * (x_layer)-1 - 2) / 6.0);
+      x1 = (float)((float)(4 * (x_layer)-1 + 2) / 6.0);
+      y_1 = (float)((float)(4 * (y_layer)-1 - 2) / 6.0);
+      y1 = (float)((float)(4 * (y_layer)-1 + 2) / 6.0);
+    } else {
+      x_1 = (float)(6 * (x_layer)-1 - 3) / 8.0f;
+      x1 = (float)(6 * (x_layer)-1 + 3) / 8.0f;
+      y_1 = (float)(6 * (y_layer)-1 - 3) / 8.0f;
+      y1 = (float)(6 * (y_layer)-1 + 3) / 8.0f;
+    }
+  } else {
+    if (!odd) {
+      x_1 = (float)((float)(8 * (x_layer) + 1 - 4) / 6.0);
+      x1 = (float)((float)(8 * (x_layer) + 1 + 4) / 6.0);
+      y_1 = (float)((float)(8 * (y_layer) + 1 - 4) / 6.0);
+      y1 = (float)((float)(8 * (y_layer) + 1 + 4) / 6.0);
+    } else {
+      x_1 = (float)((float)(6 * (x_layer) + 1 - 3) / 4.0);
+      x1 = (float)((float)(6 * (x_layer) + 1 + 3) / 4.0);
+      y_1 = (float)((float)(6 * (y_layer) + 1 - 3) / 4.0);
+      y1 = (float)((float)(6 * (y_layer) + 1 + 3) / 4.0);
+    }
+  }
+  if (t->on) {
+    t->x0 = (int)x_1 - 1;
+    t->y0 = (int)y_1 - 1;
+  }
+  const int xs = (int)(x_1 + 1), xe = (int)x1, ys = (int)(y_1 + 1), ye = (int)y1;
+  int max_x = xs;
+  int max_y = ys;
+  float tmp_max;
+  float max = (float)brisk_Vf(Lo, x_1, y_1, t);
+  if (max > threshold) return 0;
+  for (int x = xs; x <= xe; x++) {
+    tmp_max = (float)brisk_Vf(Lo, (float)x, y_1, t);
+    if (tmp_max > threshold) return 0;
+    if (tmp_max > max) { max = tmp_max; max_x = x; }
+  }
+  tmp_max = (float)brisk_Vf(Lo, x1, y_1, t);
+  if (tmp_max > threshold) return 0;
+  if (tmp_max > max) { max = tmp_max; max_x = xe; }
+
+  for (int y = ys; y <= ye; y++) {
+    tmp_max = (float)brisk_Vf(Lo, x_1, (float)y, t);
+    if (tmp_max > threshold) return 0;
+    if (tmp_max > max) { max = tmp_max; max_x = xs; max_y = y; }
+    for (int x = xs; x <= xe; x++) {
+      tmp_max = (float)brisk_Vt(Lo, x, y, t);
+      if (tmp_max > threshold) return 0;
+      if (!above && tmp_max == max) {  // tie rule exists only in GetScoreMaxBelow (:987-1010)
+        const int t1 = 2 * (brisk_Vt(Lo, x - 1, y, t) + brisk_Vt(Lo, x + 1, y, t) + brisk_Vt(Lo, x, y + 1, t) +
+                            brisk_Vt(Lo, x, y - 1, t)) +
+                       (brisk_Vt(Lo, x + 1, y + 1, t) + brisk_Vt(Lo, x - 1, y + 1, t) + brisk_Vt(Lo, x + 1, y - 1, t) +
+                        brisk_Vt(Lo, x - 1, y - 1, t));
+        const int t2 = 2 * (brisk_Vt(Lo, max_x - 1, max_y, t) + brisk_Vt(Lo, max_x + 1, max_y, t) +
+                            brisk_Vt(Lo, max_x, max_y + 1, t) + brisk_Vt(Lo, max_x, max_y - 1, t)) +
+                       (brisk_Vt(Lo, max_x + 1, max_y + 1, t) + brisk_Vt(Lo, max_x - 1, max_y + 1, t) +
+                        brisk_Vt(Lo, max_x + 1, max_y - 1, t) + brisk_Vt(Lo, max_x - 1, max_y - 1, t));
+        if (t1 > t2) { max_x = x; max_y = y; }
+      }
+      if (tmp_max > max) { max = tmp_max; max_x = x; max_y = y; }
+    }
+    tmp_max = (float)brisk_Vf(Lo, x1, (float)y, t);
+    if (tmp_max > threshold) return 0;
+    if (tmp_max > max) { max = tmp_max; max_x = xe; max_y = y; }
+  }
+
+  // bottom row: never tested against the drop threshold (:843-863, :1027-1047)
+  tmp_max = (float)brisk_Vf(Lo, x_1, y1, t);
+  if (tmp_max > max) { max = tmp_max; max_x = xs; max_y = ye; }
+  for (int x = xs; x <= xe; x++) {
+    tmp_max = (float)brisk_Vf(Lo, (float)x, y1, t);
+    if (tmp_max > max) { max = tmp_max; max_x = x; max_y = ye; }
+  }
+  tmp_max = (float)brisk_Vf(Lo, x1, y1, t);
+  if (tmp_max > max) { max = tmp_max; max_x = xe; max_y = ye; }
+
+  float dx_1, dy_1;
+  const float refined_max = brisk_patch_subpixel(Lo, max_x, max_y, t, dx_1, dy_1, nullptr);
+  const float real_x = (float)max_x + dx_1;
+  const float real_y = (float)max_y + dy_1;
+  bool returnrefined = true;
+  if (above) {
+    if (!odd) {
+      dx = (real_x * 6.0f + 1.0f) / 4.0f - (float)x_layer;
+      dy = (real_y * 6.0f + 1.0f) / 4.0f - (float)y_layer;
+    } else {
+      dx = (float)((real_x * 8.0 + 1.0) / 6.0 - (float)x_layer);
+      dy = (float)((real_y * 8.0 + 1.0) / 6.0 - (float)y_layer);
+    }
+  } else {
+    if (!odd) {
+      dx = (float)((real_x * 6.0 + 1.0) / 8.0 - (float)x_layer);
+      dy = (float)((real_y * 6.0 + 1.0) / 8.0 - (float)y_layer);
+    } else {
+      dx = (float)((real_x * 4.0 - 1.0) / 6.0 - (float)x_layer);
+      dy = (float)((real_y * 4.0 - 1.0) / 6.0 - (float)y_layer);
+    }
+  }
+  if (dx > 1.0f) { dx = 1.0f; returnrefined = false; }
+  if (dx < -1.0f) { dx = -1.0f; returnrefined = false; }
+  if (dy > 1.0f) { dy = 1.0f; returnrefined = false; }
+  if (dy < -1.0f) { dy = -1.0f; returnrefined = false; }
+  ismax = true;
+  if (returnrefined) return refined_max > max ? refined_max : max;
+  return max;
+}
+
+// ---------------------------------------------------------------------------------------------
+// IsMax2D steps 1-2 (brisk-scale-space.cc:430-498): history-free classification.
+// Probe order W, E, N, S, SW, SE, NE, NW with early exit.
+// ---------------------------------------------------------------------------------------------
+#define BRISK_PROBE_DX(k) ((int)((0x0FF5F5u >> (2 * (k))) & 3u) - 1)
+// k:        0   1   2   3   4   5   6   7
+// dx:      -1  +1   0   0  -1  +1  +1  -1
+// dy:       0   0  -1  +1  +1  +1  -1  -1
+BRISK_HD int brisk_probe_dx(int k) { const int t[8] = {-1, 1, 0, 0, -1, 1, 1, -1}; return t[k]; }
+BRISK_HD int brisk_probe_dy(int k) { const int t[8] = {0, 0, -1, 1, 1, 1, -1, -1}; return t[k]; }
+// probe index of neighbour offset (dx, dy), |dx|,|dy| <= 1, not both 0
+BRISK_HD int brisk_probe_index(int dx, int dy) {
+  const int t[9] = {7, 2, 6, 0, -1, 1, 4, 3, 5};  // (dy+1)*3 + (dx+1)
+  return t[(dy + 1) * 3 + (dx + 1)];
+}
+
+// returns status (REJ / PASS / TIE) and the number of probes issued
+BRISK_HD unsigned brisk_classify(const BriskLayerView& L, int x, int y, int centre, int* nprobed) {
+  bool tie = false;
+  for (int k = 0; k < 8; ++k) {
+    const int nx = x + brisk_probe_dx(k), ny = y + brisk_probe_dy(k);
+    int s = 0;
+    if (!brisk_border3(L, nx, ny)) {
+      const int D = BRISK_SM_D(L.smap[(long)ny * L.stride + nx]);
+      if (D > 2) {
+        s = D;
+      } else {
+        const int K = brisk_Kp(L, nx, ny);
+        s = (K >= centre) ? K : 0;
+      }
+    }
+    if (centre < s) {
+      *nprobed = k + 1;
+      return BRISK_ST_REJ;
+    }
+    if (centre == s) tie = true;
+  }
+  *nprobed = 8;
+  return tie ? BRISK_ST_TIE : BRISK_ST_PASS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Refinement of a 2D maximum (brisk-scale-space.cc:211-287 + Refine3D :534-754).
+// Returns true if a keypoint results.  e5 = the candidate reaches its own-layer patch reads;
+// touch = score-touches on the layer above (event e3).
+// ---------------------------------------------------------------------------------------------
+BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView* Lv, const int layer, const int x_layer,
+                           const int y_layer, BriskKeyPoint* kp, bool* e5, BriskTouch* touch) {
+  const BriskLayerView& tl = Lv[layer];
+  const float lscale = G.L[layer].scale, loffset = G.L[layer].offset;
+  BriskTouch none;
+  none.on = false; none.mask = 0; none.x0 = 0; none.y0 = 0;
+  *e5 = false;
+  touch->mask = 0;
+  kp->angle = -1.0f;
+  kp->class_id = -1;
+  kp->octave = layer;
+
+  if (G.single_layer) {  // :172-209 (patch via float access: 4x4 touch footprint)
+    float delta_x, delta_y;
+    *e5 = true;
+    const float max = brisk_patch_subpixel(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
+    kp->x = (float)x_layer + delta_x;
+    kp->y = (float)y_layer + delta_y;
+    kp->size = BRISK_BASIC_SIZE;
+    kp->response = max;
+    kp->octave = 0;
+    return true;
+  }
+
+  if (layer == G.nlayers - 1) {  // :215-256
+    bool ismax;
+    float dx, dy;
+    const int centre = brisk_V(tl, x_layer, y_layer);
+    brisk_score_max_other(Lv[layer - 1], false, (layer & 1) != 0, x_layer, y_layer, centre, ismax, dx, dy, &none);
+    if (!ismax) return false;
+    *e5 = true;
+    float delta_x, delta_y;
+    const float max = brisk_patch_subpixel(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
+    kp->x = ((float)x_layer + delta_x) * lscale + loffset;
+    kp->y = ((float)y_layer + delta_y) * lscale + loffset;
+    kp->size = BRISK_BASIC_SIZE * lscale;
+    kp->response = max;
+    return true;
+  }
+
+  // Refine3D
+  const int center = brisk_V(tl, x_layer, y_layer);
+  bool ismax = true;
+  float delta_x_above = 0, delta_y_above = 0;
+  touch->on = true;
+  const float max_above = brisk_score_max_other(Lv[layer + 1], true, (layer & 1) != 0, x_layer, y_layer, center,
+                                                ismax, delta_x_above, delta_y_above, touch);
+  if (!ismax) return false;
+
+  float x, y, scale, max;
+  bool doScaleRefinement = true;
+  if ((layer & 1) == 0) {
+    float delta_x_below, delta_y_below;
+    float max_below_float;
+    if (layer == 0) {  // virtual layer below octave 0 via AGAST 5_8 (:558-592)
+      const int s_0_0 = brisk_V58(tl, x_layer - 1, y_layer - 1);
+      const int s_1_0 = brisk_V58(tl, x_layer, y_layer - 1);
+      const int s_2_0 = brisk_V58(tl, x_layer + 1, y_layer - 1);
+      const int s_2_1 = brisk_V58(tl, x_layer + 1, y_layer);
+      const int s_1_1 = brisk_V58(tl, x_layer, y_layer);
+      const int s_0_1 = brisk_V58(tl, x_layer - 1, y_layer);
+      const int s_0_2 = brisk_V58(tl, x_layer - 1, y_layer + 1);
+      const int s_1_2 = brisk_V58(tl, x_layer, y_layer + 1);
+      const int s_2_2 = brisk_V58(tl, x_layer + 1, y_layer + 1);
+      int mb = s_0_0;
+      mb = brisk_max(mb, s_1_0); mb = brisk_max(mb, s_2_0); mb = brisk_max(mb, s_2_1); mb = brisk_max(mb, s_1_1);
+      mb = brisk_max(mb, s_0_1); mb = brisk_max(mb, s_0_2); mb = brisk_max(mb, s_1_2); mb = brisk_max(mb, s_2_2);
+      brisk_subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, delta_x_below, delta_y_below);
+      max_below_float = (float)mb;
+    } else {
+      max_below_float = brisk_score_max_other(Lv[layer - 1], false, false, x_layer, y_layer, center, ismax,
+                                              delta_x_below, delta_y_below, &none);
+      if (!ismax) return false;
+    }
+    *e5 = true;
+    float delta_x_layer, delta_y_layer;
+    int s_1_1;
+    const float max_layer = brisk_patch_subpixel(tl, x_layer, y_layer, &none, delta_x_layer, delta_y_layer, &s_1_1);
+    if (layer == 0) {
+      if (s_1_1 - BRISK_MAX_THRESHOLD <= (int)max_above) doScaleRefinement = false;
+    } else {
+      if ((s_1_1 - BRISK_MAX_THRESHOLD < (max_above)) || (s_1_1 - BRISK_MAX_THRESHOLD < (max_below_float))) {
+        if ((s_1_1 - BRISK_MIN_DROP > (max_above)) || (s_1_1 - BRISK_MIN_DROP > (max_below_float))) {
+          doScaleRefinement = false;
+        } else {
+          return false;
+        }
+      }
+    }
+    const float s0 = ((float)center < max_layer) ? max_layer : (float)center;  // std::max(float(center), max_layer)
+    if (doScaleRefinement) {
+      if (layer == 0) scale = brisk_refine1d_2(max_below_float, s0, max_above, max);
+      else scale = brisk_refine1d(max_below_float, s0, max_above, max);
+    } else {
+      scale = 1.0f;
+      max = max_layer;
+    }
+    if (scale > 1.0) {
+      const float r0 = (float)((1.5 - scale) / .5);
+      const float r1 = (float)(1.0 - r0);
+      x = (r0 * delta_x_layer + r1 * delta_x_above + (float)x_layer) * lscale + loffset;
+      y = (r0 * delta_y_layer + r1 * delta_y_above + (float)y_layer) * lscale + loffset;
+    } else {
+      if (layer == 0) {
+        const float r0 = (float)((scale - 0.5) / 0.5);
+        const float r_1 = (float)(1.0 - r0);
+        x = r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer;
+        y = r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer;
+      } else {
+        const float r0 = (float)((scale - 0.75) / 0.25);
+        const float r_1 = (float)(1.0 - r0);
+        x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer) * lscale + loffset;
+        y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer) * lscale + loffset;
+      }
+    }
+  } else {
+    float delta_x_below, delta_y_below;
+    const float max_below = brisk_score_max_other(Lv[layer - 1], false, true, x_layer, y_layer, center, ismax,
+                                                  delta_x_below, delta_y_below, &none);
+    if (!ismax) return false;
+    *e5 = true;
+    float delta_x_layer, delta_y_layer;
+    int s_1_1;
+    const float max_layer = brisk_patch_subpixel(tl, x_layer, y_layer, &none, delta_x_layer, delta_y_layer, &s_1_1);
+    if ((s_1_1 - BRISK_MAX_THRESHOLD < (max_above)) || (s_1_1 - BRISK_MAX_THRESHOLD < (max_below))) {
+      if ((s_1_1 - BRISK_MIN_DROP > (max_above)) || (s_1_1 - BRISK_MIN_DROP > (max_below))) {
+        doScaleRefinement = false;
+      } else {
+        return false;
+      }
+    }
+    const float s0 = ((float)center < max_layer) ? max_layer : (float)center;
+    if (doScaleRefinement) {
+      scale = brisk_refine1d_1(max_below, s0, max_above, max);
+    } else {
+      scale = 1.0f;
+      max = max_layer;
+    }
+    if (scale > 1.0) {
+      const float r0 = (float)(4.0 - scale * 3.0);
+      const float r1 = (float)(1.0 - r0);
+      x = (r0 * delta_x_layer + r1 * delta_x_above + (float)x_layer) * lscale + loffset;
+      y = (r0 * delta_y_layer + r1 * delta_y_above + (float)y_layer) * lscale + loffset;
+    } else {
+      const float r0 = (float)(scale * 3.0 - 2.0);
+      const float r_1 = (float)(1.0 - r0);
+      x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer) * lscale + loffset;
+      y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer) * lscale + loffset;
+    }
+  }
+  scale *= lscale;
+  kp->x = x;
+  kp->y = y;
+  kp->size = BRISK_BASIC_SIZE * scale;
+  kp->response = max;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Order-faithful replay of the lazy score cache for tie candidates.
+//
+// raw map value of pixel p as candidate c = (cx, cy) sees it; `own` = c's own 8 probes are done.
+// All candidates c' < c (raster order) within distance 2 of p must carry their final status.
+// `last_layer`: the layer uses the float-access touch footprints (2x2 on pass, 4x4 patch).
+// ---------------------------------------------------------------------------------------------
+BRISK_HD int brisk_state_at(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int px,
+                            int py, int cx, int cy, bool own, const uint16_t* sm_local, int lx0, int ly0, int lw) {
+  // sm_local: smap window copy [ly0..][lx0..] of width lw covering p +- 2 (values 0 outside the image)
+  if (brisk_border3(L, px, py)) return 0;
+  const unsigned smp = sm_local[(py - ly0) * lw + (px - lx0)];
+  const int D = BRISK_SM_D(smp);
+  if (D > 2) return D;
+  const int Kp = brisk_Kp(L, px, py);
+  if (Kp == 0) return 0;
+  bool cached = false, any = false;
+  int t_last = 0;
+  if (smp & BRISK_SM_TOUCH) { cached = true; any = true; t_last = 1; }
+  for (int qy = py - 2; qy <= py + 2; ++qy) {
+    for (int qx = px - 2; qx <= px + 2; ++qx) {
+      if (qy > cy || (qy == cy && qx > cx)) continue;  // later in raster order
+      if (qx < 0 || qy < 0 || qx >= L.w || qy >= L.h) continue;
+      const unsigned smq = sm_local[(qy - ly0) * lw + (qx - lx0)];
+      const int Dq = BRISK_SM_D(smq);
+      if (Dq == 0) continue;
+      const int ddx = px - qx, ddy = py - qy;
+      if (ddx == 0 && ddy == 0) continue;
+      const bool self = (qx == cx && qy == cy);
+      if (self && !own) continue;
+      // phase 1: IsMax2D probe of p by q
+      if (ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1) {
+        if (brisk_probe_index(ddx, ddy) < (int)BRISK_SM_NPROBED(smq)) {
+          any = true;
+          t_last = Dq;
+          if (Dq <= Kp) cached = true;
+        }
+      }
+      if (self) continue;
+      // phase 2: threshold-1 touches of a candidate that passed IsMax2D
+      if (BRISK_SM_STATUS(smq) != BRISK_ST_PASS) continue;
+      bool touched = false;
+      if (!float_patch) {
+        touched = (smq & BRISK_SM_E5) && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1;
+      } else {
+        if (pass_touch2x2 && ddx >= 0 && ddx <= 1 && ddy >= 0 && ddy <= 1) touched = true;
+        if ((smq & BRISK_SM_E5) && ddx >= -1 && ddx <= 2 && ddy >= -1 && ddy <= 2) touched = true;
+      }
+      if (touched) { any = true; t_last = 1; cached = true; }
+    }
+  }
+  if (Kp >= 3 && cached) return Kp;
+  if (!any) return 0;
+  return (Kp >= t_last) ? Kp : 0;
+}
+
+// IsMax2D steps 3-4 (brisk-scale-space.cc:499-530) for a tie candidate.  Returns pass / fail.
+BRISK_HD bool brisk_tie_eval(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
+                             int cy, const uint16_t* sm_local, int lx0, int ly0, int lw) {
+  const int centre = BRISK_SM_D(sm_local[(cy - ly0) * lw + (cx - lx0)]);
+  int s[8];
+  for (int k = 0; k < 8; ++k) {
+    const int nx = cx + brisk_probe_dx(k), ny = cy + brisk_probe_dy(k);
+    const int m = brisk_state_at(L, float_patch, pass_touch2x2, nx, ny, cx, cy, false, sm_local, lx0, ly0, lw);
+    if (m > 2) {
+      s[k] = m;
+    } else if (brisk_border3(L, nx, ny)) {
+      s[k] = 0;
+    } else {
+      const int K = brisk_Kp(L, nx, ny);
+      s[k] = (K >= centre) ? K : 0;
+    }
+  }
+  // s: W,E,N,S,SW,SE,NE,NW
+  const int smoothedcenter = 4 * centre + 2 * (s[0] + s[1] + s[2] + s[3]) + s[7] + s[6] + s[4] + s[5];
+  // tie list order: (-1,-1),(0,-1),(1,-1),(-1,0),(1,0),(-1,1),(0,1),(1,1)
+  const int order[8] = {7, 2, 6, 0, 1, 4, 3, 5};
+  for (int o = 0; o < 8; ++o) {
+    const int k = order[o];
+    if (s[k] != centre) continue;
+    const int nx = cx + brisk_probe_dx(k), ny = cy + brisk_probe_dy(k);
+    int other = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int wgt = (dx == 0 ? 2 : 1) * (dy == 0 ? 2 : 1);
+        const int qx = nx + dx, qy = ny + dy;
+        int m;
+        if (qx == cx && qy == cy) m = centre;
+        else m = brisk_state_at(L, float_patch, pass_touch2x2, qx, qy, cx, cy, true, sm_local, lx0, ly0, lw);
+        other += wgt * m;
+      }
+    if (other > smoothedcenter) return false;
+  }
+  return true;
+}

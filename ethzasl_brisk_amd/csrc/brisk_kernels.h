@@ -1,0 +1,48 @@
+// brisk_kernels.h - host-visible launch interface of brisk_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "brisk_common.h"
+
+#define BRISK_DETECT_TILE_W 64
+#define BRISK_DETECT_TILE_H 16
+
+struct BriskTileTable {
+  int first_tile[BRISK_MAX_LAYERS + 1];
+  int tiles_x[BRISK_MAX_LAYERS];
+  int total_tiles;
+};
+
+// per-batch device buffers of the detector (arrays over frame slots)
+struct BriskDetectBuffers {
+  uint8_t* pyr;                  // [slots][pyr_elems]
+  uint16_t* smap;                // [slots][pyr_elems]
+  BriskCand* cand;               // [slots][cand_cap]
+  int* tie_idx;                  // [slots][BRISK_MAX_LAYERS][tie_cap]
+  unsigned* keys;                // [slots][2 * cand_cap]
+  BriskFrameCounters* counters;  // [slots]
+  BriskKeyPoint* kp_out;         // [slots][kp_cap]
+  int cand_cap, tie_cap, kp_cap;
+};
+
+struct BriskDescribeBuffers {
+  uint32_t* integral;  // [slots][iframe_elems]
+  int istride;         // integral row stride (elements)
+  long iframe_elems;
+  BriskKeyPoint* dkp;  // [slots][kp_cap] filtered keypoints (angle filled in)
+  int* dscale;         // [slots][kp_cap]
+  uint8_t* desc;       // [slots][kp_cap][desc_pitch]
+  int desc_pitch;
+};
+
+// frames: u8 images, frame f at frames + f*frame_pitch, row pitch row_pitch (device memory)
+void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
+                         const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
+                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s);
+// only stages layer 0 (descriptor-only calls)
+void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
+                              long frame_pitch, int row_pitch, hipStream_t s);
+// kp_in: [slots][kp_cap]; n_in: per-frame counts at byte stride n_in_stride
+void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
+                           const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
+                           long n_in_stride, hipStream_t s);

@@ -1,0 +1,579 @@
+// brisk_kernels.hip - hand-written HIP kernels (gfx950 / CDNA4) of the BRISK detect+describe engine.
+//
+// Kernel inventory (one launch handles a whole batch of frames; blockIdx.y = frame):
+//   k_pyramid_level   halfsample / twothirdsample of one pyramid level pair     (HBM-bound)
+//   k_detect          threshold map + adaptive OAST 9_16 test, LDS-tiled        (dominant kernel)
+//   k_classify_refine IsMax2D steps 1-2 + 3-D refinement per candidate          (sparse)
+//   k_tie_resolve     order-faithful replay of the lazy score cache for ties    (sparse, 1 WG/frame)
+//   k_finalize        (layer, y, x) ordering + keypoint output                  (sparse)
+//   k_integral_rows / k_integral_cols   exclusive 2-D prefix sum (u32)          (HBM-bound)
+//   k_desc_prepare    scale index + border filter + stable compaction           (sparse)
+//   k_describe        pattern sampling, orientation, 384/512 bit tests          (gather-bound)
+// No MFMA: the path is byte/integer stencil + gather work.
+#include <hip/hip_runtime.h>
+
+#include "brisk_common.h"
+#include "brisk_device_describe.h"
+#include "brisk_device_detect.h"
+#include "brisk_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ BriskLayerView make_view(const BriskGeom& G, uint8_t* pyr, uint16_t* smap, int frame,
+                                                    int l) {
+  BriskLayerView v;
+  const long base = (long)frame * G.pyr_elems + G.L[l].off;
+  v.img = pyr + base;
+  v.smap = smap + base;
+  v.w = G.L[l].w;
+  v.h = G.L[l].h;
+  v.stride = G.L[l].stride;
+  return v;
+}
+
+// 16-bit field update inside the u32 word that holds it
+__device__ __forceinline__ void smap_or(uint16_t* smap, long idx, unsigned bits) {
+  unsigned* w = reinterpret_cast<unsigned*>(smap + (idx & ~1L));
+  atomicOr(w, bits << ((idx & 1) ? 16 : 0));
+}
+__device__ __forceinline__ void smap_xor(uint16_t* smap, long idx, unsigned bits) {
+  unsigned* w = reinterpret_cast<unsigned*>(smap + (idx & ~1L));
+  atomicXor(w, bits << ((idx & 1) ? 16 : 0));
+}
+// L1-bypassing read (other waves of this launch update smap with atomics)
+__device__ __forceinline__ unsigned smap_load_fresh(const uint16_t* smap, long idx) {
+  const unsigned* w = reinterpret_cast<const unsigned*>(smap + (idx & ~1L));
+  const unsigned v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (idx & 1) ? (v >> 16) : (v & 0xFFFFu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_copy_layer0: frame (arbitrary stride) -> pyramid layer 0 (aligned stride).  4 px / thread.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_copy_layer0(BriskGeom G, const uint8_t* __restrict__ frames,
+                                                      long frame_pitch, int row_pitch, uint8_t* __restrict__ pyr) {
+  const int frame = blockIdx.y;
+  const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
+  const uint8_t* src = frames + (long)frame * frame_pitch;
+  uint8_t* dst = pyr + (long)frame * G.pyr_elems + G.L[0].off;
+  const int words = stride / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)words * h; i += (long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / words), x = (int)(i % words) * 4;
+    unsigned v = 0;
+    if (x + 3 < w && ((row_pitch | (uintptr_t)src) & 3) == 0) {
+      v = *reinterpret_cast<const unsigned*>(src + (long)y * row_pitch + x);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (x + k < w) v |= (unsigned)src[(long)y * row_pitch + x + k] << (8 * k);
+    }
+    *reinterpret_cast<unsigned*>(dst + (long)y * stride + x) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pyramid_level: builds destination layer `dl` from source layer `sl` (mode 0 half, 1 two-third).
+// One thread produces 4 horizontally adjacent output pixels (one dword store).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pyramid_level(BriskGeom G, uint8_t* __restrict__ pyr, int sl, int dl,
+                                                        int mode) {
+  const int frame = blockIdx.y;
+  const uint8_t* src = pyr + (long)frame * G.pyr_elems + G.L[sl].off;
+  uint8_t* dst = pyr + (long)frame * G.pyr_elems + G.L[dl].off;
+  const int sw = G.L[sl].w, sstride = G.L[sl].stride;
+  const int dw = G.L[dl].w, dh = G.L[dl].h, dstride = G.L[dl].stride;
+  const int words = dstride / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)words * dh; i += (long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / words), x = (int)(i % words) * 4;
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (x + k < dw) {
+        const unsigned px = mode ? brisk_twothird_px(src, sstride, sw, x + k, y) : brisk_half_px(src, sstride, sw, x + k, y);
+        v |= px << (8 * k);
+      }
+    }
+    *reinterpret_cast<unsigned*>(dst + (long)y * dstride + x) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_detect: per-pixel threshold map (37-px disc contrast) + contrast-adaptive OAST 9_16 segment test.
+// Tile of 64x16 output pixels, (64+8)x(16+6) u8 halo tile staged in LDS with coalesced dword loads;
+// each thread evaluates 4 adjacent pixels and emits one 8-byte smap store.  Detections are appended
+// to the frame's candidate list (order is restored later from the (layer,y,x) key).
+// grid.x enumerates tiles of all layers (tile table in G via prefix), grid.y = frame.
+// ------------------------------------------------------------------------------------------------
+#define DT_W 64
+#define DT_H 16
+#define DT_LW (DT_W + 8)
+#define DT_LH (DT_H + 6)
+
+__global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, const uint8_t* __restrict__ pyr,
+                                                 uint16_t* __restrict__ smap, BriskCand* __restrict__ cand,
+                                                 BriskFrameCounters* __restrict__ counters, int cand_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[DT_LH * DT_LW];
+  const int frame = blockIdx.y;
+  // locate the layer of this tile
+  int l = 0;
+  while (l + 1 < G.nlayers && (int)blockIdx.x >= T.first_tile[l + 1]) ++l;
+  const int t = blockIdx.x - T.first_tile[l];
+  const int tx = t % T.tiles_x[l], ty = t / T.tiles_x[l];
+  const int w = G.L[l].w, h = G.L[l].h, stride = G.L[l].stride;
+  const long base = (long)frame * G.pyr_elems + G.L[l].off;
+  const uint8_t* img = pyr + base;
+  const int x0 = tx * DT_W, y0 = ty * DT_H;
+
+  // stage halo tile: rows y0-3 .. y0+DT_H+2, columns x0-4 .. x0+DT_W+3 (dword granularity)
+  for (int i = threadIdx.x; i < DT_LH * (DT_LW / 4); i += 256) {
+    const int r = i / (DT_LW / 4), c4 = i % (DT_LW / 4);
+    const int gy = y0 - 3 + r, gx = x0 - 4 + c4 * 4;
+    unsigned v = 0;
+    if (gy >= 0 && gy < h && gx >= 0 && gx < stride) v = *reinterpret_cast<const unsigned*>(img + (long)gy * stride + gx);
+    *reinterpret_cast<unsigned*>(&tile[r * DT_LW + c4 * 4]) = v;
+  }
+  __syncthreads();
+
+  const int lx = (threadIdx.x & 15) * 4, ly = threadIdx.x >> 4;
+  const int gy = y0 + ly;
+  if (gy >= h) return;
+  unsigned short out[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int gx = x0 + lx + k;
+    int D = 0;
+    if (gx >= 3 && gx <= w - 4 && gy >= 3 && gy <= h - 4)
+      D = brisk_detect_px(&tile[(ly + 3) * DT_LW + lx + k + 4], DT_LW, G.threshold);
+    out[k] = (unsigned short)D;
+    if (D) {
+      const int idx = atomicAdd(&counters[frame].ncand, 1);
+      if (idx < cand_cap) {
+        BriskCand c;
+        c.x = (uint16_t)gx; c.y = (uint16_t)gy; c.layer = (uint8_t)l; c.D = (uint8_t)D;
+        c.status = 0; c.flags = 0; c.fp_x0 = 0; c.fp_y0 = 0; c.fp_mask = 0; c.pad = 0;
+        c.kx = c.ky = c.ksize = c.kresp = 0.f;
+        c.key = ((unsigned)l << 26) | ((unsigned)gy << 13) | (unsigned)gx;
+        cand[(long)frame * cand_cap + idx] = c;
+      } else {
+        atomicOr(&counters[frame].overflow, 1);
+      }
+    }
+  }
+  if (x0 + lx < stride) {
+    uint2 o;
+    o.x = (unsigned)out[0] | ((unsigned)out[1] << 16);
+    o.y = (unsigned)out[2] | ((unsigned)out[3] << 16);
+    *reinterpret_cast<uint2*>(smap + base + (long)gy * stride + x0 + lx) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_classify_refine: one thread per candidate.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_classify_refine(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
+                                                          BriskFrameCounters* counters, int* tie_idx, int cand_cap,
+                                                          int tie_cap) {
+  const int frame = blockIdx.y;
+  const int n = min(counters[frame].ncand, cand_cap);
+  BriskLayerView Lv[BRISK_MAX_LAYERS];
+  for (int l = 0; l < G.nlayers; ++l) Lv[l] = make_view(G, pyr, smap, frame, l);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    BriskCand* c = &cand[(long)frame * cand_cap + i];
+    const int l = c->layer, x = c->x, y = c->y, D = c->D;
+    int nprobed;
+    const unsigned status = brisk_classify(Lv[l], x, y, D, &nprobed);
+    unsigned bits = ((unsigned)nprobed << 8) | (status << 12);
+    unsigned flags = 0;
+    if (status != BRISK_ST_REJ) {
+      BriskKeyPoint kp;
+      bool e5;
+      BriskTouch touch;
+      touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
+      const bool ok = brisk_refine(G, Lv, l, x, y, &kp, &e5, &touch);
+      if (ok) {
+        flags |= 1;
+        c->kx = kp.x; c->ky = kp.y; c->ksize = kp.size; c->kresp = kp.response;
+      }
+      if (e5) { flags |= 2; bits |= BRISK_SM_E5; }
+      c->fp_x0 = (int16_t)touch.x0; c->fp_y0 = (int16_t)touch.y0; c->fp_mask = (uint16_t)touch.mask;
+      if (status == BRISK_ST_PASS && touch.mask) {  // event e3: score-touch the layer above
+        const BriskLayerView& La = Lv[l + 1];
+        for (int b = 0; b < 16; ++b)
+          if (touch.mask & (1u << b)) smap_or(La.smap, (long)(touch.y0 + (b >> 2)) * La.stride + touch.x0 + (b & 3), BRISK_SM_TOUCH);
+      }
+      if (status == BRISK_ST_TIE) {
+        const int j = atomicAdd(&counters[frame].ntie[l], 1);
+        if (j < tie_cap) tie_idx[((long)frame * BRISK_MAX_LAYERS + l) * tie_cap + j] = i;
+        else atomicOr(&counters[frame].overflow, 2);
+      }
+    }
+    c->status = (uint8_t)status;
+    c->flags = (uint8_t)flags;
+    smap_or(Lv[l].smap, (long)y * Lv[l].stride + x, bits);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tie_resolve: one workgroup per frame; layers in ascending order (layer i+1 needs the e3 touches
+// of layer i's resolved ties); inside a layer a Jacobi-style relaxation: a tie candidate is decided
+// once every raster-earlier tie candidate within Chebyshev distance 4 is decided.
+// ------------------------------------------------------------------------------------------------
+#define TR_THREADS 256
+#define TR_WIN 9
+__global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
+                                                             BriskFrameCounters* counters, const int* tie_idx,
+                                                             int cand_cap, int tie_cap) {
+  __shared__ uint16_t win[TR_THREADS][TR_WIN * TR_WIN + 1];
+  __shared__ int remaining, progressed;
+  const int frame = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int l = 0; l < G.nlayers; ++l) {
+    const int n = min(counters[frame].ntie[l], tie_cap);
+    if (n == 0) continue;
+    const BriskLayerView L = make_view(G, pyr, smap, frame, l);
+    const bool last = (l == G.nlayers - 1);
+    const bool float_patch = last || G.single_layer;
+    const bool touch2x2 = last && !G.single_layer;
+    const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
+    for (int iter = 0; iter < 4096; ++iter) {
+      if (tid == 0) { remaining = 0; progressed = 0; }
+      __syncthreads();
+      for (int j = tid; j < n; j += TR_THREADS) {
+        BriskCand* c = &cand[(long)frame * cand_cap + list[j]];
+        if (c->status != BRISK_ST_TIE) continue;
+        const int cx = c->x, cy = c->y;
+        uint16_t* wl = win[tid];
+        bool ready = true;
+        for (int dy = -4; dy <= 4; ++dy)
+          for (int dx = -4; dx <= 4; ++dx) {
+            const int qx = cx + dx, qy = cy + dy;
+            unsigned v = 0;
+            if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
+            wl[(dy + 4) * TR_WIN + dx + 4] = (uint16_t)v;
+            if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) ready = false;
+          }
+        if (!ready) { atomicAdd(&remaining, 1); continue; }
+        const bool pass = brisk_tie_eval(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, TR_WIN);
+        if (pass) {
+          if (c->fp_mask && l + 1 < G.nlayers) {
+            const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
+            for (int b = 0; b < 16; ++b)
+              if (c->fp_mask & (1u << b))
+                smap_or(La.smap, (long)(c->fp_y0 + (b >> 2)) * La.stride + c->fp_x0 + (b & 3), BRISK_SM_TOUCH);
+          }
+          c->status = BRISK_ST_PASS;
+          smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
+        } else {
+          c->status = BRISK_ST_FAIL;
+          smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);   // TIE (10b) -> FAIL (11b)
+        }
+        atomicAdd(&progressed, 1);
+      }
+      __threadfence();
+      __syncthreads();
+      const int rem = remaining, prog = progressed;
+      __syncthreads();
+      if (rem == 0 || prog == 0) break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finalize: keypoints of a frame in (layer, y, x) order.  One workgroup per frame; ranks by
+// counting smaller keys among the valid candidates (a few thousand at most).
+// ------------------------------------------------------------------------------------------------
+#define FN_THREADS 256
+__global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
+                                                          unsigned* keys_scratch, BriskKeyPoint* kp_out, int cand_cap,
+                                                          int kp_cap, const uint8_t* mask, long mask_pitch_frame,
+                                                          int mask_row_pitch) {
+  __shared__ int nvalid;
+  __shared__ unsigned tilek[FN_THREADS];
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  const int n = min(counters[frame].ncand, cand_cap);
+  const BriskCand* C = cand + (long)frame * cand_cap;
+  unsigned* keys = keys_scratch + (long)frame * cand_cap * 2;  // [key][cand index]
+  if (tid == 0) nvalid = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += FN_THREADS) {
+    const BriskCand& c = C[i];
+    bool valid = (c.status == BRISK_ST_PASS) && (c.flags & 1);
+    if (valid && mask) {  // RemoveInvalidKeyPoints (brisk-feature-detector.cc:49-66)
+      const uint8_t* m = mask + (long)frame * mask_pitch_frame;
+      valid = m[(long)(int)(c.ky + 0.5f) * mask_row_pitch + (int)(c.kx + 0.5f)] != 0;
+    }
+    if (valid) {
+      const int j = atomicAdd(&nvalid, 1);
+      keys[2 * j] = c.key;
+      keys[2 * j + 1] = (unsigned)i;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int nv = nvalid;
+  for (int j0 = 0; j0 < nv; j0 += FN_THREADS) {
+    const int j = j0 + tid;
+    const unsigned myk = (j < nv) ? keys[2 * j] : 0xFFFFFFFFu;
+    int rank = 0;
+    for (int t0 = 0; t0 < nv; t0 += FN_THREADS) {
+      __syncthreads();
+      tilek[tid] = (t0 + tid < nv) ? keys[2 * (t0 + tid)] : 0xFFFFFFFFu;
+      __syncthreads();
+      const int m = min(FN_THREADS, nv - t0);
+      for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
+    }
+    if (j < nv) {
+      if (rank < kp_cap) {
+        const BriskCand& c = C[keys[2 * j + 1]];
+        BriskKeyPoint kp;
+        kp.x = c.kx; kp.y = c.ky; kp.size = c.ksize; kp.angle = -1.0f; kp.response = c.kresp;
+        kp.octave = G.single_layer ? 0 : c.layer; kp.class_id = -1;
+        kp_out[(long)frame * kp_cap + rank] = kp;
+      }
+    }
+  }
+  if (tid == 0) {
+    counters[frame].nkp = min(nv, kp_cap);
+    if (nv > kp_cap) atomicOr(&counters[frame].overflow, 4);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Integral image (brisk/include/brisk/internal/integral-image.h:56-161): exclusive prefix sums, u32.
+// Pass 1: horizontal prefix per row (one wave per row segment chain); pass 2: vertical prefix per column.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_integral_rows(BriskGeom G, const uint8_t* __restrict__ pyr,
+                                                        uint32_t* __restrict__ integral, int istride, long iframe_elems) {
+  // one workgroup per row; 256 threads x 16 px = 4096 columns per pass
+  __shared__ unsigned partial[256];
+  const int frame = blockIdx.y, y = blockIdx.x;
+  const int w = G.L[0].w, stride = G.L[0].stride;
+  const uint8_t* row = pyr + (long)frame * G.pyr_elems + G.L[0].off + (long)y * stride;
+  uint32_t* out = integral + (long)frame * iframe_elems + (long)(y + 1) * istride;
+  unsigned carry = 0;
+  if (threadIdx.x == 0) out[0] = 0;
+  for (int x0 = 0; x0 < w; x0 += 4096) {
+    const int xb = x0 + threadIdx.x * 16;
+    unsigned v[16];
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      unsigned wd = 0;
+      if (xb + k < stride) wd = *reinterpret_cast<const unsigned*>(row + xb + k);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned px = (xb + k + b < w) ? ((wd >> (8 * b)) & 0xFF) : 0;
+        s += px;
+        v[k + b] = s;
+      }
+    }
+    partial[threadIdx.x] = s;
+    __syncthreads();
+    // inclusive scan of the 256 segment totals (Hillis-Steele in LDS)
+    for (int off = 1; off < 256; off <<= 1) {
+      unsigned add = (threadIdx.x >= off) ? partial[threadIdx.x - off] : 0;
+      __syncthreads();
+      partial[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const unsigned before = carry + (threadIdx.x ? partial[threadIdx.x - 1] : 0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (xb + k < w) out[xb + k + 1] = before + v[k];
+    carry += partial[255];
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_integral_cols(BriskGeom G, uint32_t* __restrict__ integral, int istride,
+                                                        long iframe_elems) {
+  const int frame = blockIdx.y;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = G.L[0].w, h = G.L[0].h;
+  if (x > w) return;
+  uint32_t* col = integral + (long)frame * iframe_elems + x;
+  unsigned s = 0;
+  col[0] = 0;
+  for (int y = 1; y <= h; ++y) {
+    s += col[(long)y * istride];
+    col[(long)y * istride] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_desc_prepare: per frame, scale index + border filter (brisk-descriptor-extractor.cc:636-662),
+// stable compaction into dkp (keypoints) / dscale.  One workgroup per frame.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
+                                                       const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
+                                                       BriskKeyPoint* dkp, int* dscale, int kp_cap) {
+  __shared__ int scan[256];
+  __shared__ int base;
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
+  const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    int keep = 0, sc = 0;
+    BriskKeyPoint kp;
+    if (i < n) {
+      kp = K[i];
+      sc = brisk_scale_index(P, kp.size);
+      keep = brisk_inside_border(P, sc, kp.x, kp.y, G.L[0].w, G.L[0].h) ? 1 : 0;
+    }
+    scan[tid] = keep;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      int add = (tid >= off) ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    if (keep) {
+      const int j = base + scan[tid] - 1;
+      dkp[(long)frame * kp_cap + j] = kp;
+      dscale[(long)frame * kp_cap + j] = sc;
+    }
+    __syncthreads();
+    if (tid == 0) base += scan[255];
+    __syncthreads();
+  }
+  if (tid == 0) counters[frame].ndesc = base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_describe: one 128-thread workgroup per keypoint (grid-stride over the frame's keypoints).
+// Lane i < npoints samples pattern point i; long pairs are reduced with integer wave reductions
+// (order independent); the short-pair bits are packed with 64-wide ballots.
+// ------------------------------------------------------------------------------------------------
+#define DS_THREADS 128
+__global__ void __launch_bounds__(DS_THREADS) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
+                                                          const uint32_t* __restrict__ integral, int istride,
+                                                          long iframe_elems, const BriskFrameCounters* counters,
+                                                          BriskKeyPoint* dkp, const int* dscale, uint8_t* desc, int kp_cap,
+                                                          int desc_pitch) {
+  __shared__ int values[BRISK_MAX_POINTS];
+  __shared__ int red[2][DS_THREADS / 64];
+  __shared__ int theta_s;
+  const int frame = blockIdx.y, tid = threadIdx.x;
+  const int n = counters[frame].ndesc;
+  const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
+  const int stride = G.L[0].stride;
+  const uint32_t* integ = integral + (long)frame * iframe_elems;
+  for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    BriskKeyPoint* kp = &dkp[(long)frame * kp_cap + k];
+    const int scale = dscale[(long)frame * kp_cap + k];
+    const float kx = kp->x, ky = kp->y, kangle = kp->angle;
+    int theta = 0;
+    if (P.rotation_invariant) {
+      if (kangle == -1.0f) {
+        for (int i = tid; i < P.npoints; i += DS_THREADS) {
+          float bx, by, sg;
+          brisk_pattern_point(P, scale, 0, i, &bx, &by, &sg);
+          values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, bx, by, sg);
+        }
+        __syncthreads();
+        int d0 = 0, d1 = 0;
+        for (int p = tid; p < P.nlong; p += DS_THREADS) {
+          int a, b;
+          brisk_long_pair(values, P.long_pairs + 4 * p, &a, &b);
+          d0 += a;
+          d1 += b;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          d0 += __shfl_down(d0, off, 64);
+          d1 += __shfl_down(d1, off, 64);
+        }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = d0; red[1][tid >> 6] = d1; }
+        __syncthreads();
+        if (tid == 0) {
+          int s0 = 0, s1 = 0;
+          for (int q = 0; q < DS_THREADS / 64; ++q) { s0 += red[0][q]; s1 += red[1][q]; }
+          const float ang = brisk_angle_from_direction(s0, s1);
+          kp->angle = ang;
+          theta_s = brisk_theta_from_angle(ang, true);
+        }
+        __syncthreads();
+        theta = theta_s;
+      } else {
+        theta = brisk_theta_from_angle(kangle, false);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < P.npoints; i += DS_THREADS) {
+      float bx, by, sg;
+      brisk_pattern_point(P, scale, theta, i, &bx, &by, &sg);
+      values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, bx, by, sg);
+    }
+    __syncthreads();
+    // bit p = values[i] > values[j], LSB first in little-endian u32 words (:538-564)
+    uint8_t* drow = desc + ((long)frame * kp_cap + k) * desc_pitch;
+    const int nbits = P.strings * 8;
+    for (int p0 = 0; p0 < nbits; p0 += DS_THREADS) {
+      const int p = p0 + tid;
+      bool bit = false;
+      if (p < P.nshort) bit = values[P.short_pairs[2 * p]] > values[P.short_pairs[2 * p + 1]];
+      const unsigned long long m = __ballot(bit);
+      if ((tid & 63) == 0 && p < nbits) *reinterpret_cast<unsigned long long*>(drow + p / 8) = m;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (called from the C ABI implementation)
+// ------------------------------------------------------------------------------------------------
+static inline int grid_for(long items, int per_block, int cap) {
+  long b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
+                         const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
+                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s) {
+  hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
+  {
+    const long items = (long)(G.L[0].stride / 4) * G.L[0].h;
+    hipLaunchKernelGGL(k_copy_layer0, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, frames, frame_pitch,
+                       row_pitch, B.pyr);
+  }
+  for (int l = 1; l < G.nlayers; ++l) {
+    const int sl = (l == 1) ? 0 : l - 2;
+    const long items = (long)(G.L[l].stride / 4) * G.L[l].h;
+    hipLaunchKernelGGL(k_pyramid_level, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, B.pyr, sl, l,
+                       (l == 1) ? 1 : 0);
+  }
+  hipLaunchKernelGGL(k_detect, dim3(T.total_tiles, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,
+                     B.cand_cap);
+  hipLaunchKernelGGL(k_classify_refine, dim3(grid_for(B.cand_cap, 128, 64), nframes), dim3(128), 0, s, G, B.pyr, B.smap,
+                     B.cand, B.counters, B.tie_idx, B.cand_cap, B.tie_cap);
+  hipLaunchKernelGGL(k_tie_resolve, dim3(nframes), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
+                     B.cand_cap, B.tie_cap);
+  hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,
+                     B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);
+}
+
+void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
+                              long frame_pitch, int row_pitch, hipStream_t s) {
+  const long items = (long)(G.L[0].stride / 4) * G.L[0].h;
+  hipLaunchKernelGGL(k_copy_layer0, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, frames, frame_pitch,
+                     row_pitch, B.pyr);
+}
+
+void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
+                           const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
+                           long n_in_stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_integral_rows, dim3(G.L[0].h, nframes), dim3(256), 0, s, G, B.pyr, Dd.integral, Dd.istride,
+                     Dd.iframe_elems);
+  hipLaunchKernelGGL(k_integral_cols, dim3((G.L[0].w + 1 + 255) / 256, nframes), dim3(256), 0, s, G, Dd.integral,
+                     Dd.istride, Dd.iframe_elems);
+  hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
+                     Dd.dscale, B.kp_cap);
+  hipLaunchKernelGGL(k_describe, dim3(grid_for(B.kp_cap, 1, 1024), nframes), dim3(DS_THREADS), 0, s, G, P, B.pyr,
+                     Dd.integral, Dd.istride, Dd.iframe_elems, B.counters, Dd.dkp, Dd.dscale, Dd.desc, B.kp_cap,
+                     Dd.desc_pitch);
+}

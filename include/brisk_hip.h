@@ -1,0 +1,110 @@
+/*
+ * brisk_hip.h - C ABI of the MI355X-native BRISK detect+describe engine (libbrisk_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  The two host classes
+ * brisk::BriskFeatureDetector / brisk::BriskDescriptorExtractor (include/brisk/, mirroring the
+ * reference headers) are thin wrappers over these entry points, and a maintainer of the reference
+ * would bind exactly these from brisk-feature-detector.cc / brisk-descriptor-extractor.cc
+ * (see INTEGRATION.md).  Reference paths below are relative to the ethzasl_brisk tree.
+ *
+ * All functions return BRISK_HIP_OK (0) or an error code; brisk_hip_last_error() gives the text.
+ * There is no CPU fallback: without a HIP device every compute entry point fails with
+ * BRISK_HIP_ERR_NO_DEVICE.
+ */
+#ifndef BRISK_HIP_H_
+#define BRISK_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  BRISK_HIP_OK = 0,
+  BRISK_HIP_ERR_ARG = 1,        /* null pointer / non-positive size / bad enum */
+  BRISK_HIP_ERR_NO_DEVICE = 2,  /* no usable HIP device */
+  BRISK_HIP_ERR_HIP = 3,        /* a HIP runtime call failed */
+  BRISK_HIP_ERR_CAPACITY = 4,   /* more candidates / keypoints than the configured capacity */
+  BRISK_HIP_ERR_THRESHOLD = 5,  /* AGAST threshold outside [20, 255] (deviations) */
+  BRISK_HIP_ERR_PATTERN = 6,    /* malformed pattern (reference: CHECK_EQ(noShortPairs_, 384), :286) */
+  BRISK_HIP_ERR_UNSUPPORTED = 7 /* mode not implemented on the device path */
+};
+
+/* Binary-identical to cv::KeyPoint {Point2f pt; float size, angle, response; int octave, class_id;} */
+typedef struct brisk_hip_keypoint {
+  float x, y, size, angle, response;
+  int octave, class_id;
+} brisk_hip_keypoint;
+
+typedef struct brisk_hip_ctx brisk_hip_ctx;          /* device workspace + stream          */
+typedef struct brisk_hip_pattern brisk_hip_pattern;  /* sampling pattern tables (extractor) */
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* device: HIP device ordinal.  Buffers are sized lazily for the largest (w, h, octaves, batch) seen. */
+int brisk_hip_create(int device, brisk_hip_ctx** out);
+void brisk_hip_destroy(brisk_hip_ctx* ctx);
+const char* brisk_hip_last_error(const brisk_hip_ctx* ctx);
+/* per-frame capacities: AGAST candidates (default 65536) and keypoints (default 16384) */
+int brisk_hip_set_capacity(brisk_hip_ctx* ctx, int max_candidates, int max_keypoints);
+int brisk_hip_device_count(void);
+
+/* ---- pattern: replaces the BriskDescriptorExtractor constructors ---------------------------- */
+/* brisk-descriptor-extractor.cc:293-343: version 2 = built-in 66-point pattern (InitFromStream :180-291),
+ * version 1 = generated 60-point BRISK 1.0 kernel (generateKernel :65-178, 512 bits). */
+int brisk_hip_pattern_create(brisk_hip_ctx* ctx, int version, float pattern_scale, brisk_hip_pattern** out);
+/* :345-367: pattern file contents (.ptn syntax: N, N x {x y sigma}, S, S x {i j}, L, L x {i j}) */
+int brisk_hip_pattern_create_from_text(brisk_hip_ctx* ctx, const char* ptn_text, float pattern_scale,
+                                       brisk_hip_pattern** out);
+void brisk_hip_pattern_destroy(brisk_hip_pattern* p);
+int brisk_hip_pattern_descriptor_size(const brisk_hip_pattern* p); /* descriptorSize() :780-782 (48 / 64) */
+int brisk_hip_pattern_points(const brisk_hip_pattern* p);
+/* host copies of the derived tables, for inspection / tests: 64 entries each */
+int brisk_hip_pattern_tables(const brisk_hip_pattern* p, float* scale_list, int* size_list, float* size_thresh);
+
+/* ---- host-buffer calls: what the two host classes forward to --------------------------------- */
+/* BriskFeatureDetector::detectImpl (brisk-feature-detector.cc:77-85): clears/overwrites `out`.
+ * img: h x w u8, row pitch `stride` bytes.  mask: optional h x w u8 (0 = drop keypoint), or NULL.
+ * suppress_scale_nonmaxima must be 1 (the only mode the reference's detector default uses).
+ * out: capacity `cap` keypoints; *n receives the count (BRISK_HIP_ERR_CAPACITY if cap is too small). */
+int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                     int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, brisk_hip_keypoint* out,
+                     int cap, int* n);
+/* BriskDescriptorExtractor::compute (brisk-descriptor-extractor.cc:612-778): filters `kps` in place
+ * (border test), fills kps[i].angle, writes *n rows of descriptorSize() bytes at pitch desc_stride. */
+int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
+                       brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
+                       int scale_invariant);
+
+/* ---- device-resident batch path (frames already in HBM; results stay in HBM) ----------------- */
+/* d_frames: nframes images, frame f at d_frames + f*frame_pitch, row pitch row_pitch.  Runs
+ * detect (threshold, octaves) then describe (pat) for every frame on `stream` (hipStream_t, may be
+ * NULL = the context's stream).  Asynchronous: synchronise the stream before reading results. */
+int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames,
+                                    int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
+                                    int octaves, void* stream);
+/* detect only / describe only variants of the batch path (roofline + stage timing) */
+int brisk_hip_detect_batch(brisk_hip_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, long frame_pitch,
+                           int row_pitch, int threshold, int octaves, void* stream);
+/* Device pointers of the last batch's results.  d_counts: per frame {detected, described} at
+ * byte stride *count_stride (ints); keypoints [frame][kp_cap]; descriptors [frame][kp_cap][desc_pitch]. */
+int brisk_hip_batch_results(brisk_hip_ctx* ctx, const int** d_detected, const int** d_described, int* count_stride,
+                            const brisk_hip_keypoint** d_detected_kps, const brisk_hip_keypoint** d_described_kps,
+                            const uint8_t** d_desc, int* kp_cap, int* desc_pitch);
+/* Copies one frame's results of the last batch to the host (synchronises). kps/desc may be NULL. */
+int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which /*0 detected, 1 described*/,
+                             brisk_hip_keypoint* kps, int cap, int* n, uint8_t* desc, int desc_stride);
+/* error / overflow flags of the last batch, OR-ed over frames (0 = clean); synchronises */
+int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags);
+
+/* ---- per-stage device entry points (parity tests of individual kernels) ---------------------- */
+/* which: 0 pyramid image, 1 score-state map low byte (D), after the last detect on frame slot 0.
+ * Copies layer `layer` (w x h, tightly packed u8) to the host buffer. */
+int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, uint8_t* out, int* w, int* h);
+/* integral image of frame slot `frame` after the last describe: (h+1) x (w+1) u32, tightly packed */
+int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRISK_HIP_H_ */

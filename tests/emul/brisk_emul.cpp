@@ -1,0 +1,326 @@
+// brisk_emul.cpp - TEST-ONLY host emulation of the HIP kernels' control flow.
+//
+// Runs the very same __host__ __device__ per-item functions the kernels use
+// (ethzasl_brisk_amd/csrc/brisk_device_{detect,describe}.h) in plain loops that mirror the kernels
+// in brisk_kernels.hip, so the order-faithful NMS logic, the float semantics and the pattern tables
+// can be checked against the oracle in a container without a GPU.  It is never linked into or loaded
+// by the product library; it is not a CPU fallback.
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../ethzasl_brisk_amd/csrc/brisk_common.h"
+#include "../../ethzasl_brisk_amd/csrc/brisk_device_describe.h"
+#include "../../ethzasl_brisk_amd/csrc/brisk_device_detect.h"
+#include "../../ethzasl_brisk_amd/csrc/brisk_pattern.h"
+
+namespace {
+
+void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G) {  // == brisk_capi.hip
+  memset(G, 0, sizeof(*G));
+  G->nlayers = (octaves == 0) ? 1 : 2 * octaves;
+  G->single_layer = (octaves == 0);
+  G->w = w; G->h = h; G->threshold = threshold;
+  int off = 0;
+  for (int l = 0; l < G->nlayers; ++l) {
+    BriskLayerGeom& L = G->L[l];
+    if (l == 0) { L.w = w; L.h = h; L.scale = 1.0f; L.offset = 0.0f; }
+    else if (l == 1) {
+      L.w = 2 * (G->L[0].w / 3); L.h = 2 * (G->L[0].h / 3);
+      L.scale = (float)(G->L[0].scale * 1.5); L.offset = (float)(0.5 * L.scale - 0.5);
+    } else {
+      L.w = G->L[l - 2].w / 2; L.h = G->L[l - 2].h / 2;
+      L.scale = G->L[l - 2].scale * 2; L.offset = (float)(0.5 * L.scale - 0.5);
+    }
+    L.stride = brisk_align_up(L.w > 0 ? L.w : 1, BRISK_STRIDE_ALIGN);
+    L.off = off;
+    off += brisk_align_up(L.stride * (L.h > 0 ? L.h : 1), 256);
+  }
+  G->pyr_elems = off;
+}
+
+struct Emul {
+  BriskGeom G;
+  std::vector<uint8_t> pyr;
+  std::vector<uint16_t> smap;
+  std::vector<BriskCand> cand;
+  std::vector<int> ties[BRISK_MAX_LAYERS];
+  std::vector<BriskKeyPoint> kps;
+  int relax_iters = 0, max_chain = 0;
+};
+
+BriskLayerView view(Emul& E, int l) {
+  BriskLayerView v;
+  v.img = E.pyr.data() + E.G.L[l].off;
+  v.smap = E.smap.data() + E.G.L[l].off;
+  v.w = E.G.L[l].w; v.h = E.G.L[l].h; v.stride = E.G.L[l].stride;
+  return v;
+}
+
+void touch_apply(Emul& E, int l_above, int x0, int y0, unsigned mask) {
+  BriskLayerView La = view(E, l_above);
+  for (int b = 0; b < 16; ++b)
+    if (mask & (1u << b)) La.smap[(long)(y0 + (b >> 2)) * La.stride + x0 + (b & 3)] |= BRISK_SM_TOUCH;
+}
+
+// mirrors k_copy_layer0 + k_pyramid_level + k_detect + k_classify_refine + k_tie_resolve + k_finalize
+void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int octaves, unsigned shuffle_seed, int jacobi) {
+  make_geometry(w, h, threshold, octaves, &E.G);
+  const BriskGeom& G = E.G;
+  E.pyr.assign((size_t)G.pyr_elems + 256, 0);
+  E.smap.assign((size_t)G.pyr_elems + 256, 0);
+  for (int y = 0; y < h; ++y) memcpy(E.pyr.data() + G.L[0].off + (size_t)y * G.L[0].stride, img + (size_t)y * w, w);
+  for (int l = 1; l < G.nlayers; ++l) {
+    const int sl = (l == 1) ? 0 : l - 2;
+    const uint8_t* src = E.pyr.data() + G.L[sl].off;
+    uint8_t* dst = E.pyr.data() + G.L[l].off;
+    for (int y = 0; y < G.L[l].h; ++y)
+      for (int x = 0; x < G.L[l].w; ++x)
+        dst[(size_t)y * G.L[l].stride + x] = (l == 1) ? brisk_twothird_px(src, G.L[sl].stride, G.L[sl].w, x, y)
+                                                      : brisk_half_px(src, G.L[sl].stride, G.L[sl].w, x, y);
+  }
+  // k_detect
+  E.cand.clear();
+  for (int l = 0; l < G.nlayers; ++l) {
+    BriskLayerView L = view(E, l);
+    for (int y = 3; y <= L.h - 4; ++y)
+      for (int x = 3; x <= L.w - 4; ++x) {
+        const int D = brisk_detect_px(L.img + (long)y * L.stride + x, L.stride, threshold);
+        if (!D) continue;
+        L.smap[(long)y * L.stride + x] = (uint16_t)D;
+        BriskCand c;
+        memset(&c, 0, sizeof(c));
+        c.x = (uint16_t)x; c.y = (uint16_t)y; c.layer = (uint8_t)l; c.D = (uint8_t)D;
+        c.key = ((unsigned)l << 26) | ((unsigned)y << 13) | (unsigned)x;
+        E.cand.push_back(c);
+      }
+  }
+  if (shuffle_seed) {  // atomic-append order is arbitrary on the GPU
+    srand(shuffle_seed);
+    for (size_t i = E.cand.size(); i > 1; --i) std::swap(E.cand[i - 1], E.cand[(size_t)rand() % i]);
+  }
+  // k_classify_refine
+  BriskLayerView Lv[BRISK_MAX_LAYERS];
+  for (int l = 0; l < G.nlayers; ++l) { Lv[l] = view(E, l); E.ties[l].clear(); }
+  for (size_t i = 0; i < E.cand.size(); ++i) {
+    BriskCand* c = &E.cand[i];
+    const int l = c->layer, x = c->x, y = c->y, D = c->D;
+    int nprobed;
+    const unsigned status = brisk_classify(Lv[l], x, y, D, &nprobed);
+    unsigned bits = ((unsigned)nprobed << 8) | (status << 12);
+    unsigned flags = 0;
+    if (status != BRISK_ST_REJ) {
+      BriskKeyPoint kp;
+      bool e5;
+      BriskTouch touch;
+      touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
+      const bool ok = brisk_refine(G, Lv, l, x, y, &kp, &e5, &touch);
+      if (ok) { flags |= 1; c->kx = kp.x; c->ky = kp.y; c->ksize = kp.size; c->kresp = kp.response; }
+      if (e5) { flags |= 2; bits |= BRISK_SM_E5; }
+      c->fp_x0 = (int16_t)touch.x0; c->fp_y0 = (int16_t)touch.y0; c->fp_mask = (uint16_t)touch.mask;
+      if (status == BRISK_ST_PASS && touch.mask) touch_apply(E, l + 1, touch.x0, touch.y0, touch.mask);
+      if (status == BRISK_ST_TIE) E.ties[l].push_back((int)i);
+    }
+    c->status = (uint8_t)status;
+    c->flags = (uint8_t)flags;
+    Lv[l].smap[(long)y * Lv[l].stride + x] |= (uint16_t)bits;
+  }
+  // k_tie_resolve
+  E.relax_iters = 0;
+  for (int l = 0; l < G.nlayers; ++l) {
+    const BriskLayerView L = Lv[l];
+    const bool last = (l == G.nlayers - 1);
+    const bool float_patch = last || G.single_layer;
+    const bool touch2x2 = last && !G.single_layer;
+    for (int iter = 0; iter < 100000; ++iter) {
+      int remaining = 0, progressed = 0;
+      std::vector<std::pair<int, bool>> decided;  // jacobi mode: apply after the sweep
+      for (int idx : E.ties[l]) {
+        BriskCand* c = &E.cand[idx];
+        if (c->status != BRISK_ST_TIE) continue;
+        const int cx = c->x, cy = c->y;
+        uint16_t wl[81];
+        bool ready = true;
+        for (int dy = -4; dy <= 4; ++dy)
+          for (int dx = -4; dx <= 4; ++dx) {
+            const int qx = cx + dx, qy = cy + dy;
+            unsigned v = 0;
+            if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = L.smap[(long)qy * L.stride + qx];
+            wl[(dy + 4) * 9 + dx + 4] = (uint16_t)v;
+            if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) ready = false;
+          }
+        if (!ready) { remaining++; continue; }
+        const bool pass = brisk_tie_eval(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, 9);
+        progressed++;
+        if (jacobi) { decided.push_back({idx, pass}); continue; }
+        if (pass) {
+          if (c->fp_mask && l + 1 < G.nlayers) touch_apply(E, l + 1, c->fp_x0, c->fp_y0, c->fp_mask);
+          c->status = BRISK_ST_PASS;
+          L.smap[(long)cy * L.stride + cx] ^= 0x3000u;
+        } else {
+          c->status = BRISK_ST_FAIL;
+          L.smap[(long)cy * L.stride + cx] |= 0x1000u;
+        }
+      }
+      for (auto& d : decided) {
+        BriskCand* c = &E.cand[d.first];
+        if (d.second) {
+          if (c->fp_mask && l + 1 < G.nlayers) touch_apply(E, l + 1, c->fp_x0, c->fp_y0, c->fp_mask);
+          c->status = BRISK_ST_PASS;
+          L.smap[(long)c->y * L.stride + c->x] ^= 0x3000u;
+        } else {
+          c->status = BRISK_ST_FAIL;
+          L.smap[(long)c->y * L.stride + c->x] |= 0x1000u;
+        }
+      }
+      if (progressed) E.relax_iters++;
+      if (iter + 1 > E.max_chain && progressed) E.max_chain = iter + 1;
+      if (remaining == 0 || progressed == 0) break;
+    }
+  }
+  // k_finalize
+  std::vector<std::pair<unsigned, int>> keys;
+  for (size_t i = 0; i < E.cand.size(); ++i)
+    if (E.cand[i].status == BRISK_ST_PASS && (E.cand[i].flags & 1)) keys.push_back({E.cand[i].key, (int)i});
+  std::sort(keys.begin(), keys.end());
+  E.kps.clear();
+  for (auto& k : keys) {
+    const BriskCand& c = E.cand[k.second];
+    BriskKeyPoint kp;
+    kp.x = c.kx; kp.y = c.ky; kp.size = c.ksize; kp.angle = -1.0f; kp.response = c.kresp;
+    kp.octave = G.single_layer ? 0 : c.layer; kp.class_id = -1;
+    E.kps.push_back(kp);
+  }
+}
+
+struct EmulPattern {
+  BriskPatternHost H;
+  BriskPatternDev P;
+};
+
+}  // namespace
+
+extern "C" {
+
+// returns keypoint count; *out malloc'd (free with emul_free). stats[0]=#candidates, [1]=#ties, [2]=relaxation sweeps,
+// [3]=longest per-layer chain
+int emul_detect(const uint8_t* img, int w, int h, int threshold, int octaves, unsigned shuffle_seed, int jacobi,
+                BriskKeyPoint** out, int* stats) {
+  Emul E;
+  run_detect(E, img, w, h, threshold, octaves, shuffle_seed, jacobi);
+  *out = (BriskKeyPoint*)malloc(sizeof(BriskKeyPoint) * (E.kps.size() + 1));
+  memcpy(*out, E.kps.data(), sizeof(BriskKeyPoint) * E.kps.size());
+  if (stats) {
+    stats[0] = (int)E.cand.size();
+    int nt = 0;
+    for (int l = 0; l < E.G.nlayers; ++l) nt += (int)E.ties[l].size();
+    stats[1] = nt; stats[2] = E.relax_iters; stats[3] = E.max_chain;
+  }
+  return (int)E.kps.size();
+}
+
+void emul_free(void* p) { free(p); }
+
+// closed-form scores vs the oracle's bisection (per pixel)
+int emul_oast_Kp(const uint8_t* p, int stride) { return brisk_Kp_from_M(brisk_oast9_16_M(p, stride)); }
+int emul_agast58_Kp(const uint8_t* p, int stride) { return brisk_Kp_from_M(brisk_agast5_8_M(p, stride)); }
+int emul_detect_px(const uint8_t* p, int stride, int thr) { return brisk_detect_px(p, stride, thr); }
+
+void* emul_pattern_create(int version, float pattern_scale, const char* text) {
+  EmulPattern* e = new EmulPattern();
+  std::string err;
+  const bool ok = text ? brisk_pattern_build_from_text(text, pattern_scale, &e->H, &err)
+                       : brisk_pattern_build_default(version, pattern_scale, &e->H, &err);
+  if (!ok) { delete e; return nullptr; }
+  BriskPatternDev& d = e->P;
+  d.npoints = e->H.npoints; d.nshort = e->H.nshort; d.nlong = e->H.nlong; d.strings = e->H.strings;
+  d.rotation_invariant = 1; d.scale_invariant = 1; d.basicscale = e->H.basicscale;
+  d.mult = e->H.mult.data(); d.sigma = e->H.sigma.data(); d.uv = e->H.uv.data();
+  d.size_thresh = e->H.size_thresh.data(); d.size_list = e->H.size_list.data();
+  d.short_pairs = e->H.short_pairs.data(); d.long_pairs = e->H.long_pairs.data();
+  return e;
+}
+void emul_pattern_destroy(void* p) { delete (EmulPattern*)p; }
+int emul_pattern_strings(void* p) { return ((EmulPattern*)p)->H.strings; }
+int emul_pattern_points(void* p) { return ((EmulPattern*)p)->H.npoints; }
+void emul_pattern_tables(void* p, float* scale_list, int* size_list, float* size_thresh) {
+  EmulPattern* e = (EmulPattern*)p;
+  memcpy(scale_list, e->H.scale_list.data(), 256);
+  memcpy(size_list, e->H.size_list.data(), 256);
+  memcpy(size_thresh, e->H.size_thresh.data(), 256);
+}
+// full pattern LUT entry as the reference tabulates it
+void emul_pattern_point(void* p, int scale, int rot, int i, float* xyz) {
+  brisk_pattern_point(((EmulPattern*)p)->P, scale, rot, i, &xyz[0], &xyz[1], &xyz[2]);
+}
+int emul_scale_index(void* p, float size, int scale_invariant) {
+  BriskPatternDev P = ((EmulPattern*)p)->P;
+  P.scale_invariant = scale_invariant;
+  return brisk_scale_index(P, size);
+}
+int emul_scale_index_host(float size) { return brisk_pattern_scale_index_host(size); }
+
+// mirrors k_integral_* + k_desc_prepare + k_describe; returns surviving count
+int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kps, int n, uint8_t* desc, int desc_pitch,
+                  int rotation_invariant, int scale_invariant) {
+  BriskPatternDev P = ((EmulPattern*)pat)->P;
+  P.rotation_invariant = rotation_invariant;
+  P.scale_invariant = scale_invariant;
+  const int istride = brisk_align_up(w + 1, 16);
+  std::vector<uint32_t> integ((size_t)istride * (h + 1), 0);
+  for (int y = 0; y < h; ++y) {
+    uint32_t s = 0;
+    for (int x = 0; x < w; ++x) {
+      s += img[(size_t)y * w + x];
+      integ[(size_t)(y + 1) * istride + x + 1] = integ[(size_t)y * istride + x + 1] + s;
+    }
+  }
+  std::vector<int> dscale;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const int sc = brisk_scale_index(P, kps[i].size);
+    if (brisk_inside_border(P, sc, kps[i].x, kps[i].y, w, h)) { kps[m++] = kps[i]; dscale.push_back(sc); }
+  }
+  std::vector<int> values(BRISK_MAX_POINTS);
+  for (int k = 0; k < m; ++k) {
+    BriskKeyPoint* kp = &kps[k];
+    const int scale = dscale[k];
+    int theta = 0;
+    if (P.rotation_invariant) {
+      if (kp->angle == -1.0f) {
+        for (int i = 0; i < P.npoints; ++i) {
+          float bx, by, sg;
+          brisk_pattern_point(P, scale, 0, i, &bx, &by, &sg);
+          values[i] = brisk_smoothed_intensity(img, w, integ.data(), istride, kp->x, kp->y, bx, by, sg);
+        }
+        int d0 = 0, d1 = 0;
+        for (int p = 0; p < P.nlong; ++p) {
+          int a, b;
+          brisk_long_pair(values.data(), P.long_pairs + 4 * p, &a, &b);
+          d0 += a; d1 += b;
+        }
+        kp->angle = brisk_angle_from_direction(d0, d1);
+        theta = brisk_theta_from_angle(kp->angle, true);
+      } else {
+        theta = brisk_theta_from_angle(kp->angle, false);
+      }
+    }
+    for (int i = 0; i < P.npoints; ++i) {
+      float bx, by, sg;
+      brisk_pattern_point(P, scale, theta, i, &bx, &by, &sg);
+      values[i] = brisk_smoothed_intensity(img, w, integ.data(), istride, kp->x, kp->y, bx, by, sg);
+    }
+    uint8_t* drow = desc + (size_t)k * desc_pitch;
+    memset(drow, 0, P.strings);
+    for (int p = 0; p < P.nshort; ++p)
+      if (values[P.short_pairs[2 * p]] > values[P.short_pairs[2 * p + 1]]) drow[p >> 3] |= (uint8_t)(1u << (p & 7));
+  }
+  return m;
+}
+
+}  // extern "C"

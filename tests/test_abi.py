@@ -1,0 +1,43 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports what the header declares."""
+import os
+import re
+
+import pytest
+
+import ethzasl_brisk_amd as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ethzasl_brisk_amd import build
+    build.build()
+    return B.load_library()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "brisk_hip.h")).read()
+    declared = set(re.findall(r"\b(brisk_hip_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(B.ABI_SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU every compute entry point must fail loudly."""
+    if lib.brisk_hip_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(B.BriskHipError) as ei:
+        B.Context()
+    assert ei.value.code == 2   # BRISK_HIP_ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    for d, _, files in os.walk(os.path.join(ROOT, "ethzasl_brisk_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".inc")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "brisk_oracle" not in txt and "liboracle" not in txt and "oracle_lib" not in txt, f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f), errors="ignore").read()

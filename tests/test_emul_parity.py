@@ -1,0 +1,134 @@
+"""CPU checks of the device-side logic (no GPU needed).
+
+The HIP kernels' per-item functions are `__host__ __device__`; tests/emul/brisk_emul.cpp runs them in
+plain loops that mirror the kernels.  These tests pin that logic (parallel IsMax2D classification,
+history-free refinement, order-faithful tie replay, factorised pattern tables, box sampling) against
+the oracle, so that GPU minutes are only spent on GPU-specific behaviour.  The emulation is test
+infrastructure, never loaded by the product.
+"""
+import numpy as np
+import pytest
+
+import emul_lib as E
+import oracle_lib as O
+import synth
+
+
+def same_kps(a, b):
+    if len(a) != len(b):
+        return False
+    return all(np.array_equal(a[f].view(np.uint32) if a[f].dtype == np.float32 else a[f],
+                              b[f].view(np.uint32) if b[f].dtype == np.float32 else b[f]) for f in a.dtype.names)
+
+
+def test_closed_form_scores_match_bisection():
+    """K' = clamp(M-1, 0, 254) equals cornerScore(b=0) of the oracle, 9_16 and 5_8."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    L, Lo = E.lib(), O.lib()
+    for trial in range(6):
+        if trial < 3:
+            img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+        else:  # smooth-ish patches with strong corners
+            img = np.clip(rng.integers(0, 2, (8, 8)).repeat(8, 0).repeat(8, 1) * 150 + rng.integers(0, 40, (64, 64)), 0, 255).astype(np.uint8)
+        for y in range(3, 61):
+            for x in range(3, 61):
+                p = img.ctypes.data + y * 64 + x
+                assert L.emul_oast_Kp(p, 64) == Lo.bo_oast9_16_corner_score(p, 64, 0)
+                assert L.emul_agast58_Kp(p, 64) == Lo.bo_agast5_8_corner_score(p, 64, 0)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_detect_matches_oracle_golden_images(golden_ast, idx):
+    img = golden_ast[idx]["image"]
+    ko = O.detect(img, 70, 3)
+    for seed, jacobi in ((0, 0), (7, 0), (9, 1)):   # candidate order / sweep style must not matter
+        ke, stats = E.detect(img, 70, 3, seed, jacobi)
+        assert same_kps(ke, ko)
+    assert stats[1] > 100                            # tie candidates exist
+
+
+CASES = [
+    ("vga_thr70_o4", lambda: synth.frame_vga(1), 70, 4),
+    ("vga_thr30_o4", lambda: synth.frame_vga(2), 30, 4),
+    ("vga_thr20_o3", lambda: synth.frame_vga(3), 20, 3),
+    ("odd_333x217_o3", lambda: synth.gen(333, 217, 5, 40), 40, 3),
+    ("tiny_101x77_o2", lambda: synth.gen(101, 77, 6, 12), 30, 2),
+    ("single_layer", lambda: synth.frame_vga(4), 50, 0),
+    ("one_octave", lambda: synth.frame_vga(5), 50, 1),
+]
+
+
+@pytest.mark.parametrize("name,mk,thr,octaves", CASES, ids=[c[0] for c in CASES])
+def test_detect_matches_oracle_synthetic(name, mk, thr, octaves):
+    img = mk()
+    ko = O.detect(img, thr, octaves)
+    ke, _ = E.detect(img, thr, octaves, 3, 0)
+    assert len(ko) > 0 and same_kps(ke, ko)
+
+
+def test_detect_tie_heavy_blocks():
+    """Blocky image: almost every 2D maximum ties with a neighbour; relaxation chains > 50 deep."""
+    rng = np.random.default_rng(5)
+    b = (rng.integers(0, 2, (30, 40)) * 200 + 20).astype(np.uint8)
+    b = np.kron(b, np.ones((8, 8), np.uint8))
+    ko = O.detect(b, 60, 3)
+    ke, stats = E.detect(b, 60, 3, 11, 1)
+    assert same_kps(ke, ko)
+    assert stats[1] > 0.8 * stats[0] and stats[3] > 50
+
+
+def test_detect_1080p_config2():
+    img = synth.frame_1080p(0)
+    ko = O.detect(img, 80, 4)
+    assert len(ko) == 1194                           # SURVEY §8(d) config 2 probe
+    ke, _ = E.detect(img, 80, 4, 1, 0)
+    assert same_kps(ke, ko)
+
+
+@pytest.mark.parametrize("version", [2, 1])
+def test_pattern_tables_match_oracle(version):
+    P, X = E.Pattern(version=version), O.Extractor(version=version)
+    assert (P.strings, P.points) == (X.strings, X.points)
+    sl, szl, thr = P.tables()
+    assert np.array_equal(sl, X.scale_list()) and np.array_equal(szl.astype(np.uint32), X.size_list())
+    lut = X.pattern()                                 # the reference's 51.9 MB LUT
+    for s in (0, 1, 17, 63):
+        for r in range(0, 1024, 41):
+            got = np.array([P.point(s, r, i) for i in range(P.points)])
+            assert np.array_equal(got.view(np.uint32), lut[s, r].view(np.uint32))
+    rng = np.random.default_rng(1)
+    sizes = np.concatenate([rng.uniform(1, 400, 4000).astype(np.float32), thr[1:], np.nextafter(thr[1:], np.float32(0)),
+                            np.nextafter(thr[1:], np.float32(1e9))])
+    for s in sizes:
+        assert P.scale_index(s) == X.scale_index(s)
+
+
+@pytest.mark.parametrize("version", [2, 1])
+def test_describe_matches_oracle(golden_ast, version):
+    P, X = E.Pattern(version=version), O.Extractor(version=version)
+    for e, thr, octv in ((golden_ast[0], 70, 3), (golden_ast[1], 40, 4)):
+        k = O.detect(e["image"], thr, octv)
+        ko, do = X.compute(e["image"], k)
+        ke, de = P.describe(e["image"], k)
+        assert same_kps(ke, ko) and np.array_equal(de, do)
+
+
+def test_describe_flags_and_custom_pattern(golden_harris):
+    e = golden_harris[0]
+    g = e["keypoints"]
+    k = np.zeros(len(g), O.KP)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        k[f] = g[f]
+    k["angle"] = -1
+    ke, de = E.Pattern().describe(e["image"], k)
+    assert np.array_equal(ke["angle"].view(np.uint32), g["angle"].view(np.uint32))
+    assert np.array_equal(de, e["descriptors"])
+    for rot, sc in ((False, True), (True, False), (False, False)):
+        ko, do = O.Extractor(rot, sc).compute(e["image"], k)
+        ke, de = E.Pattern().describe(e["image"], k, rot, sc)
+        assert same_kps(ke, ko) and np.array_equal(de, do)
+    # pattern scale 0.8 (and, via the text path, the same default pattern re-serialised)
+    ko, do = O.Extractor(pattern_scale=0.8).compute(e["image"], k)
+    ke, de = E.Pattern(pattern_scale=0.8).describe(e["image"], k)
+    assert same_kps(ke, ko) and np.array_equal(de, do)

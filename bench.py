@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py - frames/sec detect+describe @1080p on N MI355X GPUs (BASELINE.json metric).
+
+A "step" is one pass of the hot path (pyramid -> AGAST detect -> NMS/refine -> integral -> describe) over one
+batch of synthetic 1080p frames that already sit in HBM (BASELINE config 2: Appendix-C recipe, 4 octaves,
+threshold 80, ~1k keypoints/frame).  Frames shard over ranks (one process per GPU, no data-path collective in the
+detect/describe path itself); with N > 1 every step ends with the RCCL gather of the packed keypoints+descriptors
+to rank 0 that BASELINE config 3 describes.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+W, H, OCTAVES, THRESHOLD = 1920, 1080, 4, 80
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def algorithmic_bytes(w, h, octaves, kp):
+    """SURVEY §8(d) stage model.  Returns (total per frame, detect-kernel bytes per frame)."""
+    sizes = [(w, h)]
+    if octaves:
+        sizes.append((2 * (w // 3), 2 * (h // 3)))
+        for i in range(2, 2 * octaves):
+            sizes.append((sizes[i - 2][0] // 2, sizes[i - 2][1] // 2))
+    px = [a * b for a, b in sizes]
+    P = sum(px)
+    parents = sum(px[0 if i == 1 else i - 2] for i in range(1, len(px)))
+    s1 = parents + (P - px[0])
+    s2 = 2 * P
+    s3 = P + 28 * kp
+    s4 = px[0] + 4 * (w + 1) * (h + 1)
+    s5 = kp * 8524
+    return s1 + s2 + s3 + s4 + s5, s2
+
+
+def cpu_baseline(frames, seconds_budget=20.0):
+    """Oracle (CPU port of the reference path) on a bounded sample of the same workload, one process per core."""
+    import multiprocessing as mp
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    sample = frames[:max(cores, 4)]
+    t0 = time.time()
+    _cpu_one(sample[0])                      # single-thread time for one frame
+    t1 = time.time() - t0
+    reps = max(1, int(seconds_budget / max(t1, 1e-3) / 2))
+    work = [sample[i % len(sample)] for i in range(min(cores * reps, cores * 8))]
+    ctx = mp.get_context("fork")
+    t0 = time.time()
+    with ctx.Pool(cores) as pool:
+        counts = pool.map(_cpu_one, work, chunksize=1)
+    dt = time.time() - t0
+    return {"value": round(len(work) / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "single_thread_fps": round(1.0 / t1, 3),
+            "sample": "%d synthetic 1080p frames (same recipe/params), oracle detect+describe, %d processes; "
+                      "mean %d keypoints/frame" % (len(work), cores, int(np.mean(counts)))}
+
+
+_EXT = None
+
+
+def _cpu_one(img):
+    global _EXT
+    import oracle_lib as O
+    if _EXT is None:
+        _EXT = O.Extractor()
+    k = O.detect(img, THRESHOLD, OCTAVES)
+    k2, _ = _EXT.compute(img, k)
+    return len(k2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per GPU (ring)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    import synth
+    import ethzasl_brisk_amd as B
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- synthetic frame ring, resident in HBM before the timed region
+    nd = max(1, min(args.distinct, args.batch))
+    host = np.stack([synth.frame_1080p(rank * 100000 + i) for i in range(nd)])
+    ring = torch.from_numpy(host).to(dev)
+    idx = torch.arange(args.batch, device=dev) % nd
+    frames = ring[idx].contiguous()          # [batch, H, W] u8 in HBM
+    del ring
+
+    ctx = B.Context(local_rank)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    stream = torch.cuda.current_stream().cuda_stream
+    strings = ext.descriptorSize()
+
+    # result buffers as torch views (for the multi-GPU gather)
+    def step():
+        ctx.detect_describe_batch(ext, frames.data_ptr(), args.batch, W, H, W * H, W, THRESHOLD, OCTAVES, stream)
+
+    gather = None
+    if world > 1:
+        gather = ResultGather(ctx, args.batch, strings, dev, rank, world)
+
+    for _ in range(args.warmup):
+        step()
+        if gather:
+            gather.run()
+    torch.cuda.synchronize()
+    assert ctx.batch_status(args.batch) == 0
+    kps0, _ = ctx.batch_download(0, True, strings)
+    mean_kp = float(np.mean([len(ctx.batch_download(f, True, strings)[0]) for f in range(min(args.batch, 8))]))
+
+    ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if gather:
+            gather.run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stage_ms, ncalls = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_frames = args.batch * args.steps * world
+    fps = total_frames / dt
+    per_frame_bytes, detect_bytes = algorithmic_bytes(W, H, OCTAVES, int(round(mean_kp)))
+    det_ms = stage_ms.get("k_detect", 0.0)
+    achieved = (detect_bytes * args.batch) / (det_ms * 1e-3) / 1e9 if det_ms > 0 else 0.0
+    out = {
+        "metric": "frames/sec detect+describe @1080p (1/2/4/8 GPU); % HBM roofline",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "1080p synthetic textured stream (SURVEY App. C recipe, 300 rects), 4 octaves, "
+                               "AGAST threshold 80, default 66-point pattern (48-byte descriptors)",
+                   "frames_per_step_per_gpu": args.batch, "distinct_frames_per_gpu": nd,
+                   "mean_keypoints_per_frame": round(mean_kp, 1),
+                   "parallelism": "frames sharded over %d rank(s)%s" % (world, ", RCCL gather of keypoints+descriptors to rank 0 each step" if world > 1 else ""),
+                   "algorithmic_MB_per_frame": round(per_frame_bytes / 1e6, 3),
+                   "pipeline_achieved_GBps": round(per_frame_bytes * fps / 1e9, 2),
+                   "pipeline_frac_of_hbm_peak": round(per_frame_bytes * fps / 1e9 / (HBM_PEAK_GBS * world), 5),
+                   "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}},
+        "roofline": {"bound": "hbm", "kernel": "k_detect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(),
+                     "algorithmic_bytes_per_launch": detect_bytes * args.batch, "avg_launch_ms": round(det_ms, 4),
+                     "launches_timed": ncalls},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(list(host[:16]))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def load_traffic():
+    """HBM bytes per k_detect launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic_k_detect.json")
+    try:
+        return json.load(open(p))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+class ResultGather:
+    """RCCL gather of the packed per-frame results to rank 0 (BASELINE config 3).  Counts first (all_gather),
+    then one gather of fixed-size padded slabs sized to the largest rank's payload."""
+
+    def __init__(self, ctx, batch, strings, dev, rank, world):
+        import ctypes as C
+        import torch
+        self.torch = torch
+        self.dev, self.rank, self.world, self.batch, self.strings = dev, rank, world, batch, strings
+        L = ctx._L
+        vp = C.c_void_p
+        d_det, d_desc_n, d_kd, d_kp, d_desc = vp(), vp(), vp(), vp(), vp()
+        stride, cap, pitch = C.c_int(), C.c_int(), C.c_int()
+        ctx.check(L.brisk_hip_batch_results(ctx._h, C.byref(d_det), C.byref(d_desc_n), C.byref(stride), C.byref(d_kd),
+                                            C.byref(d_kp), C.byref(d_desc), C.byref(cap), C.byref(pitch)))
+        self.cap, self.pitch, self.cstride = cap.value, pitch.value, stride.value
+        self.counts = self._wrap(d_desc_n.value, (batch, self.cstride // 4), torch.int32, (self.cstride // 4, 1))[:, 0]
+        self.kps = self._wrap(d_kp.value, (batch, self.cap, 7), torch.float32, (self.cap * 7, 7, 1))
+        self.desc = self._wrap(d_desc.value, (batch, self.cap, self.pitch), torch.uint8, (self.cap * self.pitch, self.pitch, 1))
+
+    def _wrap(self, ptr, shape, dtype, strides):
+        torch = self.torch
+        itemsize = torch.tensor([], dtype=dtype).element_size()
+        typestr = {torch.int32: "<i4", torch.float32: "<f4", torch.uint8: "|u1"}[dtype]
+
+        class _A:
+            pass
+        a = _A()
+        a.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 3,
+                                      "strides": tuple(s * itemsize for s in strides)}
+        return torch.as_tensor(a, device=self.dev)
+
+    def run(self):
+        import torch.distributed as dist
+        torch = self.torch
+        counts = self.counts.contiguous()
+        mask = torch.arange(self.cap, device=self.dev)[None, :] < counts[:, None]
+        kp = self.kps[mask]                                   # [n, 7] packed in frame order
+        ds = self.desc[mask][:, :self.strings]                # [n, strings]
+        n = torch.tensor([kp.shape[0]], device=self.dev, dtype=torch.int64)
+        allc = [torch.empty_like(counts) for _ in range(self.world)]
+        dist.all_gather(allc, counts)
+        alln = [torch.empty_like(n) for _ in range(self.world)]
+        dist.all_gather(alln, n)
+        nmax = int(max(int(x.item()) for x in alln))
+        pk = torch.zeros((nmax, 7), device=self.dev, dtype=torch.float32)
+        pd = torch.zeros((nmax, self.strings), device=self.dev, dtype=torch.uint8)
+        pk[:kp.shape[0]] = kp
+        pd[:ds.shape[0]] = ds
+        gk = [torch.empty_like(pk) for _ in range(self.world)] if self.rank == 0 else None
+        gd = [torch.empty_like(pd) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(pk, gk, dst=0)
+        dist.gather(pd, gd, dst=0)
+        self.last = (allc, alln, gk, gd)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "brisk_hip_pattern_destroy", "brisk_hip_pattern_descriptor_size", "brisk_hip_pattern_points",
     "brisk_hip_pattern_tables", "brisk_hip_detect", "brisk_hip_describe", "brisk_hip_detect_describe_batch",
     "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
-    "brisk_hip_debug_layer", "brisk_hip_debug_integral",
+    "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
+    "brisk_hip_profile_stage_name", "brisk_hip_profile_read",
 ]
 
 
@@ -43,6 +44,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch wheels bundle their own HIP runtime under the same SONAME (libamdhip64.so.7).  If torch is
+        # going to be used in this process (tests, bench.py) it must be loaded first so that this library
+        # binds to the runtime already in the process: two HIP runtimes in one process cannot both own the GPU.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("libbrisk_hip.so is missing: run `python -m ethzasl_brisk_amd.build` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
@@ -73,6 +81,10 @@ def load_library():
     L.brisk_hip_batch_status.argtypes = [vp, C.c_int, ip]
     L.brisk_hip_debug_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, ip]
     L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
+    L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
+    L.brisk_hip_profile_stage_name.argtypes = [C.c_int]
+    L.brisk_hip_profile_stage_name.restype = C.c_char_p
+    L.brisk_hip_profile_read.argtypes = [vp, vp, ip]
     _lib = L
     return L
 
@@ -122,6 +134,18 @@ class Context:
         out = np.zeros((h + 1, w + 1), np.uint32)
         self.check(self._L.brisk_hip_debug_integral(self._h, frame, _ptr(out)))
         return out
+
+    # -- per-stage HIP-event timing of the batch path --
+    def profile_enable(self, on=True):
+        self.check(self._L.brisk_hip_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """{stage name: average ms per call}, number of calls averaged."""
+        n = self._L.brisk_hip_profile_stages()
+        ms = np.zeros(n, np.float32)
+        calls = C.c_int()
+        self.check(self._L.brisk_hip_profile_read(self._h, _ptr(ms), C.byref(calls)))
+        return {self._L.brisk_hip_profile_stage_name(i).decode(): float(ms[i]) for i in range(n)}, calls.value
 
     # -- device-resident batch path --
     def detect_describe_batch(self, pattern, d_frames_ptr, nframes, w, h, frame_pitch, row_pitch, threshold, octaves,

@@ -43,6 +43,7 @@ struct brisk_hip_ctx {
   BriskTileTable T{};
   int last_nframes = 0;
   bool last_has_desc = false;
+  BriskProfiler prof;
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -305,15 +306,17 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
   make_geometry(w, h, threshold, octaves, &ctx->G, &ctx->T);
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
+  brisk_prof_begin_call(&ctx->prof);
   if (do_detect) {
     brisk_launch_detect(ctx->G, ctx->T, ctx->B, nframes, d_frames, frame_pitch, row_pitch, d_mask, mask_frame_pitch,
-                        mask_row_pitch, s);
+                        mask_row_pitch, s, &ctx->prof);
   }
   if (do_describe) {
     BriskPatternDev P = pat->dev;
     brisk_launch_describe(ctx->G, P, ctx->B, ctx->D, nframes, ctx->B.kp_out, &ctx->B.counters[0].nkp,
-                          sizeof(BriskFrameCounters), s);
+                          sizeof(BriskFrameCounters), s, &ctx->prof);
   }
+  if (ctx->prof.on) ctx->prof.calls++;
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = nframes;
   ctx->last_has_desc = do_describe;
@@ -465,11 +468,46 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   BriskPatternDev P = pat->dev;
   P.rotation_invariant = rotation_invariant ? 1 : 0;
   P.scale_invariant = scale_invariant ? 1 : 0;
-  brisk_launch_describe(ctx->G, P, ctx->B, ctx->D, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream);
+  brisk_launch_describe(ctx->G, P, ctx->B, ctx->D, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, nullptr);
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;
   ctx->last_has_desc = true;
   return download_locked(ctx, 0, 1, kps, n_in, n, desc, desc_stride, pat->host.strings);
+}
+
+// ---- per-stage timing (HIP events on the launch stream) -----------------------------------------------
+int brisk_hip_profile_enable(brisk_hip_ctx* ctx, int enable) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->prof.on = enable != 0;
+  ctx->prof.calls = 0;
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_profile_stages(void) { return BRISK_PROF_STAGES; }
+const char* brisk_hip_profile_stage_name(int i) { return brisk_stage_name(i); }
+
+int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls) {
+  if (!ctx || !avg_ms) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  BriskProfiler& P = ctx->prof;
+  const int n = P.calls < BRISK_PROF_MAX_CALLS ? P.calls : BRISK_PROF_MAX_CALLS;
+  for (int k = 0; k < BRISK_PROF_STAGES; ++k) {
+    double sum = 0;
+    int cnt = 0;
+    for (int c = 0; c < n; ++c) {
+      if (!P.used[c][k] || !P.used[c][k + 1]) continue;
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, P.ev[c][k], P.ev[c][k + 1]) == hipSuccess) { sum += ms; cnt++; }
+    }
+    avg_ms[k] = cnt ? (float)(sum / cnt) : 0.f;
+  }
+  if (calls) *calls = n;
+  P.calls = 0;
+  return BRISK_HIP_OK;
 }
 
 // ---- debug / per-stage parity ------------------------------------------------------------------

@@ -35,14 +35,31 @@ struct BriskDescribeBuffers {
   int desc_pitch;
 };
 
+// Optional per-stage timing with HIP events on the launch stream (bench.py roofline leg).
+#define BRISK_PROF_STAGES 9
+#define BRISK_PROF_MAX_CALLS 64
+struct BriskProfiler {
+  bool on = false;
+  int calls = 0;                                                   // calls recorded since the last reset
+  hipEvent_t ev[BRISK_PROF_MAX_CALLS][BRISK_PROF_STAGES + 1] = {};  // created lazily
+  bool used[BRISK_PROF_MAX_CALLS][BRISK_PROF_STAGES + 1] = {};
+  bool created = false;
+};
+// stage ids
+enum { BRISK_STG_PYRAMID = 0, BRISK_STG_DETECT, BRISK_STG_CLASSIFY, BRISK_STG_TIES, BRISK_STG_FINALIZE,
+       BRISK_STG_INTEGRAL_ROWS, BRISK_STG_INTEGRAL_COLS, BRISK_STG_DESC_PREPARE, BRISK_STG_DESCRIBE };
+const char* brisk_stage_name(int i);
+void brisk_prof_begin_call(BriskProfiler* P);
+void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s);  // slot k = start of stage k (k == stages: end)
+
 // frames: u8 images, frame f at frames + f*frame_pitch, row pitch row_pitch (device memory)
 void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
                          const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
-                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s);
+                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof);
 // only stages layer 0 (descriptor-only calls)
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
                               long frame_pitch, int row_pitch, hipStream_t s);
 // kp_in: [slots][kp_cap]; n_in: per-frame counts at byte stride n_in_stride
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
-                           long n_in_stride, hipStream_t s);
+                           long n_in_stride, hipStream_t s, BriskProfiler* prof);

@@ -532,10 +532,35 @@ static inline int grid_for(long items, int per_block, int cap) {
   return (int)b;
 }
 
+const char* brisk_stage_name(int i) {
+  static const char* n[BRISK_PROF_STAGES] = {"k_pyramid", "k_detect", "k_classify_refine", "k_tie_resolve", "k_finalize",
+                                             "k_integral_rows", "k_integral_cols", "k_desc_prepare", "k_describe"};
+  return (i >= 0 && i < BRISK_PROF_STAGES) ? n[i] : "?";
+}
+
+void brisk_prof_begin_call(BriskProfiler* P) {
+  if (!P || !P->on) return;
+  if (!P->created) {
+    for (int c = 0; c < BRISK_PROF_MAX_CALLS; ++c)
+      for (int k = 0; k <= BRISK_PROF_STAGES; ++k) (void)hipEventCreate(&P->ev[c][k]);
+    P->created = true;
+  }
+  const int c = P->calls % BRISK_PROF_MAX_CALLS;
+  for (int k = 0; k <= BRISK_PROF_STAGES; ++k) P->used[c][k] = false;
+}
+
+void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s) {
+  if (!P || !P->on) return;
+  const int c = P->calls % BRISK_PROF_MAX_CALLS;
+  (void)hipEventRecord(P->ev[c][slot], s);
+  P->used[c][slot] = true;
+}
+
 void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
                          const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
-                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s) {
-  hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
+                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof) {
+  (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
+  brisk_prof_mark(prof, BRISK_STG_PYRAMID, s);
   {
     const long items = (long)(G.L[0].stride / 4) * G.L[0].h;
     hipLaunchKernelGGL(k_copy_layer0, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, frames, frame_pitch,
@@ -547,14 +572,19 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     hipLaunchKernelGGL(k_pyramid_level, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, B.pyr, sl, l,
                        (l == 1) ? 1 : 0);
   }
+  brisk_prof_mark(prof, BRISK_STG_DETECT, s);
   hipLaunchKernelGGL(k_detect, dim3(T.total_tiles, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,
                      B.cand_cap);
+  brisk_prof_mark(prof, BRISK_STG_CLASSIFY, s);
   hipLaunchKernelGGL(k_classify_refine, dim3(grid_for(B.cand_cap, 128, 64), nframes), dim3(128), 0, s, G, B.pyr, B.smap,
                      B.cand, B.counters, B.tie_idx, B.cand_cap, B.tie_cap);
+  brisk_prof_mark(prof, BRISK_STG_TIES, s);
   hipLaunchKernelGGL(k_tie_resolve, dim3(nframes), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
                      B.cand_cap, B.tie_cap);
+  brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,
                      B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);
+  brisk_prof_mark(prof, BRISK_STG_INTEGRAL_ROWS, s);
 }
 
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
@@ -566,14 +596,19 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
 
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
-                           long n_in_stride, hipStream_t s) {
+                           long n_in_stride, hipStream_t s, BriskProfiler* prof) {
+  brisk_prof_mark(prof, BRISK_STG_INTEGRAL_ROWS, s);
   hipLaunchKernelGGL(k_integral_rows, dim3(G.L[0].h, nframes), dim3(256), 0, s, G, B.pyr, Dd.integral, Dd.istride,
                      Dd.iframe_elems);
+  brisk_prof_mark(prof, BRISK_STG_INTEGRAL_COLS, s);
   hipLaunchKernelGGL(k_integral_cols, dim3((G.L[0].w + 1 + 255) / 256, nframes), dim3(256), 0, s, G, Dd.integral,
                      Dd.istride, Dd.iframe_elems);
+  brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, B.kp_cap);
+  brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
   hipLaunchKernelGGL(k_describe, dim3(grid_for(B.kp_cap, 1, 1024), nframes), dim3(DS_THREADS), 0, s, G, P, B.pyr,
                      Dd.integral, Dd.istride, Dd.iframe_elems, B.counters, Dd.dkp, Dd.dscale, Dd.desc, B.kp_cap,
                      Dd.desc_pitch);
+  brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);
 }

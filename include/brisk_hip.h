@@ -97,6 +97,13 @@ int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which /*0 detect
 /* error / overflow flags of the last batch, OR-ed over frames (0 = clean); synchronises */
 int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags);
 
+/* ---- per-stage timing: HIP events recorded on the launch stream around every kernel of the batch path ---- */
+int brisk_hip_profile_enable(brisk_hip_ctx* ctx, int enable);       /* resets the accumulated calls */
+int brisk_hip_profile_stages(void);                                 /* number of stages */
+const char* brisk_hip_profile_stage_name(int stage);
+/* average milliseconds per stage over the calls since enable/read (at most the last 64); synchronises */
+int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls);
+
 /* ---- per-stage device entry points (parity tests of individual kernels) ---------------------- */
 /* which: 0 pyramid image, 1 score-state map low byte (D), after the last detect on frame slot 0.
  * Copies layer `layer` (w x h, tightly packed u8) to the host buffer. */

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "brisk_hip_pattern_tables", "brisk_hip_detect", "brisk_hip_describe", "brisk_hip_detect_describe_batch",
     "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
     "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
-    "brisk_hip_profile_stage_name", "brisk_hip_profile_read",
+    "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags",
 ]
 
 
@@ -82,6 +82,7 @@ def load_library():
     L.brisk_hip_debug_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, ip]
     L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
+    L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
     L.brisk_hip_profile_stage_name.argtypes = [C.c_int]
     L.brisk_hip_profile_stage_name.restype = C.c_char_p
     L.brisk_hip_profile_read.argtypes = [vp, vp, ip]
@@ -134,6 +135,9 @@ class Context:
         out = np.zeros((h + 1, w + 1), np.uint32)
         self.check(self._L.brisk_hip_debug_integral(self._h, frame, _ptr(out)))
         return out
+
+    def debug_set_flags(self, flags):
+        self.check(self._L.brisk_hip_debug_set_flags(self._h, flags))
 
     # -- per-stage HIP-event timing of the batch path --
     def profile_enable(self, on=True):

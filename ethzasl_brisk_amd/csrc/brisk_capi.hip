@@ -44,6 +44,7 @@ struct brisk_hip_ctx {
   int last_nframes = 0;
   bool last_has_desc = false;
   BriskProfiler prof;
+  int debug_flags = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -99,7 +100,7 @@ static void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G
 }
 
 static void free_buffers(brisk_hip_ctx* c) {
-  hipFree(c->B.pyr); hipFree(c->B.smap); hipFree(c->B.cand); hipFree(c->B.tie_idx); hipFree(c->B.keys);
+  hipFree(c->B.pyr); hipFree(c->B.smap); hipFree(c->B.cand); hipFree(c->B.blocks); hipFree(c->B.tie_idx); hipFree(c->B.keys);
   hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->D.dkp); hipFree(c->D.dscale);
   hipFree(c->D.desc); hipFree(c->d_kp_in); hipFree(c->d_n_in);
   c->B = BriskDetectBuffers{};
@@ -126,6 +127,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMalloc(&c->B.pyr, (size_t)slots * pyr + 256));
   HIPCHK(c, hipMalloc(&c->B.smap, ((size_t)slots * pyr + 256) * sizeof(uint16_t)));
   HIPCHK(c, hipMalloc(&c->B.cand, (size_t)slots * c->cand_cap * sizeof(BriskCand)));
+  HIPCHK(c, hipMalloc(&c->B.blocks, (size_t)slots * c->cand_cap * 64));
   HIPCHK(c, hipMalloc(&c->B.tie_idx, (size_t)slots * BRISK_MAX_LAYERS * c->tie_cap * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->B.keys, (size_t)slots * c->cand_cap * 2 * sizeof(unsigned)));
   HIPCHK(c, hipMalloc(&c->B.counters, (size_t)slots * sizeof(BriskFrameCounters)));
@@ -304,6 +306,7 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   make_geometry(w, h, threshold, octaves, &ctx->G, &ctx->T);
+  ctx->G.debug_flags = ctx->debug_flags;
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
   brisk_prof_begin_call(&ctx->prof);
@@ -507,6 +510,13 @@ int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls) {
   }
   if (calls) *calls = n;
   P.calls = 0;
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_debug_set_flags(brisk_hip_ctx* ctx, int flags) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->debug_flags = flags;
   return BRISK_HIP_OK;
 }
 

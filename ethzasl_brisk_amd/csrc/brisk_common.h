@@ -61,6 +61,7 @@ struct BriskGeom {
   int pyr_elems;       // total elements per frame (sum of stride*h, 256-aligned per layer)
   int threshold;       // AGAST threshold (20..255)
   int single_layer;    // octaves == 0
+  int debug_flags;     // bit0: send every candidate through k_classify_refine_direct (tests the safety net)
   BriskLayerGeom L[BRISK_MAX_LAYERS];
 };
 
@@ -87,7 +88,8 @@ struct BriskFrameCounters {
   int nkp;                          // final keypoints (detect order)
   int ndesc;                        // keypoints surviving the descriptor border filter
   int overflow;                     // bit0 cand overflow, bit1 tie overflow, bit2 keypoint overflow
-  int pad[4];
+  int nredo;                        // candidates deferred to k_classify_refine_direct
+  int pad[3];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)

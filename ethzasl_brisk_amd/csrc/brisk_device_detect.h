@@ -17,11 +17,48 @@ BRISK_HD int brisk_max(int a, int b) { return a > b ? a : b; }
 BRISK_HD int brisk_min3(int a, int b, int c) { return brisk_min(brisk_min(a, b), c); }
 BRISK_HD int brisk_max3(int a, int b, int c) { return brisk_max(brisk_max(a, b), c); }
 
+// Block of up to 16 pre-evaluated score values, held in four 32-bit words (registers, not memory):
+// the kernels evaluate a candidate's score patches with one lane per pixel and then run the scalar
+// classification / refinement logic on these blocks.  A read outside the block raises *miss and the
+// caller redoes the candidate with direct evaluation, so a block can never change a result.
+struct BriskScoreBlock {
+  uint32_t w0, w1, w2, w3;
+  int x0, y0, cw, ch;  // block origin and extent (cw * ch <= 16); cw == 0: no block
+};
+
 struct BriskLayerView {
   const uint8_t* img;   // layer image
   uint16_t* smap;       // score-state map (same stride)
   int w, h, stride;
+  BriskScoreBlock blk;    // brisk_V() values
+  BriskScoreBlock blk58;  // brisk_V58<DIRECT>() values (3x3)
+  mutable int miss;       // set to 1 when a block is enabled but does not cover an access
 };
+
+BRISK_HD void brisk_block_clear(BriskScoreBlock* b) { b->w0 = b->w1 = b->w2 = b->w3 = 0; b->x0 = b->y0 = b->cw = b->ch = 0; }
+BRISK_HD void brisk_block_from_bytes(BriskScoreBlock* b, const uint8_t* v, int n, int x0, int y0, int cw, int ch) {
+  uint32_t w[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) w[i >> 2] |= (uint32_t)v[i] << (8 * (i & 3));
+  b->w0 = w[0]; b->w1 = w[1]; b->w2 = w[2]; b->w3 = w[3];
+  b->x0 = x0; b->y0 = y0; b->cw = cw; b->ch = ch;
+}
+BRISK_HD int brisk_block_get(const BriskScoreBlock& b, int idx) {
+  const uint32_t w = (idx < 8) ? ((idx < 4) ? b.w0 : b.w1) : ((idx < 12) ? b.w2 : b.w3);
+  return (int)((w >> ((idx & 3) * 8)) & 0xFFu);
+}
+
+// Large helpers that are called from several places are kept out of line in device code (register
+// pressure / code size of the refinement kernel); on the host they are ordinary static functions.
+#if defined(__HIPCC__)
+#ifdef BRISK_OUTLINE_HELPERS
+#define BRISK_HD_OUTLINE __host__ __device__ static __attribute__((noinline))
+#else
+#define BRISK_HD_OUTLINE __host__ __device__ static inline
+#endif
+#else
+#define BRISK_HD_OUTLINE static
+#endif
+
 
 // ---------------------------------------------------------------------------------------------
 // Down-sampling (brisk/src/image-down-sampling.cc)
@@ -159,17 +196,63 @@ BRISK_HD int brisk_Kp(const BriskLayerView& L, int x, int y) {
   return brisk_Kp_from_M(brisk_oast9_16_M(L.img + (long)y * L.stride + x, L.stride));
 }
 
-BRISK_HD int brisk_V(const BriskLayerView& L, int x, int y) {
+BRISK_HD int brisk_V_eval(const BriskLayerView& L, int x, int y) {
   if (brisk_border3(L, x, y)) return 0;
   const int D = BRISK_SM_D(L.smap[(long)y * L.stride + x]);
   if (D > 2) return D;
   return brisk_Kp(L, x, y);
 }
+// DIRECT = true: evaluate from the image.  DIRECT = false: read the view's pre-evaluated score block
+// (kernel fast path; contains no evaluation code at all, a miss only raises the flag).
+template <bool DIRECT>
+BRISK_HD int brisk_V(const BriskLayerView& L, int x, int y) {
+  if (DIRECT) return brisk_V_eval(L, x, y);
+  const unsigned ux = (unsigned)(x - L.blk.x0), uy = (unsigned)(y - L.blk.y0);
+  if (ux < (unsigned)L.blk.cw && uy < (unsigned)L.blk.ch) return brisk_block_get(L.blk, (int)(uy * L.blk.cw + ux));
+  L.miss = 1;
+  return 0;
+}
 
 // GetAgastScore_5_8(x, y, 1) (brisk-layer.cc:134-145)
-BRISK_HD int brisk_V58(const BriskLayerView& L, int x, int y) {
+BRISK_HD int brisk_V58_eval(const BriskLayerView& L, int x, int y) {
   if (x < 2 || y < 2 || x >= L.w - 2 || y >= L.h - 2) return 0;
   return brisk_Kp_from_M(brisk_agast5_8_M(L.img + (long)y * L.stride + x, L.stride));
+}
+template <bool DIRECT>
+BRISK_HD int brisk_V58(const BriskLayerView& L, int x, int y) {
+  if (DIRECT) return brisk_V58_eval(L, x, y);
+  const unsigned ux = (unsigned)(x - L.blk58.x0), uy = (unsigned)(y - L.blk58.y0);
+  if (L.blk58.cw && ux < 3u && uy < 3u) return brisk_block_get(L.blk58, (int)(uy * 3 + ux));
+  L.miss = 1;
+  return 0;
+}
+
+// Anchors of the score blocks a candidate at (x, y) on `layer` can read on the neighbouring layers
+// (GetScoreMaxAbove / GetScoreMaxBelow windows incl. the 3x3 patch around their maximum and the tie rule):
+// 4x4 blocks, above anchored at (int(x_1) - 1, ...), below at (int(x_1), ...).
+BRISK_HD void brisk_block_anchor(bool above, bool odd, int x_layer, int y_layer, int* ax, int* ay) {
+  float x_1, y_1;
+  if (above) {
+    if (!odd) {
+      x_1 = (float)((float)(4 * (x_layer)-1 - 2) / 6.0);
+      y_1 = (float)((float)(4 * (y_layer)-1 - 2) / 6.0);
+    } else {
+      x_1 = (float)(6 * (x_layer)-1 - 3) / 8.0f;
+      y_1 = (float)(6 * (y_layer)-1 - 3) / 8.0f;
+    }
+    *ax = (int)x_1 - 1;
+    *ay = (int)y_1 - 1;
+  } else {
+    if (!odd) {
+      x_1 = (float)((float)(8 * (x_layer) + 1 - 4) / 6.0);
+      y_1 = (float)((float)(8 * (y_layer) + 1 - 4) / 6.0);
+    } else {
+      x_1 = (float)((float)(6 * (x_layer) + 1 - 3) / 4.0);
+      y_1 = (float)((float)(6 * (y_layer) + 1 - 3) / 4.0);
+    }
+    *ax = (int)x_1;
+    *ay = (int)y_1;
+  }
 }
 
 // Touch recorder: which pixels of the layer above a GetScoreMaxAbove call score-touches
@@ -186,13 +269,15 @@ BRISK_HD void brisk_touch(BriskTouch* t, const BriskLayerView& L, int x, int y) 
   if (bx >= 0 && bx < 4 && by >= 0 && by < 4) t->mask |= 1u << (by * 4 + bx);
 }
 
+template <bool DIRECT>
 BRISK_HD int brisk_Vt(const BriskLayerView& L, int x, int y, BriskTouch* t) {
   brisk_touch(t, L, x, y);
-  return brisk_V(L, x, y);
+  return brisk_V<DIRECT>(L, x, y);
 }
 
 // GetAgastScore(float, float, 1) (brisk-layer.cc:147-161): bilinear blend of 4 integer scores,
 // all four always evaluated (and touched), result truncated to u8.
+template <bool DIRECT>
 BRISK_HD int brisk_Vf(const BriskLayerView& L, float xf, float yf, BriskTouch* t) {
   const int x = (int)xf;
   const float rx1 = xf - (float)x;
@@ -200,17 +285,17 @@ BRISK_HD int brisk_Vf(const BriskLayerView& L, float xf, float yf, BriskTouch* t
   const int y = (int)yf;
   const float ry1 = yf - (float)y;
   const float ry = 1.0f - ry1;
-  const int s00 = brisk_Vt(L, x, y, t);
-  const int s10 = brisk_Vt(L, x + 1, y, t);
-  const int s01 = brisk_Vt(L, x, y + 1, t);
-  const int s11 = brisk_Vt(L, x + 1, y + 1, t);
+  const int s00 = brisk_Vt<DIRECT>(L, x, y, t);
+  const int s10 = brisk_Vt<DIRECT>(L, x + 1, y, t);
+  const int s01 = brisk_Vt<DIRECT>(L, x, y + 1, t);
+  const int s11 = brisk_Vt<DIRECT>(L, x + 1, y + 1, t);
   return (int)(uint8_t)(rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Subpixel2D (brisk/src/brisk-scale-space.cc:1230-1364), including delta_y = delta_x1/2 (:1351,1355)
 // ---------------------------------------------------------------------------------------------
-BRISK_HD float brisk_subpixel2d(const int s_0_0, const int s_0_1, const int s_0_2, const int s_1_0,
+BRISK_HD_OUTLINE float brisk_subpixel2d(const int s_0_0, const int s_0_1, const int s_0_2, const int s_1_0,
                                 const int s_1_1, const int s_1_2, const int s_2_0, const int s_2_1,
                                 const int s_2_2, float& delta_x, float& delta_y) {
   const int tmp1 = s_0_0 + s_0_2 - 2 * s_1_1 + s_2_0 + s_2_2;
@@ -286,17 +371,18 @@ BRISK_HD float brisk_subpixel2d(const int s_0_0, const int s_0_1, const int s_0_
 }
 
 // 3x3 patch around (x, y) with integer score access + Subpixel2D
+template <bool DIRECT>
 BRISK_HD float brisk_patch_subpixel(const BriskLayerView& L, int x, int y, BriskTouch* t, float& dx, float& dy,
                                     int* centre) {
-  const int s_0_0 = brisk_Vt(L, x - 1, y - 1, t);
-  const int s_1_0 = brisk_Vt(L, x, y - 1, t);
-  const int s_2_0 = brisk_Vt(L, x + 1, y - 1, t);
-  const int s_2_1 = brisk_Vt(L, x + 1, y, t);
-  const int s_1_1 = brisk_Vt(L, x, y, t);
-  const int s_0_1 = brisk_Vt(L, x - 1, y, t);
-  const int s_0_2 = brisk_Vt(L, x - 1, y + 1, t);
-  const int s_1_2 = brisk_Vt(L, x, y + 1, t);
-  const int s_2_2 = brisk_Vt(L, x + 1, y + 1, t);
+  const int s_0_0 = brisk_Vt<DIRECT>(L, x - 1, y - 1, t);
+  const int s_1_0 = brisk_Vt<DIRECT>(L, x, y - 1, t);
+  const int s_2_0 = brisk_Vt<DIRECT>(L, x + 1, y - 1, t);
+  const int s_2_1 = brisk_Vt<DIRECT>(L, x + 1, y, t);
+  const int s_1_1 = brisk_Vt<DIRECT>(L, x, y, t);
+  const int s_0_1 = brisk_Vt<DIRECT>(L, x - 1, y, t);
+  const int s_0_2 = brisk_Vt<DIRECT>(L, x - 1, y + 1, t);
+  const int s_1_2 = brisk_Vt<DIRECT>(L, x, y + 1, t);
+  const int s_2_2 = brisk_Vt<DIRECT>(L, x + 1, y + 1, t);
   if (centre) *centre = s_1_1;
   return brisk_subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, dx, dy);
 }
@@ -304,7 +390,7 @@ BRISK_HD float brisk_patch_subpixel(const BriskLayerView& L, int x, int y, Brisk
 // ---------------------------------------------------------------------------------------------
 // Refine1D family (brisk-scale-space.cc:1101-1228)
 // ---------------------------------------------------------------------------------------------
-BRISK_HD float brisk_refine1d(const float s_05, const float s0, const float s05, float& max) {
+BRISK_HD_OUTLINE float brisk_refine1d(const float s_05, const float s0, const float s05, float& max) {
   const int i_05 = (int)(1024.0 * s_05 + 0.5);
   const int i0 = (int)(1024.0 * s0 + 0.5);
   const int i05 = (int)(1024.0 * s05 + 0.5);
@@ -324,7 +410,7 @@ BRISK_HD float brisk_refine1d(const float s_05, const float s0, const float s05,
   return ret_val;
 }
 
-BRISK_HD float brisk_refine1d_1(const float s_05, const float s0, const float s05, float& max) {
+BRISK_HD_OUTLINE float brisk_refine1d_1(const float s_05, const float s0, const float s05, float& max) {
   const int i_05 = (int)(1024.0 * s_05 + 0.5);
   const int i0 = (int)(1024.0 * s0 + 0.5);
   const int i05 = (int)(1024.0 * s05 + 0.5);
@@ -344,7 +430,7 @@ BRISK_HD float brisk_refine1d_1(const float s_05, const float s0, const float s0
   return ret_val;
 }
 
-BRISK_HD float brisk_refine1d_2(const float s_05, const float s0, const float s05, float& max) {
+BRISK_HD_OUTLINE float brisk_refine1d_2(const float s_05, const float s0, const float s05, float& max) {
   const int i_05 = (int)(1024.0 * s_05 + 0.5);
   const int i0 = (int)(1024.0 * s0 + 0.5);
   const int i05 = (int)(1024.0 * s05 + 0.5);
@@ -368,6 +454,7 @@ BRISK_HD float brisk_refine1d_2(const float s_05, const float s0, const float s0
 // GetScoreMaxAbove / GetScoreMaxBelow (brisk-scale-space.cc:757-1099), history-free evaluation
 // with touch recording.  `above` selects the window mapping; `odd` = (layer % 2 == 1).
 // ---------------------------------------------------------------------------------------------
+template <bool DIRECT>
 BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above, const bool odd, const int x_layer,
                                      const int y_layer, const int thr, bool& ismax, float& dx, float& dy,
                                      BriskTouch* t) {
@@ -407,54 +494,54 @@ BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above,
   int max_x = xs;
   int max_y = ys;
   float tmp_max;
-  float max = (float)brisk_Vf(Lo, x_1, y_1, t);
+  float max = (float)brisk_Vf<DIRECT>(Lo, x_1, y_1, t);
   if (max > threshold) return 0;
   for (int x = xs; x <= xe; x++) {
-    tmp_max = (float)brisk_Vf(Lo, (float)x, y_1, t);
+    tmp_max = (float)brisk_Vf<DIRECT>(Lo, (float)x, y_1, t);
     if (tmp_max > threshold) return 0;
     if (tmp_max > max) { max = tmp_max; max_x = x; }
   }
-  tmp_max = (float)brisk_Vf(Lo, x1, y_1, t);
+  tmp_max = (float)brisk_Vf<DIRECT>(Lo, x1, y_1, t);
   if (tmp_max > threshold) return 0;
   if (tmp_max > max) { max = tmp_max; max_x = xe; }
 
   for (int y = ys; y <= ye; y++) {
-    tmp_max = (float)brisk_Vf(Lo, x_1, (float)y, t);
+    tmp_max = (float)brisk_Vf<DIRECT>(Lo, x_1, (float)y, t);
     if (tmp_max > threshold) return 0;
     if (tmp_max > max) { max = tmp_max; max_x = xs; max_y = y; }
     for (int x = xs; x <= xe; x++) {
-      tmp_max = (float)brisk_Vt(Lo, x, y, t);
+      tmp_max = (float)brisk_Vt<DIRECT>(Lo, x, y, t);
       if (tmp_max > threshold) return 0;
       if (!above && tmp_max == max) {  // tie rule exists only in GetScoreMaxBelow (:987-1010)
-        const int t1 = 2 * (brisk_Vt(Lo, x - 1, y, t) + brisk_Vt(Lo, x + 1, y, t) + brisk_Vt(Lo, x, y + 1, t) +
-                            brisk_Vt(Lo, x, y - 1, t)) +
-                       (brisk_Vt(Lo, x + 1, y + 1, t) + brisk_Vt(Lo, x - 1, y + 1, t) + brisk_Vt(Lo, x + 1, y - 1, t) +
-                        brisk_Vt(Lo, x - 1, y - 1, t));
-        const int t2 = 2 * (brisk_Vt(Lo, max_x - 1, max_y, t) + brisk_Vt(Lo, max_x + 1, max_y, t) +
-                            brisk_Vt(Lo, max_x, max_y + 1, t) + brisk_Vt(Lo, max_x, max_y - 1, t)) +
-                       (brisk_Vt(Lo, max_x + 1, max_y + 1, t) + brisk_Vt(Lo, max_x - 1, max_y + 1, t) +
-                        brisk_Vt(Lo, max_x + 1, max_y - 1, t) + brisk_Vt(Lo, max_x - 1, max_y - 1, t));
+        const int t1 = 2 * (brisk_Vt<DIRECT>(Lo, x - 1, y, t) + brisk_Vt<DIRECT>(Lo, x + 1, y, t) + brisk_Vt<DIRECT>(Lo, x, y + 1, t) +
+                            brisk_Vt<DIRECT>(Lo, x, y - 1, t)) +
+                       (brisk_Vt<DIRECT>(Lo, x + 1, y + 1, t) + brisk_Vt<DIRECT>(Lo, x - 1, y + 1, t) + brisk_Vt<DIRECT>(Lo, x + 1, y - 1, t) +
+                        brisk_Vt<DIRECT>(Lo, x - 1, y - 1, t));
+        const int t2 = 2 * (brisk_Vt<DIRECT>(Lo, max_x - 1, max_y, t) + brisk_Vt<DIRECT>(Lo, max_x + 1, max_y, t) +
+                            brisk_Vt<DIRECT>(Lo, max_x, max_y + 1, t) + brisk_Vt<DIRECT>(Lo, max_x, max_y - 1, t)) +
+                       (brisk_Vt<DIRECT>(Lo, max_x + 1, max_y + 1, t) + brisk_Vt<DIRECT>(Lo, max_x - 1, max_y + 1, t) +
+                        brisk_Vt<DIRECT>(Lo, max_x + 1, max_y - 1, t) + brisk_Vt<DIRECT>(Lo, max_x - 1, max_y - 1, t));
         if (t1 > t2) { max_x = x; max_y = y; }
       }
       if (tmp_max > max) { max = tmp_max; max_x = x; max_y = y; }
     }
-    tmp_max = (float)brisk_Vf(Lo, x1, (float)y, t);
+    tmp_max = (float)brisk_Vf<DIRECT>(Lo, x1, (float)y, t);
     if (tmp_max > threshold) return 0;
     if (tmp_max > max) { max = tmp_max; max_x = xe; max_y = y; }
   }
 
   // bottom row: never tested against the drop threshold (:843-863, :1027-1047)
-  tmp_max = (float)brisk_Vf(Lo, x_1, y1, t);
+  tmp_max = (float)brisk_Vf<DIRECT>(Lo, x_1, y1, t);
   if (tmp_max > max) { max = tmp_max; max_x = xs; max_y = ye; }
   for (int x = xs; x <= xe; x++) {
-    tmp_max = (float)brisk_Vf(Lo, (float)x, y1, t);
+    tmp_max = (float)brisk_Vf<DIRECT>(Lo, (float)x, y1, t);
     if (tmp_max > max) { max = tmp_max; max_x = x; max_y = ye; }
   }
-  tmp_max = (float)brisk_Vf(Lo, x1, y1, t);
+  tmp_max = (float)brisk_Vf<DIRECT>(Lo, x1, y1, t);
   if (tmp_max > max) { max = tmp_max; max_x = xe; max_y = ye; }
 
   float dx_1, dy_1;
-  const float refined_max = brisk_patch_subpixel(Lo, max_x, max_y, t, dx_1, dy_1, nullptr);
+  const float refined_max = brisk_patch_subpixel<DIRECT>(Lo, max_x, max_y, t, dx_1, dy_1, nullptr);
   const float real_x = (float)max_x + dx_1;
   const float real_y = (float)max_y + dy_1;
   bool returnrefined = true;
@@ -501,6 +588,7 @@ BRISK_HD int brisk_probe_index(int dx, int dy) {
 }
 
 // returns status (REJ / PASS / TIE) and the number of probes issued
+template <bool DIRECT>
 BRISK_HD unsigned brisk_classify(const BriskLayerView& L, int x, int y, int centre, int* nprobed) {
   bool tie = false;
   for (int k = 0; k < 8; ++k) {
@@ -511,7 +599,7 @@ BRISK_HD unsigned brisk_classify(const BriskLayerView& L, int x, int y, int cent
       if (D > 2) {
         s = D;
       } else {
-        const int K = brisk_Kp(L, nx, ny);
+        const int K = brisk_V<DIRECT>(L, nx, ny);  // == K' for a non-detection
         s = (K >= centre) ? K : 0;
       }
     }
@@ -530,9 +618,11 @@ BRISK_HD unsigned brisk_classify(const BriskLayerView& L, int x, int y, int cent
 // Returns true if a keypoint results.  e5 = the candidate reaches its own-layer patch reads;
 // touch = score-touches on the layer above (event e3).
 // ---------------------------------------------------------------------------------------------
-BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView* Lv, const int layer, const int x_layer,
-                           const int y_layer, BriskKeyPoint* kp, bool* e5, BriskTouch* touch) {
-  const BriskLayerView& tl = Lv[layer];
+// Lbelow / tl / Labove: views of layer-1, layer, layer+1 (the neighbours may be dummies where they do not exist).
+template <bool DIRECT>
+BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, const BriskLayerView& tl,
+                           const BriskLayerView& Labove, const int layer, const int x_layer, const int y_layer,
+                           BriskKeyPoint* kp, bool* e5, BriskTouch* touch) {
   const float lscale = G.L[layer].scale, loffset = G.L[layer].offset;
   BriskTouch none;
   none.on = false; none.mask = 0; none.x0 = 0; none.y0 = 0;
@@ -545,7 +635,7 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView* Lv, const i
   if (G.single_layer) {  // :172-209 (patch via float access: 4x4 touch footprint)
     float delta_x, delta_y;
     *e5 = true;
-    const float max = brisk_patch_subpixel(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
+    const float max = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
     kp->x = (float)x_layer + delta_x;
     kp->y = (float)y_layer + delta_y;
     kp->size = BRISK_BASIC_SIZE;
@@ -557,12 +647,12 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView* Lv, const i
   if (layer == G.nlayers - 1) {  // :215-256
     bool ismax;
     float dx, dy;
-    const int centre = brisk_V(tl, x_layer, y_layer);
-    brisk_score_max_other(Lv[layer - 1], false, (layer & 1) != 0, x_layer, y_layer, centre, ismax, dx, dy, &none);
+    const int centre = brisk_V<DIRECT>(tl, x_layer, y_layer);
+    brisk_score_max_other<DIRECT>(Lbelow, false, (layer & 1) != 0, x_layer, y_layer, centre, ismax, dx, dy, &none);
     if (!ismax) return false;
     *e5 = true;
     float delta_x, delta_y;
-    const float max = brisk_patch_subpixel(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
+    const float max = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
     kp->x = ((float)x_layer + delta_x) * lscale + loffset;
     kp->y = ((float)y_layer + delta_y) * lscale + loffset;
     kp->size = BRISK_BASIC_SIZE * lscale;
@@ -571,11 +661,11 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView* Lv, const i
   }
 
   // Refine3D
-  const int center = brisk_V(tl, x_layer, y_layer);
+  const int center = brisk_V<DIRECT>(tl, x_layer, y_layer);
   bool ismax = true;
   float delta_x_above = 0, delta_y_above = 0;
   touch->on = true;
-  const float max_above = brisk_score_max_other(Lv[layer + 1], true, (layer & 1) != 0, x_layer, y_layer, center,
+  const float max_above = brisk_score_max_other<DIRECT>(Labove, true, (layer & 1) != 0, x_layer, y_layer, center,
                                                 ismax, delta_x_above, delta_y_above, touch);
   if (!ismax) return false;
 
@@ -585,29 +675,29 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView* Lv, const i
     float delta_x_below, delta_y_below;
     float max_below_float;
     if (layer == 0) {  // virtual layer below octave 0 via AGAST 5_8 (:558-592)
-      const int s_0_0 = brisk_V58(tl, x_layer - 1, y_layer - 1);
-      const int s_1_0 = brisk_V58(tl, x_layer, y_layer - 1);
-      const int s_2_0 = brisk_V58(tl, x_layer + 1, y_layer - 1);
-      const int s_2_1 = brisk_V58(tl, x_layer + 1, y_layer);
-      const int s_1_1 = brisk_V58(tl, x_layer, y_layer);
-      const int s_0_1 = brisk_V58(tl, x_layer - 1, y_layer);
-      const int s_0_2 = brisk_V58(tl, x_layer - 1, y_layer + 1);
-      const int s_1_2 = brisk_V58(tl, x_layer, y_layer + 1);
-      const int s_2_2 = brisk_V58(tl, x_layer + 1, y_layer + 1);
+      const int s_0_0 = brisk_V58<DIRECT>(tl, x_layer - 1, y_layer - 1);
+      const int s_1_0 = brisk_V58<DIRECT>(tl, x_layer, y_layer - 1);
+      const int s_2_0 = brisk_V58<DIRECT>(tl, x_layer + 1, y_layer - 1);
+      const int s_2_1 = brisk_V58<DIRECT>(tl, x_layer + 1, y_layer);
+      const int s_1_1 = brisk_V58<DIRECT>(tl, x_layer, y_layer);
+      const int s_0_1 = brisk_V58<DIRECT>(tl, x_layer - 1, y_layer);
+      const int s_0_2 = brisk_V58<DIRECT>(tl, x_layer - 1, y_layer + 1);
+      const int s_1_2 = brisk_V58<DIRECT>(tl, x_layer, y_layer + 1);
+      const int s_2_2 = brisk_V58<DIRECT>(tl, x_layer + 1, y_layer + 1);
       int mb = s_0_0;
       mb = brisk_max(mb, s_1_0); mb = brisk_max(mb, s_2_0); mb = brisk_max(mb, s_2_1); mb = brisk_max(mb, s_1_1);
       mb = brisk_max(mb, s_0_1); mb = brisk_max(mb, s_0_2); mb = brisk_max(mb, s_1_2); mb = brisk_max(mb, s_2_2);
       brisk_subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, delta_x_below, delta_y_below);
       max_below_float = (float)mb;
     } else {
-      max_below_float = brisk_score_max_other(Lv[layer - 1], false, false, x_layer, y_layer, center, ismax,
+      max_below_float = brisk_score_max_other<DIRECT>(Lbelow, false, false, x_layer, y_layer, center, ismax,
                                               delta_x_below, delta_y_below, &none);
       if (!ismax) return false;
     }
     *e5 = true;
     float delta_x_layer, delta_y_layer;
     int s_1_1;
-    const float max_layer = brisk_patch_subpixel(tl, x_layer, y_layer, &none, delta_x_layer, delta_y_layer, &s_1_1);
+    const float max_layer = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x_layer, delta_y_layer, &s_1_1);
     if (layer == 0) {
       if (s_1_1 - BRISK_MAX_THRESHOLD <= (int)max_above) doScaleRefinement = false;
     } else {
@@ -647,13 +737,13 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView* Lv, const i
     }
   } else {
     float delta_x_below, delta_y_below;
-    const float max_below = brisk_score_max_other(Lv[layer - 1], false, true, x_layer, y_layer, center, ismax,
+    const float max_below = brisk_score_max_other<DIRECT>(Lbelow, false, true, x_layer, y_layer, center, ismax,
                                                   delta_x_below, delta_y_below, &none);
     if (!ismax) return false;
     *e5 = true;
     float delta_x_layer, delta_y_layer;
     int s_1_1;
-    const float max_layer = brisk_patch_subpixel(tl, x_layer, y_layer, &none, delta_x_layer, delta_y_layer, &s_1_1);
+    const float max_layer = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x_layer, delta_y_layer, &s_1_1);
     if ((s_1_1 - BRISK_MAX_THRESHOLD < (max_above)) || (s_1_1 - BRISK_MAX_THRESHOLD < (max_below))) {
       if ((s_1_1 - BRISK_MIN_DROP > (max_above)) || (s_1_1 - BRISK_MIN_DROP > (max_below))) {
         doScaleRefinement = false;
@@ -744,23 +834,29 @@ BRISK_HD int brisk_state_at(const BriskLayerView& L, const bool float_patch, con
   return (Kp >= t_last) ? Kp : 0;
 }
 
-// IsMax2D steps 3-4 (brisk-scale-space.cc:499-530) for a tie candidate.  Returns pass / fail.
-BRISK_HD bool brisk_tie_eval(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
-                             int cy, const uint16_t* sm_local, int lx0, int ly0, int lw) {
-  const int centre = BRISK_SM_D(sm_local[(cy - ly0) * lw + (cx - lx0)]);
-  int s[8];
-  for (int k = 0; k < 8; ++k) {
-    const int nx = cx + brisk_probe_dx(k), ny = cy + brisk_probe_dy(k);
-    const int m = brisk_state_at(L, float_patch, pass_touch2x2, nx, ny, cx, cy, false, sm_local, lx0, ly0, lw);
-    if (m > 2) {
-      s[k] = m;
-    } else if (brisk_border3(L, nx, ny)) {
-      s[k] = 0;
-    } else {
-      const int K = brisk_Kp(L, nx, ny);
-      s[k] = (K >= centre) ? K : 0;
-    }
-  }
+// IsMax2D steps 3-4 (brisk-scale-space.cc:499-530) for a tie candidate, split so that the per-pixel
+// cache replays can run one lane per pixel:
+//   ret[k]   (k = 0..7, probe order)  value the candidate's k-th probe returns
+//   raw[25]  raw map values of the 5x5 block around the candidate after its 8 probes
+BRISK_HD int brisk_tie_probe_value(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
+                                   int cy, int centre, int k, const uint16_t* sm_local, int lx0, int ly0, int lw) {
+  const int nx = cx + brisk_probe_dx(k), ny = cy + brisk_probe_dy(k);
+  const int m = brisk_state_at(L, float_patch, pass_touch2x2, nx, ny, cx, cy, false, sm_local, lx0, ly0, lw);
+  if (m > 2) return m;
+  if (brisk_border3(L, nx, ny)) return 0;
+  const int K = brisk_Kp(L, nx, ny);
+  return (K >= centre) ? K : 0;
+}
+
+BRISK_HD int brisk_tie_raw_value(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
+                                 int cy, int centre, int q /* 0..24, row-major 5x5 */, const uint16_t* sm_local,
+                                 int lx0, int ly0, int lw) {
+  const int qx = cx + (q % 5) - 2, qy = cy + (q / 5) - 2;
+  if (qx == cx && qy == cy) return centre;
+  return brisk_state_at(L, float_patch, pass_touch2x2, qx, qy, cx, cy, true, sm_local, lx0, ly0, lw);
+}
+
+BRISK_HD bool brisk_tie_decide(int centre, const int* s /* 8 probe values */, const int* raw /* 25 */) {
   // s: W,E,N,S,SW,SE,NE,NW
   const int smoothedcenter = 4 * centre + 2 * (s[0] + s[1] + s[2] + s[3]) + s[7] + s[6] + s[4] + s[5];
   // tie list order: (-1,-1),(0,-1),(1,-1),(-1,0),(1,0),(-1,1),(0,1),(1,1)
@@ -768,18 +864,20 @@ BRISK_HD bool brisk_tie_eval(const BriskLayerView& L, const bool float_patch, co
   for (int o = 0; o < 8; ++o) {
     const int k = order[o];
     if (s[k] != centre) continue;
-    const int nx = cx + brisk_probe_dx(k), ny = cy + brisk_probe_dy(k);
+    const int nx = brisk_probe_dx(k) + 2, ny = brisk_probe_dy(k) + 2;  // position inside the 5x5 block
     int other = 0;
     for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int wgt = (dx == 0 ? 2 : 1) * (dy == 0 ? 2 : 1);
-        const int qx = nx + dx, qy = ny + dy;
-        int m;
-        if (qx == cx && qy == cy) m = centre;
-        else m = brisk_state_at(L, float_patch, pass_touch2x2, qx, qy, cx, cy, true, sm_local, lx0, ly0, lw);
-        other += wgt * m;
-      }
+      for (int dx = -1; dx <= 1; ++dx) other += (dx == 0 ? 2 : 1) * (dy == 0 ? 2 : 1) * raw[(ny + dy) * 5 + nx + dx];
     if (other > smoothedcenter) return false;
   }
   return true;
+}
+
+BRISK_HD bool brisk_tie_eval(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
+                             int cy, const uint16_t* sm_local, int lx0, int ly0, int lw) {
+  const int centre = BRISK_SM_D(sm_local[(cy - ly0) * lw + (cx - lx0)]);
+  int s[8], raw[25];
+  for (int k = 0; k < 8; ++k) s[k] = brisk_tie_probe_value(L, float_patch, pass_touch2x2, cx, cy, centre, k, sm_local, lx0, ly0, lw);
+  for (int q = 0; q < 25; ++q) raw[q] = brisk_tie_raw_value(L, float_patch, pass_touch2x2, cx, cy, centre, q, sm_local, lx0, ly0, lw);
+  return brisk_tie_decide(centre, s, raw);
 }

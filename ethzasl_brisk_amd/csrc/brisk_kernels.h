@@ -18,6 +18,7 @@ struct BriskDetectBuffers {
   uint8_t* pyr;                  // [slots][pyr_elems]
   uint16_t* smap;                // [slots][pyr_elems]
   BriskCand* cand;               // [slots][cand_cap]
+  uint8_t* blocks;               // [slots][cand_cap][64] score blocks of the candidates
   int* tie_idx;                  // [slots][BRISK_MAX_LAYERS][tie_cap]
   unsigned* keys;                // [slots][2 * cand_cap]
   BriskFrameCounters* counters;  // [slots]

@@ -29,6 +29,9 @@ __device__ __forceinline__ BriskLayerView make_view(const BriskGeom& G, uint8_t*
   v.w = G.L[l].w;
   v.h = G.L[l].h;
   v.stride = G.L[l].stride;
+  brisk_block_clear(&v.blk);
+  brisk_block_clear(&v.blk58);
+  v.miss = 0;
   return v;
 }
 
@@ -168,65 +171,191 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_classify_refine: one thread per candidate.
+// k_score_blocks: lane-parallel evaluation of every candidate's score blocks - own 3x3, AGAST 5_8 3x3
+// (layer 0), 4x4 on the layer above, 4x4 on the layer below - one pixel per lane (16 ring loads + closed-form
+// segment test), 64 bytes per candidate.  A wave takes SB_PER_WAVE candidates, unrolled so that their loads
+// overlap (the kernel is latency-bound otherwise).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) k_classify_refine(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
-                                                          BriskFrameCounters* counters, int* tie_idx, int cand_cap,
-                                                          int tie_cap) {
+#define SB_WAVES 4
+#define SB_PER_WAVE 4
+__global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, const uint8_t* pyr, const uint16_t* smap,
+                                                                const BriskCand* cand, const BriskFrameCounters* counters,
+                                                                uint8_t* blocks, int cand_cap) {
   const int frame = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = min(counters[frame].ncand, cand_cap);
-  BriskLayerView Lv[BRISK_MAX_LAYERS];
-  for (int l = 0; l < G.nlayers; ++l) Lv[l] = make_view(G, pyr, smap, frame, l);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    BriskCand* c = &cand[(long)frame * cand_cap + i];
-    const int l = c->layer, x = c->x, y = c->y, D = c->D;
-    int nprobed;
-    const unsigned status = brisk_classify(Lv[l], x, y, D, &nprobed);
-    unsigned bits = ((unsigned)nprobed << 8) | (status << 12);
-    unsigned flags = 0;
-    if (status != BRISK_ST_REJ) {
-      BriskKeyPoint kp;
-      bool e5;
-      BriskTouch touch;
-      touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
-      const bool ok = brisk_refine(G, Lv, l, x, y, &kp, &e5, &touch);
-      if (ok) {
-        flags |= 1;
-        c->kx = kp.x; c->ky = kp.y; c->ksize = kp.size; c->kresp = kp.response;
+  const int q = lane >> 4, p = lane & 15;
+  for (int base = (blockIdx.x * SB_WAVES + wave) * SB_PER_WAVE; base < n; base += gridDim.x * SB_WAVES * SB_PER_WAVE) {
+#pragma unroll
+    for (int k = 0; k < SB_PER_WAVE; ++k) {
+      const int i = base + k;
+      if (i >= n) break;
+      const BriskCand* c = &cand[(long)frame * cand_cap + i];
+      const int x = c->x, y = c->y, l = c->layer;
+      const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
+      const bool has_below = !G.single_layer && (l > 0);
+      const bool has_58 = !G.single_layer && (l == 0);
+      int v = 0;
+      if (q == 0) {
+        if (p < 9) v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l), x - 1 + p % 3, y - 1 + p / 3);
+      } else if (q == 1) {
+        if (p < 9 && has_58) v = brisk_V58_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l), x - 1 + p % 3, y - 1 + p / 3);
+      } else if (q == 2) {
+        if (has_above) {
+          int ax, ay;
+          brisk_block_anchor(true, (l & 1) != 0, x, y, &ax, &ay);
+          v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l + 1), ax + (p & 3), ay + (p >> 2));
+        }
+      } else {
+        if (has_below) {
+          int bx, by;
+          brisk_block_anchor(false, (l & 1) != 0, x, y, &bx, &by);
+          v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l - 1), bx + (p & 3), by + (p >> 2));
+        }
       }
-      if (e5) { flags |= 2; bits |= BRISK_SM_E5; }
-      c->fp_x0 = (int16_t)touch.x0; c->fp_y0 = (int16_t)touch.y0; c->fp_mask = (uint16_t)touch.mask;
-      if (status == BRISK_ST_PASS && touch.mask) {  // event e3: score-touch the layer above
-        const BriskLayerView& La = Lv[l + 1];
-        for (int b = 0; b < 16; ++b)
-          if (touch.mask & (1u << b)) smap_or(La.smap, (long)(touch.y0 + (b >> 2)) * La.stride + touch.x0 + (b & 3), BRISK_SM_TOUCH);
-      }
-      if (status == BRISK_ST_TIE) {
-        const int j = atomicAdd(&counters[frame].ntie[l], 1);
-        if (j < tie_cap) tie_idx[((long)frame * BRISK_MAX_LAYERS + l) * tie_cap + j] = i;
-        else atomicOr(&counters[frame].overflow, 2);
-      }
+      blocks[((long)frame * cand_cap + i) * 64 + lane] = (uint8_t)v;
     }
-    c->status = (uint8_t)status;
-    c->flags = (uint8_t)flags;
-    smap_or(Lv[l].smap, (long)y * Lv[l].stride + x, bits);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tie_resolve: one workgroup per frame; layers in ascending order (layer i+1 needs the e3 touches
-// of layer i's resolved ties); inside a layer a Jacobi-style relaxation: a tie candidate is decided
-// once every raster-earlier tie candidate within Chebyshev distance 4 is decided.
+// k_classify_refine: IsMax2D steps 1-2 + 3-D refinement, one lane per candidate.  The lane pulls the
+// candidate's 64 score bytes (k_score_blocks) into registers and runs the scalar logic on them: no memory
+// access and no score evaluation code in this kernel.  A block miss (never observed) hands the candidate to
+// k_classify_refine_direct.
 // ------------------------------------------------------------------------------------------------
-#define TR_THREADS 256
+__global__ void __launch_bounds__(64) k_classify_refine(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
+                                                         BriskFrameCounters* counters, const uint8_t* blocks, int* tie_idx,
+                                                         int cand_cap, int tie_cap) {
+  const int frame = blockIdx.y;
+  const int n = min(counters[frame].ncand, cand_cap);
+  for (int mine = blockIdx.x * blockDim.x + threadIdx.x; mine < n; mine += gridDim.x * blockDim.x) {
+    BriskCand* c = &cand[(long)frame * cand_cap + mine];
+    const int x = c->x, y = c->y, l = c->layer, D = c->D;
+    const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
+    const bool has_below = !G.single_layer && (l > 0);
+    const bool has_58 = !G.single_layer && (l == 0);
+    BriskLayerView Lo = make_view(G, pyr, smap, frame, l);
+    BriskLayerView La = make_view(G, pyr, smap, frame, has_above ? l + 1 : l);
+    BriskLayerView Lb = make_view(G, pyr, smap, frame, has_below ? l - 1 : l);
+    const uint4* blk = reinterpret_cast<const uint4*>(blocks + ((long)frame * cand_cap + mine) * 64);
+    const uint4 o = blk[0], f = blk[1], a = blk[2], b = blk[3];
+    Lo.blk.w0 = o.x; Lo.blk.w1 = o.y; Lo.blk.w2 = o.z; Lo.blk.w3 = o.w; Lo.blk.x0 = x - 1; Lo.blk.y0 = y - 1; Lo.blk.cw = 3; Lo.blk.ch = 3;
+    if (has_58) { Lo.blk58.w0 = f.x; Lo.blk58.w1 = f.y; Lo.blk58.w2 = f.z; Lo.blk58.w3 = f.w; Lo.blk58.x0 = x - 1; Lo.blk58.y0 = y - 1; Lo.blk58.cw = 3; Lo.blk58.ch = 3; }
+    if (has_above) {
+      int ax, ay;
+      brisk_block_anchor(true, (l & 1) != 0, x, y, &ax, &ay);
+      La.blk.w0 = a.x; La.blk.w1 = a.y; La.blk.w2 = a.z; La.blk.w3 = a.w; La.blk.x0 = ax; La.blk.y0 = ay; La.blk.cw = 4; La.blk.ch = 4;
+    }
+    if (has_below) {
+      int bx, by;
+      brisk_block_anchor(false, (l & 1) != 0, x, y, &bx, &by);
+      Lb.blk.w0 = b.x; Lb.blk.w1 = b.y; Lb.blk.w2 = b.z; Lb.blk.w3 = b.w; Lb.blk.x0 = bx; Lb.blk.y0 = by; Lb.blk.cw = 4; Lb.blk.ch = 4;
+    }
+    int nprobed = 0;
+    unsigned flags = 0;
+    BriskKeyPoint kp;
+    kp.x = kp.y = kp.size = kp.response = 0.f;
+    BriskTouch touch;
+    touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
+    bool e5 = false;
+    const unsigned status = brisk_classify<false>(Lo, x, y, D, &nprobed);
+    if (status != BRISK_ST_REJ && brisk_refine<false>(G, Lb, Lo, La, l, x, y, &kp, &e5, &touch)) flags |= 1;
+    if ((Lo.miss | La.miss | Lb.miss) || (G.debug_flags & 1)) {  // leave the candidate to k_classify_refine_direct
+      c->status = 0xFF;
+      atomicAdd(&counters[frame].nredo, 1);
+      continue;
+    }
+    unsigned bits = ((unsigned)nprobed << 8) | (status << 12);
+    if (e5) { flags |= 2; bits |= BRISK_SM_E5; }
+    if (flags & 1) { c->kx = kp.x; c->ky = kp.y; c->ksize = kp.size; c->kresp = kp.response; }
+    c->fp_x0 = (int16_t)touch.x0; c->fp_y0 = (int16_t)touch.y0; c->fp_mask = (uint16_t)touch.mask;
+    c->status = (uint8_t)status;
+    c->flags = (uint8_t)flags;
+    if (status == BRISK_ST_PASS && touch.mask) {  // event e3: score-touch the layer above
+      for (int bb = 0; bb < 16; ++bb)
+        if (touch.mask & (1u << bb)) smap_or(La.smap, (long)(touch.y0 + (bb >> 2)) * La.stride + touch.x0 + (bb & 3), BRISK_SM_TOUCH);
+    }
+    if (status == BRISK_ST_TIE) {
+      const int j = atomicAdd(&counters[frame].ntie[l], 1);
+      if (j < tie_cap) tie_idx[((long)frame * BRISK_MAX_LAYERS + l) * tie_cap + j] = mine;
+      else atomicOr(&counters[frame].overflow, 2);
+    }
+    smap_or(Lo.smap, (long)y * Lo.stride + x, bits);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_classify_refine_direct: safety net of k_classify_refine.  Handles the candidates whose score blocks
+// did not cover an access (status 0xFF; none has ever been observed) with direct evaluation, one thread per
+// candidate.  Exits immediately when the frame has no such candidate.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_classify_refine_direct(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
+                                                                BriskFrameCounters* counters, int* tie_idx, int cand_cap,
+                                                                int tie_cap) {
+  const int frame = blockIdx.y;
+  if (counters[frame].nredo == 0) return;
+  const int n = min(counters[frame].ncand, cand_cap);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    BriskCand* c = &cand[(long)frame * cand_cap + i];
+    if (c->status != 0xFF) continue;
+    const int l = c->layer, x = c->x, y = c->y, D = c->D;
+    const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
+    const bool has_below = !G.single_layer && (l > 0);
+    const BriskLayerView Lo = make_view(G, pyr, smap, frame, l);
+    const BriskLayerView La = make_view(G, pyr, smap, frame, has_above ? l + 1 : l);
+    const BriskLayerView Lb = make_view(G, pyr, smap, frame, has_below ? l - 1 : l);
+    int nprobed = 0;
+    unsigned flags = 0;
+    BriskKeyPoint kp;
+    kp.x = kp.y = kp.size = kp.response = 0.f;
+    BriskTouch touch;
+    touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
+    bool e5 = false;
+    const unsigned status = brisk_classify<true>(Lo, x, y, D, &nprobed);
+    if (status != BRISK_ST_REJ && brisk_refine<true>(G, Lb, Lo, La, l, x, y, &kp, &e5, &touch)) flags |= 1;
+    unsigned bits = ((unsigned)nprobed << 8) | (status << 12);
+    if (e5) { flags |= 2; bits |= BRISK_SM_E5; }
+    if (flags & 1) { c->kx = kp.x; c->ky = kp.y; c->ksize = kp.size; c->kresp = kp.response; }
+    c->fp_x0 = (int16_t)touch.x0; c->fp_y0 = (int16_t)touch.y0; c->fp_mask = (uint16_t)touch.mask;
+    c->status = (uint8_t)status;
+    c->flags = (uint8_t)flags;
+    if (status == BRISK_ST_PASS && touch.mask) {
+      for (int b = 0; b < 16; ++b)
+        if (touch.mask & (1u << b)) smap_or(La.smap, (long)(touch.y0 + (b >> 2)) * La.stride + touch.x0 + (b & 3), BRISK_SM_TOUCH);
+    }
+    if (status == BRISK_ST_TIE) {
+      const int j = atomicAdd(&counters[frame].ntie[l], 1);
+      if (j < tie_cap) tie_idx[((long)frame * BRISK_MAX_LAYERS + l) * tie_cap + j] = i;
+      else atomicOr(&counters[frame].overflow, 2);
+    }
+    smap_or(Lo.smap, (long)y * Lo.stride + x, bits);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tie_resolve: one workgroup per frame; layers in ascending order (layer i+1 needs the e3 touches of layer
+// i's resolved ties).  Inside a layer the tie candidates are rank-sorted into raster order and dealt to the
+// waves round-robin; a wave spins until every raster-earlier tie candidate within Chebyshev distance 4 of its
+// candidate is decided (the earliest undecided candidate never waits, so the scheme cannot deadlock), then
+// replays the lazy score cache with one lane per pixel (8 probe values + the 5x5 raw block).
+// Layers with more ties than the sort buffer fall back to a Jacobi relaxation with one thread per candidate.
+// ------------------------------------------------------------------------------------------------
+#define TR_WAVES 8
+#define TR_THREADS (TR_WAVES * 64)
 #define TR_WIN 9
+#define TR_MAXSORT 2048
+#define TR_JACOBI 128
 __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                              BriskFrameCounters* counters, const int* tie_idx,
                                                              int cand_cap, int tie_cap) {
-  __shared__ uint16_t win[TR_THREADS][TR_WIN * TR_WIN + 1];
+  __shared__ uint16_t win[TR_JACOBI][TR_WIN * TR_WIN + 1];  // per-wave windows (sorted path) / per-thread (fallback)
+  __shared__ unsigned skey[TR_MAXSORT];
+  __shared__ int sorder[TR_MAXSORT];
+  __shared__ int vals[TR_WAVES][40];
   __shared__ int remaining, progressed;
   const int frame = blockIdx.x;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int l = 0; l < G.nlayers; ++l) {
     const int n = min(counters[frame].ntie[l], tie_cap);
     if (n == 0) continue;
@@ -235,39 +364,101 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     const bool float_patch = last || G.single_layer;
     const bool touch2x2 = last && !G.single_layer;
     const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
-    for (int iter = 0; iter < 4096; ++iter) {
-      if (tid == 0) { remaining = 0; progressed = 0; }
+    if (n <= TR_MAXSORT) {
+      for (int j = tid; j < n; j += TR_THREADS) skey[j] = cand[(long)frame * cand_cap + list[j]].key;
       __syncthreads();
       for (int j = tid; j < n; j += TR_THREADS) {
-        BriskCand* c = &cand[(long)frame * cand_cap + list[j]];
-        if (c->status != BRISK_ST_TIE) continue;
+        const unsigned k = skey[j];
+        int r = 0;
+        for (int q = 0; q < n; ++q) r += (skey[q] < k) ? 1 : 0;
+        sorder[r] = list[j];
+      }
+      __syncthreads();
+      uint16_t* wl = win[wave];
+      for (int j = wave; j < n; j += TR_WAVES) {
+        BriskCand* c = &cand[(long)frame * cand_cap + sorder[j]];
         const int cx = c->x, cy = c->y;
-        uint16_t* wl = win[tid];
-        bool ready = true;
-        for (int dy = -4; dy <= 4; ++dy)
-          for (int dx = -4; dx <= 4; ++dx) {
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+          bool pending = false;
+          for (int e = lane; e < TR_WIN * TR_WIN; e += 64) {
+            const int dy = e / TR_WIN - 4, dx = e % TR_WIN - 4;
             const int qx = cx + dx, qy = cy + dy;
             unsigned v = 0;
             if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
-            wl[(dy + 4) * TR_WIN + dx + 4] = (uint16_t)v;
-            if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) ready = false;
+            wl[e] = (uint16_t)v;
+            if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) pending = true;
           }
-        if (!ready) { atomicAdd(&remaining, 1); continue; }
-        const bool pass = brisk_tie_eval(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, TR_WIN);
-        if (pass) {
-          if (c->fp_mask && l + 1 < G.nlayers) {
-            const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
-            for (int b = 0; b < 16; ++b)
-              if (c->fp_mask & (1u << b))
-                smap_or(La.smap, (long)(c->fp_y0 + (b >> 2)) * La.stride + c->fp_x0 + (b & 3), BRISK_SM_TOUCH);
-          }
-          c->status = BRISK_ST_PASS;
-          smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
-        } else {
-          c->status = BRISK_ST_FAIL;
-          smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);   // TIE (10b) -> FAIL (11b)
+          if (!__any(pending)) break;
+          __builtin_amdgcn_s_sleep(8);
         }
-        atomicAdd(&progressed, 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int centre = c->D;
+        if (lane < 8) vals[wave][lane] = brisk_tie_probe_value(L, float_patch, touch2x2, cx, cy, centre, lane, wl, cx - 4, cy - 4, TR_WIN);
+        else if (lane >= 32 && lane < 57)
+          vals[wave][8 + lane - 32] = brisk_tie_raw_value(L, float_patch, touch2x2, cx, cy, centre, lane - 32, wl, cx - 4, cy - 4, TR_WIN);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+          const bool pass = brisk_tie_decide(centre, &vals[wave][0], &vals[wave][8]);
+          if (pass) {
+            if (c->fp_mask && l + 1 < G.nlayers) {
+              const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
+              for (int b = 0; b < 16; ++b)
+                if (c->fp_mask & (1u << b))
+                  smap_or(La.smap, (long)(c->fp_y0 + (b >> 2)) * La.stride + c->fp_x0 + (b & 3), BRISK_SM_TOUCH);
+            }
+            c->status = BRISK_ST_PASS;
+            smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
+          } else {
+            c->status = BRISK_ST_FAIL;
+            smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);   // TIE (10b) -> FAIL (11b)
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      __threadfence();
+      __syncthreads();
+      continue;
+    }
+    // ---- fallback: Jacobi relaxation, one thread per candidate (first TR_JACOBI threads)
+    for (int iter = 0; iter < (1 << 20); ++iter) {
+      if (tid == 0) { remaining = 0; progressed = 0; }
+      __syncthreads();
+      if (tid < TR_JACOBI) {
+        for (int j = tid; j < n; j += TR_JACOBI) {
+          BriskCand* c = &cand[(long)frame * cand_cap + list[j]];
+          if (c->status != BRISK_ST_TIE) continue;
+          const int cx = c->x, cy = c->y;
+          uint16_t* wl = win[tid];
+          bool ready = true;
+          for (int dy = -4; dy <= 4; ++dy)
+            for (int dx = -4; dx <= 4; ++dx) {
+              const int qx = cx + dx, qy = cy + dy;
+              unsigned v = 0;
+              if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
+              wl[(dy + 4) * TR_WIN + dx + 4] = (uint16_t)v;
+              if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) ready = false;
+            }
+          if (!ready) { atomicAdd(&remaining, 1); continue; }
+          const bool pass = brisk_tie_eval(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, TR_WIN);
+          if (pass) {
+            if (c->fp_mask && l + 1 < G.nlayers) {
+              const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
+              for (int b = 0; b < 16; ++b)
+                if (c->fp_mask & (1u << b))
+                  smap_or(La.smap, (long)(c->fp_y0 + (b >> 2)) * La.stride + c->fp_x0 + (b & 3), BRISK_SM_TOUCH);
+            }
+            c->status = BRISK_ST_PASS;
+            smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);
+          } else {
+            c->status = BRISK_ST_FAIL;
+            smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);
+          }
+          atomicAdd(&progressed, 1);
+        }
       }
       __threadfence();
       __syncthreads();
@@ -576,8 +767,12 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   hipLaunchKernelGGL(k_detect, dim3(T.total_tiles, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,
                      B.cand_cap);
   brisk_prof_mark(prof, BRISK_STG_CLASSIFY, s);
-  hipLaunchKernelGGL(k_classify_refine, dim3(grid_for(B.cand_cap, 128, 64), nframes), dim3(128), 0, s, G, B.pyr, B.smap,
-                     B.cand, B.counters, B.tie_idx, B.cand_cap, B.tie_cap);
+  hipLaunchKernelGGL(k_score_blocks, dim3(grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, 256), nframes), dim3(SB_WAVES * 64), 0,
+                     s, G, B.pyr, B.smap, B.cand, B.counters, B.blocks, B.cand_cap);
+  hipLaunchKernelGGL(k_classify_refine, dim3(grid_for(B.cand_cap, 64, 64), nframes), dim3(64), 0, s, G, B.pyr, B.smap,
+                     B.cand, B.counters, B.blocks, B.tie_idx, B.cand_cap, B.tie_cap);
+  hipLaunchKernelGGL(k_classify_refine_direct, dim3(64, nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters,
+                     B.tie_idx, B.cand_cap, B.tie_cap);
   brisk_prof_mark(prof, BRISK_STG_TIES, s);
   hipLaunchKernelGGL(k_tie_resolve, dim3(nframes), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
                      B.cand_cap, B.tie_cap);

@@ -1,0 +1,122 @@
+// brisk/brisk-descriptor-extractor.h - BriskDescriptorExtractor of the MI355X engine.
+//
+// Drop-in for the reference class (brisk/include/brisk/brisk-descriptor-extractor.h:54-202): the eight
+// constructors, Version enum, kDescriptorLength, public rotationInvariance / scaleInvariance, descriptorSize(),
+// descriptorType() and both compute() overloads.  Tables are built by the engine (host libm, as the reference
+// does) and kept on the GPU; compute() forwards to brisk_hip_describe.
+#ifndef BRISK_BRISK_DESCRIPTOR_EXTRACTOR_H_
+#define BRISK_BRISK_DESCRIPTOR_EXTRACTOR_H_
+
+#include <agast/wrap-opencv.h>
+#include <brisk/hip-context.h>
+
+#include <bitset>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace brisk {
+
+#ifdef BRISK_HAVE_OPENCV
+class BriskDescriptorExtractor : public cv::Feature2D {
+#else
+class BriskDescriptorExtractor {
+#endif
+ public:
+  static const unsigned int kDescriptorLength = 384;
+  enum Version { briskV1 = 1, briskV2 = 2 };
+
+  explicit BriskDescriptorExtractor() : BriskDescriptorExtractor(true, true) {}
+  explicit BriskDescriptorExtractor(bool rotationInvariant, bool scaleInvariant)
+      : BriskDescriptorExtractor(rotationInvariant, scaleInvariant, briskV2, 1.0f) {}
+  explicit BriskDescriptorExtractor(bool rotationInvariant, bool scaleInvariant, int version)
+      : BriskDescriptorExtractor(rotationInvariant, scaleInvariant, version, 1.0f) {}
+  explicit BriskDescriptorExtractor(bool rotationInvariant, bool scaleInvariant, int version, float patternScale)
+      : rotationInvariance(rotationInvariant), scaleInvariance(scaleInvariant) {
+    if (version != briskV1 && version != briskV2)
+      throw std::runtime_error("only Version::briskV1 or Version::briskV2 supported!");
+    brisk_hip_ctx* ctx = hip::DefaultContext();
+    hip::Check(ctx, brisk_hip_pattern_create(ctx, version, patternScale, &pattern_), "brisk_hip_pattern_create");
+  }
+  explicit BriskDescriptorExtractor(const std::string& fname) : BriskDescriptorExtractor(fname, true) {}
+  explicit BriskDescriptorExtractor(const std::string& fname, bool rotationInvariant)
+      : BriskDescriptorExtractor(fname, rotationInvariant, true) {}
+  explicit BriskDescriptorExtractor(const std::string& fname, bool rotationInvariant, bool scaleInvariant)
+      : BriskDescriptorExtractor(fname, rotationInvariant, scaleInvariant, 1.0f) {}
+  explicit BriskDescriptorExtractor(const std::string& fname, bool rotationInvariant, bool scaleInvariant,
+                                    float patternScale)
+      : rotationInvariance(rotationInvariant), scaleInvariance(scaleInvariant) {
+    std::ifstream f(fname.c_str());
+    if (!f.is_open()) throw std::runtime_error("BriskDescriptorExtractor: cannot open pattern file " + fname);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    brisk_hip_ctx* ctx = hip::DefaultContext();
+    hip::Check(ctx, brisk_hip_pattern_create_from_text(ctx, ss.str().c_str(), patternScale, &pattern_),
+               "brisk_hip_pattern_create_from_text");
+  }
+  BriskDescriptorExtractor(const BriskDescriptorExtractor&) = delete;
+  BriskDescriptorExtractor& operator=(const BriskDescriptorExtractor&) = delete;
+  virtual ~BriskDescriptorExtractor() { brisk_hip_pattern_destroy(pattern_); }
+
+  int descriptorSize() const { return brisk_hip_pattern_descriptor_size(pattern_); }
+  int descriptorType() const { return CV_8U; }
+
+  bool rotationInvariance;
+  bool scaleInvariance;
+
+  // compute(): filters `keypoints` (border test), writes their orientation, allocates `descriptors`
+  // as keypoints.size() x descriptorSize() CV_8UC1 (brisk-descriptor-extractor.cc:601-604, 612-778).
+  virtual void compute(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints, agast::Mat& descriptors) const {
+    computeImpl(image, keypoints, descriptors);
+  }
+  virtual void compute(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,
+                       std::vector<std::bitset<kDescriptorLength> >& descriptors) const {
+    computeImpl(image, keypoints, descriptors);
+  }
+#ifdef BRISK_HAVE_OPENCV
+  virtual void detectAndCompute(cv::InputArray image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& keypoints,
+                                cv::OutputArray descriptors, bool /*useProvidedKeypoints*/ = false) {
+    computeImpl(image.getMat(), keypoints, descriptors.getMatRef());
+  }
+#else
+  virtual void detectAndCompute(const agast::Mat& image, const agast::Mat& /*mask*/, std::vector<agast::KeyPoint>& keypoints,
+                                agast::Mat& descriptors, bool /*useProvidedKeypoints*/ = false) {
+    computeImpl(image, keypoints, descriptors);
+  }
+#endif
+
+ protected:
+  virtual void computeImpl(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,
+                           agast::Mat& descriptors) const {
+    if (image.type() != CV_8UC1)  // the reference's 16-bit branch is broken; 8-bit only
+      throw std::runtime_error("Unsupported image format. Must be CV_16UC1 or CV_8UC1.");
+    const int strings = descriptorSize();
+    int n = (int)keypoints.size();
+    agast::Mat tmp = agast::Mat::zeros(n > 0 ? n : 1, strings, CV_8UC1);
+    brisk_hip_ctx* ctx = hip::DefaultContext();
+    brisk_hip_set_capacity(ctx, 65536 > 4 * n ? 65536 : 4 * n, 16384 > n ? 16384 : n);
+    hip::Check(ctx,
+               brisk_hip_describe(ctx, pattern_, image.data, image.cols, image.rows, (int)image.step,
+                                  reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), &n, tmp.data, (int)tmp.step,
+                                  rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0),
+               "brisk_hip_describe");
+    keypoints.resize((size_t)n);
+    descriptors = agast::Mat::zeros(n, strings, CV_8UC1);
+    for (int i = 0; i < n; ++i) memcpy(descriptors.data + (size_t)i * descriptors.step, tmp.data + (size_t)i * tmp.step, strings);
+  }
+  virtual void computeImpl(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,
+                           std::vector<std::bitset<kDescriptorLength> >& descriptors) const {
+    agast::Mat d;
+    computeImpl(image, keypoints, d);
+    descriptors.assign(keypoints.size(), std::bitset<kDescriptorLength>());
+    for (size_t k = 0; k < keypoints.size(); ++k)
+      for (unsigned b = 0; b < kDescriptorLength && b < (unsigned)d.cols * 8; ++b)
+        if (d.data[k * d.step + (b >> 3)] & (1u << (b & 7))) descriptors[k].set(b, true);
+  }
+
+  brisk_hip_pattern* pattern_ = nullptr;
+};
+
+}  // namespace brisk
+#endif  // BRISK_BRISK_DESCRIPTOR_EXTRACTOR_H_

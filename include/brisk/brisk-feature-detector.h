@@ -1,0 +1,83 @@
+// brisk/brisk-feature-detector.h - BriskFeatureDetector of the MI355X engine.
+//
+// Drop-in for the reference class (brisk/include/brisk/brisk-feature-detector.h:51-83): same constructor,
+// public members and methods; detectImpl forwards to brisk_hip_detect (pyramid, contrast-adaptive AGAST,
+// 2-D/3-D non-maximum suppression and refinement all run on the GPU).
+#ifndef BRISK_BRISK_FEATURE_DETECTOR_H_
+#define BRISK_BRISK_FEATURE_DETECTOR_H_
+
+#include <agast/wrap-opencv.h>
+#include <brisk/hip-context.h>
+
+#include <vector>
+
+namespace brisk {
+
+#ifdef BRISK_HAVE_OPENCV
+class BriskFeatureDetector : public cv::Feature2D {
+#else
+class BriskFeatureDetector {
+#endif
+ public:
+  BriskFeatureDetector(int thresh, int octaves = 3, bool suppressScaleNonmaxima = true)
+      : threshold(thresh), octaves(octaves), m_suppressScaleNonmaxima(suppressScaleNonmaxima) {}
+  virtual ~BriskFeatureDetector() {}
+  int threshold;
+  int octaves;
+
+#ifndef BRISK_HAVE_OPENCV
+  void detect(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,
+              const agast::Mat& mask = agast::Mat()) const {
+    detectImpl(image, keypoints, mask);
+  }
+  // cv::Feature2D-style entry (descriptors are not produced by the detector)
+  virtual void detectAndCompute(const agast::Mat& image, const agast::Mat& mask, std::vector<agast::KeyPoint>& keypoints,
+                                agast::Mat& /*descriptors*/, bool /*useProvidedKeypoints*/ = false) {
+    detectImpl(image, keypoints, mask);
+  }
+#else
+  virtual void detectAndCompute(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints,
+                                cv::OutputArray /*descriptors*/, bool /*useProvidedKeypoints*/ = false) {
+    detectImpl(image.getMat(), keypoints, mask.getMat());
+  }
+#endif
+
+  // Reference: brisk-feature-detector.cc:87-92 (scores for provided keypoints).  SURVEY §8(f)#3 "next" row:
+  // not implemented on the device path yet.
+  void ComputeScale(const agast::Mat& /*image*/, std::vector<agast::KeyPoint>& /*keypoints*/) const {
+    throw std::runtime_error("BriskFeatureDetector::ComputeScale is not implemented by the MI355X engine");
+  }
+
+ protected:
+  // brisk-feature-detector.cc:77-85
+  virtual void detectImpl(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,
+                          const agast::Mat& mask = agast::Mat()) const {
+    keypoints.clear();
+    if (image.empty()) throw std::runtime_error("BriskFeatureDetector: empty image");
+    if (image.type() != CV_8UC1) throw std::runtime_error("BriskFeatureDetector: image must be CV_8UC1");
+    brisk_hip_ctx* ctx = hip::DefaultContext();
+    size_t cap = 16384;
+    for (;;) {
+      keypoints.resize(cap);
+      int n = 0;
+      const int rc = brisk_hip_detect(ctx, image.data, image.cols, image.rows, (int)image.step, threshold, octaves,
+                                      m_suppressScaleNonmaxima ? 1 : 0, mask.empty() ? nullptr : mask.data,
+                                      mask.empty() ? 0 : (int)mask.step,
+                                      reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), (int)cap, &n);
+      if (rc == BRISK_HIP_ERR_CAPACITY && cap < (1u << 22)) {  // output buffer too small: retry larger
+        keypoints.clear();
+        cap *= 4;
+        brisk_hip_set_capacity(ctx, (int)(cap * 4), (int)cap);
+        continue;
+      }
+      if (rc != BRISK_HIP_OK) keypoints.clear();
+      hip::Check(ctx, rc, "brisk_hip_detect");
+      keypoints.resize((size_t)n);
+      return;
+    }
+  }
+  bool m_suppressScaleNonmaxima;
+};
+
+}  // namespace brisk
+#endif  // BRISK_BRISK_FEATURE_DETECTOR_H_

@@ -108,6 +108,8 @@ int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls);
 /* which: 0 pyramid image, 1 score-state map low byte (D), after the last detect on frame slot 0.
  * Copies layer `layer` (w x h, tightly packed u8) to the host buffer. */
 int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, uint8_t* out, int* w, int* h);
+/* test knobs: bit0 = route every AGAST candidate through the direct-evaluation safety-net kernel */
+int brisk_hip_debug_set_flags(brisk_hip_ctx* ctx, int flags);
 /* integral image of frame slot `frame` after the last describe: (h+1) x (w+1) u32, tightly packed */
 int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out);
 

@@ -19,6 +19,8 @@
 #include "../../ethzasl_brisk_amd/csrc/brisk_device_detect.h"
 #include "../../ethzasl_brisk_amd/csrc/brisk_pattern.h"
 
+long brisk_cache_misses = 0;
+
 namespace {
 
 void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G) {  // == brisk_capi.hip
@@ -59,6 +61,7 @@ BriskLayerView view(Emul& E, int l) {
   v.img = E.pyr.data() + E.G.L[l].off;
   v.smap = E.smap.data() + E.G.L[l].off;
   v.w = E.G.L[l].w; v.h = E.G.L[l].h; v.stride = E.G.L[l].stride;
+  brisk_block_clear(&v.blk); brisk_block_clear(&v.blk58); v.miss = 0;
   return v;
 }
 
@@ -69,7 +72,8 @@ void touch_apply(Emul& E, int l_above, int x0, int y0, unsigned mask) {
 }
 
 // mirrors k_copy_layer0 + k_pyramid_level + k_detect + k_classify_refine + k_tie_resolve + k_finalize
-void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int octaves, unsigned shuffle_seed, int jacobi) {
+void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int octaves, unsigned shuffle_seed, int jacobi,
+                bool use_cache) {
   make_geometry(w, h, threshold, octaves, &E.G);
   const BriskGeom& G = E.G;
   E.pyr.assign((size_t)G.pyr_elems + 256, 0);
@@ -104,14 +108,30 @@ void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int oc
     srand(shuffle_seed);
     for (size_t i = E.cand.size(); i > 1; --i) std::swap(E.cand[i - 1], E.cand[(size_t)rand() % i]);
   }
-  // k_classify_refine
-  BriskLayerView Lv[BRISK_MAX_LAYERS];
-  for (int l = 0; l < G.nlayers; ++l) { Lv[l] = view(E, l); E.ties[l].clear(); }
+  // k_classify_refine (one wave per candidate: lane-parallel score blocks, then uniform scalar logic)
+  for (int l = 0; l < G.nlayers; ++l) E.ties[l].clear();
   for (size_t i = 0; i < E.cand.size(); ++i) {
     BriskCand* c = &E.cand[i];
     const int l = c->layer, x = c->x, y = c->y, D = c->D;
+    const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
+    const bool has_below = !G.single_layer && (l > 0);
+    BriskLayerView Lo = view(E, l), La = view(E, has_above ? l + 1 : l), Lb = view(E, has_below ? l - 1 : l);
+    uint8_t c_own[9], c_58[9], c_above[16], c_below[16];
+    int aax = 0, aay = 0, bax = 0, bay = 0;
+    if (has_above) brisk_block_anchor(true, (l & 1) != 0, x, y, &aax, &aay);
+    if (has_below) brisk_block_anchor(false, (l & 1) != 0, x, y, &bax, &bay);
+    if (use_cache) {
+      for (int k = 0; k < 9; ++k) c_own[k] = (uint8_t)brisk_V_eval(Lo, x - 1 + k % 3, y - 1 + k / 3);
+      if (l == 0 && !G.single_layer) for (int k = 0; k < 9; ++k) c_58[k] = (uint8_t)brisk_V58_eval(Lo, x - 1 + k % 3, y - 1 + k / 3);
+      if (has_above) for (int k = 0; k < 16; ++k) c_above[k] = (uint8_t)brisk_V_eval(La, aax + (k & 3), aay + (k >> 2));
+      if (has_below) for (int k = 0; k < 16; ++k) c_below[k] = (uint8_t)brisk_V_eval(Lb, bax + (k & 3), bay + (k >> 2));
+      brisk_block_from_bytes(&Lo.blk, c_own, 9, x - 1, y - 1, 3, 3);
+      if (l == 0 && !G.single_layer) brisk_block_from_bytes(&Lo.blk58, c_58, 9, x - 1, y - 1, 3, 3);
+      if (has_above) brisk_block_from_bytes(&La.blk, c_above, 16, aax, aay, 4, 4);
+      if (has_below) brisk_block_from_bytes(&Lb.blk, c_below, 16, bax, bay, 4, 4);
+    }
     int nprobed;
-    const unsigned status = brisk_classify(Lv[l], x, y, D, &nprobed);
+    const unsigned status = use_cache ? brisk_classify<false>(Lo, x, y, D, &nprobed) : brisk_classify<true>(Lo, x, y, D, &nprobed);
     unsigned bits = ((unsigned)nprobed << 8) | (status << 12);
     unsigned flags = 0;
     if (status != BRISK_ST_REJ) {
@@ -119,7 +139,9 @@ void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int oc
       bool e5;
       BriskTouch touch;
       touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
-      const bool ok = brisk_refine(G, Lv, l, x, y, &kp, &e5, &touch);
+      const bool ok = use_cache ? brisk_refine<false>(G, Lb, Lo, La, l, x, y, &kp, &e5, &touch)
+                                : brisk_refine<true>(G, Lb, Lo, La, l, x, y, &kp, &e5, &touch);
+      brisk_cache_misses += Lo.miss + La.miss + Lb.miss;
       if (ok) { flags |= 1; c->kx = kp.x; c->ky = kp.y; c->ksize = kp.size; c->kresp = kp.response; }
       if (e5) { flags |= 2; bits |= BRISK_SM_E5; }
       c->fp_x0 = (int16_t)touch.x0; c->fp_y0 = (int16_t)touch.y0; c->fp_mask = (uint16_t)touch.mask;
@@ -128,8 +150,10 @@ void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int oc
     }
     c->status = (uint8_t)status;
     c->flags = (uint8_t)flags;
-    Lv[l].smap[(long)y * Lv[l].stride + x] |= (uint16_t)bits;
+    view(E, l).smap[(long)y * G.L[l].stride + x] |= (uint16_t)bits;
   }
+  BriskLayerView Lv[BRISK_MAX_LAYERS];
+  for (int l = 0; l < G.nlayers; ++l) Lv[l] = view(E, l);
   // k_tie_resolve
   E.relax_iters = 0;
   for (int l = 0; l < G.nlayers; ++l) {
@@ -137,6 +161,37 @@ void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int oc
     const bool last = (l == G.nlayers - 1);
     const bool float_patch = last || G.single_layer;
     const bool touch2x2 = last && !G.single_layer;
+    if (jacobi == 2) {  // kernel's main path: raster-sorted, in order, lane-split evaluation
+      std::vector<std::pair<unsigned, int>> order;
+      for (int idx : E.ties[l]) order.push_back({E.cand[idx].key, idx});
+      std::sort(order.begin(), order.end());
+      for (auto& o : order) {
+        BriskCand* c = &E.cand[o.second];
+        const int cx = c->x, cy = c->y;
+        uint16_t wl[81];
+        for (int dy = -4; dy <= 4; ++dy)
+          for (int dx = -4; dx <= 4; ++dx) {
+            const int qx = cx + dx, qy = cy + dy;
+            unsigned v = 0;
+            if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = L.smap[(long)qy * L.stride + qx];
+            wl[(dy + 4) * 9 + dx + 4] = (uint16_t)v;
+            if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) abort();  // would spin forever
+          }
+        const int centre = c->D;
+        int sv[8], raw[25];
+        for (int k = 0; k < 8; ++k) sv[k] = brisk_tie_probe_value(L, float_patch, touch2x2, cx, cy, centre, k, wl, cx - 4, cy - 4, 9);
+        for (int q = 0; q < 25; ++q) raw[q] = brisk_tie_raw_value(L, float_patch, touch2x2, cx, cy, centre, q, wl, cx - 4, cy - 4, 9);
+        if (brisk_tie_decide(centre, sv, raw)) {
+          if (c->fp_mask && l + 1 < G.nlayers) touch_apply(E, l + 1, c->fp_x0, c->fp_y0, c->fp_mask);
+          c->status = BRISK_ST_PASS;
+          L.smap[(long)cy * L.stride + cx] ^= 0x3000u;
+        } else {
+          c->status = BRISK_ST_FAIL;
+          L.smap[(long)cy * L.stride + cx] |= 0x1000u;
+        }
+      }
+      continue;
+    }
     for (int iter = 0; iter < 100000; ++iter) {
       int remaining = 0, progressed = 0;
       std::vector<std::pair<int, bool>> decided;  // jacobi mode: apply after the sweep
@@ -208,18 +263,20 @@ struct EmulPattern {
 extern "C" {
 
 // returns keypoint count; *out malloc'd (free with emul_free). stats[0]=#candidates, [1]=#ties, [2]=relaxation sweeps,
-// [3]=longest per-layer chain
+// [3]=longest per-layer chain, [4]=score-block cache misses.  mode: bits 0-1 tie scheme (0 Gauss-Seidel sweeps, 1 Jacobi
+// sweeps, 2 sorted in-order = the kernel's main path), bit 2 = use the lane-parallel score-block caches
 int emul_detect(const uint8_t* img, int w, int h, int threshold, int octaves, unsigned shuffle_seed, int jacobi,
                 BriskKeyPoint** out, int* stats) {
   Emul E;
-  run_detect(E, img, w, h, threshold, octaves, shuffle_seed, jacobi);
+  brisk_cache_misses = 0;
+  run_detect(E, img, w, h, threshold, octaves, shuffle_seed, jacobi & 3, (jacobi & 4) != 0);
   *out = (BriskKeyPoint*)malloc(sizeof(BriskKeyPoint) * (E.kps.size() + 1));
   memcpy(*out, E.kps.data(), sizeof(BriskKeyPoint) * E.kps.size());
   if (stats) {
     stats[0] = (int)E.cand.size();
     int nt = 0;
     for (int l = 0; l < E.G.nlayers; ++l) nt += (int)E.ties[l].size();
-    stats[1] = nt; stats[2] = E.relax_iters; stats[3] = E.max_chain;
+    stats[1] = nt; stats[2] = E.relax_iters; stats[3] = E.max_chain; stats[4] = (int)brisk_cache_misses;
   }
   return (int)E.kps.size();
 }

@@ -39,5 +39,6 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".inc")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "brisk_oracle" not in txt and "liboracle" not in txt and "oracle_lib" not in txt, f
-    for f in os.listdir(os.path.join(ROOT, "include")):
-        assert "oracle" not in open(os.path.join(ROOT, "include", f), errors="ignore").read()
+    for d, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            assert "oracle" not in open(os.path.join(d, f), errors="ignore").read(), f

@@ -1,0 +1,39 @@
+"""The drop-in C++ host classes (include/brisk/*.h) over the C ABI, exercised by a C++ program that mirrors the
+reference's own golden test (tests/cpp/test_binary_equal.cc)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "test_binary_equal")
+
+
+def build_binary():
+    from ethzasl_brisk_amd import build
+    build.build()
+    src = os.path.join(ROOT, "tests", "cpp", "test_binary_equal.cc")
+    hdrs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs]
+    if not os.path.exists(BIN) or any(os.path.getmtime(p) > os.path.getmtime(BIN) for p in [src] + hdrs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", BIN, src,
+                               "-L" + os.path.join(ROOT, "ethzasl_brisk_amd"), "-lbrisk_hip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "ethzasl_brisk_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return BIN
+
+
+def test_host_classes_compile_and_fail_loudly_without_gpu():
+    import ethzasl_brisk_amd as B
+    b = build_binary()
+    if B.load_library().brisk_hip_device_count() > 0:
+        pytest.skip("GPU present")
+    r = subprocess.run([b, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True)
+    assert r.returncode == 2 and "brisk_hip_create failed" in r.stdout   # no CPU fallback behind the classes
+
+
+@pytest.mark.gpu
+def test_reference_golden_through_cpp_classes():
+    b = build_binary()
+    r = subprocess.run([b, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "Verification success" in r.stdout
+    assert r.stdout.count("OK") == 4

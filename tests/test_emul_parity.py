@@ -42,9 +42,12 @@ def test_closed_form_scores_match_bisection():
 def test_detect_matches_oracle_golden_images(golden_ast, idx):
     img = golden_ast[idx]["image"]
     ko = O.detect(img, 70, 3)
-    for seed, jacobi in ((0, 0), (7, 0), (9, 1)):   # candidate order / sweep style must not matter
-        ke, stats = E.detect(img, 70, 3, seed, jacobi)
+    # mode bits 0-1: tie scheme (0 Gauss-Seidel sweeps, 1 Jacobi sweeps, 2 raster-sorted in order = kernel main
+    # path); bit 2: lane-parallel score-block caches.  Candidate order / scheme must not matter.
+    for seed, mode in ((0, 0), (7, 4 | 2), (9, 4 | 1), (3, 2)):
+        ke, stats = E.detect(img, 70, 3, seed, mode)
         assert same_kps(ke, ko)
+        assert stats[4] == 0                         # the 3x3 / 4x4 score blocks cover every access
     assert stats[1] > 100                            # tie candidates exist
 
 
@@ -63,8 +66,9 @@ CASES = [
 def test_detect_matches_oracle_synthetic(name, mk, thr, octaves):
     img = mk()
     ko = O.detect(img, thr, octaves)
-    ke, _ = E.detect(img, thr, octaves, 3, 0)
-    assert len(ko) > 0 and same_kps(ke, ko)
+    for mode in (0, 4 | 2):
+        ke, st = E.detect(img, thr, octaves, 3, mode)
+        assert len(ko) > 0 and same_kps(ke, ko) and st[4] == 0
 
 
 def test_detect_tie_heavy_blocks():
@@ -76,14 +80,16 @@ def test_detect_tie_heavy_blocks():
     ke, stats = E.detect(b, 60, 3, 11, 1)
     assert same_kps(ke, ko)
     assert stats[1] > 0.8 * stats[0] and stats[3] > 50
+    ke, stats = E.detect(b, 60, 3, 12, 4 | 2)
+    assert same_kps(ke, ko) and stats[4] == 0
 
 
 def test_detect_1080p_config2():
     img = synth.frame_1080p(0)
     ko = O.detect(img, 80, 4)
     assert len(ko) == 1194                           # SURVEY §8(d) config 2 probe
-    ke, _ = E.detect(img, 80, 4, 1, 0)
-    assert same_kps(ke, ko)
+    ke, st = E.detect(img, 80, 4, 1, 4 | 2)
+    assert same_kps(ke, ko) and st[4] == 0
 
 
 @pytest.mark.parametrize("version", [2, 1])

@@ -135,6 +135,18 @@ def test_tie_heavy_blocks(B):
     assert same_kps(kg, ko), explain(kg, ko)
 
 
+def test_direct_evaluation_safety_net(B, ctx, golden_ast):
+    """k_classify_refine_direct (used only if a score block misses an access) gives the same result."""
+    img = golden_ast[0]["image"]
+    ko = O.detect(img, 70, 3)
+    ctx.debug_set_flags(1)
+    try:
+        kg = B.BriskFeatureDetector(70, 3).detect(img)
+    finally:
+        ctx.debug_set_flags(0)
+    assert same_kps(kg, ko), explain(kg, ko)
+
+
 def test_mask_and_errors(B, golden_ast):
     img = golden_ast[1]["image"]
     mask = np.zeros_like(img)

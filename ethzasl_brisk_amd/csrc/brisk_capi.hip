@@ -101,7 +101,7 @@ static void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G
 
 static void free_buffers(brisk_hip_ctx* c) {
   hipFree(c->B.pyr); hipFree(c->B.smap); hipFree(c->B.cand); hipFree(c->B.blocks); hipFree(c->B.tie_idx); hipFree(c->B.keys);
-  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->D.dkp); hipFree(c->D.dscale);
+  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->D.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale);
   hipFree(c->D.desc); hipFree(c->d_kp_in); hipFree(c->d_n_in);
   c->B = BriskDetectBuffers{};
   c->D = BriskDescribeBuffers{};
@@ -133,6 +133,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMalloc(&c->B.counters, (size_t)slots * sizeof(BriskFrameCounters)));
   HIPCHK(c, hipMalloc(&c->B.kp_out, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
   HIPCHK(c, hipMalloc(&c->D.integral, (size_t)slots * ifr * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&c->D.bandsum, (size_t)slots * ((ifr / 64) + 4 * 8192 + 64) * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc(&c->D.dkp, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
   HIPCHK(c, hipMalloc(&c->D.dscale, (size_t)slots * c->kp_cap * sizeof(int)));
   c->D.desc_pitch = 64;

@@ -28,6 +28,7 @@ struct BriskDetectBuffers {
 
 struct BriskDescribeBuffers {
   uint32_t* integral;  // [slots][iframe_elems]
+  uint32_t* bandsum;   // [slots][max_bands][istride] column sums of 64-row bands
   int istride;         // integral row stride (elements)
   long iframe_elems;
   BriskKeyPoint* dkp;  // [slots][kp_cap] filtered keypoints (angle filled in)

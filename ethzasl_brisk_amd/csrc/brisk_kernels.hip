@@ -6,7 +6,7 @@
 //   k_classify_refine IsMax2D steps 1-2 + 3-D refinement per candidate          (sparse)
 //   k_tie_resolve     order-faithful replay of the lazy score cache for ties    (sparse, 1 WG/frame)
 //   k_finalize        (layer, y, x) ordering + keypoint output                  (sparse)
-//   k_integral_rows / k_integral_cols   exclusive 2-D prefix sum (u32)          (HBM-bound)
+//   k_integral_bandsums / k_integral_final   exclusive 2-D prefix sum (u32)     (HBM-bound)
 //   k_desc_prepare    scale index + border filter + stable compaction           (sparse)
 //   k_describe        pattern sampling, orientation, 384/512 bit tests          (gather-bound)
 // No MFMA: the path is byte/integer stencil + gather work.
@@ -101,23 +101,34 @@ __global__ void __launch_bounds__(256) k_pyramid_level(BriskGeom G, uint8_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_detect: per-pixel threshold map (37-px disc contrast) + contrast-adaptive OAST 9_16 segment test.
-// Tile of 64x16 output pixels, (64+8)x(16+6) u8 halo tile staged in LDS with coalesced dword loads;
-// each thread evaluates 4 adjacent pixels and emits one 8-byte smap store.  Detections are appended
-// to the frame's candidate list (order is restored later from the (layer,y,x) key).
-// grid.x enumerates tiles of all layers (tile table in G via prefix), grid.y = frame.
+// k_detect: per-pixel threshold map (37-px disc contrast, brisk-layer.cc:278-598) + contrast-adaptive OAST 9_16
+// segment test (oast9-16.cc:79-100).  Dominant kernel of the pipeline.
+//
+// Tile = 64x16 output pixels per 256-thread workgroup; the (64+8)x(16+6) u8 halo tile is staged in LDS with
+// coalesced dword loads.  Phase A (all pixels): every thread owns 4 adjacent pixels, pulls its 7x12-byte window
+// out of LDS with 21 dword reads, computes the disc min/max in registers and applies a cascade of necessary
+// conditions for a 9-of-16 arc (contrast gate, range gate, two adjacent compass points); survivors (a few %) are
+// compacted into an LDS queue with wave ballots.  Phase B (survivors only): one lane per queued pixel runs the
+// closed-form segment test.  Detections go to an LDS result tile that is written out as the smap tile with
+// 8-byte stores; candidates are appended to the frame's list (order is restored later from the (layer,y,x) key).
+// grid.x enumerates the tiles of all layers, grid.y = frame.
 // ------------------------------------------------------------------------------------------------
 #define DT_W 64
 #define DT_H 16
 #define DT_LW (DT_W + 8)
 #define DT_LH (DT_H + 6)
 
+// byte i (-4..7, relative to the thread's first pixel) of a 3-dword row window
+#define DT_B(w0, w1, w2, i) ((int)((((i) < 0) ? ((w0) >> (8 * ((i) + 4))) : ((i) < 4) ? ((w1) >> (8 * (i))) : ((w2) >> (8 * ((i)-4)))) & 0xFFu))
+
 __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, const uint8_t* __restrict__ pyr,
                                                  uint16_t* __restrict__ smap, BriskCand* __restrict__ cand,
                                                  BriskFrameCounters* __restrict__ counters, int cand_cap) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[DT_LH * DT_LW];
+  __shared__ __attribute__((aligned(16))) uint8_t dres[DT_H * DT_W];  // D of detected pixels, 0 elsewhere
+  __shared__ unsigned queue[DT_H * DT_W];                              // idx | D << 16 | b2 << 24
+  __shared__ int qcount;
   const int frame = blockIdx.y;
-  // locate the layer of this tile
   int l = 0;
   while (l + 1 < G.nlayers && (int)blockIdx.x >= T.first_tile[l + 1]) ++l;
   const int t = blockIdx.x - T.first_tile[l];
@@ -126,6 +137,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   const long base = (long)frame * G.pyr_elems + G.L[l].off;
   const uint8_t* img = pyr + base;
   const int x0 = tx * DT_W, y0 = ty * DT_H;
+  const int thr = G.threshold;
 
   // stage halo tile: rows y0-3 .. y0+DT_H+2, columns x0-4 .. x0+DT_W+3 (dword granularity)
   for (int i = threadIdx.x; i < DT_LH * (DT_LW / 4); i += 256) {
@@ -135,37 +147,89 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
     if (gy >= 0 && gy < h && gx >= 0 && gx < stride) v = *reinterpret_cast<const unsigned*>(img + (long)gy * stride + gx);
     *reinterpret_cast<unsigned*>(&tile[r * DT_LW + c4 * 4]) = v;
   }
+  *reinterpret_cast<unsigned*>(&dres[threadIdx.x * 4]) = 0;
+  if (threadIdx.x == 0) qcount = 0;
   __syncthreads();
 
+  // ---- phase A
   const int lx = (threadIdx.x & 15) * 4, ly = threadIdx.x >> 4;
   const int gy = y0 + ly;
-  if (gy >= h) return;
-  unsigned short out[4];
+  unsigned R[7][3];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int gx = x0 + lx + k;
-    int D = 0;
-    if (gx >= 3 && gx <= w - 4 && gy >= 3 && gy <= h - 4)
-      D = brisk_detect_px(&tile[(ly + 3) * DT_LW + lx + k + 4], DT_LW, G.threshold);
-    out[k] = (unsigned short)D;
-    if (D) {
-      const int idx = atomicAdd(&counters[frame].ncand, 1);
-      if (idx < cand_cap) {
-        BriskCand c;
-        c.x = (uint16_t)gx; c.y = (uint16_t)gy; c.layer = (uint8_t)l; c.D = (uint8_t)D;
-        c.status = 0; c.flags = 0; c.fp_x0 = 0; c.fp_y0 = 0; c.fp_mask = 0; c.pad = 0;
-        c.kx = c.ky = c.ksize = c.kresp = 0.f;
-        c.key = ((unsigned)l << 26) | ((unsigned)gy << 13) | (unsigned)gx;
-        cand[(long)frame * cand_cap + idx] = c;
+  for (int r = 0; r < 7; ++r) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(&tile[(ly + r) * DT_LW + lx]);
+    R[r][0] = p[0]; R[r][1] = p[1]; R[r][2] = p[2];
+  }
+  const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gx = x0 + lx + j;
+    int mn = 255, mx = 0;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int rad = (r == 0 || r == 6) ? 1 : (r == 1 || r == 5) ? 2 : 3;
+#pragma unroll
+      for (int i = -3; i <= 3; ++i) {
+        if (i < -rad || i > rad) continue;
+        const int v = DT_B(R[r][0], R[r][1], R[r][2], j + i);
+        mn = min(mn, v);
+        mx = max(mx, v);
+      }
+    }
+    const int tt = mx - mn;
+    const int tc = min(max(tt, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
+    const int b2 = (tc * thr) / 100;
+    const int c = DT_B(R[3][0], R[3][1], R[3][2], j);
+    bool pass = (gx >= 3) && (gx <= w - 4) && (gy >= 3) && (gy <= h - 4) && (tt >= cmp) && ((mx - c > b2) || (c - mn > b2));
+    // a 9-of-16 arc contains two adjacent compass points (W, N, E, S); lazy evaluation on purpose: the exec-mask
+    // branches skip the compass work for the ~70 % of lanes that already failed (measured faster than branch-free)
+    const int pw = DT_B(R[3][0], R[3][1], R[3][2], j - 3), pe = DT_B(R[3][0], R[3][1], R[3][2], j + 3);
+    const int pn = DT_B(R[0][0], R[0][1], R[0][2], j), ps = DT_B(R[6][0], R[6][1], R[6][2], j);
+    const int cb = c + b2, c_b = c - b2;
+    const bool bw = pw > cb, bn = pn > cb, be = pe > cb, bs = ps > cb;
+    const bool dw = pw < c_b, dn = pn < c_b, de = pe < c_b, ds = ps < c_b;
+    pass = pass && (((bw && bn) || (bn && be) || (be && bs) || (bs && bw)) || ((dw && dn) || (dn && de) || (de && ds) || (ds && dw)));
+    const unsigned long long m = __ballot(pass);
+    if (m) {
+      int qb = 0;
+      const int lane = threadIdx.x & 63;
+      if (lane == 0) qb = atomicAdd(&qcount, __popcll(m));
+      qb = __builtin_amdgcn_readfirstlane(qb);
+      if (pass) queue[qb + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(ly * DT_W + lx + j) | ((unsigned)tt << 16) | ((unsigned)b2 << 24);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: closed-form segment test on the survivors
+  const int nq = qcount;
+  for (int i = threadIdx.x; i < nq; i += 256) {
+    const unsigned e = queue[i];
+    const int idx = e & 0xFFFF, D = (e >> 16) & 0xFF, b2 = e >> 24;
+    const int py = idx / DT_W, px = idx % DT_W;
+    if (brisk_oast9_16_M(&tile[(py + 3) * DT_LW + px + 4], DT_LW) > b2) {
+      dres[idx] = (uint8_t)D;
+      const int ci = atomicAdd(&counters[frame].ncand, 1);
+      if (ci < cand_cap) {
+        const int gx = x0 + px, gyy = y0 + py;
+        BriskCand cnd;
+        cnd.x = (uint16_t)gx; cnd.y = (uint16_t)gyy; cnd.layer = (uint8_t)l; cnd.D = (uint8_t)D;
+        cnd.status = 0; cnd.flags = 0; cnd.fp_x0 = 0; cnd.fp_y0 = 0; cnd.fp_mask = 0; cnd.pad = 0;
+        cnd.kx = cnd.ky = cnd.ksize = cnd.kresp = 0.f;
+        cnd.key = ((unsigned)l << 26) | ((unsigned)gyy << 13) | (unsigned)gx;
+        cand[(long)frame * cand_cap + ci] = cnd;
       } else {
         atomicOr(&counters[frame].overflow, 1);
       }
     }
   }
-  if (x0 + lx < stride) {
+  __syncthreads();
+
+  // ---- smap tile: D in the low byte, all state bits cleared
+  if (gy < h && x0 + lx < stride) {
+    const unsigned d4 = *reinterpret_cast<const unsigned*>(&dres[ly * DT_W + lx]);
     uint2 o;
-    o.x = (unsigned)out[0] | ((unsigned)out[1] << 16);
-    o.y = (unsigned)out[2] | ((unsigned)out[3] << 16);
+    o.x = (d4 & 0xFFu) | ((d4 & 0xFF00u) << 8);
+    o.y = ((d4 >> 16) & 0xFFu) | ((d4 >> 8) & 0xFF0000u);
     *reinterpret_cast<uint2*>(smap + base + (long)gy * stride + x0 + lx) = o;
   }
 }
@@ -530,64 +594,122 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
 }
 
 // ------------------------------------------------------------------------------------------------
-// Integral image (brisk/include/brisk/internal/integral-image.h:56-161): exclusive prefix sums, u32.
-// Pass 1: horizontal prefix per row (one wave per row segment chain); pass 2: vertical prefix per column.
+// Integral image (brisk/include/brisk/internal/integral-image.h:56-161): exclusive 2-D prefix sums, u32,
+// (h+1) x (w+1) with row stride istride.  Two kernels, the image is read twice and the integral written once:
+//   k_integral_bandsums  column sums of every 64-row band                      (reads 1 B/px, writes ~w*4 B/band)
+//   k_integral_final     per band: carry row = prefix over the bands above, then row after row the
+//                        workgroup scans the row (wave shuffles + one barrier) and adds it to the running
+//                        column accumulators it keeps in registers; 16-byte aligned stores.
+// Thread t of a 512-thread workgroup owns integral columns 4t..4t+3 (= pixels 4t-1..4t+2) of a 2048-column chunk.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_integral_rows(BriskGeom G, const uint8_t* __restrict__ pyr,
-                                                        uint32_t* __restrict__ integral, int istride, long iframe_elems) {
-  // one workgroup per row; 256 threads x 16 px = 4096 columns per pass
-  __shared__ unsigned partial[256];
-  const int frame = blockIdx.y, y = blockIdx.x;
-  const int w = G.L[0].w, stride = G.L[0].stride;
-  const uint8_t* row = pyr + (long)frame * G.pyr_elems + G.L[0].off + (long)y * stride;
-  uint32_t* out = integral + (long)frame * iframe_elems + (long)(y + 1) * istride;
-  unsigned carry = 0;
-  if (threadIdx.x == 0) out[0] = 0;
-  for (int x0 = 0; x0 < w; x0 += 4096) {
-    const int xb = x0 + threadIdx.x * 16;
-    unsigned v[16];
-    unsigned s = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k += 4) {
-      unsigned wd = 0;
-      if (xb + k < stride) wd = *reinterpret_cast<const unsigned*>(row + xb + k);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const unsigned px = (xb + k + b < w) ? ((wd >> (8 * b)) & 0xFF) : 0;
-        s += px;
-        v[k + b] = s;
-      }
+#define II_THREADS 512
+#define II_BAND 64
+#define II_CHUNK (II_THREADS * 4)
+
+// pixels 4t-1 .. 4t+2 of a row (0 outside [0, w))
+__device__ __forceinline__ void ii_load4(const uint8_t* row, int stride, int w, int c0 /* first integral column */,
+                                         unsigned* px) {
+  unsigned prev = 0, cur = 0;
+  if (c0 >= 4 && c0 - 4 < stride) prev = *reinterpret_cast<const unsigned*>(row + c0 - 4);
+  if (c0 < stride) cur = *reinterpret_cast<const unsigned*>(row + c0);
+  px[0] = (c0 - 1 >= 0 && c0 - 1 < w) ? (prev >> 24) : 0;
+  px[1] = (c0 < w) ? (cur & 0xFF) : 0;
+  px[2] = (c0 + 1 < w) ? ((cur >> 8) & 0xFF) : 0;
+  px[3] = (c0 + 2 < w) ? ((cur >> 16) & 0xFF) : 0;
+}
+
+__global__ void __launch_bounds__(II_THREADS) k_integral_bandsums(BriskGeom G, const uint8_t* __restrict__ pyr,
+                                                                  uint32_t* __restrict__ bandsum, int istride, int nbands) {
+  const int frame = blockIdx.y, band = blockIdx.x;
+  const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
+  const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
+  const int y0 = band * II_BAND, y1 = min(h, y0 + II_BAND);
+  for (int c0 = threadIdx.x * 4; c0 <= w; c0 += II_CHUNK) {
+    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int y = y0; y < y1; ++y) {
+      unsigned px[4];
+      ii_load4(img + (long)y * stride, stride, w, c0, px);
+      s0 += px[0]; s1 += px[1]; s2 += px[2]; s3 += px[3];
     }
-    partial[threadIdx.x] = s;
-    __syncthreads();
-    // inclusive scan of the 256 segment totals (Hillis-Steele in LDS)
-    for (int off = 1; off < 256; off <<= 1) {
-      unsigned add = (threadIdx.x >= off) ? partial[threadIdx.x - off] : 0;
-      __syncthreads();
-      partial[threadIdx.x] += add;
-      __syncthreads();
-    }
-    const unsigned before = carry + (threadIdx.x ? partial[threadIdx.x - 1] : 0);
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (xb + k < w) out[xb + k + 1] = before + v[k];
-    carry += partial[255];
-    __syncthreads();
+    *reinterpret_cast<uint4*>(bandsum + ((long)frame * nbands + band) * istride + c0) = make_uint4(s0, s1, s2, s3);
   }
 }
 
-__global__ void __launch_bounds__(256) k_integral_cols(BriskGeom G, uint32_t* __restrict__ integral, int istride,
-                                                        long iframe_elems) {
-  const int frame = blockIdx.y;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int w = G.L[0].w, h = G.L[0].h;
-  if (x > w) return;
-  uint32_t* col = integral + (long)frame * iframe_elems + x;
-  unsigned s = 0;
-  col[0] = 0;
-  for (int y = 1; y <= h; ++y) {
-    s += col[(long)y * istride];
-    col[(long)y * istride] = s;
+// exclusive offset of `total` among the workgroup's threads (thread order) + the workgroup total
+__device__ __forceinline__ unsigned ii_wg_scan(unsigned total, unsigned (*wave_tot)[II_THREADS / 64], int buf, unsigned* wg_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = total;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[buf][wave] = incl;
+  __syncthreads();
+  unsigned woff = 0, tot = 0;
+#pragma unroll
+  for (int q = 0; q < II_THREADS / 64; ++q) {
+    const unsigned v = wave_tot[buf][q];
+    woff += (q < wave) ? v : 0;
+    tot += v;
+  }
+  *wg_total = tot;
+  return woff + incl - total;
+}
+
+#define II_MAXCHUNKS 4  // 4 x 2048 columns >= the 8191-pixel width limit of the engine
+__global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, const uint8_t* __restrict__ pyr,
+                                                               const uint32_t* __restrict__ bandsum,
+                                                               uint32_t* __restrict__ integral, int istride, long iframe_elems,
+                                                               int nbands) {
+  __shared__ unsigned wave_tot[2][II_THREADS / 64];
+  const int frame = blockIdx.y, band = blockIdx.x;
+  const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
+  const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
+  uint32_t* out = integral + (long)frame * iframe_elems;
+  const int y0 = band * II_BAND, y1 = min(h, y0 + II_BAND);
+  const int nchunks = (w + 1 + II_CHUNK - 1) / II_CHUNK;
+  int buf = 0;
+  unsigned acc[II_MAXCHUNKS][4];  // running integral values of this thread's columns (row above the current one)
+  // carry row of the band: column sums of the bands above, prefix over the columns (left to right over the chunks)
+  {
+    unsigned carry = 0;
+#pragma unroll
+    for (int ch = 0; ch < II_MAXCHUNKS; ++ch) {
+      if (ch >= nchunks) break;
+      const int c0 = ch * II_CHUNK + threadIdx.x * 4;
+      uint4 C = make_uint4(0, 0, 0, 0);
+      if (c0 <= w)
+        for (int b = 0; b < band; ++b) {
+          const uint4 v = *reinterpret_cast<const uint4*>(bandsum + ((long)frame * nbands + b) * istride + c0);
+          C.x += v.x; C.y += v.y; C.z += v.z; C.w += v.w;
+        }
+      const unsigned s0 = C.x, s1 = s0 + C.y, s2 = s1 + C.z, s3 = s2 + C.w;
+      unsigned tot;
+      const unsigned o = ii_wg_scan(s3, wave_tot, buf, &tot) + carry;
+      buf ^= 1;
+      carry += tot;
+      acc[ch][0] = o + s0; acc[ch][1] = o + s1; acc[ch][2] = o + s2; acc[ch][3] = o + s3;
+      if (band == 0 && c0 <= w) *reinterpret_cast<uint4*>(out + c0) = make_uint4(0, 0, 0, 0);  // integral row 0
+    }
+  }
+  for (int y = y0; y < y1; ++y) {
+    unsigned carry = 0;
+#pragma unroll
+    for (int ch = 0; ch < II_MAXCHUNKS; ++ch) {
+      if (ch >= nchunks) break;
+      const int c0 = ch * II_CHUNK + threadIdx.x * 4;
+      unsigned px[4] = {0, 0, 0, 0};
+      if (c0 <= w) ii_load4(img + (long)y * stride, stride, w, c0, px);
+      const unsigned s0 = px[0], s1 = s0 + px[1], s2 = s1 + px[2], s3 = s2 + px[3];
+      unsigned tot;
+      const unsigned o = ii_wg_scan(s3, wave_tot, buf, &tot) + carry;
+      buf ^= 1;
+      carry += tot;
+      acc[ch][0] += o + s0; acc[ch][1] += o + s1; acc[ch][2] += o + s2; acc[ch][3] += o + s3;
+      if (c0 <= w)
+        *reinterpret_cast<uint4*>(out + (long)(y + 1) * istride + c0) = make_uint4(acc[ch][0], acc[ch][1], acc[ch][2], acc[ch][3]);
+    }
   }
 }
 
@@ -635,81 +757,77 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_describe: one 128-thread workgroup per keypoint (grid-stride over the frame's keypoints).
-// Lane i < npoints samples pattern point i; long pairs are reduced with integer wave reductions
-// (order independent); the short-pair bits are packed with 64-wide ballots.
+// k_describe: one WAVE per keypoint (4 waves per workgroup, wave-strided over the frame's keypoints), no
+// workgroup barriers.  Lane i samples pattern point i (points 64.. take a second round), the long pairs are
+// reduced with integer wave reductions (order independent), the short-pair bits are packed with 64-wide ballots.
 // ------------------------------------------------------------------------------------------------
-#define DS_THREADS 128
-__global__ void __launch_bounds__(DS_THREADS) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
-                                                          const uint32_t* __restrict__ integral, int istride,
-                                                          long iframe_elems, const BriskFrameCounters* counters,
-                                                          BriskKeyPoint* dkp, const int* dscale, uint8_t* desc, int kp_cap,
-                                                          int desc_pitch) {
-  __shared__ int values[BRISK_MAX_POINTS];
-  __shared__ int red[2][DS_THREADS / 64];
-  __shared__ int theta_s;
-  const int frame = blockIdx.y, tid = threadIdx.x;
+#define DS_WAVES 4
+__global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
+                                                            const uint32_t* __restrict__ integral, int istride,
+                                                            long iframe_elems, const BriskFrameCounters* counters,
+                                                            BriskKeyPoint* dkp, const int* dscale, uint8_t* desc, int kp_cap,
+                                                            int desc_pitch) {
+  __shared__ int values_s[DS_WAVES][BRISK_MAX_POINTS];
+  const int frame = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* values = values_s[wave];
   const int n = counters[frame].ndesc;
   const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
   const int stride = G.L[0].stride;
   const uint32_t* integ = integral + (long)frame * iframe_elems;
-  for (int k = blockIdx.x; k < n; k += gridDim.x) {
+  for (int k = blockIdx.x * DS_WAVES + wave; k < n; k += gridDim.x * DS_WAVES) {
     BriskKeyPoint* kp = &dkp[(long)frame * kp_cap + k];
     const int scale = dscale[(long)frame * kp_cap + k];
     const float kx = kp->x, ky = kp->y, kangle = kp->angle;
     int theta = 0;
     if (P.rotation_invariant) {
       if (kangle == -1.0f) {
-        for (int i = tid; i < P.npoints; i += DS_THREADS) {
+        for (int i = lane; i < P.npoints; i += 64) {
           float bx, by, sg;
           brisk_pattern_point(P, scale, 0, i, &bx, &by, &sg);
           values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, bx, by, sg);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int d0 = 0, d1 = 0;
-        for (int p = tid; p < P.nlong; p += DS_THREADS) {
+        for (int p = lane; p < P.nlong; p += 64) {
           int a, b;
           brisk_long_pair(values, P.long_pairs + 4 * p, &a, &b);
           d0 += a;
           d1 += b;
         }
         for (int off = 32; off > 0; off >>= 1) {
-          d0 += __shfl_down(d0, off, 64);
-          d1 += __shfl_down(d1, off, 64);
+          d0 += __shfl_xor(d0, off, 64);
+          d1 += __shfl_xor(d1, off, 64);
         }
-        if ((tid & 63) == 0) { red[0][tid >> 6] = d0; red[1][tid >> 6] = d1; }
-        __syncthreads();
-        if (tid == 0) {
-          int s0 = 0, s1 = 0;
-          for (int q = 0; q < DS_THREADS / 64; ++q) { s0 += red[0][q]; s1 += red[1][q]; }
-          const float ang = brisk_angle_from_direction(s0, s1);
-          kp->angle = ang;
-          theta_s = brisk_theta_from_angle(ang, true);
-        }
-        __syncthreads();
-        theta = theta_s;
+        const float ang = brisk_angle_from_direction(d0, d1);  // every lane, same value
+        if (lane == 0) kp->angle = ang;
+        theta = brisk_theta_from_angle(ang, true);
+        __builtin_amdgcn_wave_barrier();
       } else {
         theta = brisk_theta_from_angle(kangle, false);
       }
     }
-    __syncthreads();
-    for (int i = tid; i < P.npoints; i += DS_THREADS) {
+    for (int i = lane; i < P.npoints; i += 64) {
       float bx, by, sg;
       brisk_pattern_point(P, scale, theta, i, &bx, &by, &sg);
       values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, bx, by, sg);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // bit p = values[i] > values[j], LSB first in little-endian u32 words (:538-564)
     uint8_t* drow = desc + ((long)frame * kp_cap + k) * desc_pitch;
     const int nbits = P.strings * 8;
-    for (int p0 = 0; p0 < nbits; p0 += DS_THREADS) {
-      const int p = p0 + tid;
+    for (int p0 = 0; p0 < nbits; p0 += 64) {
+      const int p = p0 + lane;
       bool bit = false;
       if (p < P.nshort) bit = values[P.short_pairs[2 * p]] > values[P.short_pairs[2 * p + 1]];
       const unsigned long long m = __ballot(bit);
-      if ((tid & 63) == 0 && p < nbits) *reinterpret_cast<unsigned long long*>(drow + p / 8) = m;
+      if (lane == 0) *reinterpret_cast<unsigned long long*>(drow + p0 / 8) = m;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();  // values[] is reused by the wave's next keypoint
   }
 }
 
@@ -725,7 +843,7 @@ static inline int grid_for(long items, int per_block, int cap) {
 
 const char* brisk_stage_name(int i) {
   static const char* n[BRISK_PROF_STAGES] = {"k_pyramid", "k_detect", "k_classify_refine", "k_tie_resolve", "k_finalize",
-                                             "k_integral_rows", "k_integral_cols", "k_desc_prepare", "k_describe"};
+                                             "k_integral_bandsums", "k_integral_final", "k_desc_prepare", "k_describe"};
   return (i >= 0 && i < BRISK_PROF_STAGES) ? n[i] : "?";
 }
 
@@ -792,17 +910,18 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
                            long n_in_stride, hipStream_t s, BriskProfiler* prof) {
+  const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL_ROWS, s);
-  hipLaunchKernelGGL(k_integral_rows, dim3(G.L[0].h, nframes), dim3(256), 0, s, G, B.pyr, Dd.integral, Dd.istride,
-                     Dd.iframe_elems);
+  hipLaunchKernelGGL(k_integral_bandsums, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, Dd.bandsum, Dd.istride,
+                     nbands);
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL_COLS, s);
-  hipLaunchKernelGGL(k_integral_cols, dim3((G.L[0].w + 1 + 255) / 256, nframes), dim3(256), 0, s, G, Dd.integral,
-                     Dd.istride, Dd.iframe_elems);
+  hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, Dd.bandsum, Dd.integral,
+                     Dd.istride, Dd.iframe_elems, nbands);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, B.kp_cap);
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
-  hipLaunchKernelGGL(k_describe, dim3(grid_for(B.kp_cap, 1, 1024), nframes), dim3(DS_THREADS), 0, s, G, P, B.pyr,
+  hipLaunchKernelGGL(k_describe, dim3(grid_for(B.kp_cap, DS_WAVES, 512), nframes), dim3(DS_WAVES * 64), 0, s, G, P, B.pyr,
                      Dd.integral, Dd.istride, Dd.iframe_elems, B.counters, Dd.dkp, Dd.dscale, Dd.desc, B.kp_cap,
                      Dd.desc_pitch);
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);

@@ -203,6 +203,18 @@ def test_integral_kernel(B, ctx, golden_ast):
     assert np.array_equal(got.astype(np.int64), O.integral(img).astype(np.int64) & 0xFFFFFFFF)
 
 
+def test_integral_kernel_wide_and_tall(B, ctx):
+    """More than one 2048-column chunk and more than one 64-row band (4K-style row length)."""
+    rng = np.random.default_rng(11)
+    for shape in ((150, 3840), (131, 2049), (65, 2047), (64, 4100)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        k = np.zeros(1, B.KEYPOINT)
+        k["x"], k["y"], k["size"], k["angle"] = shape[1] // 2, shape[0] // 2, 12, -1
+        B.BriskDescriptorExtractor().compute(img, k)
+        got = ctx.debug_integral(0, shape[1], shape[0])
+        assert np.array_equal(got.astype(np.int64), O.integral(img).astype(np.int64) & 0xFFFFFFFF), shape
+
+
 def test_batch_path_device_resident(B, ctx):
     """Frames resident in HBM (torch tensor), results downloaded per frame; config-3 style batch."""
     import torch

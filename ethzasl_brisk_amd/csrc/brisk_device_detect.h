@@ -785,14 +785,18 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
 // All candidates c' < c (raster order) within distance 2 of p must carry their final status.
 // `last_layer`: the layer uses the float-access touch footprints (2x2 on pass, 4x4 patch).
 // ---------------------------------------------------------------------------------------------
+// kp5: optional 5x5 block (row-major, origin (cx-2, cy-2)) of pre-evaluated brisk_V() values (k_score_blocks);
+// for a non-detection that value is K'.  EVAL = true ignores kp5 and evaluates from the image.
+template <bool EVAL>
 BRISK_HD int brisk_state_at(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int px,
-                            int py, int cx, int cy, bool own, const uint16_t* sm_local, int lx0, int ly0, int lw) {
+                            int py, int cx, int cy, bool own, const uint16_t* sm_local, int lx0, int ly0, int lw,
+                            const uint8_t* kp5) {
   // sm_local: smap window copy [ly0..][lx0..] of width lw covering p +- 2 (values 0 outside the image)
   if (brisk_border3(L, px, py)) return 0;
   const unsigned smp = sm_local[(py - ly0) * lw + (px - lx0)];
   const int D = BRISK_SM_D(smp);
   if (D > 2) return D;
-  const int Kp = brisk_Kp(L, px, py);
+  const int Kp = EVAL ? brisk_Kp(L, px, py) : (int)kp5[(py - cy + 2) * 5 + (px - cx + 2)];
   if (Kp == 0) return 0;
   bool cached = false, any = false;
   int t_last = 0;
@@ -838,22 +842,25 @@ BRISK_HD int brisk_state_at(const BriskLayerView& L, const bool float_patch, con
 // cache replays can run one lane per pixel:
 //   ret[k]   (k = 0..7, probe order)  value the candidate's k-th probe returns
 //   raw[25]  raw map values of the 5x5 block around the candidate after its 8 probes
+template <bool EVAL>
 BRISK_HD int brisk_tie_probe_value(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
-                                   int cy, int centre, int k, const uint16_t* sm_local, int lx0, int ly0, int lw) {
+                                   int cy, int centre, int k, const uint16_t* sm_local, int lx0, int ly0, int lw,
+                                   const uint8_t* kp5) {
   const int nx = cx + brisk_probe_dx(k), ny = cy + brisk_probe_dy(k);
-  const int m = brisk_state_at(L, float_patch, pass_touch2x2, nx, ny, cx, cy, false, sm_local, lx0, ly0, lw);
+  const int m = brisk_state_at<EVAL>(L, float_patch, pass_touch2x2, nx, ny, cx, cy, false, sm_local, lx0, ly0, lw, kp5);
   if (m > 2) return m;
   if (brisk_border3(L, nx, ny)) return 0;
-  const int K = brisk_Kp(L, nx, ny);
+  const int K = EVAL ? brisk_Kp(L, nx, ny) : (int)kp5[(ny - cy + 2) * 5 + (nx - cx + 2)];
   return (K >= centre) ? K : 0;
 }
 
+template <bool EVAL>
 BRISK_HD int brisk_tie_raw_value(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
                                  int cy, int centre, int q /* 0..24, row-major 5x5 */, const uint16_t* sm_local,
-                                 int lx0, int ly0, int lw) {
+                                 int lx0, int ly0, int lw, const uint8_t* kp5) {
   const int qx = cx + (q % 5) - 2, qy = cy + (q / 5) - 2;
   if (qx == cx && qy == cy) return centre;
-  return brisk_state_at(L, float_patch, pass_touch2x2, qx, qy, cx, cy, true, sm_local, lx0, ly0, lw);
+  return brisk_state_at<EVAL>(L, float_patch, pass_touch2x2, qx, qy, cx, cy, true, sm_local, lx0, ly0, lw, kp5);
 }
 
 BRISK_HD bool brisk_tie_decide(int centre, const int* s /* 8 probe values */, const int* raw /* 25 */) {
@@ -873,11 +880,12 @@ BRISK_HD bool brisk_tie_decide(int centre, const int* s /* 8 probe values */, co
   return true;
 }
 
+template <bool EVAL>
 BRISK_HD bool brisk_tie_eval(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
-                             int cy, const uint16_t* sm_local, int lx0, int ly0, int lw) {
+                             int cy, const uint16_t* sm_local, int lx0, int ly0, int lw, const uint8_t* kp5) {
   const int centre = BRISK_SM_D(sm_local[(cy - ly0) * lw + (cx - lx0)]);
   int s[8], raw[25];
-  for (int k = 0; k < 8; ++k) s[k] = brisk_tie_probe_value(L, float_patch, pass_touch2x2, cx, cy, centre, k, sm_local, lx0, ly0, lw);
-  for (int q = 0; q < 25; ++q) raw[q] = brisk_tie_raw_value(L, float_patch, pass_touch2x2, cx, cy, centre, q, sm_local, lx0, ly0, lw);
+  for (int k = 0; k < 8; ++k) s[k] = brisk_tie_probe_value<EVAL>(L, float_patch, pass_touch2x2, cx, cy, centre, k, sm_local, lx0, ly0, lw, kp5);
+  for (int q = 0; q < 25; ++q) raw[q] = brisk_tie_raw_value<EVAL>(L, float_patch, pass_touch2x2, cx, cy, centre, q, sm_local, lx0, ly0, lw, kp5);
   return brisk_tie_decide(centre, s, raw);
 }

@@ -235,8 +235,8 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_score_blocks: lane-parallel evaluation of every candidate's score blocks - own 3x3, AGAST 5_8 3x3
-// (layer 0), 4x4 on the layer above, 4x4 on the layer below - one pixel per lane (16 ring loads + closed-form
+// k_score_blocks: lane-parallel evaluation of every candidate's score blocks - own 5x5 (bytes 0-24), 4x4 on the
+// layer above (bytes 32-47), 4x4 on the layer below or, on layer 0, the AGAST 5_8 3x3 (bytes 48-63) - one pixel per lane (16 ring loads + closed-form
 // segment test), 64 bytes per candidate.  A wave takes SB_PER_WAVE candidates, unrolled so that their loads
 // overlap (the kernel is latency-bound otherwise).
 // ------------------------------------------------------------------------------------------------
@@ -248,7 +248,6 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
   const int frame = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = min(counters[frame].ncand, cand_cap);
-  const int q = lane >> 4, p = lane & 15;
   for (int base = (blockIdx.x * SB_WAVES + wave) * SB_PER_WAVE; base < n; base += gridDim.x * SB_WAVES * SB_PER_WAVE) {
 #pragma unroll
     for (int k = 0; k < SB_PER_WAVE; ++k) {
@@ -260,21 +259,22 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
       const bool has_below = !G.single_layer && (l > 0);
       const bool has_58 = !G.single_layer && (l == 0);
       int v = 0;
-      if (q == 0) {
-        if (p < 9) v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l), x - 1 + p % 3, y - 1 + p / 3);
-      } else if (q == 1) {
-        if (p < 9 && has_58) v = brisk_V58_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l), x - 1 + p % 3, y - 1 + p / 3);
-      } else if (q == 2) {
+      if (lane < 25) {  // own 5x5 (classification / refinement use its 3x3 centre, the tie replay all of it)
+        v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l), x - 2 + lane % 5, y - 2 + lane / 5);
+      } else if (lane >= 32 && lane < 48) {
         if (has_above) {
           int ax, ay;
           brisk_block_anchor(true, (l & 1) != 0, x, y, &ax, &ay);
-          v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l + 1), ax + (p & 3), ay + (p >> 2));
+          v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l + 1), ax + (lane & 3), ay + ((lane - 32) >> 2));
         }
-      } else {
+      } else if (lane >= 48) {
+        const int p = lane - 48;
         if (has_below) {
           int bx, by;
           brisk_block_anchor(false, (l & 1) != 0, x, y, &bx, &by);
           v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l - 1), bx + (p & 3), by + (p >> 2));
+        } else if (has_58 && p < 9) {  // layer 0 has no layer below: the slot holds the AGAST 5_8 3x3 block
+          v = brisk_V58_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l), x - 1 + p % 3, y - 1 + p / 3);
         }
       }
       blocks[((long)frame * cand_cap + i) * 64 + lane] = (uint8_t)v;
@@ -303,9 +303,16 @@ __global__ void __launch_bounds__(64) k_classify_refine(BriskGeom G, uint8_t* py
     BriskLayerView La = make_view(G, pyr, smap, frame, has_above ? l + 1 : l);
     BriskLayerView Lb = make_view(G, pyr, smap, frame, has_below ? l - 1 : l);
     const uint4* blk = reinterpret_cast<const uint4*>(blocks + ((long)frame * cand_cap + mine) * 64);
-    const uint4 o = blk[0], f = blk[1], a = blk[2], b = blk[3];
-    Lo.blk.w0 = o.x; Lo.blk.w1 = o.y; Lo.blk.w2 = o.z; Lo.blk.w3 = o.w; Lo.blk.x0 = x - 1; Lo.blk.y0 = y - 1; Lo.blk.cw = 3; Lo.blk.ch = 3;
-    if (has_58) { Lo.blk58.w0 = f.x; Lo.blk58.w1 = f.y; Lo.blk58.w2 = f.z; Lo.blk58.w3 = f.w; Lo.blk58.x0 = x - 1; Lo.blk58.y0 = y - 1; Lo.blk58.cw = 3; Lo.blk58.ch = 3; }
+    const uint4 o = blk[0], o2 = blk[1], a = blk[2], b = blk[3];
+    {  // 3x3 centre of the own 5x5 block: bytes 6,7,8, 11,12,13, 16,17,18
+      const unsigned w1 = o.y, w2 = o.z, w3 = o.w, w4 = o2.x;
+      Lo.blk.w0 = ((w1 >> 16) & 0xFFFFu) | ((w2 & 0xFFu) << 16) | (w2 & 0xFF000000u);                 // b6 b7 b8 b11
+      Lo.blk.w1 = (w3 & 0xFFFFu) | ((w4 & 0xFFFFu) << 16);                                              // b12 b13 b16 b17
+      Lo.blk.w2 = (w4 >> 16) & 0xFFu;                                                                   // b18
+      Lo.blk.w3 = 0;
+      Lo.blk.x0 = x - 1; Lo.blk.y0 = y - 1; Lo.blk.cw = 3; Lo.blk.ch = 3;
+    }
+    if (has_58) { Lo.blk58.w0 = b.x; Lo.blk58.w1 = b.y; Lo.blk58.w2 = b.z; Lo.blk58.w3 = b.w; Lo.blk58.x0 = x - 1; Lo.blk58.y0 = y - 1; Lo.blk58.cw = 3; Lo.blk58.ch = 3; }
     if (has_above) {
       int ax, ay;
       brisk_block_anchor(true, (l & 1) != 0, x, y, &ax, &ay);
@@ -400,22 +407,24 @@ __global__ void __launch_bounds__(64) k_classify_refine_direct(BriskGeom G, uint
 // ------------------------------------------------------------------------------------------------
 // k_tie_resolve: one workgroup per frame; layers in ascending order (layer i+1 needs the e3 touches of layer
 // i's resolved ties).  Inside a layer the tie candidates are rank-sorted into raster order and dealt to the
-// waves round-robin; a wave spins until every raster-earlier tie candidate within Chebyshev distance 4 of its
+// waves in contiguous segments; a wave spins until every raster-earlier tie candidate within Chebyshev distance 4 of its
 // candidate is decided (the earliest undecided candidate never waits, so the scheme cannot deadlock), then
 // replays the lazy score cache with one lane per pixel (8 probe values + the 5x5 raw block).
 // Layers with more ties than the sort buffer fall back to a Jacobi relaxation with one thread per candidate.
 // ------------------------------------------------------------------------------------------------
-#define TR_WAVES 8
+#define TR_WAVES 16
 #define TR_THREADS (TR_WAVES * 64)
 #define TR_WIN 9
 #define TR_MAXSORT 2048
-#define TR_JACOBI 128
+#define TR_JACOBI 64
 __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                              BriskFrameCounters* counters, const int* tie_idx,
-                                                             int cand_cap, int tie_cap) {
+                                                             const uint8_t* blocks, int cand_cap, int tie_cap) {
+  __shared__ uint8_t kp5s[TR_WAVES][32];
   __shared__ uint16_t win[TR_JACOBI][TR_WIN * TR_WIN + 1];  // per-wave windows (sorted path) / per-thread (fallback)
   __shared__ unsigned skey[TR_MAXSORT];
-  __shared__ int sorder[TR_MAXSORT];
+  __shared__ int sorder[TR_MAXSORT];    // candidate index of the tie with raster rank r
+  __shared__ unsigned sxyd[TR_MAXSORT]; // its x | y << 13 | ... (the key) - D is taken from the window
   __shared__ int vals[TR_WAVES][40];
   __shared__ int remaining, progressed;
   const int frame = blockIdx.x;
@@ -436,12 +445,17 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
         int r = 0;
         for (int q = 0; q < n; ++q) r += (skey[q] < k) ? 1 : 0;
         sorder[r] = list[j];
+        sxyd[r] = k;
       }
       __syncthreads();
       uint16_t* wl = win[wave];
+      // round-robin over the raster-sorted ties: neighbouring ties (which depend on each other) run on different
+      // waves back to back, everything a wave needs except the fresh smap window is already on chip
       for (int j = wave; j < n; j += TR_WAVES) {
-        BriskCand* c = &cand[(long)frame * cand_cap + sorder[j]];
-        const int cx = c->x, cy = c->y;
+        const int ci = sorder[j];
+        const unsigned key = sxyd[j];
+        const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
+        if (lane < 25) kp5s[wave][lane] = blocks[((long)frame * cand_cap + ci) * 64 + lane];
         for (int spin = 0; spin < (1 << 22); ++spin) {
           bool pending = false;
           for (int e = lane; e < TR_WIN * TR_WIN; e += 64) {
@@ -453,32 +467,33 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
             if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) pending = true;
           }
           if (!__any(pending)) break;
-          __builtin_amdgcn_s_sleep(8);
+          __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int centre = c->D;
-        if (lane < 8) vals[wave][lane] = brisk_tie_probe_value(L, float_patch, touch2x2, cx, cy, centre, lane, wl, cx - 4, cy - 4, TR_WIN);
+        const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
+        if (lane < 8) vals[wave][lane] = brisk_tie_probe_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
         else if (lane >= 32 && lane < 57)
-          vals[wave][8 + lane - 32] = brisk_tie_raw_value(L, float_patch, touch2x2, cx, cy, centre, lane - 32, wl, cx - 4, cy - 4, TR_WIN);
+          vals[wave][8 + lane - 32] = brisk_tie_raw_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane - 32, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane == 0) {
           const bool pass = brisk_tie_decide(centre, &vals[wave][0], &vals[wave][8]);
-          if (pass) {
-            if (c->fp_mask && l + 1 < G.nlayers) {
+          // publish the decision first (other waves spin on it), then the bookkeeping
+          if (pass) smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
+          else smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);       // TIE (10b) -> FAIL (11b)
+          BriskCand* c = &cand[(long)frame * cand_cap + ci];
+          c->status = pass ? BRISK_ST_PASS : BRISK_ST_FAIL;
+          if (pass && l + 1 < G.nlayers) {
+            const unsigned fpm = c->fp_mask;
+            if (fpm) {
+              const int fx = c->fp_x0, fy = c->fp_y0;
               const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
               for (int b = 0; b < 16; ++b)
-                if (c->fp_mask & (1u << b))
-                  smap_or(La.smap, (long)(c->fp_y0 + (b >> 2)) * La.stride + c->fp_x0 + (b & 3), BRISK_SM_TOUCH);
+                if (fpm & (1u << b)) smap_or(La.smap, (long)(fy + (b >> 2)) * La.stride + fx + (b & 3), BRISK_SM_TOUCH);
             }
-            c->status = BRISK_ST_PASS;
-            smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
-          } else {
-            c->status = BRISK_ST_FAIL;
-            smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);   // TIE (10b) -> FAIL (11b)
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -507,7 +522,8 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
               if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) ready = false;
             }
           if (!ready) { atomicAdd(&remaining, 1); continue; }
-          const bool pass = brisk_tie_eval(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, TR_WIN);
+          const bool pass = brisk_tie_eval<false>(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, TR_WIN,
+                                                 blocks + ((long)frame * cand_cap + list[j]) * 64);
           if (pass) {
             if (c->fp_mask && l + 1 < G.nlayers) {
               const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
@@ -889,11 +905,11 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                      s, G, B.pyr, B.smap, B.cand, B.counters, B.blocks, B.cand_cap);
   hipLaunchKernelGGL(k_classify_refine, dim3(grid_for(B.cand_cap, 64, 64), nframes), dim3(64), 0, s, G, B.pyr, B.smap,
                      B.cand, B.counters, B.blocks, B.tie_idx, B.cand_cap, B.tie_cap);
-  hipLaunchKernelGGL(k_classify_refine_direct, dim3(64, nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters,
+  hipLaunchKernelGGL(k_classify_refine_direct, dim3(8, nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters,
                      B.tie_idx, B.cand_cap, B.tie_cap);
   brisk_prof_mark(prof, BRISK_STG_TIES, s);
   hipLaunchKernelGGL(k_tie_resolve, dim3(nframes), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                     B.cand_cap, B.tie_cap);
+                     B.blocks, B.cand_cap, B.tie_cap);
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,
                      B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);

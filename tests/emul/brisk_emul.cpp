@@ -179,8 +179,10 @@ void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int oc
           }
         const int centre = c->D;
         int sv[8], raw[25];
-        for (int k = 0; k < 8; ++k) sv[k] = brisk_tie_probe_value(L, float_patch, touch2x2, cx, cy, centre, k, wl, cx - 4, cy - 4, 9);
-        for (int q = 0; q < 25; ++q) raw[q] = brisk_tie_raw_value(L, float_patch, touch2x2, cx, cy, centre, q, wl, cx - 4, cy - 4, 9);
+        uint8_t kp5[25];  // k_score_blocks bytes 0-24
+        for (int q = 0; q < 25; ++q) kp5[q] = (uint8_t)brisk_V_eval(L, cx - 2 + q % 5, cy - 2 + q / 5);
+        for (int k = 0; k < 8; ++k) sv[k] = brisk_tie_probe_value<false>(L, float_patch, touch2x2, cx, cy, centre, k, wl, cx - 4, cy - 4, 9, kp5);
+        for (int q = 0; q < 25; ++q) raw[q] = brisk_tie_raw_value<false>(L, float_patch, touch2x2, cx, cy, centre, q, wl, cx - 4, cy - 4, 9, kp5);
         if (brisk_tie_decide(centre, sv, raw)) {
           if (c->fp_mask && l + 1 < G.nlayers) touch_apply(E, l + 1, c->fp_x0, c->fp_y0, c->fp_mask);
           c->status = BRISK_ST_PASS;
@@ -210,7 +212,7 @@ void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int oc
             if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) ready = false;
           }
         if (!ready) { remaining++; continue; }
-        const bool pass = brisk_tie_eval(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, 9);
+        const bool pass = brisk_tie_eval<true>(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, 9, nullptr);
         progressed++;
         if (jacobi) { decided.push_back({idx, pass}); continue; }
         if (pass) {

@@ -227,27 +227,8 @@ class ResultGather:
         return torch.as_tensor(a, device=self.dev)
 
     def run(self):
-        import torch.distributed as dist
-        torch = self.torch
-        counts = self.counts.contiguous()
-        mask = torch.arange(self.cap, device=self.dev)[None, :] < counts[:, None]
-        kp = self.kps[mask]                                   # [n, 7] packed in frame order
-        ds = self.desc[mask][:, :self.strings]                # [n, strings]
-        n = torch.tensor([kp.shape[0]], device=self.dev, dtype=torch.int64)
-        allc = [torch.empty_like(counts) for _ in range(self.world)]
-        dist.all_gather(allc, counts)
-        alln = [torch.empty_like(n) for _ in range(self.world)]
-        dist.all_gather(alln, n)
-        nmax = int(max(int(x.item()) for x in alln))
-        pk = torch.zeros((nmax, 7), device=self.dev, dtype=torch.float32)
-        pd = torch.zeros((nmax, self.strings), device=self.dev, dtype=torch.uint8)
-        pk[:kp.shape[0]] = kp
-        pd[:ds.shape[0]] = ds
-        gk = [torch.empty_like(pk) for _ in range(self.world)] if self.rank == 0 else None
-        gd = [torch.empty_like(pd) for _ in range(self.world)] if self.rank == 0 else None
-        dist.gather(pk, gk, dst=0)
-        dist.gather(pd, gd, dst=0)
-        self.last = (allc, alln, gk, gd)
+        from ethzasl_brisk_amd import sharding
+        self.last = sharding.gather_results(self.counts, self.kps, self.desc, self.strings, dst=0)
 
 
 if __name__ == "__main__":

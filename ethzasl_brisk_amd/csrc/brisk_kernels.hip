@@ -129,9 +129,15 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   __shared__ unsigned queue[DT_H * DT_W];                              // idx | D << 16 | b2 << 24
   __shared__ int qcount;
   const int frame = blockIdx.y;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so blocks with equal blockIdx.x % 8
+  // share an XCD (and its L2) within a frame.  Give each residue a contiguous eighth of the frame's tile list so
+  // that the halo rows/columns shared by neighbouring tiles are fetched into one L2 instead of eight.
+  const int nt = T.total_tiles;
+  const int res = blockIdx.x & 7;
+  const int tid_sw = res * (nt >> 3) + min(res, nt & 7) + (blockIdx.x >> 3);
   int l = 0;
-  while (l + 1 < G.nlayers && (int)blockIdx.x >= T.first_tile[l + 1]) ++l;
-  const int t = blockIdx.x - T.first_tile[l];
+  while (l + 1 < G.nlayers && tid_sw >= T.first_tile[l + 1]) ++l;
+  const int t = tid_sw - T.first_tile[l];
   const int tx = t % T.tiles_x[l], ty = t / T.tiles_x[l];
   const int w = G.L[l].w, h = G.L[l].h, stride = G.L[l].stride;
   const long base = (long)frame * G.pyr_elems + G.L[l].off;
@@ -782,16 +788,23 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
                                                             const uint32_t* __restrict__ integral, int istride,
                                                             long iframe_elems, const BriskFrameCounters* counters,
                                                             BriskKeyPoint* dkp, const int* dscale, uint8_t* desc, int kp_cap,
-                                                            int desc_pitch) {
+                                                            int desc_pitch, int bpf, int nframes) {
   __shared__ int values_s[DS_WAVES][BRISK_MAX_POINTS];
-  const int frame = blockIdx.y;
+  // 1-D grid of bpf blocks per frame.  All blocks of a frame get the same blockIdx.x % 8, i.e. the same XCD: a
+  // frame's integral image (8.3 MB @1080p, gathered ~16 times per 128-B line) then lives in ONE L2 while the frame
+  // is being described instead of being pulled through all eight.
+  const int xcd = blockIdx.x & 7;
+  const int jj = blockIdx.x >> 3;
+  const int frame = (jj / bpf) * 8 + xcd;
+  const int block_in_frame = jj % bpf;
+  if (frame >= nframes) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int* values = values_s[wave];
   const int n = counters[frame].ndesc;
   const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
   const int stride = G.L[0].stride;
   const uint32_t* integ = integral + (long)frame * iframe_elems;
-  for (int k = blockIdx.x * DS_WAVES + wave; k < n; k += gridDim.x * DS_WAVES) {
+  for (int k = block_in_frame * DS_WAVES + wave; k < n; k += bpf * DS_WAVES) {
     BriskKeyPoint* kp = &dkp[(long)frame * kp_cap + k];
     const int scale = dscale[(long)frame * kp_cap + k];
     const float kx = kp->x, ky = kp->y, kangle = kp->angle;
@@ -937,8 +950,11 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, B.kp_cap);
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
-  hipLaunchKernelGGL(k_describe, dim3(grid_for(B.kp_cap, DS_WAVES, 512), nframes), dim3(DS_WAVES * 64), 0, s, G, P, B.pyr,
-                     Dd.integral, Dd.istride, Dd.iframe_elems, B.counters, Dd.dkp, Dd.dscale, Dd.desc, B.kp_cap,
-                     Dd.desc_pitch);
+  {
+    const int bpf = 128;  // blocks per frame = what one XCD (32 CUs x 4 workgroups) holds at once
+    const int groups = (nframes + 7) / 8;
+    hipLaunchKernelGGL(k_describe, dim3(groups * 8 * bpf), dim3(DS_WAVES * 64), 0, s, G, P, B.pyr, Dd.integral, Dd.istride,
+                       Dd.iframe_elems, B.counters, Dd.dkp, Dd.dscale, Dd.desc, B.kp_cap, Dd.desc_pitch, bpf, nframes);
+  }
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);
 }

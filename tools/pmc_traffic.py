@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) into
+HBM bytes per launch for every engine kernel, with the gfx950 corrections of that guide:
+  * counters are in KiB;
+  * FETCH_SIZE under-reports wide coalesced streaming reads (exactly 1/2 for 16 B/lane).  Our kernels read with
+    4 B/lane dword loads, an uncalibrated width, so the read side is calibrated on a kernel of the same access
+    width with a known byte count in the same run: k_copy_layer0 reads exactly stride*h bytes per frame.
+Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames_per_launch> <w> <h> [out.json]
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]) * 1024.0)
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    frames, w, h = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    stride = (w + 63) // 64 * 64
+    known_read = stride * h * frames
+    corr = known_read / fetch["k_copy_layer0"]
+    out = {"frames_per_launch": frames, "fetch_correction_from_k_copy_layer0": corr, "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("k_"):
+            continue
+        f, wr = fetch.get(k, 0.0), write.get(k, 0.0)
+        out["kernels"][k] = {"fetch_raw": f, "fetch_corrected": f * corr, "write": wr, "hbm_bytes_per_launch": f * corr + wr}
+    out["hbm_bytes_per_launch"] = out["kernels"]["k_detect"]["hbm_bytes_per_launch"]
+    txt = json.dumps(out, indent=1)
+    if len(sys.argv) > 6:
+        open(sys.argv[6], "w").write(txt + "\n")
+    print(txt)
+
+
+if __name__ == "__main__":
+    main()

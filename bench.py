@@ -79,9 +79,9 @@ def _cpu_one(img):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per GPU (ring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -173,7 +173,7 @@ def main():
                    "pipeline_frac_of_hbm_peak": round(per_frame_bytes * fps / 1e9 / (HBM_PEAK_GBS * world), 5),
                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}},
         "roofline": {"bound": "hbm", "kernel": "k_detect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(),
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(args.batch),
                      "algorithmic_bytes_per_launch": detect_bytes * args.batch, "avg_launch_ms": round(det_ms, 4),
                      "launches_timed": ncalls},
     }
@@ -185,11 +185,13 @@ def main():
         dist.destroy_process_group()
 
 
-def load_traffic():
-    """HBM bytes per k_detect launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+def load_traffic(frames_per_launch):
+    """HBM bytes per k_detect launch from the committed rocprofv3 PMC passes (profiles/traffic_k_detect.json, made by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs), scaled to this run's frames per launch; or None."""
     p = os.path.join(ROOT, "profiles", "traffic_k_detect.json")
     try:
-        return json.load(open(p))["hbm_bytes_per_launch"]
+        d = json.load(open(p))
+        return round(d["hbm_bytes_per_launch"] * frames_per_launch / d["frames_per_launch"])
     except Exception:
         return None
 

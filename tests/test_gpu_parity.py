@@ -254,3 +254,40 @@ def test_full_size_properties_1080p_stream(B, ctx):
     k = r[0][0]
     assert len(k) == 986 and np.all(np.diff(k["octave"]) >= 0)
     assert np.all(k["x"] >= 13) and np.all(k["x"] < 1920 - 13) and np.all(k["angle"] != -1)
+
+
+def test_config4_4k_six_octaves(B):
+    """BASELINE config 4 geometry: 3840x2160, 6 octaves (12 layers down to 80x45), ~4k keypoints, vs the oracle."""
+    img = synth.frame_4k(2)
+    ko = O.detect(img, 80, 6)
+    kg = B.BriskFeatureDetector(80, 6).detect(img, capacity=65536)
+    assert same_kps(kg, ko), explain(kg, ko)
+    ko2, do = O.Extractor().compute(img, ko)
+    assert (len(ko), len(ko2)) == (4745, 4298)               # SURVEY §8(d) probe: 4298 described
+    kg2, dg = B.BriskDescriptorExtractor().compute(img, kg)
+    assert same_kps(kg2, ko2) and np.array_equal(dg, do)
+
+
+def test_config5_descriptor_only_100k_keypoints(B):
+    """BASELINE config 5: one 1080p frame + 100 000 synthetic keypoints (size log-uniform in [8.64, 200], angle -1)."""
+    img = synth.frame_1080p(0)
+    rng = np.random.default_rng(7)
+    n = 100000
+    size = np.exp(rng.uniform(np.log(8.64), np.log(200.0), n)).astype(np.float32)
+    ext_o = O.Extractor()
+    border = ext_o.size_list()[[ext_o.scale_index(s) for s in size[:2000]]]
+    k = np.zeros(n, B.KEYPOINT)
+    k["size"] = size
+    k["x"] = rng.uniform(0, 1920, n).astype(np.float32)      # some fall outside the border -> filtered
+    k["y"] = rng.uniform(0, 1080, n).astype(np.float32)
+    k["angle"] = -1
+    k["class_id"] = -1
+    ctx = B.Context(0, max_candidates=65536, max_keypoints=131072)
+    try:
+        kg, dg = B.BriskDescriptorExtractor(context=ctx).compute(img, k)
+    finally:
+        pass
+    ko, do = ext_o.compute(img, k)
+    assert 20000 < len(ko) < n
+    assert same_kps(kg, ko) and np.array_equal(dg, do)
+    ctx.close()

@@ -107,26 +107,26 @@ void bo_twothirdsample8(const uint8_t* src, int w, int h, uint8_t* dst) {
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
-static void thr_pass1_px(const uint8_t* img, int w, int x, int y, uint8_t* tmax, uint8_t* tmin) {
-  int mx = 0, mn = 255;
-  for (int dy = -1; dy <= 1; ++dy)
-    for (int dx = -1; dx <= 1; ++dx) {
-      int v = img[(long)(y + dy) * w + x + dx];
-      mx = imax(mx, v);
-      mn = imin(mn, v);
-    }
+
+static inline void thr_pass1_px(const uint8_t* img, int w, int x, int y, uint8_t* tmax, uint8_t* tmin) {
+  const uint8_t* r0 = img + (long)(y - 1) * w + x - 1;
+  const uint8_t* r1 = r0 + w;
+  const uint8_t* r2 = r1 + w;
+  int mx = r0[0], mn = r0[0];
+#define BO_MM(v) do { int v_ = (v); if (v_ > mx) mx = v_; if (v_ < mn) mn = v_; } while (0)
+  BO_MM(r0[1]); BO_MM(r0[2]); BO_MM(r1[0]); BO_MM(r1[1]); BO_MM(r1[2]); BO_MM(r2[0]); BO_MM(r2[1]); BO_MM(r2[2]);
   tmax[(long)y * w + x] = (uint8_t)mx;
   tmin[(long)y * w + x] = (uint8_t)mn;
 }
 
-static void thr_pass2_px(const uint8_t* img, int w, int x, int y, const uint8_t* tmax,
-                         const uint8_t* tmin, uint8_t* thr) {
+static inline void thr_pass2_px(const uint8_t* img, int w, int x, int y, const uint8_t* tmax,
+                                const uint8_t* tmin, uint8_t* thr) {
   const long o = (long)y * w + x;
+  const long w2 = 2L * w;
   int mx = img[o], mn = img[o];
-  const long c[4] = {o - 2 - 2L * w, o + 2 - 2L * w, o + 2 + 2L * w, o - 2 + 2L * w};
-  for (int k = 0; k < 4; ++k) { mx = imax(mx, img[c[k]]); mn = imin(mn, img[c[k]]); }
-  const long t[4] = {o - 2L * w, o + 2L * w, o - 2, o + 2};
-  for (int k = 0; k < 4; ++k) { mx = imax(mx, tmax[t[k]]); mn = imin(mn, tmin[t[k]]); }
+  BO_MM(img[o - 2 - w2]); BO_MM(img[o + 2 - w2]); BO_MM(img[o + 2 + w2]); BO_MM(img[o - 2 + w2]);
+  mx = imax(imax(mx, tmax[o - w2]), imax(tmax[o + w2], imax(tmax[o - 2], tmax[o + 2])));
+  mn = imin(imin(mn, tmin[o - w2]), imin(tmin[o + w2], imin(tmin[o - 2], tmin[o + 2])));
   thr[o] = (uint8_t)(mx - mn);
 }
 
@@ -227,6 +227,16 @@ int bo_oast9_16_detect(const uint8_t* img, int w, int h, const uint8_t* thrmap, 
         b2 = (t * b) / 100;
       } else {
         b2 = b;
+      }
+      {
+        /* early out, same result: 9 contiguous ring pixels contain two adjacent compass points
+         * (the generated tree likewise rejects most pixels after 2-3 comparisons) */
+        const uint8_t* p = img + (long)y * w + x;
+        const int cb = *p + b2, c_b = *p - b2;
+        const int pw = p[-3], pe = p[3], pn = p[-3 * w], ps = p[3 * w];
+        const int bw = pw > cb, be = pe > cb, bn = pn > cb, bs = ps > cb;
+        const int dw = pw < c_b, de = pe < c_b, dn = pn < c_b, ds = ps < c_b;
+        if (!((bw & bn) | (bn & be) | (be & bs) | (bs & bw) | (dw & dn) | (dn & de) | (de & ds) | (ds & dw))) continue;
       }
       if (!is_corner(img + (long)y * w + x, w, b2, kRing16, 16, 9)) continue;
       if (total < cap) { xy[2 * total] = x; xy[2 * total + 1] = y; }

@@ -83,7 +83,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per GPU (ring)")
+    ap.add_argument("--streams", type=int, default=1, help="internal stream slices per batch (1..8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results become wrong)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +113,8 @@ def main():
     del ring
 
     ctx = B.Context(local_rank)
+    ctx.set_streams(args.streams)
+    ctx.debug_set_flags(args.debug_flags)
     ext = B.BriskDescriptorExtractor(context=ctx)
     stream = torch.cuda.current_stream().cuda_stream
     strings = ext.descriptorSize()
@@ -128,7 +132,7 @@ def main():
         if gather:
             gather.run()
     torch.cuda.synchronize()
-    assert ctx.batch_status(args.batch) == 0
+    assert ctx.batch_status(args.batch) == 0 or args.debug_flags
     kps0, _ = ctx.batch_download(0, True, strings)
     mean_kp = float(np.mean([len(ctx.batch_download(f, True, strings)[0]) for f in range(min(args.batch, 8))]))
 
@@ -146,6 +150,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     stage_ms, ncalls = ctx.profile_read()
+    fpl = ctx.profile_frames_per_launch() or args.batch   # frames per timed kernel launch (one stream slice)
     ctx.profile_enable(False)
 
     if world > 1:
@@ -157,7 +162,7 @@ def main():
     fps = total_frames / dt
     per_frame_bytes, detect_bytes = algorithmic_bytes(W, H, OCTAVES, int(round(mean_kp)))
     det_ms = stage_ms.get("k_detect", 0.0)
-    achieved = (detect_bytes * args.batch) / (det_ms * 1e-3) / 1e9 if det_ms > 0 else 0.0
+    achieved = (detect_bytes * fpl) / (det_ms * 1e-3) / 1e9 if det_ms > 0 else 0.0
     out = {
         "metric": "frames/sec detect+describe @1080p (1/2/4/8 GPU); % HBM roofline",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +170,7 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "1080p synthetic textured stream (SURVEY App. C recipe, 300 rects), 4 octaves, "
                                "AGAST threshold 80, default 66-point pattern (48-byte descriptors)",
-                   "frames_per_step_per_gpu": args.batch, "distinct_frames_per_gpu": nd,
+                   "frames_per_step_per_gpu": args.batch, "stream_slices": args.streams, "frames_per_kernel_launch": fpl, "distinct_frames_per_gpu": nd,
                    "mean_keypoints_per_frame": round(mean_kp, 1),
                    "parallelism": "frames sharded over %d rank(s)%s" % (world, ", RCCL gather of keypoints+descriptors to rank 0 each step" if world > 1 else ""),
                    "algorithmic_MB_per_frame": round(per_frame_bytes / 1e6, 3),
@@ -173,8 +178,8 @@ def main():
                    "pipeline_frac_of_hbm_peak": round(per_frame_bytes * fps / 1e9 / (HBM_PEAK_GBS * world), 5),
                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}},
         "roofline": {"bound": "hbm", "kernel": "k_detect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(args.batch),
-                     "algorithmic_bytes_per_launch": detect_bytes * args.batch, "avg_launch_ms": round(det_ms, 4),
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(fpl),
+                     "algorithmic_bytes_per_launch": detect_bytes * fpl, "avg_launch_ms": round(det_ms, 4),
                      "launches_timed": ncalls},
     }
     if rank == 0:

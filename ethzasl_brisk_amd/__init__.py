@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
     "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
     "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags",
+    "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
 ]
 
 
@@ -83,6 +84,8 @@ def load_library():
     L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
+    L.brisk_hip_set_streams.argtypes = [vp, C.c_int]
+    L.brisk_hip_profile_frames_per_launch.argtypes = [vp]
     L.brisk_hip_profile_stage_name.argtypes = [C.c_int]
     L.brisk_hip_profile_stage_name.restype = C.c_char_p
     L.brisk_hip_profile_read.argtypes = [vp, vp, ip]
@@ -135,6 +138,12 @@ class Context:
         out = np.zeros((h + 1, w + 1), np.uint32)
         self.check(self._L.brisk_hip_debug_integral(self._h, frame, _ptr(out)))
         return out
+
+    def set_streams(self, n):
+        self.check(self._L.brisk_hip_set_streams(self._h, n))
+
+    def profile_frames_per_launch(self):
+        return self._L.brisk_hip_profile_frames_per_launch(self._h)
 
     def debug_set_flags(self, flags):
         self.check(self._L.brisk_hip_debug_set_flags(self._h, flags))

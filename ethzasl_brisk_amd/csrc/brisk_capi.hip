@@ -45,6 +45,14 @@ struct brisk_hip_ctx {
   bool last_has_desc = false;
   BriskProfiler prof;
   int debug_flags = 0;
+  // sub-batch streams: a batch is split into nsub slices that run on their own streams, so that the latency-bound
+  // kernels of one slice (tie resolution: one workgroup per frame) overlap with the throughput-bound kernels of the
+  // others instead of leaving most CUs idle
+  int nsub = 1;
+  hipStream_t sub[8] = {};
+  hipEvent_t fork_ev = nullptr, join_ev[8] = {};
+  bool sub_created = false;
+  int last_frames_per_launch = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -118,7 +126,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
     c->D.iframe_elems = iframe;
     return BRISK_HIP_OK;
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipDeviceSynchronize());
   const int slots = nframes > c->slots ? nframes : c->slots;
   const long pyr = G.pyr_elems > c->pyr_elems_alloc ? G.pyr_elems : c->pyr_elems_alloc;
   const long ifr = iframe > c->iframe_elems_alloc ? iframe : c->iframe_elems_alloc;
@@ -193,9 +201,13 @@ int brisk_hip_create(int device, brisk_hip_ctx** out) {
 void brisk_hip_destroy(brisk_hip_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  hipDeviceSynchronize();
   free_buffers(c);
   hipFree(c->d_stage);
+  if (c->sub_created) {
+    for (int i = 0; i < 8; ++i) { hipStreamDestroy(c->sub[i]); hipEventDestroy(c->join_ev[i]); }
+    hipEventDestroy(c->fork_ev);
+  }
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -219,12 +231,14 @@ static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_mult = take(64 * n * 4), o_sigma = take(64 * n * 4), o_uv = take((size_t)BRISK_NROT * n * 16);
+  const size_t o_scl = take(64 * n * 8);
   const size_t o_thr = take(64 * 4), o_size = take(64 * 4), o_sp = take((size_t)H.nshort * 4), o_lp = take((size_t)H.nlong * 16);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMalloc(&p->blob, off));
   char* b = (char*)p->blob;
   HIPCHK(ctx, hipMemcpy(b + o_mult, H.mult.data(), 64 * n * 4, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(b + o_sigma, H.sigma.data(), 64 * n * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(b + o_scl, H.scaling.data(), 64 * n * 8, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(b + o_uv, H.uv.data(), (size_t)BRISK_NROT * n * 16, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(b + o_thr, H.size_thresh.data(), 64 * 4, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(b + o_size, H.size_list.data(), 64 * 4, hipMemcpyHostToDevice));
@@ -234,6 +248,7 @@ static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
   d.npoints = H.npoints; d.nshort = H.nshort; d.nlong = H.nlong; d.strings = H.strings;
   d.rotation_invariant = 1; d.scale_invariant = 1; d.basicscale = H.basicscale;
   d.mult = (const float*)(b + o_mult); d.sigma = (const float*)(b + o_sigma); d.uv = (const double*)(b + o_uv);
+  d.scaling = (const int*)(b + o_scl);
   d.size_thresh = (const float*)(b + o_thr); d.size_list = (const int*)(b + o_size);
   d.short_pairs = (const uint16_t*)(b + o_sp); d.long_pairs = (const int*)(b + o_lp);
   return BRISK_HIP_OK;
@@ -311,14 +326,57 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
   brisk_prof_begin_call(&ctx->prof);
-  if (do_detect) {
-    brisk_launch_detect(ctx->G, ctx->T, ctx->B, nframes, d_frames, frame_pitch, row_pitch, d_mask, mask_frame_pitch,
-                        mask_row_pitch, s, &ctx->prof);
+  int nsub = ctx->nsub;
+  if (nsub > 8) nsub = 8;
+  if (nframes < 16 * nsub) nsub = nframes >= 32 ? 2 : 1;
+  if (nsub > 1 && !ctx->sub_created) {
+    for (int i = 0; i < 8; ++i) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->sub[i], hipStreamNonBlocking));
+      HIPCHK(ctx, hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
+    }
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    ctx->sub_created = true;
   }
-  if (do_describe) {
-    BriskPatternDev P = pat->dev;
-    brisk_launch_describe(ctx->G, P, ctx->B, ctx->D, nframes, ctx->B.kp_out, &ctx->B.counters[0].nkp,
-                          sizeof(BriskFrameCounters), s, &ctx->prof);
+  if (nsub > 1) HIPCHK(ctx, hipEventRecord(ctx->fork_ev, s));
+  const int nbands = (h + 63) / 64;
+  for (int i = 0; i < nsub; ++i) {
+    const long f0 = (long)nframes * i / nsub, f1 = (long)nframes * (i + 1) / nsub;
+    const int nf = (int)(f1 - f0);
+    if (nf <= 0) continue;
+    hipStream_t si = s;
+    if (nsub > 1) {
+      si = ctx->sub[i];
+      HIPCHK(ctx, hipStreamWaitEvent(si, ctx->fork_ev, 0));
+    }
+    BriskDetectBuffers Bi = ctx->B;
+    Bi.pyr += f0 * ctx->G.pyr_elems;
+    Bi.smap += f0 * ctx->G.pyr_elems;
+    Bi.cand += f0 * Bi.cand_cap;
+    Bi.blocks += f0 * Bi.cand_cap * 64;
+    Bi.tie_idx += f0 * BRISK_MAX_LAYERS * Bi.tie_cap;
+    Bi.keys += f0 * Bi.cand_cap * 2;
+    Bi.counters += f0;
+    Bi.kp_out += f0 * Bi.kp_cap;
+    BriskDescribeBuffers Di = ctx->D;
+    Di.integral += f0 * Di.iframe_elems;
+    Di.bandsum += f0 * nbands * Di.istride;
+    Di.dkp += f0 * Bi.kp_cap;
+    Di.dscale += f0 * Bi.kp_cap;
+    Di.desc += f0 * Bi.kp_cap * Di.desc_pitch;
+    BriskProfiler* prof = (i == 0) ? &ctx->prof : nullptr;  // per-kernel timing on the first slice's stream
+    if (i == 0) ctx->last_frames_per_launch = nf;
+    if (do_detect) {
+      brisk_launch_detect(ctx->G, ctx->T, Bi, nf, d_frames + f0 * frame_pitch, frame_pitch, row_pitch,
+                          d_mask ? d_mask + f0 * mask_frame_pitch : nullptr, mask_frame_pitch, mask_row_pitch, si, prof);
+    }
+    if (do_describe) {
+      BriskPatternDev P = pat->dev;
+      brisk_launch_describe(ctx->G, P, Bi, Di, nf, Bi.kp_out, &Bi.counters[0].nkp, sizeof(BriskFrameCounters), si, prof);
+    }
+    if (nsub > 1) {
+      HIPCHK(ctx, hipEventRecord(ctx->join_ev[i], si));
+      HIPCHK(ctx, hipStreamWaitEvent(s, ctx->join_ev[i], 0));
+    }
   }
   if (ctx->prof.on) ctx->prof.calls++;
   HIPCHK(ctx, hipGetLastError());
@@ -491,6 +549,15 @@ int brisk_hip_profile_enable(brisk_hip_ctx* ctx, int enable) {
 
 int brisk_hip_profile_stages(void) { return BRISK_PROF_STAGES; }
 const char* brisk_hip_profile_stage_name(int i) { return brisk_stage_name(i); }
+
+int brisk_hip_set_streams(brisk_hip_ctx* ctx, int n) {
+  if (!ctx || n < 1 || n > 8) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->nsub = n;
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_profile_frames_per_launch(brisk_hip_ctx* ctx) { return ctx ? ctx->last_frames_per_launch : 0; }
 
 int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls) {
   if (!ctx || !avg_ms) return BRISK_HIP_ERR_ARG;

@@ -98,6 +98,7 @@ struct BriskPatternDev {
   int rotation_invariant, scale_invariant, basicscale;
   const float* mult;      // [64][npoints]  multiplier m so that x = (float)((double)m * U)
   const float* sigma;     // [64][npoints]  box half side
+  const int* scaling;     // [64][npoints][2] {scaling, scaling2} of the box (functions of sigma only, :412-413)
   const double* uv;       // [1024][npoints][2] unit-scale rotated offsets (x, y)
   const float* size_thresh;  // [64] size_thresh[s] = smallest keypoint size with scale index >= s
   const int* size_list;   // [64] border per scale index

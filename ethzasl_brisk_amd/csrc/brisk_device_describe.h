@@ -35,13 +35,22 @@ BRISK_HD bool brisk_inside_border(const BriskPatternDev& P, int scale, float x, 
 //   x = float(scaleList[s] * r * cos(alpha + theta))                 (:105-108, V1)
 // for all 64 x 1024 x points (51.9 MB).  Both are float(double(m[s][i]) * U[rot][i]) with a
 // scale-independent double U, so the engine keeps U (1 MB, L2-resident) and m, sigma (34 KB).
-BRISK_HD void brisk_pattern_point(const BriskPatternDev& P, int scale, int rot, int i, float* x, float* y,
-                                  float* sigma) {
-  const double m = (double)P.mult[scale * P.npoints + i];
+struct BriskSamplePoint {
+  float x, y, sigma;
+  int scaling, scaling2;  // int(4194304.0 / area), int(float(scaling) * area / 1024.0) with area = float(4 sigma^2)
+};
+
+BRISK_HD BriskSamplePoint brisk_pattern_point(const BriskPatternDev& P, int scale, int rot, int i) {
+  BriskSamplePoint sp;
+  const int si = scale * P.npoints + i;
+  const double m = (double)P.mult[si];
   const double* uv = P.uv + ((long)rot * P.npoints + i) * 2;
-  *x = (float)(m * uv[0]);
-  *y = (float)(m * uv[1]);
-  *sigma = P.sigma[scale * P.npoints + i];
+  sp.x = (float)(m * uv[0]);
+  sp.y = (float)(m * uv[1]);
+  sp.sigma = P.sigma[si];
+  sp.scaling = P.scaling[2 * si];
+  sp.scaling2 = P.scaling[2 * si + 1];
+  return sp;
 }
 
 // SmoothedIntensity<uchar,int> (:370-530).  Weighted box sum: 4 corner pixels (weights A..D), 4 edge
@@ -52,10 +61,10 @@ BRISK_HD void brisk_pattern_point(const BriskPatternDev& P, int scale, int rot, 
 // golden vectors contain this behaviour, so it is reproduced.
 // integral: exclusive prefix sums, (rows+1) x (cols+1), row stride istride (u32, wrap-around).
 BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, const uint32_t* integral, int istride,
-                                      float key_x, float key_y, float bx, float by, float sigma_half) {
-  const float xf = bx + key_x;
-  const float yf = by + key_y;
-  const float area = (float)(4.0 * sigma_half * sigma_half);
+                                      float key_x, float key_y, const BriskSamplePoint& sp) {
+  const float sigma_half = sp.sigma;
+  const float xf = sp.x + key_x;
+  const float yf = sp.y + key_y;
   if (sigma_half < 0.5) {  // :391-408
     const int x = (int)xf, y = (int)yf;
     const int r_x = (int)((xf - x) * 1024);
@@ -69,8 +78,8 @@ BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, const uint
     ret_val += (r_x_1 * r_y * (int)ptr[stride]);
     return (ret_val) / 1024;
   }
-  const int scaling = (int)(4194304.0 / area);
-  const int scaling2 = (int)((float)scaling * area / 1024.0);
+  const int scaling = sp.scaling;
+  const int scaling2 = sp.scaling2;
   const float x_1 = xf - sigma_half;
   const float x1 = xf + sigma_half;
   const float y_1 = yf - sigma_half;
@@ -106,9 +115,18 @@ BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, const uint
   const uint32_t* r3 = r2 + istride;
   const int c0 = x_left, c1 = x_left + 1, c2 = x_right, c3 = x_right + 1;
   const uint32_t i01 = r0[c1], i02 = r0[c2];
+  const uint32_t i31 = r3[c1], i32 = r3[c2];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // adjacent column pairs as one 8-byte gather each (4-byte aligned is enough for global_load_dwordx2)
+  typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) u32x2_t;
+  const u32x2_t p10 = *reinterpret_cast<const u32x2_t*>(r1 + c0), p12 = *reinterpret_cast<const u32x2_t*>(r1 + c2);
+  const u32x2_t p20 = *reinterpret_cast<const u32x2_t*>(r2 + c0), p22 = *reinterpret_cast<const u32x2_t*>(r2 + c2);
+  const uint32_t i10 = p10.x, i11 = p10.y, i12 = p12.x, i13 = p12.y;
+  const uint32_t i20 = p20.x, i21 = p20.y, i22 = p22.x, i23 = p22.y;
+#else
   const uint32_t i10 = r1[c0], i11 = r1[c1], i12 = r1[c2], i13 = r1[c3];
   const uint32_t i20 = r2[c0], i21 = r2[c1], i22 = r2[c2], i23 = r2[c3];
-  const uint32_t i31 = r3[c1], i32 = r3[c2];
+#endif
   const uint32_t top = i12 - i11 - i02 + i01;     // first row, interior columns
   const uint32_t bottom = i32 - i31 - i22 + i21;  // last row, interior columns
   const uint32_t left = i21 - i20 - i11 + i10;    // first column, interior rows

@@ -5,7 +5,7 @@
 #include "brisk_common.h"
 
 #define BRISK_DETECT_TILE_W 64
-#define BRISK_DETECT_TILE_H 16
+#define BRISK_DETECT_TILE_H 32
 
 struct BriskTileTable {
   int first_tile[BRISK_MAX_LAYERS + 1];

@@ -104,9 +104,10 @@ __global__ void __launch_bounds__(256) k_pyramid_level(BriskGeom G, uint8_t* __r
 // k_detect: per-pixel threshold map (37-px disc contrast, brisk-layer.cc:278-598) + contrast-adaptive OAST 9_16
 // segment test (oast9-16.cc:79-100).  Dominant kernel of the pipeline.
 //
-// Tile = 64x16 output pixels per 256-thread workgroup; the (64+8)x(16+6) u8 halo tile is staged in LDS with
-// coalesced dword loads.  Phase A (all pixels): every thread owns 4 adjacent pixels, pulls its 7x12-byte window
-// out of LDS with 21 dword reads, computes the disc min/max in registers and applies a cascade of necessary
+// Tile = 64x32 output pixels per 256-thread workgroup; the (64+8)x(32+6) u8 halo tile is staged in LDS with
+// coalesced dword loads.  Phase A (all pixels): every thread owns 4 columns x 2 rows, pulls its 8x12-byte window
+// out of LDS with 24 dword reads, computes the disc min/max in registers (the horizontal partial extrema of a
+// window row are shared by the two output rows) and applies a cascade of necessary
 // conditions for a 9-of-16 arc (contrast gate, range gate, two adjacent compass points); survivors (a few %) are
 // compacted into an LDS queue with wave ballots.  Phase B (survivors only): one lane per queued pixel runs the
 // closed-form segment test.  Detections go to an LDS result tile that is written out as the smap tile with
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256) k_pyramid_level(BriskGeom G, uint8_t* __r
 // grid.x enumerates the tiles of all layers, grid.y = frame.
 // ------------------------------------------------------------------------------------------------
 #define DT_W 64
-#define DT_H 16
+#define DT_H 32
 #define DT_LW (DT_W + 8)
 #define DT_LH (DT_H + 6)
 
@@ -153,61 +154,93 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
     if (gy >= 0 && gy < h && gx >= 0 && gx < stride) v = *reinterpret_cast<const unsigned*>(img + (long)gy * stride + gx);
     *reinterpret_cast<unsigned*>(&tile[r * DT_LW + c4 * 4]) = v;
   }
-  *reinterpret_cast<unsigned*>(&dres[threadIdx.x * 4]) = 0;
+  *reinterpret_cast<uint2*>(&dres[threadIdx.x * 8]) = make_uint2(0, 0);
   if (threadIdx.x == 0) qcount = 0;
   __syncthreads();
 
-  // ---- phase A
-  const int lx = (threadIdx.x & 15) * 4, ly = threadIdx.x >> 4;
-  const int gy = y0 + ly;
-  unsigned R[7][3];
+  // ---- phase A: 4 columns x 2 rows per thread.  Row window rows 0..7 = image rows gy-3 .. gy+4; the horizontal
+  // partial extrema (widths 3, 5, 7 around each of the 4 columns) of a window row are shared by both output rows:
+  //   output row A (gy)   = max(h3[r0], h5[r1], h7[r2], h7[r3], h7[r4], h5[r5], h3[r6])
+  //   output row B (gy+1) = max(h3[r1], h5[r2], h7[r3], h7[r4], h7[r5], h5[r6], h3[r7])       (same for min)
+  const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * 2;
+  unsigned R[8][3];
 #pragma unroll
-  for (int r = 0; r < 7; ++r) {
+  for (int r = 0; r < 8; ++r) {
     const unsigned* p = reinterpret_cast<const unsigned*>(&tile[(ly + r) * DT_LW + lx]);
     R[r][0] = p[0]; R[r][1] = p[1]; R[r][2] = p[2];
   }
-  const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
+  int X3[8][4], N3[8][4], X5[8][4], N5[8][4], X7[8][4], N7[8][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int gx = x0 + lx + j;
-    int mn = 255, mx = 0;
+  for (int r = 0; r < 8; ++r) {
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
-      const int rad = (r == 0 || r == 6) ? 1 : (r == 1 || r == 5) ? 2 : 3;
-#pragma unroll
-      for (int i = -3; i <= 3; ++i) {
-        if (i < -rad || i > rad) continue;
-        const int v = DT_B(R[r][0], R[r][1], R[r][2], j + i);
-        mn = min(mn, v);
-        mx = max(mx, v);
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int a = DT_B(R[r][0], R[r][1], R[r][2], j - 1), b = DT_B(R[r][0], R[r][1], R[r][2], j), c = DT_B(R[r][0], R[r][1], R[r][2], j + 1);
+      X3[r][j] = max(max(a, b), c);
+      N3[r][j] = min(min(a, b), c);
+      if (r >= 1 && r <= 6) {
+        const int d = DT_B(R[r][0], R[r][1], R[r][2], j - 2), e = DT_B(R[r][0], R[r][1], R[r][2], j + 2);
+        X5[r][j] = max(max(X3[r][j], d), e);
+        N5[r][j] = min(min(N3[r][j], d), e);
+      } else { X5[r][j] = 0; N5[r][j] = 0; }
+      if (r >= 2 && r <= 5) {
+        const int f = DT_B(R[r][0], R[r][1], R[r][2], j - 3), g = DT_B(R[r][0], R[r][1], R[r][2], j + 3);
+        X7[r][j] = max(max(X5[r][j], f), g);
+        N7[r][j] = min(min(N5[r][j], f), g);
+      } else { X7[r][j] = 0; N7[r][j] = 0; }
     }
-    const int tt = mx - mn;
-    const int tc = min(max(tt, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
-    const int b2 = (tc * thr) / 100;
-    const int c = DT_B(R[3][0], R[3][1], R[3][2], j);
-    bool pass = (gx >= 3) && (gx <= w - 4) && (gy >= 3) && (gy <= h - 4) && (tt >= cmp) && ((mx - c > b2) || (c - mn > b2));
-    // a 9-of-16 arc contains two adjacent compass points (W, N, E, S); lazy evaluation on purpose: the exec-mask
-    // branches skip the compass work for the ~70 % of lanes that already failed (measured faster than branch-free)
-    const int pw = DT_B(R[3][0], R[3][1], R[3][2], j - 3), pe = DT_B(R[3][0], R[3][1], R[3][2], j + 3);
-    const int pn = DT_B(R[0][0], R[0][1], R[0][2], j), ps = DT_B(R[6][0], R[6][1], R[6][2], j);
-    const int cb = c + b2, c_b = c - b2;
-    const bool bw = pw > cb, bn = pn > cb, be = pe > cb, bs = ps > cb;
-    const bool dw = pw < c_b, dn = pn < c_b, de = pe < c_b, ds = ps < c_b;
-    pass = pass && (((bw && bn) || (bn && be) || (be && bs) || (bs && bw)) || ((dw && dn) || (dn && de) || (de && ds) || (ds && dw)));
-    const unsigned long long m = __ballot(pass);
-    if (m) {
-      int qb = 0;
-      const int lane = threadIdx.x & 63;
-      if (lane == 0) qb = atomicAdd(&qcount, __popcll(m));
-      qb = __builtin_amdgcn_readfirstlane(qb);
-      if (pass) queue[qb + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(ly * DT_W + lx + j) | ((unsigned)tt << 16) | ((unsigned)b2 << 24);
+  }
+  // Gates as straight-line code on WAVE MASKS: every comparison is one v_cmp whose 64-bit lane mask is combined
+  // with scalar and/or (no exec-mask branches, no boolean VGPRs); the combined mask is the compaction ballot.
+  const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
+  const int lane = threadIdx.x & 63;
+  unsigned long long mk[8];
+  unsigned entry_k[8];
+  int total = 0;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {  // output row A / B
+    const int gy = y0 + ly + rr;
+    const bool row_ok = (gy >= 3) && (gy <= h - 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gx = x0 + lx + j;
+      int mx = max(max(X3[rr][j], X5[rr + 1][j]), X7[rr + 2][j]);
+      mx = max(max(mx, X7[rr + 3][j]), X7[rr + 4][j]);
+      mx = max(max(mx, X5[rr + 5][j]), X3[rr + 6][j]);
+      int mn = min(min(N3[rr][j], N5[rr + 1][j]), N7[rr + 2][j]);
+      mn = min(min(mn, N7[rr + 3][j]), N7[rr + 4][j]);
+      mn = min(min(mn, N5[rr + 5][j]), N3[rr + 6][j]);
+      const int tt = mx - mn;
+      const int tc = min(max(tt, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
+      const int b2 = (tc * thr) / 100;
+      const int c = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j);
+      const int cb = c + b2, c_b = c - b2;
+      // a 9-of-16 arc contains two adjacent compass points (W, N, E, S)
+      const int pw = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j - 3), pe = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j + 3);
+      const int pn = DT_B(R[rr][0], R[rr][1], R[rr][2], j), ps = DT_B(R[rr + 6][0], R[rr + 6][1], R[rr + 6][2], j);
+      const unsigned long long m_in = __ballot(row_ok && gx >= 3 && gx <= w - 4 && tt >= cmp);
+      const unsigned long long m_rng = __ballot(mx > cb) | __ballot(mn < c_b);
+      const unsigned long long bw = __ballot(pw > cb), bn = __ballot(pn > cb), be = __ballot(pe > cb), bs = __ballot(ps > cb);
+      const unsigned long long dw = __ballot(pw < c_b), dn = __ballot(pn < c_b), de = __ballot(pe < c_b), ds = __ballot(ps < c_b);
+      const unsigned long long m = m_in & m_rng & (((bw & bn) | (bn & be) | (be & bs) | (bs & bw)) | ((dw & dn) | (dn & de) | (de & ds) | (ds & dw)));
+      mk[rr * 4 + j] = m;
+      total += __popcll(m);
+      entry_k[rr * 4 + j] = (unsigned)((ly + rr) * DT_W + lx + j) | ((unsigned)tt << 16) | ((unsigned)b2 << 24);
+    }
+  }
+  if (total) {  // compaction: one LDS atomic per wave for all 8 pixel slots
+    int qb = 0;
+    if (lane == 0) qb = atomicAdd(&qcount, total);
+    qb = __builtin_amdgcn_readfirstlane(qb);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if ((mk[k] >> lane) & 1ull) queue[qb + __popcll(mk[k] & ((1ull << lane) - 1ull))] = entry_k[k];
+      qb += __popcll(mk[k]);
     }
   }
   __syncthreads();
 
   // ---- phase B: closed-form segment test on the survivors
-  const int nq = qcount;
+  const int nq = (G.debug_flags & 64) ? 0 : qcount;
   for (int i = threadIdx.x; i < nq; i += 256) {
     const unsigned e = queue[i];
     const int idx = e & 0xFFFF, D = (e >> 16) & 0xFF, b2 = e >> 24;
@@ -231,12 +264,16 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   __syncthreads();
 
   // ---- smap tile: D in the low byte, all state bits cleared
-  if (gy < h && x0 + lx < stride) {
-    const unsigned d4 = *reinterpret_cast<const unsigned*>(&dres[ly * DT_W + lx]);
-    uint2 o;
-    o.x = (d4 & 0xFFu) | ((d4 & 0xFF00u) << 8);
-    o.y = ((d4 >> 16) & 0xFFu) | ((d4 >> 8) & 0xFF0000u);
-    *reinterpret_cast<uint2*>(smap + base + (long)gy * stride + x0 + lx) = o;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int gy = y0 + ly + rr;
+    if (gy < h && x0 + lx < stride && !(G.debug_flags & 32)) {
+      const unsigned d4 = *reinterpret_cast<const unsigned*>(&dres[(ly + rr) * DT_W + lx]);
+      uint2 o;
+      o.x = (d4 & 0xFFu) | ((d4 & 0xFF00u) << 8);
+      o.y = ((d4 >> 16) & 0xFFu) | ((d4 >> 8) & 0xFF0000u);
+      *reinterpret_cast<uint2*>(smap + base + (long)gy * stride + x0 + lx) = o;
+    }
   }
 }
 
@@ -468,18 +505,19 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
             const int dy = e / TR_WIN - 4, dx = e % TR_WIN - 4;
             const int qx = cx + dx, qy = cy + dy;
             unsigned v = 0;
-            if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
+            if (!(G.debug_flags & 4) && qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
             wl[e] = (uint16_t)v;
             if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) pending = true;
           }
-          if (!__any(pending)) break;
+          if (!__any(pending) || (G.debug_flags & 16)) break;
           __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
-        if (lane < 8) vals[wave][lane] = brisk_tie_probe_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
+        if (G.debug_flags & 2) { if (lane < 40) vals[wave][lane] = 0; }
+        else if (lane < 8) vals[wave][lane] = brisk_tie_probe_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
         else if (lane >= 32 && lane < 57)
           vals[wave][8 + lane - 32] = brisk_tie_raw_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane - 32, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -492,7 +530,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
           else smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);       // TIE (10b) -> FAIL (11b)
           BriskCand* c = &cand[(long)frame * cand_cap + ci];
           c->status = pass ? BRISK_ST_PASS : BRISK_ST_FAIL;
-          if (pass && l + 1 < G.nlayers) {
+          if (pass && l + 1 < G.nlayers && !(G.debug_flags & 8)) {
             const unsigned fpm = c->fp_mask;
             if (fpm) {
               const int fx = c->fp_x0, fy = c->fp_y0;
@@ -812,9 +850,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
     if (P.rotation_invariant) {
       if (kangle == -1.0f) {
         for (int i = lane; i < P.npoints; i += 64) {
-          float bx, by, sg;
-          brisk_pattern_point(P, scale, 0, i, &bx, &by, &sg);
-          values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, bx, by, sg);
+          values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, brisk_pattern_point(P, scale, 0, i));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -839,9 +875,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
       }
     }
     for (int i = lane; i < P.npoints; i += 64) {
-      float bx, by, sg;
-      brisk_pattern_point(P, scale, theta, i, &bx, &by, &sg);
-      values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, bx, by, sg);
+      values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, brisk_pattern_point(P, scale, theta, i));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

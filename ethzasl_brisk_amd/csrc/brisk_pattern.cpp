@@ -46,7 +46,22 @@ void fill_size_list_v2(BriskPatternHost* P) {
   }
 }
 
+// scaling / scaling2 of SmoothedIntensity (:387, :412-413) depend only on sigma: tabulated per (scale, point)
+void fill_scaling(BriskPatternHost* P) {
+  const size_t n = P->sigma.size();
+  P->scaling.resize(2 * n);
+  for (size_t i = 0; i < n; ++i) {
+    const float sigma_half = P->sigma[i];
+    const float area = (float)(4.0 * sigma_half * sigma_half);
+    const int scaling = (int)(4194304.0 / area);
+    const int scaling2 = (int)((float)scaling * area / 1024.0);
+    P->scaling[2 * i] = scaling;
+    P->scaling[2 * i + 1] = scaling2;
+  }
+}
+
 void fill_thresholds(BriskPatternHost* P) {
+  fill_scaling(P);
   // smallest float size whose scale index (before saturation) reaches s; bisection on the bit pattern
   P->size_thresh.assign(BRISK_SCALES, 0.0f);
   for (int s = 1; s < BRISK_SCALES; ++s) {

@@ -15,6 +15,7 @@ struct BriskPatternHost {
   std::vector<float> size_thresh;   // [64]
   std::vector<float> mult;          // [64][npoints]
   std::vector<float> sigma;         // [64][npoints]
+  std::vector<int> scaling;         // [64][npoints][2]
   std::vector<double> uv;           // [1024][npoints][2]
   std::vector<uint16_t> short_pairs;  // [nshort][2]
   std::vector<int> long_pairs;        // [nlong][4]

@@ -97,12 +97,18 @@ int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which /*0 detect
 /* error / overflow flags of the last batch, OR-ed over frames (0 = clean); synchronises */
 int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags);
 
+/* Number of internal streams a batch is sliced over (1..8, default 1: measured no gain from slicing).  The slices fork from / join into the
+ * caller's stream with events, so the call stays asynchronous and ordered on that stream. */
+int brisk_hip_set_streams(brisk_hip_ctx* ctx, int n);
+
 /* ---- per-stage timing: HIP events recorded on the launch stream around every kernel of the batch path ---- */
 int brisk_hip_profile_enable(brisk_hip_ctx* ctx, int enable);       /* resets the accumulated calls */
 int brisk_hip_profile_stages(void);                                 /* number of stages */
 const char* brisk_hip_profile_stage_name(int stage);
 /* average milliseconds per stage over the calls since enable/read (at most the last 64); synchronises */
 int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls);
+/* frames handled by each timed kernel launch (= frames of the first stream slice of the last batch) */
+int brisk_hip_profile_frames_per_launch(brisk_hip_ctx* ctx);
 
 /* ---- per-stage device entry points (parity tests of individual kernels) ---------------------- */
 /* which: 0 pyramid image, 1 score-state map low byte (D), after the last detect on frame slot 0.

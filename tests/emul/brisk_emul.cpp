@@ -299,7 +299,7 @@ void* emul_pattern_create(int version, float pattern_scale, const char* text) {
   BriskPatternDev& d = e->P;
   d.npoints = e->H.npoints; d.nshort = e->H.nshort; d.nlong = e->H.nlong; d.strings = e->H.strings;
   d.rotation_invariant = 1; d.scale_invariant = 1; d.basicscale = e->H.basicscale;
-  d.mult = e->H.mult.data(); d.sigma = e->H.sigma.data(); d.uv = e->H.uv.data();
+  d.mult = e->H.mult.data(); d.sigma = e->H.sigma.data(); d.uv = e->H.uv.data(); d.scaling = e->H.scaling.data();
   d.size_thresh = e->H.size_thresh.data(); d.size_list = e->H.size_list.data();
   d.short_pairs = e->H.short_pairs.data(); d.long_pairs = e->H.long_pairs.data();
   return e;
@@ -315,7 +315,8 @@ void emul_pattern_tables(void* p, float* scale_list, int* size_list, float* size
 }
 // full pattern LUT entry as the reference tabulates it
 void emul_pattern_point(void* p, int scale, int rot, int i, float* xyz) {
-  brisk_pattern_point(((EmulPattern*)p)->P, scale, rot, i, &xyz[0], &xyz[1], &xyz[2]);
+  const BriskSamplePoint sp = brisk_pattern_point(((EmulPattern*)p)->P, scale, rot, i);
+  xyz[0] = sp.x; xyz[1] = sp.y; xyz[2] = sp.sigma;
 }
 int emul_scale_index(void* p, float size, int scale_invariant) {
   BriskPatternDev P = ((EmulPattern*)p)->P;
@@ -353,9 +354,7 @@ int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kp
     if (P.rotation_invariant) {
       if (kp->angle == -1.0f) {
         for (int i = 0; i < P.npoints; ++i) {
-          float bx, by, sg;
-          brisk_pattern_point(P, scale, 0, i, &bx, &by, &sg);
-          values[i] = brisk_smoothed_intensity(img, w, integ.data(), istride, kp->x, kp->y, bx, by, sg);
+          values[i] = brisk_smoothed_intensity(img, w, integ.data(), istride, kp->x, kp->y, brisk_pattern_point(P, scale, 0, i));
         }
         int d0 = 0, d1 = 0;
         for (int p = 0; p < P.nlong; ++p) {
@@ -370,9 +369,7 @@ int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kp
       }
     }
     for (int i = 0; i < P.npoints; ++i) {
-      float bx, by, sg;
-      brisk_pattern_point(P, scale, theta, i, &bx, &by, &sg);
-      values[i] = brisk_smoothed_intensity(img, w, integ.data(), istride, kp->x, kp->y, bx, by, sg);
+      values[i] = brisk_smoothed_intensity(img, w, integ.data(), istride, kp->x, kp->y, brisk_pattern_point(P, scale, theta, i));
     }
     uint8_t* drow = desc + (size_t)k * desc_pitch;
     memset(drow, 0, P.strings);

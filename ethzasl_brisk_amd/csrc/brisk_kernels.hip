@@ -101,6 +101,137 @@ __global__ void __launch_bounds__(256) k_pyramid_level(BriskGeom G, uint8_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused pyramid kernels.  Halfsample8 output (c, r) depends only on the source block (2c..2c+1, 2r..2r+1) and
+// Twothirdsample8 output pairs only on a 3x3 source block, so whole chains of levels can be produced from one
+// aligned source block without any halo:
+//   k_pyramid_even: 64x64 block of the input frame -> layer 0 copy (aligned pyramid layout), L2 32x32, L4 16x16,
+//                   L6 8x8; the intermediate levels stay in LDS.
+//   k_pyramid_odd : 96x96 block of layer 0 -> L1 64x64 (two-third), L3 32x32, L5 16x16, L7 8x8.
+// Layers beyond the fused depth (more than 4 octaves) are produced by k_pyramid_level.
+// The exact column classes of the reference depend on absolute output columns and source widths, which
+// brisk_half_px / brisk_twothird_px receive unchanged (LDS tiles are addressed with absolute coordinates).
+// ------------------------------------------------------------------------------------------------
+struct TileRef {  // view of an LDS tile that covers image pixels [x0, x0+tw) x [y0, y0+th)
+  const uint8_t* p;
+  int x0, y0, tw;
+};
+// pointer such that ptr[r * stride + c] addresses absolute pixel (c, r) of the tiled layer
+__device__ __forceinline__ const uint8_t* tile_origin(const TileRef& t) { return t.p - (long)t.y0 * t.tw - t.x0; }
+
+__global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t* __restrict__ frames, long frame_pitch,
+                                                       int row_pitch, uint8_t* __restrict__ pyr, int nlevels) {
+  __shared__ __attribute__((aligned(16))) uint8_t t0[64 * 64], t2[32 * 32], t4[16 * 16];
+  const int frame = blockIdx.z;
+  const int bx = blockIdx.x * 64, by = blockIdx.y * 64;
+  const int w = G.L[0].w, h = G.L[0].h;
+  const uint8_t* src = frames + (long)frame * frame_pitch;
+  uint8_t* P = pyr + (long)frame * G.pyr_elems;
+  const bool aligned = ((row_pitch | (uintptr_t)src) & 3) == 0;
+  // stage the 64x64 source block (zero outside the image) and write the layer-0 copy
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    const int gy = by + r, gx = bx + c4;
+    unsigned v = 0;
+    if (gy < h) {
+      if (aligned && gx + 3 < w) v = *reinterpret_cast<const unsigned*>(src + (long)gy * row_pitch + gx);
+      else
+        for (int k = 0; k < 4; ++k)
+          if (gx + k < w) v |= (unsigned)src[(long)gy * row_pitch + gx + k] << (8 * k);
+      if (gx < G.L[0].stride) *reinterpret_cast<unsigned*>(P + G.L[0].off + (long)gy * G.L[0].stride + gx) = v;
+    }
+    *reinterpret_cast<unsigned*>(&t0[r * 64 + c4]) = v;
+  }
+  __syncthreads();
+  // successive halvings: level k has tile (64 >> k)^2 at origin (bx >> k, by >> k)
+  TileRef srct = {t0, bx, by, 64};
+  uint8_t* dst_lds[3] = {t2, t4, nullptr};
+  int sw = w;
+#pragma unroll
+  for (int k = 1; k <= 3; ++k) {
+    if (k > nlevels) break;
+    const int l = 2 * k;
+    const int tw = 64 >> k;
+    const int ox = bx >> k, oy = by >> k;
+    const int dw = G.L[l].w, dh = G.L[l].h, dstride = G.L[l].stride;
+    const uint8_t* so = tile_origin(srct);
+    uint8_t* dl = dst_lds[k - 1];
+    for (int i = threadIdx.x; i < tw * tw; i += 256) {
+      const int r = i / tw, c = i % tw;
+      const int gx = ox + c, gy = oy + r;
+      uint8_t v = 0;
+      if (gx < dw && gy < dh) {
+        v = brisk_half_px(so, srct.tw, sw, gx, gy);
+        P[G.L[l].off + (long)gy * dstride + gx] = v;
+      }
+      if (dl) dl[r * tw + c] = v;
+    }
+    __syncthreads();
+    srct.p = dl; srct.x0 = ox; srct.y0 = oy; srct.tw = tw;
+    sw = dw;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __restrict__ pyr, int nlevels) {
+  __shared__ __attribute__((aligned(16))) uint8_t t0[96 * 96], t1[64 * 64], t3[32 * 32], t5[16 * 16];
+  const int frame = blockIdx.z;
+  const int bx = blockIdx.x * 96, by = blockIdx.y * 96;
+  uint8_t* P = pyr + (long)frame * G.pyr_elems;
+  const int w = G.L[0].w, h = G.L[0].h, s0 = G.L[0].stride;
+  const uint8_t* src = P + G.L[0].off;
+  for (int i = threadIdx.x; i < 96 * 24; i += 256) {
+    const int r = i / 24, c4 = (i % 24) * 4;
+    const int gy = by + r, gx = bx + c4;
+    unsigned v = 0;
+    if (gy < h && gx < s0) v = *reinterpret_cast<const unsigned*>(src + (long)gy * s0 + gx);
+    *reinterpret_cast<unsigned*>(&t0[r * 96 + c4]) = v;
+  }
+  __syncthreads();
+  {  // L1 = two-third sample: 64x64 outputs at origin (bx/3*2, by/3*2)
+    const int ox = bx / 3 * 2, oy = by / 3 * 2;
+    const int dw = G.L[1].w, dh = G.L[1].h, dstride = G.L[1].stride;
+    const TileRef st = {t0, bx, by, 96};
+    const uint8_t* so = tile_origin(st);
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const int gx = ox + c, gy = oy + r;
+      uint8_t v = 0;
+      if (gx < dw && gy < dh) {
+        v = brisk_twothird_px(so, 96, w, gx, gy);
+        P[G.L[1].off + (long)gy * dstride + gx] = v;
+      }
+      t1[r * 64 + c] = v;
+    }
+  }
+  __syncthreads();
+  TileRef srct = {t1, bx / 3 * 2, by / 3 * 2, 64};
+  uint8_t* dst_lds[3] = {t3, t5, nullptr};
+  int sw = G.L[1].w;
+#pragma unroll
+  for (int k = 1; k <= 3; ++k) {
+    if (k > nlevels) break;
+    const int l = 2 * k + 1;
+    const int tw = 64 >> k;
+    const int ox = srct.x0 >> 1, oy = srct.y0 >> 1;
+    const int dw = G.L[l].w, dh = G.L[l].h, dstride = G.L[l].stride;
+    const uint8_t* so = tile_origin(srct);
+    uint8_t* dl = dst_lds[k - 1];
+    for (int i = threadIdx.x; i < tw * tw; i += 256) {
+      const int r = i / tw, c = i % tw;
+      const int gx = ox + c, gy = oy + r;
+      uint8_t v = 0;
+      if (gx < dw && gy < dh) {
+        v = brisk_half_px(so, srct.tw, sw, gx, gy);
+        P[G.L[l].off + (long)gy * dstride + gx] = v;
+      }
+      if (dl) dl[r * tw + c] = v;
+    }
+    __syncthreads();
+    srct.p = dl; srct.x0 = ox; srct.y0 = oy; srct.tw = tw;
+    sw = dw;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_detect: per-pixel threshold map (37-px disc contrast, brisk-layer.cc:278-598) + contrast-adaptive OAST 9_16
 // segment test (oast9-16.cc:79-100).  Dominant kernel of the pipeline.
 //
@@ -934,15 +1065,18 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
   brisk_prof_mark(prof, BRISK_STG_PYRAMID, s);
   {
-    const long items = (long)(G.L[0].stride / 4) * G.L[0].h;
-    hipLaunchKernelGGL(k_copy_layer0, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, frames, frame_pitch,
-                       row_pitch, B.pyr);
-  }
-  for (int l = 1; l < G.nlayers; ++l) {
-    const int sl = (l == 1) ? 0 : l - 2;
-    const long items = (long)(G.L[l].stride / 4) * G.L[l].h;
-    hipLaunchKernelGGL(k_pyramid_level, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, B.pyr, sl, l,
-                       (l == 1) ? 1 : 0);
+    // even chain: layer-0 copy + L2, L4, L6 from 64x64 blocks of the frame; odd chain: L1, L3, L5, L7 from 96x96 blocks
+    const int even_levels = G.nlayers >= 7 ? 3 : G.nlayers >= 5 ? 2 : G.nlayers >= 3 ? 1 : 0;
+    const int odd_levels = G.nlayers >= 8 ? 3 : G.nlayers >= 6 ? 2 : G.nlayers >= 4 ? 1 : 0;
+    hipLaunchKernelGGL(k_pyramid_even, dim3((G.L[0].stride + 63) / 64, (G.L[0].h + 63) / 64, nframes), dim3(256), 0, s, G,
+                       frames, frame_pitch, row_pitch, B.pyr, even_levels);
+    if (G.nlayers >= 2)
+      hipLaunchKernelGGL(k_pyramid_odd, dim3((G.L[0].w + 95) / 96, (G.L[0].h + 95) / 96, nframes), dim3(256), 0, s, G, B.pyr,
+                         odd_levels);
+    for (int l = 8; l < G.nlayers; ++l) {  // more than 4 octaves: remaining levels one by one
+      const long items = (long)(G.L[l].stride / 4) * G.L[l].h;
+      hipLaunchKernelGGL(k_pyramid_level, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, B.pyr, l - 2, l, 0);
+    }
   }
   brisk_prof_mark(prof, BRISK_STG_DETECT, s);
   hipLaunchKernelGGL(k_detect, dim3(T.total_tiles, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,

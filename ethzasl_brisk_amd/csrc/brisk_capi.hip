@@ -109,7 +109,7 @@ static void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G
 
 static void free_buffers(brisk_hip_ctx* c) {
   hipFree(c->B.pyr); hipFree(c->B.smap); hipFree(c->B.cand); hipFree(c->B.blocks); hipFree(c->B.tie_idx); hipFree(c->B.keys);
-  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->D.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale);
+  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->D.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale); hipFree(c->D.dperm);
   hipFree(c->D.desc); hipFree(c->d_kp_in); hipFree(c->d_n_in);
   c->B = BriskDetectBuffers{};
   c->D = BriskDescribeBuffers{};
@@ -144,6 +144,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMalloc(&c->D.bandsum, (size_t)slots * ((ifr / 64) + 4 * 8192 + 64) * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc(&c->D.dkp, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
   HIPCHK(c, hipMalloc(&c->D.dscale, (size_t)slots * c->kp_cap * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->D.dperm, (size_t)slots * c->kp_cap * sizeof(int)));
   c->D.desc_pitch = 64;
   HIPCHK(c, hipMalloc(&c->D.desc, (size_t)slots * c->kp_cap * c->D.desc_pitch));
   HIPCHK(c, hipMalloc(&c->d_kp_in, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
@@ -362,6 +363,7 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
     Di.bandsum += f0 * nbands * Di.istride;
     Di.dkp += f0 * Bi.kp_cap;
     Di.dscale += f0 * Bi.kp_cap;
+    Di.dperm += f0 * Bi.kp_cap;
     Di.desc += f0 * Bi.kp_cap * Di.desc_pitch;
     BriskProfiler* prof = (i == 0) ? &ctx->prof : nullptr;  // per-kernel timing on the first slice's stream
     if (i == 0) ctx->last_frames_per_launch = nf;

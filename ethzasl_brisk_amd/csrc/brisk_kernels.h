@@ -33,6 +33,7 @@ struct BriskDescribeBuffers {
   long iframe_elems;
   BriskKeyPoint* dkp;  // [slots][kp_cap] filtered keypoints (angle filled in)
   int* dscale;         // [slots][kp_cap]
+  int* dperm;          // [slots][kp_cap] processing order of the keypoints (spatially sorted, L2 locality)
   uint8_t* desc;       // [slots][kp_cap][desc_pitch]
   int desc_pitch;
 };

@@ -8,7 +8,7 @@
 //   k_finalize        (layer, y, x) ordering + keypoint output                  (sparse)
 //   k_integral_bandsums / k_integral_final   exclusive 2-D prefix sum (u32)     (HBM-bound)
 //   k_desc_prepare    scale index + border filter + stable compaction           (sparse)
-//   k_describe        pattern sampling, orientation, 384/512 bit tests          (gather-bound)
+//   k_describe        pattern sampling, orientation, 384/512 bit tests          (gather / L2-miss bound)
 // No MFMA: the path is byte/integer stencil + gather work.
 #include <hip/hip_runtime.h>
 
@@ -905,14 +905,16 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+#define DP_MAXSORT 4096
 // k_desc_prepare: per frame, scale index + border filter (brisk-descriptor-extractor.cc:636-662),
 // stable compaction into dkp (keypoints) / dscale.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
                                                        const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
-                                                       BriskKeyPoint* dkp, int* dscale, int kp_cap) {
+                                                       BriskKeyPoint* dkp, int* dscale, int* dperm, int kp_cap) {
   __shared__ int scan[256];
   __shared__ int base;
+  __shared__ unsigned pkey[DP_MAXSORT];
   const int frame = blockIdx.x, tid = threadIdx.x;
   const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
   const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;
@@ -945,6 +947,26 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
     __syncthreads();
   }
   if (tid == 0) counters[frame].ndesc = base;
+  // Processing order for k_describe: keypoints sorted by 64-row band, then x, so that keypoints sampled at the
+  // same time touch the same part of the integral image (the output order stays (layer, y, x)).
+  __syncthreads();
+  const int m = base;
+  int* perm = dperm + (long)frame * kp_cap;
+  if (m <= DP_MAXSORT) {
+    for (int j = tid; j < m; j += 256) {
+      const BriskKeyPoint& q = dkp[(long)frame * kp_cap + j];
+      pkey[j] = ((unsigned)((int)q.y >> 6) << 24) | ((unsigned)((int)q.x & 0x1FFF) << 11) | (unsigned)(j & 0x7FF);
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += 256) {
+      const unsigned kj = pkey[j];
+      int r = 0;
+      for (int q = 0; q < m; ++q) r += (pkey[q] < kj || (pkey[q] == kj && q < j)) ? 1 : 0;
+      perm[r] = j;
+    }
+  } else {
+    for (int j = tid; j < m; j += 256) perm[j] = j;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -953,12 +975,21 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
 // reduced with integer wave reductions (order independent), the short-pair bits are packed with 64-wide ballots.
 // ------------------------------------------------------------------------------------------------
 #define DS_WAVES 4
+#define DS_LP_LDS 1024
 __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
                                                             const uint32_t* __restrict__ integral, int istride,
                                                             long iframe_elems, const BriskFrameCounters* counters,
-                                                            BriskKeyPoint* dkp, const int* dscale, uint8_t* desc, int kp_cap,
-                                                            int desc_pitch, int bpf, int nframes) {
+                                                            BriskKeyPoint* dkp, const int* dscale, const int* dperm,
+                                                            uint8_t* desc, int kp_cap, int desc_pitch, int bpf, int nframes) {
   __shared__ int values_s[DS_WAVES][BRISK_MAX_POINTS];
+  __shared__ int4 lp_s[DS_LP_LDS];                 // long pairs {i, j, wdx, wdy}
+  __shared__ unsigned sp_s[BRISK_MAX_SHORT];       // short pairs i | j << 16
+  // the pair tables are read once per keypoint by every wave: keep them in LDS for the block's lifetime
+  const bool lp_in_lds = P.nlong <= DS_LP_LDS;
+  if (lp_in_lds)
+    for (int p = threadIdx.x; p < P.nlong; p += DS_WAVES * 64) lp_s[p] = reinterpret_cast<const int4*>(P.long_pairs)[p];
+  for (int p = threadIdx.x; p < P.nshort; p += DS_WAVES * 64) sp_s[p] = (unsigned)P.short_pairs[2 * p] | ((unsigned)P.short_pairs[2 * p + 1] << 16);
+  __syncthreads();
   // 1-D grid of bpf blocks per frame.  All blocks of a frame get the same blockIdx.x % 8, i.e. the same XCD: a
   // frame's integral image (8.3 MB @1080p, gathered ~16 times per 128-B line) then lives in ONE L2 while the frame
   // is being described instead of being pulled through all eight.
@@ -973,7 +1004,8 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
   const int stride = G.L[0].stride;
   const uint32_t* integ = integral + (long)frame * iframe_elems;
-  for (int k = block_in_frame * DS_WAVES + wave; k < n; k += bpf * DS_WAVES) {
+  for (int jp = block_in_frame * DS_WAVES + wave; jp < n; jp += bpf * DS_WAVES) {
+    const int k = dperm[(long)frame * kp_cap + jp];
     BriskKeyPoint* kp = &dkp[(long)frame * kp_cap + k];
     const int scale = dscale[(long)frame * kp_cap + k];
     const float kx = kp->x, ky = kp->y, kangle = kp->angle;
@@ -987,11 +1019,20 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int d0 = 0, d1 = 0;
-        for (int p = lane; p < P.nlong; p += 64) {
-          int a, b;
-          brisk_long_pair(values, P.long_pairs + 4 * p, &a, &b);
-          d0 += a;
-          d1 += b;
+        if (lp_in_lds) {
+          for (int p = lane; p < P.nlong; p += 64) {
+            const int4 q = lp_s[p];
+            const int delta_t = values[q.x] - values[q.y];
+            d0 += delta_t * q.z / 1024;
+            d1 += delta_t * q.w / 1024;
+          }
+        } else {
+          for (int p = lane; p < P.nlong; p += 64) {
+            int a, b;
+            brisk_long_pair(values, P.long_pairs + 4 * p, &a, &b);
+            d0 += a;
+            d1 += b;
+          }
         }
         for (int off = 32; off > 0; off >>= 1) {
           d0 += __shfl_xor(d0, off, 64);
@@ -1017,7 +1058,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
     for (int p0 = 0; p0 < nbits; p0 += 64) {
       const int p = p0 + lane;
       bool bit = false;
-      if (p < P.nshort) bit = values[P.short_pairs[2 * p]] > values[P.short_pairs[2 * p + 1]];
+      if (p < P.nshort) { const unsigned q = sp_s[p]; bit = values[q & 0xFFFF] > values[q >> 16]; }
       const unsigned long long m = __ballot(bit);
       if (lane == 0) *reinterpret_cast<unsigned long long*>(drow + p0 / 8) = m;
     }
@@ -1116,13 +1157,13 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
                      Dd.istride, Dd.iframe_elems, nbands);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
-                     Dd.dscale, B.kp_cap);
+                     Dd.dscale, Dd.dperm, B.kp_cap);
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
   {
-    const int bpf = 128;  // blocks per frame = what one XCD (32 CUs x 4 workgroups) holds at once
+    const int bpf = (G.debug_flags >> 8) ? (G.debug_flags >> 8) : 256;  // blocks per frame = one XCD full of waves (test knob: debug bits 8+)
     const int groups = (nframes + 7) / 8;
     hipLaunchKernelGGL(k_describe, dim3(groups * 8 * bpf), dim3(DS_WAVES * 64), 0, s, G, P, B.pyr, Dd.integral, Dd.istride,
-                       Dd.iframe_elems, B.counters, Dd.dkp, Dd.dscale, Dd.desc, B.kp_cap, Dd.desc_pitch, bpf, nframes);
+                       Dd.iframe_elems, B.counters, Dd.dkp, Dd.dscale, Dd.dperm, Dd.desc, B.kp_cap, Dd.desc_pitch, bpf, nframes);
   }
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);
 }

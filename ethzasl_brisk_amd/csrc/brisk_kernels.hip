@@ -600,32 +600,58 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   __shared__ int sorder[TR_MAXSORT];    // candidate index of the tie with raster rank r
   __shared__ unsigned sxyd[TR_MAXSORT]; // its x | y << 13 | ... (the key) - D is taken from the window
   __shared__ int vals[TR_WAVES][40];
+  __shared__ int vals_ci[TR_MAXSORT];   // candidate index of the tie (unsorted order)
   __shared__ int remaining, progressed;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // ---- all layers' ties are gathered and rank-sorted once: the key is (layer, y, x), so every layer is a
+  // contiguous raster-ordered range [lstart[l], lstart[l+1]) of the sorted list
+  __shared__ int lstart[BRISK_MAX_LAYERS + 1];
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < G.nlayers; ++l) {
+      lstart[l] = acc;
+      acc += min(counters[frame].ntie[l], tie_cap);
+    }
+    for (int l = G.nlayers; l <= BRISK_MAX_LAYERS; ++l) lstart[l] = acc;
+  }
+  __syncthreads();
+  const int ntot = lstart[G.nlayers];
+  if (ntot == 0) return;
+  const bool sorted_path = ntot <= TR_MAXSORT;
+  if (sorted_path) {
+    for (int l = 0; l < G.nlayers; ++l) {
+      const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
+      const int n = lstart[l + 1] - lstart[l];
+      for (int j = tid; j < n; j += TR_THREADS) {
+        const int ci = list[j];
+        vals_ci[lstart[l] + j] = ci;
+        skey[lstart[l] + j] = cand[(long)frame * cand_cap + ci].key;
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < ntot; j += TR_THREADS) {
+      const unsigned k = skey[j];
+      int r = 0;
+      for (int q = 0; q < ntot; ++q) r += (skey[q] < k) ? 1 : 0;
+      sorder[r] = vals_ci[j];
+      sxyd[r] = k;
+    }
+    __syncthreads();
+  }
   for (int l = 0; l < G.nlayers; ++l) {
-    const int n = min(counters[frame].ntie[l], tie_cap);
+    const int n = lstart[l + 1] - lstart[l];
     if (n == 0) continue;
     const BriskLayerView L = make_view(G, pyr, smap, frame, l);
     const bool last = (l == G.nlayers - 1);
     const bool float_patch = last || G.single_layer;
     const bool touch2x2 = last && !G.single_layer;
     const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
-    if (n <= TR_MAXSORT) {
-      for (int j = tid; j < n; j += TR_THREADS) skey[j] = cand[(long)frame * cand_cap + list[j]].key;
-      __syncthreads();
-      for (int j = tid; j < n; j += TR_THREADS) {
-        const unsigned k = skey[j];
-        int r = 0;
-        for (int q = 0; q < n; ++q) r += (skey[q] < k) ? 1 : 0;
-        sorder[r] = list[j];
-        sxyd[r] = k;
-      }
-      __syncthreads();
+    if (sorted_path) {
       uint16_t* wl = win[wave];
       // round-robin over the raster-sorted ties: neighbouring ties (which depend on each other) run on different
       // waves back to back, everything a wave needs except the fresh smap window is already on chip
-      for (int j = wave; j < n; j += TR_WAVES) {
+      for (int j = lstart[l] + wave; j < lstart[l + 1]; j += TR_WAVES) {
         const int ci = sorder[j];
         const unsigned key = sxyd[j];
         const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
@@ -636,19 +662,18 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
             const int dy = e / TR_WIN - 4, dx = e % TR_WIN - 4;
             const int qx = cx + dx, qy = cy + dy;
             unsigned v = 0;
-            if (!(G.debug_flags & 4) && qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
+            if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
             wl[e] = (uint16_t)v;
             if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) pending = true;
           }
-          if (!__any(pending) || (G.debug_flags & 16)) break;
+          if (!__any(pending)) break;
           __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
-        if (G.debug_flags & 2) { if (lane < 40) vals[wave][lane] = 0; }
-        else if (lane < 8) vals[wave][lane] = brisk_tie_probe_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
+        if (lane < 8) vals[wave][lane] = brisk_tie_probe_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
         else if (lane >= 32 && lane < 57)
           vals[wave][8 + lane - 32] = brisk_tie_raw_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane - 32, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -661,7 +686,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
           else smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);       // TIE (10b) -> FAIL (11b)
           BriskCand* c = &cand[(long)frame * cand_cap + ci];
           c->status = pass ? BRISK_ST_PASS : BRISK_ST_FAIL;
-          if (pass && l + 1 < G.nlayers && !(G.debug_flags & 8)) {
+          if (pass && l + 1 < G.nlayers) {
             const unsigned fpm = c->fp_mask;
             if (fpm) {
               const int fx = c->fp_x0, fy = c->fp_y0;
@@ -673,7 +698,9 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
         }
         __builtin_amdgcn_wave_barrier();
       }
-      __threadfence();
+      // the touches / decisions are device-scope atomics performed at L2 and the next layer reads smap with
+      // L1-bypassing loads: completion of the atomics (vmcnt) + the workgroup barrier is all the ordering needed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       continue;
     }

@@ -119,10 +119,15 @@ struct TileRef {  // view of an LDS tile that covers image pixels [x0, x0+tw) x 
 __device__ __forceinline__ const uint8_t* tile_origin(const TileRef& t) { return t.p - (long)t.y0 * t.tw - t.x0; }
 
 __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t* __restrict__ frames, long frame_pitch,
-                                                       int row_pitch, uint8_t* __restrict__ pyr, int nlevels) {
+                                                       int row_pitch, uint8_t* __restrict__ pyr, int nlevels, int tiles_x,
+                                                       int tiles_y) {
   __shared__ __attribute__((aligned(16))) uint8_t t0[64 * 64], t2[32 * 32], t4[16 * 16];
-  const int frame = blockIdx.z;
-  const int bx = blockIdx.x * 64, by = blockIdx.y * 64;
+  const int frame = blockIdx.y;
+  // XCD-aware tile order (see k_detect): x-adjacent 64-byte tile rows share 128-byte lines, keep them in one L2
+  const int nt = tiles_x * tiles_y;
+  const int res = blockIdx.x & 7;
+  const int tsw = res * (nt >> 3) + min(res, nt & 7) + (blockIdx.x >> 3);
+  const int bx = (tsw % tiles_x) * 64, by = (tsw / tiles_x) * 64;
   const int w = G.L[0].w, h = G.L[0].h;
   const uint8_t* src = frames + (long)frame * frame_pitch;
   uint8_t* P = pyr + (long)frame * G.pyr_elems;
@@ -171,10 +176,14 @@ __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t
   }
 }
 
-__global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __restrict__ pyr, int nlevels) {
+__global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __restrict__ pyr, int nlevels, int tiles_x,
+                                                      int tiles_y) {
   __shared__ __attribute__((aligned(16))) uint8_t t0[96 * 96], t1[64 * 64], t3[32 * 32], t5[16 * 16];
-  const int frame = blockIdx.z;
-  const int bx = blockIdx.x * 96, by = blockIdx.y * 96;
+  const int frame = blockIdx.y;
+  const int nt = tiles_x * tiles_y;
+  const int res = blockIdx.x & 7;
+  const int tsw = res * (nt >> 3) + min(res, nt & 7) + (blockIdx.x >> 3);
+  const int bx = (tsw % tiles_x) * 96, by = (tsw / tiles_x) * 96;
   uint8_t* P = pyr + (long)frame * G.pyr_elems;
   const int w = G.L[0].w, h = G.L[0].h, s0 = G.L[0].stride;
   const uint8_t* src = P + G.L[0].off;
@@ -755,7 +764,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
 // k_finalize: keypoints of a frame in (layer, y, x) order.  One workgroup per frame; ranks by
 // counting smaller keys among the valid candidates (a few thousand at most).
 // ------------------------------------------------------------------------------------------------
-#define FN_THREADS 256
+#define FN_THREADS 1024
 __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
                                                           unsigned* keys_scratch, BriskKeyPoint* kp_out, int cand_cap,
                                                           int kp_cap, const uint8_t* mask, long mask_pitch_frame,
@@ -1136,11 +1145,12 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     // even chain: layer-0 copy + L2, L4, L6 from 64x64 blocks of the frame; odd chain: L1, L3, L5, L7 from 96x96 blocks
     const int even_levels = G.nlayers >= 7 ? 3 : G.nlayers >= 5 ? 2 : G.nlayers >= 3 ? 1 : 0;
     const int odd_levels = G.nlayers >= 8 ? 3 : G.nlayers >= 6 ? 2 : G.nlayers >= 4 ? 1 : 0;
-    hipLaunchKernelGGL(k_pyramid_even, dim3((G.L[0].stride + 63) / 64, (G.L[0].h + 63) / 64, nframes), dim3(256), 0, s, G,
-                       frames, frame_pitch, row_pitch, B.pyr, even_levels);
+    const int etx = (G.L[0].stride + 63) / 64, ety = (G.L[0].h + 63) / 64;
+    hipLaunchKernelGGL(k_pyramid_even, dim3(etx * ety, nframes), dim3(256), 0, s, G, frames, frame_pitch, row_pitch, B.pyr,
+                       even_levels, etx, ety);
+    const int otx = (G.L[0].w + 95) / 96, oty = (G.L[0].h + 95) / 96;
     if (G.nlayers >= 2)
-      hipLaunchKernelGGL(k_pyramid_odd, dim3((G.L[0].w + 95) / 96, (G.L[0].h + 95) / 96, nframes), dim3(256), 0, s, G, B.pyr,
-                         odd_levels);
+      hipLaunchKernelGGL(k_pyramid_odd, dim3(otx * oty, nframes), dim3(256), 0, s, G, B.pyr, odd_levels, otx, oty);
     for (int l = 8; l < G.nlayers; ++l) {  // more than 4 octaves: remaining levels one by one
       const long items = (long)(G.L[l].stride / 4) * G.L[l].h;
       hipLaunchKernelGGL(k_pyramid_level, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, B.pyr, l - 2, l, 0);

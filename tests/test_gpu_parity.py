@@ -291,3 +291,21 @@ def test_config5_descriptor_only_100k_keypoints(B):
     assert 20000 < len(ko) < n
     assert same_kps(kg, ko) and np.array_equal(dg, do)
     ctx.close()
+
+
+def test_capacity_overflow_is_an_error_not_a_truncation(B, golden_ast):
+    """Too small a candidate / keypoint capacity must surface as BRISK_HIP_ERR_CAPACITY (code 4)."""
+    img = golden_ast[1]["image"]
+    ctx = B.Context(0, max_candidates=256, max_keypoints=16384)
+    with pytest.raises(B.BriskHipError) as ei:
+        B.BriskFeatureDetector(70, 3, context=ctx).detect(img)
+    assert ei.value.code == 4
+    ctx.close()
+    ctx = B.Context(0, max_candidates=65536, max_keypoints=64)
+    with pytest.raises(B.BriskHipError) as ei:
+        B.BriskFeatureDetector(70, 3, context=ctx).detect(img)
+    assert ei.value.code == 4
+    ctx.close()
+    with pytest.raises(B.BriskHipError) as ei:            # caller's output array too small
+        B.BriskFeatureDetector(70, 3).detect(img, capacity=100)
+    assert ei.value.code == 4

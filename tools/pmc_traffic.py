@@ -4,7 +4,8 @@ HBM bytes per launch for every engine kernel, with the gfx950 corrections of tha
   * counters are in KiB;
   * FETCH_SIZE under-reports wide coalesced streaming reads (exactly 1/2 for 16 B/lane).  Our kernels read with
     4 B/lane dword loads, an uncalibrated width, so the read side is calibrated on a kernel of the same access
-    width with a known byte count in the same run: k_copy_layer0 reads exactly stride*h bytes per frame.
+    width with a known byte count in the same run: k_integral_bandsums reads layer 0 exactly once
+    (stride*h bytes per frame, dword loads).
 Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames_per_launch> <w> <h> [out.json]
 """
 import csv
@@ -28,8 +29,8 @@ def main():
     frames, w, h = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     stride = (w + 63) // 64 * 64
     known_read = stride * h * frames
-    corr = known_read / fetch["k_copy_layer0"]
-    out = {"frames_per_launch": frames, "fetch_correction_from_k_copy_layer0": corr, "kernels": {}}
+    corr = known_read / fetch["k_integral_bandsums"]
+    out = {"frames_per_launch": frames, "fetch_correction_from_k_integral_bandsums": corr, "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue

@@ -309,3 +309,29 @@ def test_capacity_overflow_is_an_error_not_a_truncation(B, golden_ast):
     with pytest.raises(B.BriskHipError) as ei:            # caller's output array too small
         B.BriskFeatureDetector(70, 3).detect(img, capacity=100)
     assert ei.value.code == 4
+
+
+def test_soak_1080p_batch_vs_oracle(B, ctx):
+    """BASELINE config 2 at full size: a batch of 24 distinct synthetic 1080p frames through the device-resident
+    batch path, every frame compared bit-exactly with the oracle (keypoints, orientation, descriptors)."""
+    import torch
+    seeds = list(range(100, 124))
+    frames = np.stack([synth.frame_1080p(s) for s in seeds])
+    d = torch.from_numpy(frames).cuda()
+    ext = B.BriskDescriptorExtractor()
+    ctx.detect_describe_batch(ext, d.data_ptr(), len(seeds), 1920, 1080, 1920 * 1080, 1920, 80, 4,
+                              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.batch_status(len(seeds)) == 0
+    X = O.Extractor()
+    total = 0
+    for f in range(len(seeds)):
+        ko = O.detect(frames[f], 80, 4)
+        ko2, do = X.compute(frames[f], ko)
+        kd, _ = ctx.batch_download(f, described=False)
+        kg, dg = ctx.batch_download(f, described=True)
+        assert same_kps(kd, ko), (seeds[f], explain(kd, ko))
+        assert same_kps(kg, ko2), (seeds[f], explain(kg, ko2))
+        assert np.array_equal(dg, do), seeds[f]
+        total += len(kg)
+    assert total > 20000

@@ -109,7 +109,7 @@ static void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G
 
 static void free_buffers(brisk_hip_ctx* c) {
   hipFree(c->B.pyr); hipFree(c->B.smap); hipFree(c->B.cand); hipFree(c->B.blocks); hipFree(c->B.tie_idx); hipFree(c->B.keys);
-  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->D.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale); hipFree(c->D.dperm);
+  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->B.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale); hipFree(c->D.dperm);
   hipFree(c->D.desc); hipFree(c->d_kp_in); hipFree(c->d_n_in);
   c->B = BriskDetectBuffers{};
   c->D = BriskDescribeBuffers{};
@@ -123,6 +123,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   if (nframes <= c->slots && G.pyr_elems <= c->pyr_elems_alloc && iframe <= c->iframe_elems_alloc &&
       c->B.cand_cap == c->cand_cap && c->B.kp_cap == c->kp_cap) {
     c->D.istride = istride;
+    c->B.istride = istride;
     c->D.iframe_elems = iframe;
     return BRISK_HIP_OK;
   }
@@ -141,7 +142,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMalloc(&c->B.counters, (size_t)slots * sizeof(BriskFrameCounters)));
   HIPCHK(c, hipMalloc(&c->B.kp_out, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
   HIPCHK(c, hipMalloc(&c->D.integral, (size_t)slots * ifr * sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&c->D.bandsum, (size_t)slots * ((ifr / 64) + 4 * 8192 + 64) * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&c->B.bandsum, (size_t)slots * ((ifr / 64) + 4 * 8192 + 64) * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc(&c->D.dkp, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
   HIPCHK(c, hipMalloc(&c->D.dscale, (size_t)slots * c->kp_cap * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->D.dperm, (size_t)slots * c->kp_cap * sizeof(int)));
@@ -152,6 +153,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMemset(c->B.pyr, 0, (size_t)slots * pyr + 256));
   c->slots = slots; c->pyr_elems_alloc = pyr; c->iframe_elems_alloc = ifr;
   c->D.istride = istride;
+  c->B.istride = istride;
   c->D.iframe_elems = iframe;
   return BRISK_HIP_OK;
 }
@@ -358,9 +360,9 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
     Bi.keys += f0 * Bi.cand_cap * 2;
     Bi.counters += f0;
     Bi.kp_out += f0 * Bi.kp_cap;
+    Bi.bandsum += f0 * nbands * Bi.istride;
     BriskDescribeBuffers Di = ctx->D;
     Di.integral += f0 * Di.iframe_elems;
-    Di.bandsum += f0 * nbands * Di.istride;
     Di.dkp += f0 * Bi.kp_cap;
     Di.dscale += f0 * Bi.kp_cap;
     Di.dperm += f0 * Bi.kp_cap;

@@ -23,12 +23,13 @@ struct BriskDetectBuffers {
   unsigned* keys;                // [slots][2 * cand_cap]
   BriskFrameCounters* counters;  // [slots]
   BriskKeyPoint* kp_out;         // [slots][kp_cap]
+  uint32_t* bandsum;             // [slots][nbands][istride] column sums of 64-row bands of layer 0 (for the integral)
+  int istride;                   // integral / bandsum row stride (elements)
   int cand_cap, tie_cap, kp_cap;
 };
 
 struct BriskDescribeBuffers {
   uint32_t* integral;  // [slots][iframe_elems]
-  uint32_t* bandsum;   // [slots][max_bands][istride] column sums of 64-row bands
   int istride;         // integral row stride (elements)
   long iframe_elems;
   BriskKeyPoint* dkp;  // [slots][kp_cap] filtered keypoints (angle filled in)
@@ -39,7 +40,7 @@ struct BriskDescribeBuffers {
 };
 
 // Optional per-stage timing with HIP events on the launch stream (bench.py roofline leg).
-#define BRISK_PROF_STAGES 9
+#define BRISK_PROF_STAGES 8
 #define BRISK_PROF_MAX_CALLS 64
 struct BriskProfiler {
   bool on = false;
@@ -50,7 +51,7 @@ struct BriskProfiler {
 };
 // stage ids
 enum { BRISK_STG_PYRAMID = 0, BRISK_STG_DETECT, BRISK_STG_CLASSIFY, BRISK_STG_TIES, BRISK_STG_FINALIZE,
-       BRISK_STG_INTEGRAL_ROWS, BRISK_STG_INTEGRAL_COLS, BRISK_STG_DESC_PREPARE, BRISK_STG_DESCRIBE };
+       BRISK_STG_INTEGRAL, BRISK_STG_DESC_PREPARE, BRISK_STG_DESCRIBE };
 const char* brisk_stage_name(int i);
 void brisk_prof_begin_call(BriskProfiler* P);
 void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s);  // slot k = start of stage k (k == stages: end)

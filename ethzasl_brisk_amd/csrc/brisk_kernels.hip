@@ -52,29 +52,6 @@ __device__ __forceinline__ unsigned smap_load_fresh(const uint16_t* smap, long i
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_copy_layer0: frame (arbitrary stride) -> pyramid layer 0 (aligned stride).  4 px / thread.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_copy_layer0(BriskGeom G, const uint8_t* __restrict__ frames,
-                                                      long frame_pitch, int row_pitch, uint8_t* __restrict__ pyr) {
-  const int frame = blockIdx.y;
-  const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
-  const uint8_t* src = frames + (long)frame * frame_pitch;
-  uint8_t* dst = pyr + (long)frame * G.pyr_elems + G.L[0].off;
-  const int words = stride / 4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)words * h; i += (long)gridDim.x * blockDim.x) {
-    const int y = (int)(i / words), x = (int)(i % words) * 4;
-    unsigned v = 0;
-    if (x + 3 < w && ((row_pitch | (uintptr_t)src) & 3) == 0) {
-      v = *reinterpret_cast<const unsigned*>(src + (long)y * row_pitch + x);
-    } else {
-      for (int k = 0; k < 4; ++k)
-        if (x + k < w) v |= (unsigned)src[(long)y * row_pitch + x + k] << (8 * k);
-    }
-    *reinterpret_cast<unsigned*>(dst + (long)y * stride + x) = v;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_pyramid_level: builds destination layer `dl` from source layer `sl` (mode 0 half, 1 two-third).
 // One thread produces 4 horizontally adjacent output pixels (one dword store).
 // ------------------------------------------------------------------------------------------------
@@ -120,8 +97,9 @@ __device__ __forceinline__ const uint8_t* tile_origin(const TileRef& t) { return
 
 __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t* __restrict__ frames, long frame_pitch,
                                                        int row_pitch, uint8_t* __restrict__ pyr, int nlevels, int tiles_x,
-                                                       int tiles_y) {
+                                                       int tiles_y, uint32_t* __restrict__ bandsum, int istride) {
   __shared__ __attribute__((aligned(16))) uint8_t t0[64 * 64], t2[32 * 32], t4[16 * 16];
+  __shared__ unsigned psum[4][64];
   const int frame = blockIdx.y;
   // XCD-aware tile order (see k_detect): x-adjacent 64-byte tile rows share 128-byte lines, keep them in one L2
   const int nt = tiles_x * tiles_y;
@@ -147,6 +125,22 @@ __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t
     *reinterpret_cast<unsigned*>(&t0[r * 64 + c4]) = v;
   }
   __syncthreads();
+  // column sums of this 64-row band (the integral image kernel's carry rows): integral column = pixel column + 1
+  {
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    unsigned sum = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += t0[(q * 16 + r) * 64 + c];
+    psum[q][c] = sum;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const unsigned tot = psum[0][c] + psum[1][c] + psum[2][c] + psum[3][c];
+      const int nb = tiles_y, band = by >> 6;
+      uint32_t* row = bandsum + ((long)frame * nb + band) * istride;
+      if (bx + c + 1 < istride) row[bx + c + 1] = tot;
+      if (bx == 0 && c == 0) row[0] = 0;
+    }
+  }
   // successive halvings: level k has tile (64 >> k)^2 at origin (bx >> k, by >> k)
   TileRef srct = {t0, bx, by, 64};
   uint8_t* dst_lds[3] = {t2, t4, nullptr};
@@ -822,8 +816,8 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
 
 // ------------------------------------------------------------------------------------------------
 // Integral image (brisk/include/brisk/internal/integral-image.h:56-161): exclusive 2-D prefix sums, u32,
-// (h+1) x (w+1) with row stride istride.  Two kernels, the image is read twice and the integral written once:
-//   k_integral_bandsums  column sums of every 64-row band                      (reads 1 B/px, writes ~w*4 B/band)
+// (h+1) x (w+1) with row stride istride.  The image is read once more and the integral written once:
+//   (k_pyramid_even)     column sums of every 64-row band, produced while the frame block is in LDS anyway
 //   k_integral_final     per band: carry row = prefix over the bands above, then row after row the
 //                        workgroup scans the row (wave shuffles + one barrier) and adds it to the running
 //                        column accumulators it keeps in registers; 16-byte aligned stores.
@@ -843,23 +837,6 @@ __device__ __forceinline__ void ii_load4(const uint8_t* row, int stride, int w, 
   px[1] = (c0 < w) ? (cur & 0xFF) : 0;
   px[2] = (c0 + 1 < w) ? ((cur >> 8) & 0xFF) : 0;
   px[3] = (c0 + 2 < w) ? ((cur >> 16) & 0xFF) : 0;
-}
-
-__global__ void __launch_bounds__(II_THREADS) k_integral_bandsums(BriskGeom G, const uint8_t* __restrict__ pyr,
-                                                                  uint32_t* __restrict__ bandsum, int istride, int nbands) {
-  const int frame = blockIdx.y, band = blockIdx.x;
-  const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
-  const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
-  const int y0 = band * II_BAND, y1 = min(h, y0 + II_BAND);
-  for (int c0 = threadIdx.x * 4; c0 <= w; c0 += II_CHUNK) {
-    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int y = y0; y < y1; ++y) {
-      unsigned px[4];
-      ii_load4(img + (long)y * stride, stride, w, c0, px);
-      s0 += px[0]; s1 += px[1]; s2 += px[2]; s3 += px[3];
-    }
-    *reinterpret_cast<uint4*>(bandsum + ((long)frame * nbands + band) * istride + c0) = make_uint4(s0, s1, s2, s3);
-  }
 }
 
 // exclusive offset of `total` among the workgroup's threads (thread order) + the workgroup total
@@ -911,6 +888,9 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
           const uint4 v = *reinterpret_cast<const uint4*>(bandsum + ((long)frame * nbands + b) * istride + c0);
           C.x += v.x; C.y += v.y; C.z += v.z; C.w += v.w;
         }
+      if (c0 + 1 > w) C.y = 0;  // integral columns beyond w are padding (their band sums are not written)
+      if (c0 + 2 > w) C.z = 0;
+      if (c0 + 3 > w) C.w = 0;
       const unsigned s0 = C.x, s1 = s0 + C.y, s2 = s1 + C.z, s3 = s2 + C.w;
       unsigned tot;
       const unsigned o = ii_wg_scan(s3, wave_tot, buf, &tot) + carry;
@@ -1114,7 +1094,7 @@ static inline int grid_for(long items, int per_block, int cap) {
 
 const char* brisk_stage_name(int i) {
   static const char* n[BRISK_PROF_STAGES] = {"k_pyramid", "k_detect", "k_classify_refine", "k_tie_resolve", "k_finalize",
-                                             "k_integral_bandsums", "k_integral_final", "k_desc_prepare", "k_describe"};
+                                             "k_integral_final", "k_desc_prepare", "k_describe"};
   return (i >= 0 && i < BRISK_PROF_STAGES) ? n[i] : "?";
 }
 
@@ -1147,7 +1127,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     const int odd_levels = G.nlayers >= 8 ? 3 : G.nlayers >= 6 ? 2 : G.nlayers >= 4 ? 1 : 0;
     const int etx = (G.L[0].stride + 63) / 64, ety = (G.L[0].h + 63) / 64;
     hipLaunchKernelGGL(k_pyramid_even, dim3(etx * ety, nframes), dim3(256), 0, s, G, frames, frame_pitch, row_pitch, B.pyr,
-                       even_levels, etx, ety);
+                       even_levels, etx, ety, B.bandsum, B.istride);
     const int otx = (G.L[0].w + 95) / 96, oty = (G.L[0].h + 95) / 96;
     if (G.nlayers >= 2)
       hipLaunchKernelGGL(k_pyramid_odd, dim3(otx * oty, nframes), dim3(256), 0, s, G, B.pyr, odd_levels, otx, oty);
@@ -1172,25 +1152,22 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,
                      B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);
-  brisk_prof_mark(prof, BRISK_STG_INTEGRAL_ROWS, s);
+  brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
 }
 
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
                               long frame_pitch, int row_pitch, hipStream_t s) {
-  const long items = (long)(G.L[0].stride / 4) * G.L[0].h;
-  hipLaunchKernelGGL(k_copy_layer0, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, frames, frame_pitch,
-                     row_pitch, B.pyr);
+  const int etx = (G.L[0].stride + 63) / 64, ety = (G.L[0].h + 63) / 64;
+  hipLaunchKernelGGL(k_pyramid_even, dim3(etx * ety, nframes), dim3(256), 0, s, G, frames, frame_pitch, row_pitch, B.pyr, 0,
+                     etx, ety, B.bandsum, B.istride);
 }
 
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
                            long n_in_stride, hipStream_t s, BriskProfiler* prof) {
   const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
-  brisk_prof_mark(prof, BRISK_STG_INTEGRAL_ROWS, s);
-  hipLaunchKernelGGL(k_integral_bandsums, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, Dd.bandsum, Dd.istride,
-                     nbands);
-  brisk_prof_mark(prof, BRISK_STG_INTEGRAL_COLS, s);
-  hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, Dd.bandsum, Dd.integral,
+  brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
+  hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, B.bandsum, Dd.integral,
                      Dd.istride, Dd.iframe_elems, nbands);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,

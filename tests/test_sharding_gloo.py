@@ -48,6 +48,17 @@ def _worker(rank, world, port, q):
             q.put(bool(ok))
         else:
             assert res is None
+        # fixed-size variant used inside bench.py's timed region
+        res2 = sharding.gather_results_padded(torch.from_numpy(c), torch.from_numpy(k), torch.from_numpy(d), strings, cap)
+        if rank == 0:
+            ac, gk, gd = res2
+            ok = ac.shape == (world, batch)
+            for r in range(world):
+                cr, kr, dr = _fake_results(r, batch, cap, pitch)
+                ok &= np.array_equal(ac[r].numpy(), cr) and np.array_equal(gk[r].numpy(), kr[:, :cap]) and np.array_equal(gd[r].numpy(), dr[:, :cap, :strings])
+            q.put(bool(ok))
+        else:
+            assert res2 is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -66,4 +77,5 @@ def test_gather_results_world2_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    assert q.get() is True
     assert q.get() is True

@@ -77,6 +77,11 @@ def _cpu_one(img):
 
 
 def main():
+    # Exactly ONE line may reach stdout (the JSON).  Libraries (RCCL prints a version banner at exit) write to the
+    # C-level stdout, so fd 1 is pointed at stderr for the whole run and the JSON is written to the saved fd.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -85,6 +90,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per GPU (ring)")
     ap.add_argument("--streams", type=int, default=1, help="internal stream slices per batch (1..8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="run the RCCL result gather even with one rank (self-test)")
     ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results become wrong)")
     args = ap.parse_args()
 
@@ -97,8 +103,9 @@ def main():
     import synth
     import ethzasl_brisk_amd as B
 
-    if world > 1:
+    if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
@@ -124,7 +131,9 @@ def main():
         ctx.detect_describe_batch(ext, frames.data_ptr(), args.batch, W, H, W * H, W, THRESHOLD, OCTAVES, stream)
 
     gather = None
-    if world > 1:
+    if world > 1 or args.force_gather:
+        step()                               # allocates the engine's result buffers
+        torch.cuda.synchronize()
         gather = ResultGather(ctx, args.batch, strings, dev, rank, world)
 
     for _ in range(args.warmup):
@@ -187,8 +196,15 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(list(host[:16]))
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if gather is not None and rank == 0 and args.force_gather:
+        ac, gk, gd = gather.last
+        k0, d0 = ctx.batch_download(0, True, strings)
+        n0 = int(ac[0, 0].item())
+        assert n0 == len(k0) and np.array_equal(gk[0, 0, :n0].cpu().numpy().view(np.uint32), np.stack([k0[f].view(np.uint32) for f in k0.dtype.names], 1))
+        assert np.array_equal(gd[0, 0, :n0].cpu().numpy(), d0)
+        print('gather self-test ok', file=sys.stderr)
+    if world > 1 or args.force_gather:
         dist.destroy_process_group()
 
 

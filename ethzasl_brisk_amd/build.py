@@ -27,7 +27,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("BRISK_HIPCC_EXTRA", "").split()  # tuning experiments only (e.g. -DBRISK_DETECT_ROWS_PER_THREAD=2)
+    cmd = [hipcc] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -167,6 +167,18 @@ BRISK_HD void brisk_disc_minmax(const uint8_t* p, int s, int* mn_, int* mx_) {
   *mx_ = mx;
 }
 
+// (tc * thr) / 100 without integer multiplies (quarter rate on CDNA): with k = float(thr) * 0.01f the fused
+// multiply-add tc * k + 0.005 truncates to the exact quotient for every tc in [0, 255], thr in [1, 255]
+// (exhaustively checked by tests/test_emul_parity.py::test_b2_fast_exact).
+BRISK_HD float brisk_b2_factor(int thr) { return (float)thr * 0.01f; }
+BRISK_HD int brisk_b2_fast(int tc, float k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)__fmaf_rn((float)tc, k, 0.005f);
+#else
+  return (int)fmaf((float)tc, k, 0.005f);
+#endif
+}
+
 // Per-pixel detection (agast/src/oast9-16.cc:79-100 + SURVEY F5): returns D (= thrmap value) if
 // (x,y) is an AGAST point at threshold thr, else 0.  Caller guarantees 3 <= x <= w-4, 3 <= y <= h-4.
 BRISK_HD int brisk_detect_px(const uint8_t* p, int s, int thr) {

@@ -5,7 +5,10 @@
 #include "brisk_common.h"
 
 #define BRISK_DETECT_TILE_W 64
-#define BRISK_DETECT_TILE_H 32
+#ifndef BRISK_DETECT_ROWS_PER_THREAD
+#define BRISK_DETECT_ROWS_PER_THREAD 4
+#endif
+#define BRISK_DETECT_TILE_H (16 * BRISK_DETECT_ROWS_PER_THREAD)
 
 struct BriskTileTable {
   int first_tile[BRISK_MAX_LAYERS + 1];

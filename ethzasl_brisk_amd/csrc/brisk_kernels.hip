@@ -249,9 +249,13 @@ __global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __res
 // grid.x enumerates the tiles of all layers, grid.y = frame.
 // ------------------------------------------------------------------------------------------------
 #define DT_W 64
-#define DT_H 32
+#define DT_R BRISK_DETECT_ROWS_PER_THREAD
+#define DT_H BRISK_DETECT_TILE_H
 #define DT_LW (DT_W + 8)
 #define DT_LH (DT_H + 6)
+#define DT_WR (DT_R + 6)                              // window rows per thread
+#define DT_NLD ((DT_LH * (DT_LW / 4) + 255) / 256)    // staging dwords per thread
+static_assert(DT_H == 16 * DT_R, "256 threads = 16 column groups x 16 row groups");
 
 // byte i (-4..7, relative to the thread's first pixel) of a 3-dword row window
 #define DT_B(w0, w1, w2, i) ((int)((((i) < 0) ? ((w0) >> (8 * ((i) + 4))) : ((i) < 4) ? ((w1) >> (8 * (i))) : ((w2) >> (8 * ((i)-4)))) & 0xFFu))
@@ -280,95 +284,116 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   const int x0 = tx * DT_W, y0 = ty * DT_H;
   const int thr = G.threshold;
 
-  // stage halo tile: rows y0-3 .. y0+DT_H+2, columns x0-4 .. x0+DT_W+3 (dword granularity)
-  for (int i = threadIdx.x; i < DT_LH * (DT_LW / 4); i += 256) {
-    const int r = i / (DT_LW / 4), c4 = i % (DT_LW / 4);
-    const int gy = y0 - 3 + r, gx = x0 - 4 + c4 * 4;
-    unsigned v = 0;
-    if (gy >= 0 && gy < h && gx >= 0 && gx < stride) v = *reinterpret_cast<const unsigned*>(img + (long)gy * stride + gx);
-    *reinterpret_cast<unsigned*>(&tile[r * DT_LW + c4 * 4]) = v;
+  // stage halo tile: rows y0-3 .. y0+DT_H+2, columns x0-4 .. x0+DT_W+3 (dword granularity).  All loads of a thread
+  // are issued before the first LDS write (one memory round trip per workgroup instead of one per load): the
+  // loads are unconditional on clamped addresses, out-of-image dwords are zeroed on the way to LDS.
+  {
+    unsigned stg[DT_NLD];
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < DT_NLD; ++k) {
+      const int i = min((int)threadIdx.x + k * 256, DT_LH * (DT_LW / 4) - 1);
+      const int r = i / (DT_LW / 4), c4 = i % (DT_LW / 4);
+      const int gy = y0 - 3 + r, gx = x0 - 4 + c4 * 4;
+      if (gy >= 0 && gy < h && gx >= 0 && gx < stride) keep |= 1u << k;
+      const int cy = min(max(gy, 0), h - 1), cx = min(max(gx, 0), stride - 4);
+      stg[k] = *reinterpret_cast<const unsigned*>(img + (long)cy * stride + cx);
+    }
+#pragma unroll
+    for (int k = 0; k < DT_NLD; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < DT_LH * (DT_LW / 4)) *reinterpret_cast<unsigned*>(&tile[i * 4]) = ((keep >> k) & 1u) ? stg[k] : 0u;
+    }
   }
-  *reinterpret_cast<uint2*>(&dres[threadIdx.x * 8]) = make_uint2(0, 0);
+  for (int i = threadIdx.x; i < DT_H * DT_W / 8; i += 256) *reinterpret_cast<uint2*>(&dres[i * 8]) = make_uint2(0, 0);
   if (threadIdx.x == 0) qcount = 0;
   __syncthreads();
 
-  // ---- phase A: 4 columns x 2 rows per thread.  Row window rows 0..7 = image rows gy-3 .. gy+4; the horizontal
-  // partial extrema (widths 3, 5, 7 around each of the 4 columns) of a window row are shared by both output rows:
-  //   output row A (gy)   = max(h3[r0], h5[r1], h7[r2], h7[r3], h7[r4], h5[r5], h3[r6])
-  //   output row B (gy+1) = max(h3[r1], h5[r2], h7[r3], h7[r4], h7[r5], h5[r6], h3[r7])       (same for min)
-  const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * 2;
-  unsigned R[8][3];
+  // ---- phase A: 4 columns x DT_R rows per thread.  Window rows 0..DT_R+5 = image rows gy-3 .. gy+DT_R+2; the
+  // horizontal partial extrema (widths 3, 5, 7 around each of the 4 columns) of a window row are shared by all the
+  // output rows that use it:
+  //   output row k (gy+k) = max(h3[k], h5[k+1], h7[k+2], h7[k+3], h7[k+4], h5[k+5], h3[k+6])      (same for min)
+  const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * DT_R;
+  if (!(G.debug_flags & 128)) {
+    unsigned R[DT_WR][3];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const unsigned* p = reinterpret_cast<const unsigned*>(&tile[(ly + r) * DT_LW + lx]);
-    R[r][0] = p[0]; R[r][1] = p[1]; R[r][2] = p[2];
-  }
-  int X3[8][4], N3[8][4], X5[8][4], N5[8][4], X7[8][4], N7[8][4];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int a = DT_B(R[r][0], R[r][1], R[r][2], j - 1), b = DT_B(R[r][0], R[r][1], R[r][2], j), c = DT_B(R[r][0], R[r][1], R[r][2], j + 1);
-      X3[r][j] = max(max(a, b), c);
-      N3[r][j] = min(min(a, b), c);
-      if (r >= 1 && r <= 6) {
-        const int d = DT_B(R[r][0], R[r][1], R[r][2], j - 2), e = DT_B(R[r][0], R[r][1], R[r][2], j + 2);
-        X5[r][j] = max(max(X3[r][j], d), e);
-        N5[r][j] = min(min(N3[r][j], d), e);
-      } else { X5[r][j] = 0; N5[r][j] = 0; }
-      if (r >= 2 && r <= 5) {
-        const int f = DT_B(R[r][0], R[r][1], R[r][2], j - 3), g = DT_B(R[r][0], R[r][1], R[r][2], j + 3);
-        X7[r][j] = max(max(X5[r][j], f), g);
-        N7[r][j] = min(min(N5[r][j], f), g);
-      } else { X7[r][j] = 0; N7[r][j] = 0; }
+    for (int r = 0; r < DT_WR; ++r) {
+      const unsigned* p = reinterpret_cast<const unsigned*>(&tile[(ly + r) * DT_LW + lx]);
+      R[r][0] = p[0]; R[r][1] = p[1]; R[r][2] = p[2];
     }
-  }
-  // Gates as straight-line code on WAVE MASKS: every comparison is one v_cmp whose 64-bit lane mask is combined
-  // with scalar and/or (no exec-mask branches, no boolean VGPRs); the combined mask is the compaction ballot.
-  const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
-  const int lane = threadIdx.x & 63;
-  unsigned long long mk[8];
-  unsigned entry_k[8];
-  int total = 0;
+    int X3[DT_WR][4], N3[DT_WR][4], X5[DT_WR][4], N5[DT_WR][4], X7[DT_WR][4], N7[DT_WR][4];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {  // output row A / B
-    const int gy = y0 + ly + rr;
-    const bool row_ok = (gy >= 3) && (gy <= h - 4);
+    for (int r = 0; r < DT_WR; ++r) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gx = x0 + lx + j;
-      int mx = max(max(X3[rr][j], X5[rr + 1][j]), X7[rr + 2][j]);
-      mx = max(max(mx, X7[rr + 3][j]), X7[rr + 4][j]);
-      mx = max(max(mx, X5[rr + 5][j]), X3[rr + 6][j]);
-      int mn = min(min(N3[rr][j], N5[rr + 1][j]), N7[rr + 2][j]);
-      mn = min(min(mn, N7[rr + 3][j]), N7[rr + 4][j]);
-      mn = min(min(mn, N5[rr + 5][j]), N3[rr + 6][j]);
-      const int tt = mx - mn;
-      const int tc = min(max(tt, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
-      const int b2 = (tc * thr) / 100;
-      const int c = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j);
-      const int cb = c + b2, c_b = c - b2;
-      // a 9-of-16 arc contains two adjacent compass points (W, N, E, S)
-      const int pw = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j - 3), pe = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j + 3);
-      const int pn = DT_B(R[rr][0], R[rr][1], R[rr][2], j), ps = DT_B(R[rr + 6][0], R[rr + 6][1], R[rr + 6][2], j);
-      const unsigned long long m_in = __ballot(row_ok && gx >= 3 && gx <= w - 4 && tt >= cmp);
-      const unsigned long long m_rng = __ballot(mx > cb) | __ballot(mn < c_b);
-      const unsigned long long bw = __ballot(pw > cb), bn = __ballot(pn > cb), be = __ballot(pe > cb), bs = __ballot(ps > cb);
-      const unsigned long long dw = __ballot(pw < c_b), dn = __ballot(pn < c_b), de = __ballot(pe < c_b), ds = __ballot(ps < c_b);
-      const unsigned long long m = m_in & m_rng & (((bw & bn) | (bn & be) | (be & bs) | (bs & bw)) | ((dw & dn) | (dn & de) | (de & ds) | (ds & dw)));
-      mk[rr * 4 + j] = m;
-      total += __popcll(m);
-      entry_k[rr * 4 + j] = (unsigned)((ly + rr) * DT_W + lx + j) | ((unsigned)tt << 16) | ((unsigned)b2 << 24);
+      for (int j = 0; j < 4; ++j) {
+        const int a = DT_B(R[r][0], R[r][1], R[r][2], j - 1), b = DT_B(R[r][0], R[r][1], R[r][2], j), c = DT_B(R[r][0], R[r][1], R[r][2], j + 1);
+        X3[r][j] = max(max(a, b), c);
+        N3[r][j] = min(min(a, b), c);
+        if (r >= 1 && r <= DT_WR - 2) {
+          const int d = DT_B(R[r][0], R[r][1], R[r][2], j - 2), e = DT_B(R[r][0], R[r][1], R[r][2], j + 2);
+          X5[r][j] = max(max(X3[r][j], d), e);
+          N5[r][j] = min(min(N3[r][j], d), e);
+        } else { X5[r][j] = 0; N5[r][j] = 0; }
+        if (r >= 2 && r <= DT_WR - 3) {
+          const int f = DT_B(R[r][0], R[r][1], R[r][2], j - 3), g = DT_B(R[r][0], R[r][1], R[r][2], j + 3);
+          X7[r][j] = max(max(X5[r][j], f), g);
+          N7[r][j] = min(min(N5[r][j], f), g);
+        } else { X7[r][j] = 0; N7[r][j] = 0; }
+      }
     }
-  }
-  if (total) {  // compaction: one LDS atomic per wave for all 8 pixel slots
-    int qb = 0;
-    if (lane == 0) qb = atomicAdd(&qcount, total);
-    qb = __builtin_amdgcn_readfirstlane(qb);
+    // Gates as straight-line code on WAVE MASKS: every comparison is one v_cmp whose 64-bit lane mask is combined
+    // with scalar and/or (no exec-mask branches, no boolean VGPRs); the combined mask is the compaction ballot.
+    const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
+    const float kthr = brisk_b2_factor(thr);
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if ((mk[k] >> lane) & 1ull) queue[qb + __popcll(mk[k] & ((1ull << lane) - 1ull))] = entry_k[k];
-      qb += __popcll(mk[k]);
+    for (int half = 0; half < DT_R / 2; ++half) {  // two output rows per compaction round
+      unsigned long long mk[8];
+      unsigned entry_k[8];
+      int total = 0;
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int rr = half * 2 + r2;
+        const int gy = y0 + ly + rr;
+        const bool row_ok = (gy >= 3) && (gy <= h - 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gx = x0 + lx + j;
+          int mx = max(max(X3[rr][j], X5[rr + 1][j]), X7[rr + 2][j]);
+          mx = max(max(mx, X7[rr + 3][j]), X7[rr + 4][j]);
+          mx = max(max(mx, X5[rr + 5][j]), X3[rr + 6][j]);
+          int mn = min(min(N3[rr][j], N5[rr + 1][j]), N7[rr + 2][j]);
+          mn = min(min(mn, N7[rr + 3][j]), N7[rr + 4][j]);
+          mn = min(min(mn, N5[rr + 5][j]), N3[rr + 6][j]);
+          const int tt = mx - mn;
+          const int tc = min(max(tt, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
+          const int b2 = brisk_b2_fast(tc, kthr);  // == (tc * thr) / 100 without quarter-rate integer multiplies
+          const int c = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j);
+          const int cb = c + b2, c_b = c - b2;
+          // a 9-of-16 arc contains two adjacent compass points (W, N, E, S)
+          const int pw = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j - 3), pe = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j + 3);
+          const int pn = DT_B(R[rr][0], R[rr][1], R[rr][2], j), ps = DT_B(R[rr + 6][0], R[rr + 6][1], R[rr + 6][2], j);
+          const unsigned long long m_in = __ballot(row_ok && gx >= 3 && gx <= w - 4 && tt >= cmp);
+          const unsigned long long m_rng = __ballot(mx > cb) | __ballot(mn < c_b);
+          const unsigned long long bw = __ballot(pw > cb), bn = __ballot(pn > cb), be = __ballot(pe > cb), bs = __ballot(ps > cb);
+          const unsigned long long dw = __ballot(pw < c_b), dn = __ballot(pn < c_b), de = __ballot(pe < c_b), ds = __ballot(ps < c_b);
+          const unsigned long long m = m_in & m_rng & (((bw & bn) | (bn & be) | (be & bs) | (bs & bw)) | ((dw & dn) | (dn & de) | (de & ds) | (ds & dw)));
+          mk[r2 * 4 + j] = m;
+          total += __popcll(m);
+          // (b2 < 255 for every survivor: the range gate cannot pass otherwise, so 8 bits hold it)
+          entry_k[r2 * 4 + j] = (unsigned)((ly + rr) * DT_W + lx + j) | ((unsigned)tt << 16) | ((unsigned)b2 << 24);
+        }
+      }
+      if (total) {  // compaction: one LDS atomic per wave for 8 pixel slots
+        int qb = 0;
+        if (lane == 0) qb = atomicAdd(&qcount, total);
+        qb = __builtin_amdgcn_readfirstlane(qb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if ((mk[k] >> lane) & 1ull) queue[qb + __popcll(mk[k] & ((1ull << lane) - 1ull))] = entry_k[k];
+          qb += __popcll(mk[k]);
+        }
+      }
     }
   }
   __syncthreads();
@@ -399,7 +424,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
 
   // ---- smap tile: D in the low byte, all state bits cleared
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
+  for (int rr = 0; rr < DT_R; ++rr) {
     const int gy = y0 + ly + rr;
     if (gy < h && x0 + lx < stride && !(G.debug_flags & 32)) {
       const unsigned d4 = *reinterpret_cast<const unsigned*>(&dres[(ly + rr) * DT_W + lx]);

@@ -285,6 +285,16 @@ int emul_detect(const uint8_t* img, int w, int h, int threshold, int octaves, un
 
 void emul_free(void* p) { free(p); }
 
+// exhaustive check of the multiply-free threshold scaling used by k_detect; returns the number of mismatches
+int emul_b2_fast_mismatches(void) {
+  int bad = 0;
+  for (int thr = 1; thr <= 255; ++thr) {
+    const float k = brisk_b2_factor(thr);
+    for (int tc = 0; tc <= 255; ++tc) bad += (brisk_b2_fast(tc, k) != (tc * thr) / 100);
+  }
+  return bad;
+}
+
 // closed-form scores vs the oracle's bisection (per pixel)
 int emul_oast_Kp(const uint8_t* p, int stride) { return brisk_Kp_from_M(brisk_oast9_16_M(p, stride)); }
 int emul_agast58_Kp(const uint8_t* p, int stride) { return brisk_Kp_from_M(brisk_agast5_8_M(p, stride)); }

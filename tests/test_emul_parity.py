@@ -138,3 +138,8 @@ def test_describe_flags_and_custom_pattern(golden_harris):
     ko, do = O.Extractor(pattern_scale=0.8).compute(e["image"], k)
     ke, de = E.Pattern(pattern_scale=0.8).describe(e["image"], k)
     assert same_kps(ke, ko) and np.array_equal(de, do)
+
+
+def test_b2_fast_exact():
+    """k_detect scales the contrast with an fma instead of (tc * thr) / 100: must be the same integer everywhere."""
+    assert E.lib().emul_b2_fast_mismatches() == 0

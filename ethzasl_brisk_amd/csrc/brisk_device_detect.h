@@ -591,12 +591,13 @@ BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above,
 // k:        0   1   2   3   4   5   6   7
 // dx:      -1  +1   0   0  -1  +1  +1  -1
 // dy:       0   0  -1  +1  +1  +1  -1  -1
-BRISK_HD int brisk_probe_dx(int k) { const int t[8] = {-1, 1, 0, 0, -1, 1, 1, -1}; return t[k]; }
-BRISK_HD int brisk_probe_dy(int k) { const int t[8] = {0, 0, -1, 1, 1, 1, -1, -1}; return t[k]; }
+// (2-bit packed tables: no indexed local arrays in device code)
+BRISK_HD int brisk_probe_dx(int k) { return (int)((0x2858u >> (2 * k)) & 3u) - 1; }  // {-1, 1, 0, 0, -1, 1, 1, -1}
+BRISK_HD int brisk_probe_dy(int k) { return (int)((0x0A85u >> (2 * k)) & 3u) - 1; }  // {0, 0, -1, 1, 1, 1, -1, -1}
 // probe index of neighbour offset (dx, dy), |dx|,|dy| <= 1, not both 0
-BRISK_HD int brisk_probe_index(int dx, int dy) {
-  const int t[9] = {7, 2, 6, 0, -1, 1, 4, 3, 5};  // (dy+1)*3 + (dx+1)
-  return t[(dy + 1) * 3 + (dx + 1)];
+BRISK_HD constexpr int brisk_probe_index(int dx, int dy) {  // {7, 2, 6, 0, -1, 1, 4, 3, 5}[(dy+1)*3 + (dx+1)]
+  return (int)((0x5341F0627ull >> (4 * ((dy + 1) * 3 + (dx + 1)))) & 15ull) == 15 ? -1
+       : (int)((0x5341F0627ull >> (4 * ((dy + 1) * 3 + (dx + 1)))) & 15ull);
 }
 
 // returns status (REJ / PASS / TIE) and the number of probes issued
@@ -805,45 +806,46 @@ BRISK_HD int brisk_state_at(const BriskLayerView& L, const bool float_patch, con
                             const uint8_t* kp5) {
   // sm_local: smap window copy [ly0..][lx0..] of width lw covering p +- 2 (values 0 outside the image)
   if (brisk_border3(L, px, py)) return 0;
-  const unsigned smp = sm_local[(py - ly0) * lw + (px - lx0)];
+  const uint16_t* wp = sm_local + (py - ly0) * lw + (px - lx0);
+  const unsigned smp = wp[0];
   const int D = BRISK_SM_D(smp);
   if (D > 2) return D;
   const int Kp = EVAL ? brisk_Kp(L, px, py) : (int)kp5[(py - cy + 2) * 5 + (px - cx + 2)];
   if (Kp == 0) return 0;
-  bool cached = false, any = false;
-  int t_last = 0;
-  if (smp & BRISK_SM_TOUCH) { cached = true; any = true; t_last = 1; }
-  for (int qy = py - 2; qy <= py + 2; ++qy) {
-    for (int qx = px - 2; qx <= px + 2; ++qx) {
-      if (qy > cy || (qy == cy && qx > cx)) continue;  // later in raster order
-      if (qx < 0 || qy < 0 || qx >= L.w || qy >= L.h) continue;
-      const unsigned smq = sm_local[(qy - ly0) * lw + (qx - lx0)];
-      const int Dq = BRISK_SM_D(smq);
-      if (Dq == 0) continue;
-      const int ddx = px - qx, ddy = py - qy;
-      if (ddx == 0 && ddy == 0) continue;
-      const bool self = (qx == cx && qy == cy);
-      if (self && !own) continue;
-      // phase 1: IsMax2D probe of p by q
-      if (ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1) {
-        if (brisk_probe_index(ddx, ddy) < (int)BRISK_SM_NPROBED(smq)) {
-          any = true;
-          t_last = Dq;
-          if (Dq <= Kp) cached = true;
-        }
-      }
-      if (self) continue;
-      // phase 2: threshold-1 touches of a candidate that passed IsMax2D
-      if (BRISK_SM_STATUS(smq) != BRISK_ST_PASS) continue;
-      bool touched = false;
-      if (!float_patch) {
-        touched = (smq & BRISK_SM_E5) && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1;
-      } else {
-        if (pass_touch2x2 && ddx >= 0 && ddx <= 1 && ddy >= 0 && ddy <= 1) touched = true;
-        if ((smq & BRISK_SM_E5) && ddx >= -1 && ddx <= 2 && ddy >= -1 && ddy <= 2) touched = true;
-      }
-      if (touched) { any = true; t_last = 1; cached = true; }
+  bool cached = (smp & BRISK_SM_TOUCH) != 0, any = cached;
+  int t_last = cached ? 1 : 0;
+  // the 24 neighbours q = p + (ox, oy) in raster order; straight-line code (all geometry tests fold at compile
+  // time, the window reads are unconditional: entries outside the image are 0 = "no candidate")
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    const int oy = i / 5 - 2, ox = i % 5 - 2;
+    if (ox == 0 && oy == 0) continue;
+    const int ddx = -ox, ddy = -oy;  // p - q
+    const int qx = px + ox, qy = py + oy;
+    const unsigned smq = wp[oy * lw + ox];
+    const int Dq = BRISK_SM_D(smq);
+    const bool self = (qx == cx) && (qy == cy);
+    const bool earlier = (qy < cy) || (qy == cy && qx <= cx);  // not later in raster order than the candidate
+    const bool act = earlier && (Dq != 0) && !(self && !own);
+    const bool near = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1;
+    if (near) {  // phase 1: IsMax2D probe of p by q
+      const bool pr = act && (brisk_probe_index(ddx, ddy) < (int)BRISK_SM_NPROBED(smq));
+      any = any || pr;
+      t_last = pr ? Dq : t_last;
+      cached = cached || (pr && Dq <= Kp);
     }
+    // phase 2: threshold-1 touches of a candidate that passed IsMax2D
+    bool touched = false;
+    if (!float_patch) {
+      touched = near && (smq & BRISK_SM_E5);
+    } else {
+      if (pass_touch2x2 && ddx >= 0 && ddx <= 1 && ddy >= 0 && ddy <= 1) touched = true;
+      if ((smq & BRISK_SM_E5) && ddx >= -1 && ddx <= 2 && ddy >= -1 && ddy <= 2) touched = true;
+    }
+    const bool tc = act && !self && (BRISK_SM_STATUS(smq) == BRISK_ST_PASS) && touched;
+    any = any || tc;
+    t_last = tc ? 1 : t_last;
+    cached = cached || tc;
   }
   if (Kp >= 3 && cached) return Kp;
   if (!any) return 0;
@@ -873,6 +875,22 @@ BRISK_HD int brisk_tie_raw_value(const BriskLayerView& L, const bool float_patch
   const int qx = cx + (q % 5) - 2, qy = cy + (q / 5) - 2;
   if (qx == cx && qy == cy) return centre;
   return brisk_state_at<EVAL>(L, float_patch, pass_touch2x2, qx, qy, cx, cy, true, sm_local, lx0, ly0, lw, kp5);
+}
+
+// slot 0..7 = probe values, slot 8..32 = raw values: one code path for all lanes of the tie kernel
+template <bool EVAL>
+BRISK_HD int brisk_tie_slot_value(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
+                                  int cy, int centre, int slot, const uint16_t* sm_local, int lx0, int ly0, int lw,
+                                  const uint8_t* kp5) {
+  const bool probe = slot < 8;
+  const int q = probe ? 0 : slot - 8;
+  const int px = cx + (probe ? brisk_probe_dx(slot) : (q % 5) - 2), py = cy + (probe ? brisk_probe_dy(slot) : (q / 5) - 2);
+  if (!probe && px == cx && py == cy) return centre;
+  const int m = brisk_state_at<EVAL>(L, float_patch, pass_touch2x2, px, py, cx, cy, !probe, sm_local, lx0, ly0, lw, kp5);
+  if (!probe || m > 2) return m;
+  if (brisk_border3(L, px, py)) return 0;
+  const int K = EVAL ? brisk_Kp(L, px, py) : (int)kp5[(py - cy + 2) * 5 + (px - cx + 2)];
+  return (K >= centre) ? K : 0;
 }
 
 BRISK_HD bool brisk_tie_decide(int centre, const int* s /* 8 probe values */, const int* raw /* 25 */) {

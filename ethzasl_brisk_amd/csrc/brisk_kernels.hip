@@ -110,19 +110,34 @@ __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t
   const uint8_t* src = frames + (long)frame * frame_pitch;
   uint8_t* P = pyr + (long)frame * G.pyr_elems;
   const bool aligned = ((row_pitch | (uintptr_t)src) & 3) == 0;
-  // stage the 64x64 source block (zero outside the image) and write the layer-0 copy
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
-    const int r = i >> 4, c4 = (i & 15) * 4;
-    const int gy = by + r, gx = bx + c4;
-    unsigned v = 0;
-    if (gy < h) {
-      if (aligned && gx + 3 < w) v = *reinterpret_cast<const unsigned*>(src + (long)gy * row_pitch + gx);
-      else
-        for (int k = 0; k < 4; ++k)
-          if (gx + k < w) v |= (unsigned)src[(long)gy * row_pitch + gx + k] << (8 * k);
-      if (gx < G.L[0].stride) *reinterpret_cast<unsigned*>(P + G.L[0].off + (long)gy * G.L[0].stride + gx) = v;
+  // stage the 64x64 source block (zero outside the image) and write the layer-0 copy.  The four dword loads of a
+  // thread are issued back to back (unconditional, on a safe address when the dword is not fully inside the row)
+  {
+    const long safe_off = -(long)((uintptr_t)src & 3);
+    unsigned stg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + k * 256;
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      const int gy = by + r, gx = bx + c4;
+      const bool full = aligned && gy < h && gx + 3 < w;
+      stg[k] = *reinterpret_cast<const unsigned*>(src + (full ? (long)gy * row_pitch + gx : safe_off));
     }
-    *reinterpret_cast<unsigned*>(&t0[r * 64 + c4]) = v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + k * 256;
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      const int gy = by + r, gx = bx + c4;
+      const bool full = aligned && gy < h && gx + 3 < w;
+      unsigned v = full ? stg[k] : 0u;
+      if (gy < h) {
+        if (!full)
+          for (int q = 0; q < 4; ++q)
+            if (gx + q < w) v |= (unsigned)src[(long)gy * row_pitch + gx + q] << (8 * q);
+        if (gx < G.L[0].stride) *reinterpret_cast<unsigned*>(P + G.L[0].off + (long)gy * G.L[0].stride + gx) = v;
+      }
+      *reinterpret_cast<unsigned*>(&t0[r * 64 + c4]) = v;
+    }
   }
   __syncthreads();
   // column sums of this 64-row band (the integral image kernel's carry rows): integral column = pixel column + 1
@@ -181,12 +196,21 @@ __global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __res
   uint8_t* P = pyr + (long)frame * G.pyr_elems;
   const int w = G.L[0].w, h = G.L[0].h, s0 = G.L[0].stride;
   const uint8_t* src = P + G.L[0].off;
-  for (int i = threadIdx.x; i < 96 * 24; i += 256) {
-    const int r = i / 24, c4 = (i % 24) * 4;
-    const int gy = by + r, gx = bx + c4;
-    unsigned v = 0;
-    if (gy < h && gx < s0) v = *reinterpret_cast<const unsigned*>(src + (long)gy * s0 + gx);
-    *reinterpret_cast<unsigned*>(&t0[r * 96 + c4]) = v;
+  {  // stage the 96x96 source block: nine dword loads per thread, issued back to back on clamped addresses
+    unsigned stg[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = threadIdx.x + k * 256;
+      const int r = i / 24, c4 = (i % 24) * 4;
+      const int cy = min(by + r, h - 1), cx = min(bx + c4, s0 - 4);
+      stg[k] = *reinterpret_cast<const unsigned*>(src + (long)cy * s0 + cx);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = threadIdx.x + k * 256;
+      const int r = i / 24, c4 = (i % 24) * 4;
+      *reinterpret_cast<unsigned*>(&t0[i * 4]) = (by + r < h && bx + c4 < s0) ? stg[k] : 0u;
+    }
   }
   __syncthreads();
   {  // L1 = two-third sample: 64x64 outputs at origin (bx/3*2, by/3*2)
@@ -629,7 +653,10 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   __shared__ unsigned sxyd[TR_MAXSORT]; // its x | y << 13 | ... (the key) - D is taken from the window
   __shared__ int vals[TR_WAVES][40];
   __shared__ int vals_ci[TR_MAXSORT];   // candidate index of the tie (unsorted order)
+  __shared__ uint16_t sfpm[TR_MAXSORT]; // e3 footprint mask of the tie with raster rank r
   __shared__ int remaining, progressed;
+  int* const tstat = reinterpret_cast<int*>(skey);          // after the sort: decision of rank r (0 = pending)
+  unsigned* const sfpxy = reinterpret_cast<unsigned*>(vals_ci);  // after the sort: footprint anchor of rank r
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // ---- all layers' ties are gathered and rank-sorted once: the key is (layer, y, x), so every layer is a
@@ -666,6 +693,14 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       sxyd[r] = k;
     }
     __syncthreads();
+    // everything the decision loop needs besides the smap window goes on chip: footprints by rank, decisions
+    for (int r = tid; r < ntot; r += TR_THREADS) {
+      const BriskCand* c = &cand[(long)frame * cand_cap + sorder[r]];
+      sfpxy[r] = (unsigned)(uint16_t)c->fp_x0 | ((unsigned)(uint16_t)c->fp_y0 << 16);
+      sfpm[r] = c->fp_mask;
+      tstat[r] = 0;
+    }
+    __syncthreads();
   }
   for (int l = 0; l < G.nlayers; ++l) {
     const int n = lstart[l + 1] - lstart[l];
@@ -677,57 +712,94 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
     if (sorted_path) {
       uint16_t* wl = win[wave];
-      // round-robin over the raster-sorted ties: neighbouring ties (which depend on each other) run on different
-      // waves back to back, everything a wave needs except the fresh smap window is already on chip
-      for (int j = lstart[l] + wave; j < lstart[l + 1]; j += TR_WAVES) {
+      const int lbeg = lstart[l], lend = lstart[l + 1];
+      // Round-robin over the raster-sorted ties: neighbouring ties (which depend on each other) run on different
+      // waves back to back.  The only thing a tie needs from raster-earlier ties of its 9x9 window is their
+      // decision, which is exchanged through LDS (tstat); the window itself and the 5x5 score block of a wave's
+      // NEXT tie are prefetched into registers while the current one is decided.
+      int j = lbeg + wave;
+      unsigned pw0 = 0, pw1 = 0, pkb = 0;
+#define TR_PREFETCH(jj)                                                                                          \
+  {                                                                                                              \
+    const unsigned k_ = sxyd[jj];                                                                                \
+    const int cx_ = k_ & 0x1FFF, cy_ = (k_ >> 13) & 0x1FFF;                                                      \
+    const int e1_ = min(lane + 64, TR_WIN * TR_WIN - 1);                                                         \
+    const int qx0_ = cx_ + lane % TR_WIN - 4, qy0_ = cy_ + lane / TR_WIN - 4;                                    \
+    const int qx1_ = cx_ + e1_ % TR_WIN - 4, qy1_ = cy_ + e1_ / TR_WIN - 4;                                      \
+    pw0 = smap_load_fresh(L.smap, (long)min(max(qy0_, 0), L.h - 1) * L.stride + min(max(qx0_, 0), L.w - 1));     \
+    pw1 = smap_load_fresh(L.smap, (long)min(max(qy1_, 0), L.h - 1) * L.stride + min(max(qx1_, 0), L.w - 1));     \
+    pkb = blocks[((long)frame * cand_cap + sorder[jj]) * 64 + min(lane, 24)];                                    \
+    if (qx0_ < 0 || qy0_ < 0 || qx0_ >= L.w || qy0_ >= L.h) pw0 = 0;                                            \
+    if (qx1_ < 0 || qy1_ < 0 || qx1_ >= L.w || qy1_ >= L.h) pw1 = 0;                                            \
+  }
+      if (j < lend) TR_PREFETCH(j)
+      while (j < lend) {
+        unsigned v0 = pw0;
+        const unsigned v1 = pw1, kb = pkb;
         const int ci = sorder[j];
         const unsigned key = sxyd[j];
         const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
-        if (lane < 25) kp5s[wave][lane] = blocks[((long)frame * cand_cap + ci) * 64 + lane];
-        for (int spin = 0; spin < (1 << 22); ++spin) {
-          bool pending = false;
-          for (int e = lane; e < TR_WIN * TR_WIN; e += 64) {
-            const int dy = e / TR_WIN - 4, dx = e % TR_WIN - 4;
-            const int qx = cx + dx, qy = cy + dy;
-            unsigned v = 0;
-            if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
-            wl[e] = (uint16_t)v;
-            if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) pending = true;
-          }
-          if (!__any(pending)) break;
-          __builtin_amdgcn_s_sleep(4);
+        {
+          const int jn = min(j + TR_WAVES, lend - 1);  // (the last prefetch of a wave is redundant, never out of range)
+          TR_PREFETCH(jn)
         }
+        // decisions of the raster-earlier ties of the window (entries 0..39 of the 81)
+        {
+          const int dy = lane / TR_WIN - 4, dx = lane % TR_WIN - 4;
+          if (lane < 40 && BRISK_SM_D(v0) && BRISK_SM_STATUS(v0) == BRISK_ST_TIE) {
+            const unsigned k2 = ((unsigned)l << 26) | ((unsigned)(cy + dy) << 13) | (unsigned)(cx + dx);
+            int lo = lbeg, hi = j;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (sxyd[mid] < k2) lo = mid + 1; else hi = mid;
+            }
+            if (lo < j && sxyd[lo] == k2) {
+              int st = 0;
+              for (int spin = 0; spin < (1 << 22); ++spin) {
+                st = __hip_atomic_load(&tstat[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (st) break;
+                __builtin_amdgcn_s_sleep(1);
+              }
+              if (st) v0 = (v0 & ~0x3000u) | ((unsigned)st << 12);
+            }
+          }
+        }
+        wl[lane] = (uint16_t)v0;
+        if (lane + 64 < TR_WIN * TR_WIN) wl[lane + 64] = (uint16_t)v1;
+        if (lane < 25) kp5s[wave][lane] = (uint8_t)kb;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
-        if (lane < 8) vals[wave][lane] = brisk_tie_probe_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
-        else if (lane >= 32 && lane < 57)
-          vals[wave][8 + lane - 32] = brisk_tie_raw_value<false>(L, float_patch, touch2x2, cx, cy, centre, lane - 32, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
+        {  // lanes 0-7: the 8 probe values, lanes 32-56: the 5x5 raw block (vals[8..32])
+          const int slot = (lane < 8) ? lane : (lane >= 32 && lane < 57) ? lane - 24 : -1;
+          if (slot >= 0)
+            vals[wave][slot] = brisk_tie_slot_value<false>(L, float_patch, touch2x2, cx, cy, centre, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane == 0) {
           const bool pass = brisk_tie_decide(centre, &vals[wave][0], &vals[wave][8]);
           // publish the decision first (other waves spin on it), then the bookkeeping
+          __hip_atomic_store(&tstat[j], pass ? (int)BRISK_ST_PASS : (int)BRISK_ST_FAIL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (pass) smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
           else smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);       // TIE (10b) -> FAIL (11b)
-          BriskCand* c = &cand[(long)frame * cand_cap + ci];
-          c->status = pass ? BRISK_ST_PASS : BRISK_ST_FAIL;
-          if (pass && l + 1 < G.nlayers) {
-            const unsigned fpm = c->fp_mask;
-            if (fpm) {
-              const int fx = c->fp_x0, fy = c->fp_y0;
-              const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
-              for (int b = 0; b < 16; ++b)
-                if (fpm & (1u << b)) smap_or(La.smap, (long)(fy + (b >> 2)) * La.stride + fx + (b & 3), BRISK_SM_TOUCH);
-            }
+          cand[(long)frame * cand_cap + ci].status = pass ? BRISK_ST_PASS : BRISK_ST_FAIL;
+          const unsigned fpm = sfpm[j];
+          if (pass && fpm && l + 1 < G.nlayers) {
+            const int fx = (int16_t)(sfpxy[j] & 0xFFFFu), fy = (int16_t)(sfpxy[j] >> 16);
+            const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
+            for (int b = 0; b < 16; ++b)
+              if (fpm & (1u << b)) smap_or(La.smap, (long)(fy + (b >> 2)) * La.stride + fx + (b & 3), BRISK_SM_TOUCH);
           }
         }
         __builtin_amdgcn_wave_barrier();
+        j += TR_WAVES;
       }
-      // the touches / decisions are device-scope atomics performed at L2 and the next layer reads smap with
-      // L1-bypassing loads: completion of the atomics (vmcnt) + the workgroup barrier is all the ordering needed
+#undef TR_PREFETCH
+      // the touches are device-scope atomics performed at L2 and the next layer reads smap with L1-bypassing
+      // loads: completion of the atomics (vmcnt) + the workgroup barrier is all the ordering needed
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       continue;

@@ -9,7 +9,10 @@ LIB = os.path.join(HERE, "libbrisk_hip.so")
 SOURCES = ["brisk_kernels.hip", "brisk_capi.hip", "brisk_pattern.cpp"]
 # -ffp-contract=off: the reference binary has no FMA contraction (built with -mssse3 only); the
 # sub-pixel / sub-scale float expressions must round after every operation to stay bit-exact.
+# -simplifycfg-sink-common=false: sinking the common tails of the per-layer-class branches of the refinement code
+# turns the three layer views into pointer PHIs, which forces them (and every score-block access) into scratch.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-mllvm", "-simplifycfg-sink-common=false",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 

@@ -107,14 +107,8 @@ BRISK_HD uint8_t brisk_twothird_px(const uint8_t* src, int sstride, int sw, int 
 //   M = max( max_arcs min_arc(p_i - c), max_arcs min_arc(c - p_i) ).
 // ---------------------------------------------------------------------------------------------
 
-// M for OAST 9_16 at p (ring order agast/include/agast/oast9-16.h:99-116).
-BRISK_HD int brisk_oast9_16_M(const uint8_t* p, int s) {
-  const int c = p[0];
-  int d[16];
-  d[0] = p[-3] - c;          d[1] = p[-3 - s] - c;      d[2] = p[-2 - 2 * s] - c;  d[3] = p[-1 - 3 * s] - c;
-  d[4] = p[-3 * s] - c;      d[5] = p[1 - 3 * s] - c;   d[6] = p[2 - 2 * s] - c;   d[7] = p[3 - s] - c;
-  d[8] = p[3] - c;           d[9] = p[3 + s] - c;       d[10] = p[2 + 2 * s] - c;  d[11] = p[1 + 3 * s] - c;
-  d[12] = p[3 * s] - c;      d[13] = p[-1 + 3 * s] - c; d[14] = p[-2 + 2 * s] - c; d[15] = p[-3 + s] - c;
+// M for OAST 9_16 from the 16 ring differences d[i] = ring_i - centre.
+BRISK_HD int brisk_oast9_16_M_from_d(const int* d) {
   int lo3[16], hi3[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -130,12 +124,19 @@ BRISK_HD int brisk_oast9_16_M(const uint8_t* p, int s) {
   return brisk_max(best_bright, -best_dark);
 }
 
-// M for AGAST 5_8 (ring order agast/include/agast/agast5-8.h:66-75).
-BRISK_HD int brisk_agast5_8_M(const uint8_t* p, int s) {
+// M for OAST 9_16 at p (ring order agast/include/agast/oast9-16.h:99-116).
+BRISK_HD int brisk_oast9_16_M(const uint8_t* p, int s) {
   const int c = p[0];
-  int d[8];
-  d[0] = p[-1] - c; d[1] = p[-1 - s] - c; d[2] = p[-s] - c; d[3] = p[1 - s] - c;
-  d[4] = p[1] - c;  d[5] = p[1 + s] - c;  d[6] = p[s] - c;  d[7] = p[-1 + s] - c;
+  int d[16];
+  d[0] = p[-3] - c;          d[1] = p[-3 - s] - c;      d[2] = p[-2 - 2 * s] - c;  d[3] = p[-1 - 3 * s] - c;
+  d[4] = p[-3 * s] - c;      d[5] = p[1 - 3 * s] - c;   d[6] = p[2 - 2 * s] - c;   d[7] = p[3 - s] - c;
+  d[8] = p[3] - c;           d[9] = p[3 + s] - c;       d[10] = p[2 + 2 * s] - c;  d[11] = p[1 + 3 * s] - c;
+  d[12] = p[3 * s] - c;      d[13] = p[-1 + 3 * s] - c; d[14] = p[-2 + 2 * s] - c; d[15] = p[-3 + s] - c;
+  return brisk_oast9_16_M_from_d(d);
+}
+
+// M for AGAST 5_8 from the 8 ring differences.
+BRISK_HD int brisk_agast5_8_M_from_d(const int* d) {
   int best_bright = -256, best_dark = 256;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -145,6 +146,15 @@ BRISK_HD int brisk_agast5_8_M(const uint8_t* p, int s) {
     best_dark = brisk_min(best_dark, hi);
   }
   return brisk_max(best_bright, -best_dark);
+}
+
+// M for AGAST 5_8 (ring order agast/include/agast/agast5-8.h:66-75).
+BRISK_HD int brisk_agast5_8_M(const uint8_t* p, int s) {
+  const int c = p[0];
+  int d[8];
+  d[0] = p[-1] - c; d[1] = p[-1 - s] - c; d[2] = p[-s] - c; d[3] = p[1 - s] - c;
+  d[4] = p[1] - c;  d[5] = p[1 + s] - c;  d[6] = p[s] - c;  d[7] = p[-1 + s] - c;
+  return brisk_agast5_8_M_from_d(d);
 }
 
 // K' = clamp(M - 1, 0, 254): cornerScore(b) == max(b, K') for b >= 0

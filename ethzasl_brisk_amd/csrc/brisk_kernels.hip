@@ -468,42 +468,92 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
 // ------------------------------------------------------------------------------------------------
 #define SB_WAVES 4
 #define SB_PER_WAVE 4
-__global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, const uint8_t* pyr, const uint16_t* smap,
-                                                                const BriskCand* cand, const BriskFrameCounters* counters,
-                                                                uint8_t* blocks, int cand_cap) {
+// ring offsets (dx, dy): 9_16 in the order of brisk_oast9_16_M, 5_8 in the order of brisk_agast5_8_M
+__device__ __forceinline__ constexpr int sb_dx16(int j) { constexpr int t[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3}; return t[j]; }
+__device__ __forceinline__ constexpr int sb_dy16(int j) { constexpr int t[16] = {0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1}; return t[j]; }
+__device__ __forceinline__ constexpr int sb_dx8(int j) { constexpr int t[8] = {-1, -1, 0, 1, 1, 1, 0, -1}; return t[j]; }
+__device__ __forceinline__ constexpr int sb_dy8(int j) { constexpr int t[8] = {0, -1, -1, -1, 0, 1, 1, 1}; return t[j]; }
+
+__global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, const uint8_t* __restrict__ pyr,
+                                                                const uint16_t* __restrict__ smap,
+                                                                const BriskCand* __restrict__ cand,
+                                                                const BriskFrameCounters* __restrict__ counters,
+                                                                uint8_t* __restrict__ blocks, int cand_cap) {
   const int frame = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = min(counters[frame].ncand, cand_cap);
+  const uint8_t* fimg = pyr + (long)frame * G.pyr_elems;
+  const uint16_t* fsm = smap + (long)frame * G.pyr_elems;
+  // lane role: 0 own 5x5 (lanes 0-24), 1 4x4 above (32-47), 2 4x4 below or the 5_8 3x3 on layer 0 (48-63), 3 unused
+  const int role = (lane < 25) ? 0 : (lane >= 32 && lane < 48) ? 1 : (lane >= 48) ? 2 : 3;
+  __shared__ int4 lgeo[BRISK_MAX_LAYERS];
+  if (threadIdx.x < BRISK_MAX_LAYERS) lgeo[threadIdx.x] = make_int4(G.L[threadIdx.x].w, G.L[threadIdx.x].h, G.L[threadIdx.x].stride, G.L[threadIdx.x].off);
+  __syncthreads();
   for (int base = (blockIdx.x * SB_WAVES + wave) * SB_PER_WAVE; base < n; base += gridDim.x * SB_WAVES * SB_PER_WAVE) {
+    // -- round trip 1: the candidate headers (x, y, layer) of the wave's SB_PER_WAVE candidates
+    uint2 hdr[SB_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < SB_PER_WAVE; ++k)
+      hdr[k] = *reinterpret_cast<const uint2*>(&cand[(long)frame * cand_cap + min(base + k, n - 1)]);
+    // -- round trip 2: per lane the centre, the 16 ring bytes and the smap entry of its pixel, all candidates at
+    // once (unconditional loads; lanes without a pixel or on the layer border read the layer origin)
+    int cen[SB_PER_WAVE], rng[SB_PER_WAVE][16];
+    unsigned smv[SB_PER_WAVE];
+    bool ok[SB_PER_WAVE], is8[SB_PER_WAVE];
 #pragma unroll
     for (int k = 0; k < SB_PER_WAVE; ++k) {
-      const int i = base + k;
-      if (i >= n) break;
-      const BriskCand* c = &cand[(long)frame * cand_cap + i];
-      const int x = c->x, y = c->y, l = c->layer;
+      const int x = hdr[k].x & 0xFFFF, y = hdr[k].x >> 16;
+      const int l = __builtin_amdgcn_readfirstlane((int)(hdr[k].y & 0xFF));
       const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
       const bool has_below = !G.single_layer && (l > 0);
       const bool has_58 = !G.single_layer && (l == 0);
-      int v = 0;
-      if (lane < 25) {  // own 5x5 (classification / refinement use its 3x3 centre, the tie replay all of it)
-        v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l), x - 2 + lane % 5, y - 2 + lane / 5);
-      } else if (lane >= 32 && lane < 48) {
-        if (has_above) {
-          int ax, ay;
-          brisk_block_anchor(true, (l & 1) != 0, x, y, &ax, &ay);
-          v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l + 1), ax + (lane & 3), ay + ((lane - 32) >> 2));
-        }
-      } else if (lane >= 48) {
+      int ll = l, px = 0, py = 0;
+      bool valid = false;
+      is8[k] = false;
+      if (role == 0) {
+        px = x - 2 + lane % 5; py = y - 2 + lane / 5; valid = true;
+      } else if (role == 1) {
+        int ax, ay;
+        brisk_block_anchor(true, (l & 1) != 0, x, y, &ax, &ay);
+        ll = has_above ? l + 1 : l; px = ax + (lane & 3); py = ay + ((lane - 32) >> 2); valid = has_above;
+      } else if (role == 2) {
         const int p = lane - 48;
         if (has_below) {
           int bx, by;
           brisk_block_anchor(false, (l & 1) != 0, x, y, &bx, &by);
-          v = brisk_V_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l - 1), bx + (p & 3), by + (p >> 2));
-        } else if (has_58 && p < 9) {  // layer 0 has no layer below: the slot holds the AGAST 5_8 3x3 block
-          v = brisk_V58_eval(make_view(G, (uint8_t*)pyr, (uint16_t*)smap, frame, l), x - 1 + p % 3, y - 1 + p / 3);
+          ll = l - 1; px = bx + (p & 3); py = by + (p >> 2); valid = true;
+        } else if (has_58 && p < 9) {
+          px = x - 1 + p % 3; py = y - 1 + p / 3; valid = true; is8[k] = true;
         }
       }
-      blocks[((long)frame * cand_cap + i) * 64 + lane] = (uint8_t)v;
+      const int4 gg = lgeo[ll];  // geometry of the lane's layer (LDS copy: no vector-memory round trip)
+      const int w = gg.x, h = gg.y, st = gg.z, off = gg.w;
+      const int bd = is8[k] ? 2 : 3;
+      ok[k] = valid && px >= bd && py >= bd && px < w - bd && py < h - bd;
+      const long a0 = (long)off + (ok[k] ? (long)py * st + px : 0);
+      cen[k] = fimg[a0];
+      smv[k] = fsm[a0];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int o16 = sb_dx16(j) + sb_dy16(j) * st, o8 = sb_dx8(j & 7) + sb_dy8(j & 7) * st;
+        rng[k][j] = fimg[a0 + (ok[k] ? (is8[k] ? o8 : o16) : 0)];
+      }
+    }
+    // -- evaluation: closed-form segment tests on registers
+#pragma unroll
+    for (int k = 0; k < SB_PER_WAVE; ++k) {
+      int d[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d[j] = rng[k][j] - cen[k];
+      int v = brisk_Kp_from_M(brisk_oast9_16_M_from_d(d));
+      const int D = BRISK_SM_D(smv[k]);
+      if (D > 2) v = D;
+      if (__any(is8[k])) {  // (wave-uniform per candidate: only layer-0 candidates carry the 5_8 block)
+        const int v8 = brisk_Kp_from_M(brisk_agast5_8_M_from_d(d));
+        if (is8[k]) v = v8;
+      }
+      if (!ok[k]) v = 0;
+      if (base + k < n) blocks[((long)frame * cand_cap + base + k) * 64 + lane] = (uint8_t)v;
     }
   }
 }

@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
     "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags",
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
+    "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device",
 ]
 
 
@@ -89,6 +90,10 @@ def load_library():
     L.brisk_hip_profile_stage_name.argtypes = [C.c_int]
     L.brisk_hip_profile_stage_name.restype = C.c_char_p
     L.brisk_hip_profile_read.argtypes = [vp, vp, ip]
+    L.brisk_hip_match_knn.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
+    L.brisk_hip_match_radius.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float,
+                                         C.c_int, vp, vp]
+    L.brisk_hip_match_knn_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     _lib = L
     return L
 
@@ -284,3 +289,90 @@ class BriskDescriptorExtractor:
             self.close()
         except Exception:
             pass
+
+
+DMATCH = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])  # cv::DMatch
+
+
+class BruteForceMatcher:
+    """Mirror of brisk::BruteForceMatcher with brisk::Hamming (brisk/include/brisk/brute-force-matcher.h:52-93,
+    brisk/src/brute-force-matcher.cc:80-213): add() train descriptor sets, then knnMatch / radiusMatch / match.
+    Matches come back as one structured array (DMATCH) per query, ordered by (distance, imgIdx, trainIdx)."""
+
+    def __init__(self, context=None):
+        self.ctx = context or default_context()
+        self.trainDescCollection = []
+
+    def add(self, descriptors):
+        for d in (descriptors if isinstance(descriptors, (list, tuple)) else [descriptors]):
+            self.trainDescCollection.append(np.ascontiguousarray(d, np.uint8))
+
+    def clear(self):
+        self.trainDescCollection = []
+
+    def empty(self):
+        return not self.trainDescCollection
+
+    def isMaskSupported(self):
+        return True
+
+    def _args(self, query, masks):
+        query = np.ascontiguousarray(query, np.uint8)
+        if query.ndim != 2:
+            raise ValueError("descriptors must be a 2-D uint8 array")
+        train = self.trainDescCollection
+        nimg = len(train)
+        for t in train:
+            if t.ndim != 2 or (t.shape[0] and t.shape[1] != query.shape[1]):
+                raise ValueError("train descriptors must have the query's descriptor size")
+        tptr = (C.c_void_p * max(nimg, 1))(*[t.ctypes.data for t in train])
+        ntr = np.array([t.shape[0] for t in train] + [0], np.int32)
+        tpitch = np.array([t.strides[0] if t.shape[0] else query.shape[1] for t in train] + [0], np.int32)
+        mptr, mpitch, keep = None, None, []
+        if masks is not None:
+            if len(masks) != nimg:
+                raise ValueError("one mask (or None) per train image")
+            ms = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in masks]
+            for m, t in zip(ms, train):
+                if m is not None and m.shape != (query.shape[0], t.shape[0]):
+                    raise ValueError("mask must be queries x train descriptors")
+            keep = ms
+            mptr = (C.c_void_p * max(nimg, 1))(*[None if m is None else m.ctypes.data for m in ms])
+            mpitch = np.array([0 if m is None else m.strides[0] for m in ms] + [0], np.int32)
+        return query, nimg, tptr, ntr, tpitch, mptr, mpitch, keep
+
+    def knnMatch(self, queryDescriptors, k, masks=None, compactResult=False):
+        q, nimg, tptr, ntr, tpitch, mptr, mpitch, keep = self._args(queryDescriptors, masks)
+        nq = q.shape[0]
+        out = np.zeros((nq, max(k, 1)), DMATCH)
+        cnt = np.zeros(max(nq, 1), np.int32)
+        L = self.ctx._L
+        self.ctx.check(L.brisk_hip_match_knn(self.ctx._h, _ptr(q), nq, q.strides[0] if nq else q.shape[1], q.shape[1], nimg,
+                                             tptr, _ptr(ntr), _ptr(tpitch), mptr, None if mpitch is None else _ptr(mpitch),
+                                             k, _ptr(out), _ptr(cnt)))
+        rows = [out[i, :cnt[i]].copy() for i in range(nq)]
+        return [r for r in rows if len(r)] if compactResult else rows
+
+    def radiusMatch(self, queryDescriptors, maxDistance, masks=None, compactResult=False):
+        q, nimg, tptr, ntr, tpitch, mptr, mpitch, keep = self._args(queryDescriptors, masks)
+        nq = q.shape[0]
+        L = self.ctx._L
+        cap = 64
+        while True:
+            out = np.zeros((nq, cap), DMATCH)
+            cnt = np.zeros(max(nq, 1), np.int32)
+            self.ctx.check(L.brisk_hip_match_radius(self.ctx._h, _ptr(q), nq, q.strides[0] if nq else q.shape[1], q.shape[1],
+                                                    nimg, tptr, _ptr(ntr), _ptr(tpitch), mptr,
+                                                    None if mpitch is None else _ptr(mpitch), float(maxDistance), cap,
+                                                    _ptr(out), _ptr(cnt)))
+            need = int(cnt[:nq].max()) if nq else 0
+            if need <= cap:
+                break
+            cap = need
+        rows = [out[i, :cnt[i]].copy() for i in range(nq)]
+        return [r for r in rows if len(r)] if compactResult else rows
+
+    def match(self, queryDescriptors, masks=None):
+        """cv::DescriptorMatcher::match: the best match of every query (queries without one are dropped)."""
+        rows = self.knnMatch(queryDescriptors, 1, masks, compactResult=True)
+        return np.concatenate(rows) if rows else np.zeros(0, DMATCH)

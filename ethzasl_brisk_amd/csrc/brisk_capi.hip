@@ -53,6 +53,8 @@ struct brisk_hip_ctx {
   hipEvent_t fork_ev = nullptr, join_ev[8] = {};
   bool sub_created = false;
   int last_frames_per_launch = 0;
+  void* d_match = nullptr;  // workspace of brisk_hip_match_knn_device
+  size_t match_bytes = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -207,6 +209,7 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
   hipDeviceSynchronize();
   free_buffers(c);
   hipFree(c->d_stage);
+  if (c->d_match) hipFree(c->d_match);
   if (c->sub_created) {
     for (int i = 0; i < 8; ++i) { hipStreamDestroy(c->sub[i]); hipEventDestroy(c->join_ev[i]); }
     hipEventDestroy(c->fork_ev);
@@ -542,6 +545,154 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
 }
 
 // ---- per-stage timing (HIP events on the launch stream) -----------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
+// Hamming brute-force matcher
+// ---------------------------------------------------------------------------------------------------------------
+static_assert(sizeof(brisk_hip_dmatch) == 16 && sizeof(BriskDMatch) == 16, "cv::DMatch layout");
+
+namespace {
+struct DevBuf {  // frees its allocations when the call returns
+  std::vector<void*> ptrs;
+  ~DevBuf() { for (void* p : ptrs) (void)hipFree(p); }
+  hipError_t alloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e == hipSuccess) ptrs.push_back(*p);
+    return e;
+  }
+};
+}  // namespace
+
+// mode 0: knn (param k), mode 1: radius (param cap)
+static int match_host(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pitch, int dim, int nimg,
+                      const uint8_t* const* train, const int* ntrain, const int* t_pitch, const uint8_t* const* masks,
+                      const int* mask_pitch, int mode, int k_or_cap, float max_distance, brisk_hip_dmatch* out,
+                      int* out_count) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (nq < 0 || nimg < 0 || k_or_cap < 0 || !out_count || (nq > 0 && (!query || (k_or_cap > 0 && !out))) ||
+      (nimg > 0 && (!train || !ntrain || !t_pitch)))
+    return fail(ctx, BRISK_HIP_ERR_ARG, "match: bad argument");
+  if (dim < 16 || dim > 64) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "match: descriptor size must be 16..64 bytes");
+  if (q_pitch < dim) return fail(ctx, BRISK_HIP_ERR_ARG, "match: query pitch smaller than the descriptor");
+  if (nq == 0) return BRISK_HIP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int dim16 = (dim / 16) * 16;  // brisk::Hamming ignores bytes beyond the last full 128-bit word
+  std::vector<int> img_start(nimg + 1, 0), has_mask(nimg > 0 ? nimg : 1, 0);
+  bool any_mask = false;
+  for (int i = 0; i < nimg; ++i) {
+    if (ntrain[i] < 0 || (ntrain[i] > 0 && (!train[i] || t_pitch[i] < dim)))
+      return fail(ctx, BRISK_HIP_ERR_ARG, "match: bad train set");
+    img_start[i + 1] = img_start[i] + ntrain[i];
+    if (masks && masks[i] && ntrain[i] > 0) {
+      if (!mask_pitch || mask_pitch[i] < ntrain[i]) return fail(ctx, BRISK_HIP_ERR_ARG, "match: bad mask pitch");
+      has_mask[i] = 1;
+      any_mask = true;
+    }
+  }
+  const int nt = img_start[nimg];
+  const long tp = dim16;                                        // packed train rows
+  const long dist_pitch = ((long)nt + 63) / 64 * 64 + 64;
+  long qblock = (256L << 20) / (dist_pitch * 2);                // <= 256 MB of distances at a time
+  if (qblock < 64) qblock = 64;
+  if (qblock > nq) qblock = nq;
+  DevBuf mem;
+  uint8_t *d_q = nullptr, *d_t = nullptr, *d_mask = nullptr;
+  uint16_t* d_dist = nullptr;
+  int *d_start = nullptr, *d_has = nullptr, *d_masked = nullptr, *d_cnt = nullptr;
+  BriskDMatch* d_out = nullptr;
+  HIPCHK(ctx, mem.alloc((void**)&d_q, (size_t)nq * dim16));
+  HIPCHK(ctx, mem.alloc((void**)&d_t, (size_t)(nt > 0 ? nt : 1) * tp));
+  HIPCHK(ctx, mem.alloc((void**)&d_dist, (size_t)qblock * dist_pitch * 2));
+  HIPCHK(ctx, mem.alloc((void**)&d_start, sizeof(int) * (nimg + 1)));
+  HIPCHK(ctx, mem.alloc((void**)&d_has, sizeof(int) * (nimg > 0 ? nimg : 1)));
+  HIPCHK(ctx, mem.alloc((void**)&d_masked, sizeof(int) * (size_t)qblock));
+  HIPCHK(ctx, mem.alloc((void**)&d_cnt, sizeof(int) * (size_t)nq));
+  HIPCHK(ctx, mem.alloc((void**)&d_out, sizeof(BriskDMatch) * (size_t)nq * (k_or_cap > 0 ? k_or_cap : 1)));
+  hipStream_t s = ctx->stream;
+  HIPCHK(ctx, hipMemcpy2DAsync(d_q, dim16, query, q_pitch, dim16, nq, hipMemcpyHostToDevice, s));
+  for (int i = 0; i < nimg; ++i)
+    if (ntrain[i] > 0)
+      HIPCHK(ctx, hipMemcpy2DAsync(d_t + (long)img_start[i] * tp, tp, train[i], t_pitch[i], dim16, ntrain[i],
+                                   hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(d_start, img_start.data(), sizeof(int) * (nimg + 1), hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(d_has, has_mask.data(), sizeof(int) * (nimg > 0 ? nimg : 1), hipMemcpyHostToDevice, s));
+  long mpitch = 0;
+  if (any_mask && nt > 0) {  // concatenated mask, nq x nt (255 where an image has no mask)
+    mpitch = nt;
+    HIPCHK(ctx, mem.alloc((void**)&d_mask, (size_t)nq * mpitch));
+    HIPCHK(ctx, hipMemsetAsync(d_mask, 0xFF, (size_t)nq * mpitch, s));
+    for (int i = 0; i < nimg; ++i)
+      if (has_mask[i])
+        HIPCHK(ctx, hipMemcpy2DAsync(d_mask + img_start[i], mpitch, masks[i], mask_pitch[i], ntrain[i], nq,
+                                     hipMemcpyHostToDevice, s));
+  }
+  for (long q0 = 0; q0 < nq; q0 += qblock) {
+    const int nqb = (int)((nq - q0 < qblock) ? nq - q0 : qblock);
+    brisk_launch_match_dist(d_q, dim16, (int)q0, nqb, d_t, (int)tp, nt, dim16 / 8, d_mask, mpitch, d_dist, dist_pitch, s);
+    const int* masked = nullptr;
+    if (d_mask) {
+      brisk_launch_match_masked_out(d_mask, mpitch, (int)q0, nqb, d_start, d_has, nimg, d_masked, s);
+      masked = d_masked;
+    }
+    if (mode == 0)
+      brisk_launch_match_knn(d_dist, dist_pitch, (int)q0, nqb, nt, d_start, nimg, masked, k_or_cap, d_out, d_cnt, s);
+    else
+      brisk_launch_match_radius(d_dist, dist_pitch, (int)q0, nqb, nt, d_start, nimg, masked, max_distance, k_or_cap, d_out,
+                                d_cnt, s);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out_count, d_cnt, sizeof(int) * (size_t)nq, hipMemcpyDeviceToHost, s));
+  if (k_or_cap > 0)
+    HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(BriskDMatch) * (size_t)nq * k_or_cap, hipMemcpyDeviceToHost, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_match_knn(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pitch, int dim_bytes, int nimg,
+                        const uint8_t* const* train, const int* ntrain, const int* t_pitch,
+                        const uint8_t* const* masks, const int* mask_pitch, int k, brisk_hip_dmatch* out,
+                        int* out_count) {
+  return match_host(ctx, query, nq, q_pitch, dim_bytes, nimg, train, ntrain, t_pitch, masks, mask_pitch, 0, k, 0.f, out,
+                    out_count);
+}
+
+int brisk_hip_match_radius(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pitch, int dim_bytes, int nimg,
+                           const uint8_t* const* train, const int* ntrain, const int* t_pitch,
+                           const uint8_t* const* masks, const int* mask_pitch, float max_distance,
+                           int cap_per_query, brisk_hip_dmatch* out, int* out_count) {
+  return match_host(ctx, query, nq, q_pitch, dim_bytes, nimg, train, ntrain, t_pitch, masks, mask_pitch, 1, cap_per_query,
+                    max_distance, out, out_count);
+}
+
+int brisk_hip_match_knn_device(brisk_hip_ctx* ctx, const uint8_t* d_query, int nq, int q_pitch, const uint8_t* d_train,
+                               int nt, int t_pitch, int dim_bytes, int k, brisk_hip_dmatch* d_out, int* d_out_count,
+                               void* stream) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (nq < 0 || nt < 0 || k < 0 || !d_out_count || (nq > 0 && (!d_query || (k > 0 && !d_out))) || (nt > 0 && !d_train))
+    return fail(ctx, BRISK_HIP_ERR_ARG, "match: bad argument");
+  if (dim_bytes < 16 || dim_bytes > 64) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "match: descriptor size must be 16..64 bytes");
+  if (q_pitch < dim_bytes || (nt > 0 && t_pitch < dim_bytes)) return fail(ctx, BRISK_HIP_ERR_ARG, "match: pitch smaller than the descriptor");
+  if (nq == 0) return BRISK_HIP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int dim16 = (dim_bytes / 16) * 16;
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  const long dist_pitch = ((long)nt + 63) / 64 * 64 + 64;
+  const size_t need = (size_t)nq * dist_pitch * 2;
+  if (ctx->match_bytes < need) {  // workspace kept by the context (the call is asynchronous)
+    if (ctx->d_match) (void)hipFree(ctx->d_match);
+    ctx->d_match = nullptr; ctx->match_bytes = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_match, need));
+    ctx->match_bytes = need;
+  }
+  uint16_t* d_dist = static_cast<uint16_t*>(ctx->d_match);
+  brisk_launch_match_dist(d_query, q_pitch, 0, nq, d_train, t_pitch, nt, dim16 / 8, nullptr, 0, d_dist, dist_pitch, st);
+  brisk_launch_match_knn(d_dist, dist_pitch, 0, nq, nt, nullptr, 1, nullptr, k,
+                         reinterpret_cast<BriskDMatch*>(d_out), d_out_count, st);
+  HIPCHK(ctx, hipGetLastError());
+  return BRISK_HIP_OK;
+}
+
 int brisk_hip_profile_enable(brisk_hip_ctx* ctx, int enable) {
   if (!ctx) return BRISK_HIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

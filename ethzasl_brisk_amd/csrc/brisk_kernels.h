@@ -70,3 +70,19 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
                            long n_in_stride, hipStream_t s, BriskProfiler* prof);
+
+// ---- Hamming brute-force matcher (brisk_match.hip) ----
+struct BriskDMatch {  // binary-identical to cv::DMatch
+  int queryIdx, trainIdx, imgIdx;
+  float distance;
+};
+void brisk_launch_match_dist(const uint8_t* query, int q_pitch, int q0, int nqb, const uint8_t* train, int t_pitch, int nt,
+                             int words, const uint8_t* mask, long mask_pitch, uint16_t* dist, long dist_pitch,
+                             hipStream_t s);
+void brisk_launch_match_masked_out(const uint8_t* mask, long mask_pitch, int q0, int nqb, const int* img_start,
+                                   const int* has_mask, int nimg, int* masked, hipStream_t s);
+void brisk_launch_match_knn(const uint16_t* dist, long dist_pitch, int q0, int nqb, int nt, const int* img_start, int nimg,
+                            const int* masked, int k, BriskDMatch* out, int* out_count, hipStream_t s);
+void brisk_launch_match_radius(const uint16_t* dist, long dist_pitch, int q0, int nqb, int nt, const int* img_start,
+                               int nimg, const int* masked, float max_distance, int cap, BriskDMatch* out, int* out_count,
+                               hipStream_t s);

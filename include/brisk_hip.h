@@ -101,6 +101,38 @@ int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags)
  * caller's stream with events, so the call stays asynchronous and ordered on that stream. */
 int brisk_hip_set_streams(brisk_hip_ctx* ctx, int n);
 
+/* ---- Hamming brute-force matcher (the step after the path) ----------------------- */
+/* binary-identical to cv::DMatch */
+typedef struct brisk_hip_dmatch {
+  int queryIdx, trainIdx, imgIdx;
+  float distance;
+} brisk_hip_dmatch;
+/* BruteForceMatcher::knnMatchImpl -> commonKnnMatchImpl (brisk/src/brute-force-matcher.cc:54-64, 80-162) with
+ * brisk::Hamming (brisk/include/brisk/internal/hamming.h:98-112: popcount of a ^ b over dim_bytes / 16 128-bit
+ * words).  query: nq rows of dim_bytes at pitch q_pitch; train[i]: ntrain[i] rows at pitch t_pitch[i] (the
+ * trainDescCollection, nimg images).  masks: NULL, or nimg pointers (each NULL or an nq x ntrain[i] u8 matrix at
+ * pitch mask_pitch[i]; 0 = pair not allowed).  out: nq * k matches, row q at out + q * k, sorted by
+ * (distance, imgIdx, trainIdx); out_count[q] = entries of row q (0 for a masked-out query; rows with fewer
+ * than k possible matches are topped up exactly as the reference does).
+ * All pointers are host pointers. */
+int brisk_hip_match_knn(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pitch, int dim_bytes, int nimg,
+                        const uint8_t* const* train, const int* ntrain, const int* t_pitch,
+                        const uint8_t* const* masks, const int* mask_pitch, int k, brisk_hip_dmatch* out,
+                        int* out_count);
+/* BruteForceMatcher::radiusMatchImpl -> commonRadiusMatchImpl (:66-78, 164-213): every pair with
+ * distance < max_distance.  out: nq rows of cap_per_query entries; out_count[q] = matches FOUND for query q
+ * (only the first cap_per_query of them, in (distance, imgIdx, trainIdx) order, are stored). */
+int brisk_hip_match_radius(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pitch, int dim_bytes, int nimg,
+                           const uint8_t* const* train, const int* ntrain, const int* t_pitch,
+                           const uint8_t* const* masks, const int* mask_pitch, float max_distance,
+                           int cap_per_query, brisk_hip_dmatch* out, int* out_count);
+/* Device-resident form used by pipelines that keep descriptors in HBM (e.g. the rows brisk_hip_batch_results
+ * returns): one train set, no masks, all pointers are device pointers; asynchronous on `stream` (hipStream_t,
+ * NULL = the context's stream). */
+int brisk_hip_match_knn_device(brisk_hip_ctx* ctx, const uint8_t* d_query, int nq, int q_pitch, const uint8_t* d_train,
+                               int nt, int t_pitch, int dim_bytes, int k, brisk_hip_dmatch* d_out, int* d_out_count,
+                               void* stream);
+
 /* ---- per-stage timing: HIP events recorded on the launch stream around every kernel of the batch path ---- */
 int brisk_hip_profile_enable(brisk_hip_ctx* ctx, int enable);       /* resets the accumulated calls */
 int brisk_hip_profile_stages(void);                                 /* number of stages */

@@ -78,6 +78,16 @@ int bo_extractor_scale_index(const bo_extractor* e, float size);
 int bo_extractor_compute(const bo_extractor* e, const uint8_t* img, int w, int h, bo_keypoint* kps,
                          int n, uint8_t* desc);
 
+/* ---- matcher: brisk/include/brisk/internal/hamming.h, brisk/src/brute-force-matcher.cc (brisk_oracle_match.c) ---- */
+typedef struct { int queryIdx, trainIdx, imgIdx; float distance; } bo_dmatch; /* == cv::DMatch */
+int bo_hamming(const uint8_t* a, const uint8_t* b, int size_bytes);
+void bo_match_knn(const uint8_t* query, int nq, int q_pitch, int dim, int nimg, const uint8_t* const* train,
+                  const int* ntrain, const int* t_pitch, const uint8_t* const* masks, const int* mask_pitch, int k,
+                  bo_dmatch* out, int* out_count);
+bo_dmatch* bo_match_radius(const uint8_t* query, int nq, int q_pitch, int dim, int nimg, const uint8_t* const* train,
+                           const int* ntrain, const int* t_pitch, const uint8_t* const* masks, const int* mask_pitch,
+                           float max_distance, int* out_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,11 @@ def lib():
         L.bo_extractor_pattern.argtypes = [vp]
         L.bo_extractor_scale_index.argtypes = [vp, C.c_float]
         L.bo_extractor_compute.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
+        L.bo_hamming.argtypes = [vp, vp, C.c_int]
+        L.bo_match_knn.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
+        L.bo_match_knn.restype = None
+        L.bo_match_radius.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp]
+        L.bo_match_radius.restype = vp
         _lib = L
     return _lib
 
@@ -177,3 +182,54 @@ class Extractor:
         if getattr(self, "_h", None):
             lib().bo_extractor_destroy(self._h)
             self._h = None
+
+
+DMATCH = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().bo_hamming(_p(a), _p(b), a.size)
+
+
+def _match_args(query, train, masks):
+    query = np.ascontiguousarray(query, np.uint8)
+    train = [np.ascontiguousarray(t, np.uint8) for t in train]
+    nimg = len(train)
+    tptr = (C.c_void_p * max(nimg, 1))(*[t.ctypes.data for t in train])
+    ntr = np.array([t.shape[0] for t in train] + [0], np.int32)
+    tpitch = np.array([t.strides[0] if t.shape[0] else query.shape[1] for t in train] + [0], np.int32)
+    mptr, mpitch, keep = None, None, None
+    if masks is not None:
+        keep = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in masks]
+        mptr = (C.c_void_p * max(nimg, 1))(*[None if m is None else m.ctypes.data for m in keep])
+        mpitch = np.array([0 if m is None else m.strides[0] for m in keep] + [0], np.int32)
+    return query, train, nimg, tptr, ntr, tpitch, mptr, mpitch, keep
+
+
+def match_knn(query, train, k, masks=None):
+    query, train, nimg, tptr, ntr, tpitch, mptr, mpitch, keep = _match_args(query, train, masks)
+    nq = query.shape[0]
+    out = np.zeros((nq, max(k, 1)), DMATCH)
+    cnt = np.zeros(max(nq, 1), np.int32)
+    lib().bo_match_knn(_p(query), nq, query.strides[0] if nq else query.shape[1], query.shape[1], nimg, tptr, _p(ntr),
+                       _p(tpitch), mptr, None if mpitch is None else _p(mpitch), k, _p(out), _p(cnt))
+    return [out[i, :cnt[i]].copy() for i in range(nq)]
+
+
+def match_radius(query, train, max_distance, masks=None):
+    query, train, nimg, tptr, ntr, tpitch, mptr, mpitch, keep = _match_args(query, train, masks)
+    nq = query.shape[0]
+    cnt = np.zeros(max(nq, 1), np.int32)
+    ptr = lib().bo_match_radius(_p(query), nq, query.strides[0] if nq else query.shape[1], query.shape[1], nimg, tptr,
+                                _p(ntr), _p(tpitch), mptr, None if mpitch is None else _p(mpitch), float(max_distance),
+                                _p(cnt))
+    total = int(cnt[:nq].sum())
+    flat = np.frombuffer(C.string_at(ptr, total * DMATCH.itemsize), dtype=DMATCH).copy() if total else np.zeros(0, DMATCH)
+    lib().bo_free(ptr)
+    rows, o = [], 0
+    for i in range(nq):
+        rows.append(flat[o:o + cnt[i]])
+        o += cnt[i]
+    return rows

@@ -193,3 +193,91 @@ def test_detected_score_is_contrast(golden_ast):
         for x, y in xy[:n:7]:
             p = img.ctypes.data + int(y) * w + int(x)
             assert L.bo_oast9_16_corner_score(p, w, int(thr[y, x])) == thr[y, x]
+
+
+# ---- matcher: brisk::Hamming + BruteForceMatcher restatement ------------------------------------
+
+def test_popcount_known_answer():
+    """brisk/src/test/test-popcount.cc:60-105: the reference's own vectors against a bit-by-bit count."""
+    d1 = np.zeros(16, np.uint8)
+    d2 = np.zeros(16, np.uint8)
+    for i, v in {0: 0x5, 3: 0x2, 6: 0x34, 8: 0x7, 10: 0x23, 13: 0x45, 15: 0x78}.items():
+        d1[i] = v
+    for i, v in {0: 0x22, 3: 0x78, 6: 0x12, 8: 0x32, 10: 0x1, 13: 0x23, 15: 0x75}.items():
+        d2[i] = v
+    expect = int(np.unpackbits(d1 ^ d2).sum())
+    assert expect == 25
+    assert O.hamming(d1, d2) == expect
+
+
+def test_hamming_counts_whole_128bit_words_only():
+    """hamming.h:98-112: `size / 16` words - a 40-byte descriptor is compared on its first 32 bytes."""
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, 40, dtype=np.uint8)
+    b = rng.integers(0, 256, 40, dtype=np.uint8)
+    assert O.hamming(a, b) == int(np.unpackbits(a[:32] ^ b[:32]).sum())
+    a48, b48 = rng.integers(0, 256, 48, dtype=np.uint8), rng.integers(0, 256, 48, dtype=np.uint8)
+    assert O.hamming(a48, b48) == int(np.unpackbits(a48 ^ b48).sum())
+
+
+H_1TO2 = np.array([[0.8835462624646065, 0.31399802853807735, -40.079602102472926],
+                   [-0.18170359412701342, 0.9417589525236417, 152.6910745330205],
+                   [2.0127825613685174e-4, -1.5103648761897873e-5, 1.0]])
+
+
+def homography_outliers(k1, k2, matches, thres=5.0):
+    """brisk/src/test/test-match.cc:90-121"""
+    out = 0
+    for m in matches:
+        p = H_1TO2 @ np.array([k1["x"][m["queryIdx"]], k1["y"][m["queryIdx"]], 1.0], np.float64)
+        p /= p[2]
+        q = np.array([k2["x"][m["trainIdx"]], k2["y"][m["trainIdx"]], 1.0], np.float64)
+        out += np.linalg.norm(p - q) > thres
+    return out
+
+
+def test_match_homography(golden_ast):
+    """The reference's matching test (test-match.cc:49-126): detector(70, 2 octaves), default extractor, best match
+    below Hamming 50, every match an inlier of the known homography."""
+    k1, d1 = O.Extractor().compute(golden_ast[0]["image"], O.detect(golden_ast[0]["image"], 70, 2))
+    k2, d2 = O.Extractor().compute(golden_ast[1]["image"], O.detect(golden_ast[1]["image"], 70, 2))
+    rows = O.match_knn(d1, [d2], 1)
+    best = np.concatenate([r for r in rows if len(r) and r[0]["distance"] < 50])
+    # same selection as the reference test's own loop (strict <, first index wins)
+    dist = np.unpackbits(d1[:, None, :] ^ d2[None, :, :], axis=2).sum(axis=2)
+    ref = [(i, int(np.argmin(dist[i]))) for i in range(len(d1)) if dist[i].min() < 50]
+    assert [(int(m["queryIdx"]), int(m["trainIdx"])) for m in best] == ref
+    assert len(best) > 100
+    assert homography_outliers(k1, k2, best) == 0
+
+
+def test_match_oracle_semantics():
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (7, 48), dtype=np.uint8)
+    t0 = rng.integers(0, 256, (5, 48), dtype=np.uint8)
+    t1 = np.concatenate([t0[:2], rng.integers(0, 256, (3, 48), dtype=np.uint8)])  # duplicates across images
+    rows = O.match_knn(q, [t0, t1], 3)
+    for i, r in enumerate(rows):
+        d = [(int(np.unpackbits(q[i] ^ t).sum()), im, j) for im, tt in enumerate((t0, t1)) for j, t in enumerate(tt)]
+        d.sort()
+        assert [(int(m["distance"]), int(m["imgIdx"]), int(m["trainIdx"])) for m in r] == d[:3]
+    # k larger than the number of train descriptors: the reference tops the row up with INT_MAX pseudo matches on
+    # train 0 of the LAST non-empty image (brute-force-matcher.cc:139-153)
+    rows = O.match_knn(q[:1], [t0[:2], t1[:1], np.zeros((0, 48), np.uint8)], 5)
+    r = rows[0]
+    assert len(r) == 5 and list(r["distance"][3:]) == [2147483648.0, 2147483648.0]
+    assert list(r["imgIdx"][3:]) == [1, 1] and list(r["trainIdx"][3:]) == [0, 0]
+    # masks: a query whose mask row is empty in some masked image is dropped; masked pairs are skipped
+    m0 = np.ones((7, 5), np.uint8)
+    m0[2, :] = 0
+    m0[3, 1] = 0
+    rows = O.match_knn(q, [t0, t1], 10, [m0, None])
+    assert len(rows[2]) == 0 and len(rows[0]) == 10
+    assert not any((m["imgIdx"] == 0 and m["trainIdx"] == 1 and m["distance"] < 1e9) for m in rows[3])
+    rr = O.match_radius(q, [t0, t1], 200.0, [m0, None])
+    assert len(rr[2]) == 0
+    for i in (0, 3):
+        d = [(int(np.unpackbits(q[i] ^ t).sum()), im, j) for im, tt in enumerate((t0, t1)) for j, t in enumerate(tt)
+             if not (im == 0 and m0[i, j] == 0)]
+        d = sorted(x for x in d if x[0] < 200.0)
+        assert [(int(m["distance"]), int(m["imgIdx"]), int(m["trainIdx"])) for m in rr[i]] == d

@@ -6,6 +6,7 @@
 #include <agast/wrap-opencv.h>
 #include <brisk/brisk-descriptor-extractor.h>
 #include <brisk/brisk-feature-detector.h>
+#include <brisk/brute-force-matcher.h>
 
 namespace cv {
 typedef brisk::BriskDescriptorExtractor BriskDescriptorExtractor;

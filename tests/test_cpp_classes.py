@@ -36,4 +36,4 @@ def test_reference_golden_through_cpp_classes():
     r = subprocess.run([b, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "Verification success" in r.stdout
-    assert r.stdout.count("OK") == 4
+    assert r.stdout.count("OK") == 5

@@ -489,8 +489,14 @@ int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int s
   if (!ctx || !img || !n || (cap > 0 && !out) || cap < 0) return BRISK_HIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   *n = 0;
-  if (!suppress_scale_nonmaxima)
-    return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "suppressScaleNonmaxima=false is not implemented on the device path");
+  // suppressScaleNonmaxima = false (brisk-scale-space.cc:131-170): with octaves == 0 the branch is the single-layer
+  // 2-D refinement (:172-209) verbatim, which the engine runs.  With more layers the reference takes every layer's
+  // points from layer 0's list (`agastPoints.at(0)[n]`, :137) and probes layer i's score map at layer-0 coordinates
+  // - out of range for every layer but the first - so there is no defined result to reproduce.
+  if (!suppress_scale_nonmaxima && octaves != 0)
+    return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED,
+                "suppressScaleNonmaxima=false is only defined for octaves == 0 (the reference indexes layer 0's point "
+                "list on every layer, brisk-scale-space.cc:137)");
   int rc = check_detect_args(ctx, w, h, threshold, octaves);
   if (rc) return rc;
   if (stride < w || (mask && mask_stride < w)) return fail(ctx, BRISK_HIP_ERR_ARG, "stride smaller than width");

@@ -65,7 +65,8 @@ int brisk_hip_pattern_tables(const brisk_hip_pattern* p, float* scale_list, int*
 /* ---- host-buffer calls: what the two host classes forward to --------------------------------- */
 /* BriskFeatureDetector::detectImpl (brisk-feature-detector.cc:77-85): clears/overwrites `out`.
  * img: h x w u8, row pitch `stride` bytes.  mask: optional h x w u8 (0 = drop keypoint), or NULL.
- * suppress_scale_nonmaxima must be 1 (the only mode the reference's detector default uses).
+ * suppress_scale_nonmaxima = 0 is accepted with octaves == 0 only (brisk-scale-space.cc:131-170 is then the
+ * single-layer refinement; with more layers the reference reads layer 0's point list on every layer, :137).
  * out: capacity `cap` keypoints; *n receives the count (BRISK_HIP_ERR_CAPACITY if cap is too small). */
 int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
                      int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, brisk_hip_keypoint* out,

@@ -158,7 +158,9 @@ def test_mask_and_errors(B, golden_ast):
         B.BriskFeatureDetector(10, 3).detect(img)           # documented deviation: threshold < 20
     assert ei.value.code == 5
     with pytest.raises(B.BriskHipError):
-        B.BriskFeatureDetector(70, 3, suppressScaleNonmaxima=False).detect(img)
+        B.BriskFeatureDetector(70, 3, suppressScaleNonmaxima=False).detect(img)   # undefined in the reference (:137)
+    # suppressScaleNonmaxima=false with a single layer is the 2-D refinement branch (brisk-scale-space.cc:131-170)
+    assert same_kps(B.BriskFeatureDetector(70, 0, suppressScaleNonmaxima=False).detect(img), O.detect(img, 70, 0))
     with pytest.raises(RuntimeError):
         B.BriskDescriptorExtractor(version=3)
     # empty keypoint list

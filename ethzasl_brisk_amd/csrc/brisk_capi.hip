@@ -53,6 +53,10 @@ struct brisk_hip_ctx {
   hipEvent_t fork_ev = nullptr, join_ev[8] = {};
   bool sub_created = false;
   int last_frames_per_launch = 0;
+  // second stream of a detect + describe batch (integral image beside the detector's tail)
+  hipStream_t side = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
+  int overlap = 1;
   void* d_match = nullptr;  // workspace of brisk_hip_match_knn_device
   size_t match_bytes = 0;
 };
@@ -210,6 +214,7 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
   free_buffers(c);
   hipFree(c->d_stage);
   if (c->d_match) hipFree(c->d_match);
+  if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->side_fork); hipEventDestroy(c->side_join); }
   if (c->sub_created) {
     for (int i = 0; i < 8; ++i) { hipStreamDestroy(c->sub[i]); hipEventDestroy(c->join_ev[i]); }
     hipEventDestroy(c->fork_ev);
@@ -371,14 +376,29 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
     Di.dperm += f0 * Bi.kp_cap;
     Di.desc += f0 * Bi.kp_cap * Di.desc_pitch;
     BriskProfiler* prof = (i == 0) ? &ctx->prof : nullptr;  // per-kernel timing on the first slice's stream
+    BriskOverlap ov{};
+    const BriskOverlap* ovp = nullptr;
+    if (do_detect && do_describe && nsub == 1 && ctx->overlap && !(ctx->debug_flags & 0x10000)) {
+      if (!ctx->side) {
+        // lowest priority: the detector's latency-bound kernels get their workgroups placed first, the
+        // bandwidth-bound integral kernel fills what they leave
+        int least = 0, greatest = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+      }
+      ov.side = ctx->side; ov.fork = ctx->side_fork; ov.join = ctx->side_join; ov.Dd = &Di;
+      ovp = &ov;
+    }
     if (i == 0) ctx->last_frames_per_launch = nf;
     if (do_detect) {
       brisk_launch_detect(ctx->G, ctx->T, Bi, nf, d_frames + f0 * frame_pitch, frame_pitch, row_pitch,
-                          d_mask ? d_mask + f0 * mask_frame_pitch : nullptr, mask_frame_pitch, mask_row_pitch, si, prof);
+                          d_mask ? d_mask + f0 * mask_frame_pitch : nullptr, mask_frame_pitch, mask_row_pitch, si, prof, ovp);
     }
     if (do_describe) {
       BriskPatternDev P = pat->dev;
-      brisk_launch_describe(ctx->G, P, Bi, Di, nf, Bi.kp_out, &Bi.counters[0].nkp, sizeof(BriskFrameCounters), si, prof);
+      brisk_launch_describe(ctx->G, P, Bi, Di, nf, Bi.kp_out, &Bi.counters[0].nkp, sizeof(BriskFrameCounters), si, prof, ovp);
     }
     if (nsub > 1) {
       HIPCHK(ctx, hipEventRecord(ctx->join_ev[i], si));

@@ -59,17 +59,24 @@ const char* brisk_stage_name(int i);
 void brisk_prof_begin_call(BriskProfiler* P);
 void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s);  // slot k = start of stage k (k == stages: end)
 
+// detect + describe in one batch: the integral image runs on `side` beside the detector's latency-bound tail
+struct BriskOverlap {
+  hipStream_t side;
+  hipEvent_t fork, join;
+  const BriskDescribeBuffers* Dd;
+};
 // frames: u8 images, frame f at frames + f*frame_pitch, row pitch row_pitch (device memory)
 void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
                          const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
-                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof);
+                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof,
+                         const BriskOverlap* ov = nullptr);
 // only stages layer 0 (descriptor-only calls)
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
                               long frame_pitch, int row_pitch, hipStream_t s);
 // kp_in: [slots][kp_cap]; n_in: per-frame counts at byte stride n_in_stride
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
-                           long n_in_stride, hipStream_t s, BriskProfiler* prof);
+                           long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov = nullptr);
 
 // ---- Hamming brute-force matcher (brisk_match.hip) ----
 struct BriskDMatch {  // binary-identical to cv::DMatch

@@ -1265,7 +1265,8 @@ void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s) {
 
 void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
                          const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
-                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof) {
+                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof,
+                         const BriskOverlap* ov) {
   (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
   brisk_prof_mark(prof, BRISK_STG_PYRAMID, s);
   {
@@ -1294,8 +1295,21 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   hipLaunchKernelGGL(k_classify_refine_direct, dim3(8, nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters,
                      B.tie_idx, B.cand_cap, B.tie_cap);
   brisk_prof_mark(prof, BRISK_STG_TIES, s);
+  if (ov) (void)hipEventRecord(ov->fork, s);
   hipLaunchKernelGGL(k_tie_resolve, dim3(nframes), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
                      B.blocks, B.cand_cap, B.tie_cap);
+  if (ov) {
+    // The integral image only needs layer 0 and the band sums (k_pyramid_even) and is HBM-bound; tie resolution
+    // (one workgroup per frame, a chain of dependent decisions) and the final ordering are latency-bound and leave
+    // most of the chip idle.  Run the integral kernel beside them on a second, low-priority stream (it starts when
+    // the tie kernel does: the fork event sits in front of it) and join before the descriptor kernels.  Started any
+    // earlier it would take the workgroup slots the 1024-thread tie workgroups need (measured: 0.4 -> 1.3 ms).
+    const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
+    (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
+    hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, ov->side, G, B.pyr, B.bandsum,
+                       ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, nbands);
+    (void)hipEventRecord(ov->join, ov->side);
+  }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,
                      B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);
@@ -1311,11 +1325,14 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
 
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
-                           long n_in_stride, hipStream_t s, BriskProfiler* prof) {
+                           long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov) {
   const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
-  hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, B.bandsum, Dd.integral,
-                     Dd.istride, Dd.iframe_elems, nbands);
+  if (ov)  // already running beside the detector's tail (brisk_launch_detect): this stage is only the join
+    (void)hipStreamWaitEvent(s, ov->join, 0);
+  else
+    hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, B.bandsum, Dd.integral,
+                       Dd.istride, Dd.iframe_elems, nbands);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, Dd.dperm, B.kp_cap);

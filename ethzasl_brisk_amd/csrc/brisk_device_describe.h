@@ -102,31 +102,43 @@ BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, const uint
   const unsigned r_y_1_i = (unsigned)(int)(r_y_1 * scaling);
   const unsigned r_x1_i = (unsigned)(int)(r_x1 * scaling);
   const unsigned r_y1_i = (unsigned)(int)(r_y1 * scaling);
-  // corner pixels
+  // Integral samples at columns {xl, xl+1, xr, xr+1} x rows {yt, yt+1, yb, yb+1}: 8 gathers of two adjacent
+  // columns each.  The corner PIXELS are differences of those same samples (exact in wrap-around arithmetic), so
+  // the image itself is only read for the two displaced bottom corners of the reference quirk.
   const bool quirk = (dx + dy > 2);
-  const uint8_t* ptop = img + (long)y_top * stride;
-  const uint8_t* pbot = img + (long)(quirk ? y_bottom - 1 : y_bottom) * stride;
-  const unsigned tl = ptop[x_left], tr = ptop[x_right];
-  const unsigned br = pbot[quirk ? x_right + 1 : x_right], bl = pbot[quirk ? x_left + 1 : x_left];
-  // integral samples at columns {xl, xl+1, xr, xr+1} x rows {yt, yt+1, yb, yb+1} (without the 4 outer corners)
   const uint32_t* r0 = integral + (long)y_top * istride;
   const uint32_t* r1 = r0 + istride;
   const uint32_t* r2 = integral + (long)y_bottom * istride;
   const uint32_t* r3 = r2 + istride;
-  const int c0 = x_left, c1 = x_left + 1, c2 = x_right, c3 = x_right + 1;
-  const uint32_t i01 = r0[c1], i02 = r0[c2];
-  const uint32_t i31 = r3[c1], i32 = r3[c2];
+  const int c0 = x_left, c2 = x_right;
 #if defined(__HIP_DEVICE_COMPILE__)
   // adjacent column pairs as one 8-byte gather each (4-byte aligned is enough for global_load_dwordx2)
   typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) u32x2_t;
+  const u32x2_t p00 = *reinterpret_cast<const u32x2_t*>(r0 + c0), p02 = *reinterpret_cast<const u32x2_t*>(r0 + c2);
   const u32x2_t p10 = *reinterpret_cast<const u32x2_t*>(r1 + c0), p12 = *reinterpret_cast<const u32x2_t*>(r1 + c2);
   const u32x2_t p20 = *reinterpret_cast<const u32x2_t*>(r2 + c0), p22 = *reinterpret_cast<const u32x2_t*>(r2 + c2);
+  const u32x2_t p30 = *reinterpret_cast<const u32x2_t*>(r3 + c0), p32 = *reinterpret_cast<const u32x2_t*>(r3 + c2);
+  const uint32_t i00 = p00.x, i01 = p00.y, i02 = p02.x, i03 = p02.y;
   const uint32_t i10 = p10.x, i11 = p10.y, i12 = p12.x, i13 = p12.y;
   const uint32_t i20 = p20.x, i21 = p20.y, i22 = p22.x, i23 = p22.y;
+  const uint32_t i30 = p30.x, i31 = p30.y, i32 = p32.x, i33 = p32.y;
 #else
-  const uint32_t i10 = r1[c0], i11 = r1[c1], i12 = r1[c2], i13 = r1[c3];
-  const uint32_t i20 = r2[c0], i21 = r2[c1], i22 = r2[c2], i23 = r2[c3];
+  const uint32_t i00 = r0[c0], i01 = r0[c0 + 1], i02 = r0[c2], i03 = r0[c2 + 1];
+  const uint32_t i10 = r1[c0], i11 = r1[c0 + 1], i12 = r1[c2], i13 = r1[c2 + 1];
+  const uint32_t i20 = r2[c0], i21 = r2[c0 + 1], i22 = r2[c2], i23 = r2[c2 + 1];
+  const uint32_t i30 = r3[c0], i31 = r3[c0 + 1], i32 = r3[c2], i33 = r3[c2 + 1];
 #endif
+  const unsigned tl = i11 - i01 - i10 + i00;  // pixel (x_left, y_top)
+  const unsigned tr = i13 - i03 - i12 + i02;  // pixel (x_right, y_top)
+  unsigned br, bl;
+  if (quirk) {
+    const uint8_t* pbot = img + (long)(y_bottom - 1) * stride;
+    br = pbot[x_right + 1];
+    bl = pbot[x_left + 1];
+  } else {
+    br = i33 - i23 - i32 + i22;  // pixel (x_right, y_bottom)
+    bl = i31 - i21 - i30 + i20;  // pixel (x_left, y_bottom)
+  }
   const uint32_t top = i12 - i11 - i02 + i01;     // first row, interior columns
   const uint32_t bottom = i32 - i31 - i22 + i21;  // last row, interior columns
   const uint32_t left = i21 - i20 - i11 + i10;    // first column, interior rows

@@ -337,3 +337,71 @@ def test_soak_1080p_batch_vs_oracle(B, ctx):
         assert np.array_equal(dg, do), seeds[f]
         total += len(kg)
     assert total > 20000
+
+
+EDGE_CASES = [
+    ("flat", lambda: np.full((120, 160), 77, np.uint8), 40, 3),
+    ("noise_vga_thr20", lambda: np.random.default_rng(1).integers(0, 256, (480, 640), dtype=np.uint8), 20, 4),
+    ("noise_small_thr60_o8", lambda: np.random.default_rng(2).integers(0, 256, (200, 264), dtype=np.uint8), 60, 8),
+    ("checker_2px", lambda: np.kron((np.indices((60, 80)).sum(0) % 2).astype(np.uint8) * 200 + 20, np.ones((2, 2), np.uint8)), 60, 3),
+    ("tiny_24x20_o2", lambda: np.random.default_rng(3).integers(0, 256, (20, 24), dtype=np.uint8), 30, 2),
+    ("tiny_9x9_o1", lambda: np.random.default_rng(4).integers(0, 256, (9, 9), dtype=np.uint8), 30, 1),
+    ("thin_600x12_o2", lambda: np.random.default_rng(5).integers(0, 256, (12, 600), dtype=np.uint8), 40, 2),
+    ("saturated_blobs", lambda: (np.kron(np.random.default_rng(6).integers(0, 2, (24, 32)), np.ones((10, 10))) * 255).astype(np.uint8), 100, 4),
+    ("max_threshold_255", lambda: synth.frame_vga(7), 255, 3),
+]
+
+
+@pytest.mark.parametrize("name,mk,thr,octaves", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_images_vs_oracle(B, name, mk, thr, octaves):
+    """Degenerate inputs: no corners at all, pure noise (dense candidates, long tie chains), layers that shrink to a
+    few pixels, images smaller than the descriptor pattern, saturated content, the largest threshold."""
+    img = np.ascontiguousarray(mk())
+    ko = O.detect(img, thr, octaves)
+    big = None
+    if name.startswith("noise_vga"):
+        # every tenth pixel is a keypoint: the default per-frame capacities answer with BRISK_HIP_ERR_CAPACITY
+        # (never a truncated result); a context sized for it reproduces the oracle
+        with pytest.raises(B.BriskHipError) as ei:
+            B.BriskFeatureDetector(thr, octaves).detect(img, capacity=65536)
+        assert ei.value.code == 4
+        big = B.Context(0, max_candidates=262144, max_keypoints=65536)
+    kg = B.BriskFeatureDetector(thr, octaves, context=big).detect(img, capacity=65536)
+    assert same_kps(kg, ko), explain(kg, ko)
+    ko2, do = O.Extractor().compute(img, ko)
+    kg2, dg = B.BriskDescriptorExtractor(context=big).compute(img, kg)
+    assert same_kps(kg2, ko2), explain(kg2, ko2)
+    assert np.array_equal(dg, do)
+    if name == "flat":
+        assert len(kg) == 0
+    if big is not None:
+        big.close()
+
+
+def test_row_pitch_and_unaligned_buffers(B, ctx, golden_ast):
+    """The C ABI takes any row pitch and any byte alignment of image, mask and descriptor rows."""
+    img = golden_ast[0]["image"][:333, :517]
+    ko = O.detect(np.ascontiguousarray(img), 70, 3)
+    L = B.load_library()
+    for pad, shift in ((0, 1), (37, 3), (123, 0)):
+        buf = np.zeros(shift + img.shape[0] * (img.shape[1] + pad) + 64, np.uint8)
+        view = buf[shift:shift + img.shape[0] * (img.shape[1] + pad)].reshape(img.shape[0], img.shape[1] + pad)
+        view[:, :img.shape[1]] = img
+        view[:, img.shape[1]:] = 255                       # padding bytes must never be read as pixels
+        out = np.zeros(4096, B.KEYPOINT)
+        n = C.c_int(0)
+        ctx.check(L.brisk_hip_detect(ctx._h, view.ctypes.data, img.shape[1], img.shape[0], img.shape[1] + pad, 70, 3, 1, None, 0,
+                                     out.ctypes.data, len(out), C.byref(n)))
+        kg = out[:n.value]
+        assert same_kps(kg, ko), (pad, shift, explain(kg, ko))
+        # describe through a padded, shifted descriptor matrix
+        ko2, do = O.Extractor().compute(np.ascontiguousarray(img), ko)
+        ext = B.BriskDescriptorExtractor()
+        dbuf = np.zeros(1 + len(kg) * 53 + 64, np.uint8)
+        n2 = C.c_int(len(kg))
+        kk = kg.copy()
+        ctx.check(L.brisk_hip_describe(ctx._h, ext._h, view.ctypes.data, img.shape[1], img.shape[0], img.shape[1] + pad,
+                                       kk.ctypes.data, C.byref(n2), dbuf[1:].ctypes.data, 53, 1, 1))
+        assert n2.value == len(ko2) and same_kps(kk[:n2.value], ko2)
+        dg = dbuf[1:1 + n2.value * 53].reshape(n2.value, 53)[:, :48]
+        assert np.array_equal(dg, do)

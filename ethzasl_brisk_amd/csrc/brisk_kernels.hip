@@ -474,6 +474,11 @@ __device__ __forceinline__ constexpr int sb_dy16(int j) { constexpr int t[16] = 
 __device__ __forceinline__ constexpr int sb_dx8(int j) { constexpr int t[8] = {-1, -1, 0, 1, 1, 1, 0, -1}; return t[j]; }
 __device__ __forceinline__ constexpr int sb_dy8(int j) { constexpr int t[8] = {0, -1, -1, -1, 0, 1, 1, 1}; return t[j]; }
 
+// image patches of one candidate in LDS: [0] own layer 11x11 around (x, y), [1] layer above 10x10 around the 4x4
+// block, [2] layer below 10x10; rows of 16 bytes starting at a 4-byte aligned column (SB_PROWS x 4 dwords each)
+#define SB_PROWS 11
+#define SB_PSLOTS (3 * SB_PROWS * 4)  // (patch, row, dword) load slots per candidate
+
 __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, const uint8_t* __restrict__ pyr,
                                                                 const uint16_t* __restrict__ smap,
                                                                 const BriskCand* __restrict__ cand,
@@ -487,6 +492,7 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
   // lane role: 0 own 5x5 (lanes 0-24), 1 4x4 above (32-47), 2 4x4 below or the 5_8 3x3 on layer 0 (48-63), 3 unused
   const int role = (lane < 25) ? 0 : (lane >= 32 && lane < 48) ? 1 : (lane >= 48) ? 2 : 3;
   __shared__ int4 lgeo[BRISK_MAX_LAYERS];
+  __shared__ __attribute__((aligned(16))) uint8_t patch[SB_WAVES][SB_PER_WAVE][3][SB_PROWS][16];
   if (threadIdx.x < BRISK_MAX_LAYERS) lgeo[threadIdx.x] = make_int4(G.L[threadIdx.x].w, G.L[threadIdx.x].h, G.L[threadIdx.x].stride, G.L[threadIdx.x].off);
   __syncthreads();
   for (int base = (blockIdx.x * SB_WAVES + wave) * SB_PER_WAVE; base < n; base += gridDim.x * SB_WAVES * SB_PER_WAVE) {
@@ -495,10 +501,12 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
 #pragma unroll
     for (int k = 0; k < SB_PER_WAVE; ++k)
       hdr[k] = *reinterpret_cast<const uint2*>(&cand[(long)frame * cand_cap + min(base + k, n - 1)]);
-    // -- round trip 2: per lane the centre, the 16 ring bytes and the smap entry of its pixel, all candidates at
-    // once (unconditional loads; lanes without a pixel or on the layer border read the layer origin)
-    int cen[SB_PER_WAVE], rng[SB_PER_WAVE][16];
+    // -- round trip 2: the three image patches of every candidate as coalesced dword loads (132 dwords per
+    // candidate instead of 57 x 17 byte gathers), plus the smap entry of each lane's pixel.  Loads are
+    // unconditional on clamped addresses: clamping only ever moves data that no in-image ring reads.
+    unsigned pv[SB_PER_WAVE][3];
     unsigned smv[SB_PER_WAVE];
+    int cofs[SB_PER_WAVE];   // byte offset of the lane's pixel inside its patch
     bool ok[SB_PER_WAVE], is8[SB_PER_WAVE];
 #pragma unroll
     for (int k = 0; k < SB_PER_WAVE; ++k) {
@@ -507,21 +515,36 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
       const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
       const bool has_below = !G.single_layer && (l > 0);
       const bool has_58 = !G.single_layer && (l == 0);
-      int ll = l, px = 0, py = 0;
+      int ax = 0, ay = 0, bx = 0, by = 0;
+      brisk_block_anchor(true, (l & 1) != 0, x, y, &ax, &ay);
+      brisk_block_anchor(false, (l & 1) != 0, x, y, &bx, &by);
+      // patch origins (top-left pixel each patch must contain) on the three layers
+      const int ox0 = x - 5, oy0 = y - 5, ox1 = ax - 3, oy1 = ay - 3, ox2 = bx - 3, oy2 = by - 3;
+      // (a) patch loads: slot s = which * 44 + row * 4 + dword
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int s_ = min(lane + 64 * t, SB_PSLOTS - 1);
+        const int which = s_ / (SB_PROWS * 4), r = (s_ % (SB_PROWS * 4)) >> 2, d = s_ & 3;
+        const int pl = (which == 0) ? l : (which == 1) ? (has_above ? l + 1 : l) : (has_below ? l - 1 : l);
+        const int4 pg = lgeo[pl];
+        const int pox = (which == 0) ? ox0 : (which == 1) ? ox1 : ox2;
+        const int poy = (which == 0) ? oy0 : (which == 1) ? oy1 : oy2;
+        const int gx = min(max((pox & ~3) + 4 * d, 0), pg.z - 4);
+        const int gy = min(max(poy + r, 0), pg.y - 1);
+        pv[k][t] = *reinterpret_cast<const unsigned*>(fimg + pg.w + (long)gy * pg.z + gx);
+      }
+      // (b) the lane's pixel
+      int ll = l, px = 0, py = 0, which = 0;
       bool valid = false;
       is8[k] = false;
       if (role == 0) {
         px = x - 2 + lane % 5; py = y - 2 + lane / 5; valid = true;
       } else if (role == 1) {
-        int ax, ay;
-        brisk_block_anchor(true, (l & 1) != 0, x, y, &ax, &ay);
-        ll = has_above ? l + 1 : l; px = ax + (lane & 3); py = ay + ((lane - 32) >> 2); valid = has_above;
+        ll = has_above ? l + 1 : l; px = ax + (lane & 3); py = ay + ((lane - 32) >> 2); valid = has_above; which = 1;
       } else if (role == 2) {
         const int p = lane - 48;
         if (has_below) {
-          int bx, by;
-          brisk_block_anchor(false, (l & 1) != 0, x, y, &bx, &by);
-          ll = l - 1; px = bx + (p & 3); py = by + (p >> 2); valid = true;
+          ll = l - 1; px = bx + (p & 3); py = by + (p >> 2); valid = true; which = 2;
         } else if (has_58 && p < 9) {
           px = x - 1 + p % 3; py = y - 1 + p / 3; valid = true; is8[k] = true;
         }
@@ -530,21 +553,31 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
       const int w = gg.x, h = gg.y, st = gg.z, off = gg.w;
       const int bd = is8[k] ? 2 : 3;
       ok[k] = valid && px >= bd && py >= bd && px < w - bd && py < h - bd;
-      const long a0 = (long)off + (ok[k] ? (long)py * st + px : 0);
-      cen[k] = fimg[a0];
-      smv[k] = fsm[a0];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int o16 = sb_dx16(j) + sb_dy16(j) * st, o8 = sb_dx8(j & 7) + sb_dy8(j & 7) * st;
-        rng[k][j] = fimg[a0 + (ok[k] ? (is8[k] ? o8 : o16) : 0)];
-      }
+      smv[k] = fsm[(long)off + (ok[k] ? (long)py * st + px : 0)];
+      const int pox = (which == 0) ? ox0 : (which == 1) ? ox1 : ox2;
+      const int poy = (which == 0) ? oy0 : (which == 1) ? oy1 : oy2;
+      cofs[k] = which * (SB_PROWS * 16) + (py - poy) * 16 + (px - (pox & ~3));
     }
-    // -- evaluation: closed-form segment tests on registers
+    // -- patches to LDS (the wave's own region: wave-level ordering only)
+#pragma unroll
+    for (int k = 0; k < SB_PER_WAVE; ++k)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (lane + 64 * t < SB_PSLOTS) *reinterpret_cast<unsigned*>(&patch[wave][k][0][0][0] + (lane + 64 * t) * 4) = pv[k][t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // -- evaluation: ring bytes from LDS, closed-form segment tests on registers
 #pragma unroll
     for (int k = 0; k < SB_PER_WAVE; ++k) {
+      const uint8_t* pc = &patch[wave][k][0][0][0] + (ok[k] ? cofs[k] : 5 * 16 + 8);
+      const int c = pc[0];
       int d[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) d[j] = rng[k][j] - cen[k];
+      for (int j = 0; j < 16; ++j) {
+        const int o16 = sb_dx16(j) + sb_dy16(j) * 16, o8 = sb_dx8(j & 7) + sb_dy8(j & 7) * 16;
+        d[j] = (int)pc[is8[k] ? o8 : o16] - c;
+      }
       int v = brisk_Kp_from_M(brisk_oast9_16_M_from_d(d));
       const int D = BRISK_SM_D(smv[k]);
       if (D > 2) v = D;
@@ -555,6 +588,7 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
       if (!ok[k]) v = 0;
       if (base + k < n) blocks[((long)frame * cand_cap + base + k) * 64 + lane] = (uint8_t)v;
     }
+    __builtin_amdgcn_wave_barrier();  // the patches are overwritten by the wave's next candidates
   }
 }
 

@@ -401,7 +401,8 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
           const unsigned long long m_rng = __ballot(mx > cb) | __ballot(mn < c_b);
           const unsigned long long bw = __ballot(pw > cb), bn = __ballot(pn > cb), be = __ballot(pe > cb), bs = __ballot(ps > cb);
           const unsigned long long dw = __ballot(pw < c_b), dn = __ballot(pn < c_b), de = __ballot(pe < c_b), ds = __ballot(ps < c_b);
-          const unsigned long long m = m_in & m_rng & (((bw & bn) | (bn & be) | (be & bs) | (bs & bw)) | ((dw & dn) | (dn & de) | (de & ds) | (ds & dw)));
+          // two adjacent compass points of one polarity: (N or S) and (W or E)
+          const unsigned long long m = m_in & m_rng & (((bn | bs) & (bw | be)) | ((dn | ds) & (dw | de)));
           mk[r2 * 4 + j] = m;
           total += __popcll(m);
           // (b2 < 255 for every survivor: the range gate cannot pass otherwise, so 8 bits hold it)

@@ -652,7 +652,23 @@ static int match_host(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pi
         HIPCHK(ctx, hipMemcpy2DAsync(d_mask + img_start[i], mpitch, masks[i], mask_pitch[i], ntrain[i], nq,
                                      hipMemcpyHostToDevice, s));
   }
-  for (long q0 = 0; q0 < nq; q0 += qblock) {
+  bool fused = false;
+  if (mode == 0 && !d_mask && !(ctx->debug_flags & 0x20000)) {
+    int nonempty = 0, first = -1;
+    for (int i = 0; i < nimg; ++i)
+      if (ntrain[i] > 0) { ++nonempty; if (first < 0) first = i; }
+    // one non-empty train image that is also the last one (the imgIdx the kernel writes is patched below)
+    if (nonempty == 1)
+      fused = brisk_launch_match_knn_fused(d_q, dim16, nq, d_t, (int)tp, nt, dim16 / 4, k_or_cap, d_out, d_cnt, s);
+    if (fused && first != 0) {  // imgIdx of the single non-empty image
+      HIPCHK(ctx, hipStreamSynchronize(s));
+      std::vector<BriskDMatch> tmp((size_t)nq * k_or_cap);
+      HIPCHK(ctx, hipMemcpy(tmp.data(), d_out, sizeof(BriskDMatch) * tmp.size(), hipMemcpyDeviceToHost));
+      for (BriskDMatch& m : tmp) m.imgIdx = first;
+      HIPCHK(ctx, hipMemcpy(d_out, tmp.data(), sizeof(BriskDMatch) * tmp.size(), hipMemcpyHostToDevice));
+    }
+  }
+  for (long q0 = 0; q0 < nq && !fused; q0 += qblock) {
     const int nqb = (int)((nq - q0 < qblock) ? nq - q0 : qblock);
     brisk_launch_match_dist(d_q, dim16, (int)q0, nqb, d_t, (int)tp, nt, dim16 / 8, d_mask, mpitch, d_dist, dist_pitch, s);
     const int* masked = nullptr;
@@ -703,6 +719,12 @@ int brisk_hip_match_knn_device(brisk_hip_ctx* ctx, const uint8_t* d_query, int n
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int dim16 = (dim_bytes / 16) * 16;
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  if (!(ctx->debug_flags & 0x20000) &&
+      brisk_launch_match_knn_fused(d_query, q_pitch, nq, d_train, t_pitch, nt, dim16 / 4, k,
+                                   reinterpret_cast<BriskDMatch*>(d_out), d_out_count, st)) {
+    HIPCHK(ctx, hipGetLastError());
+    return BRISK_HIP_OK;
+  }
   const long dist_pitch = ((long)nt + 63) / 64 * 64 + 64;
   const size_t need = (size_t)nq * dist_pitch * 2;
   if (ctx->match_bytes < need) {  // workspace kept by the context (the call is asynchronous)

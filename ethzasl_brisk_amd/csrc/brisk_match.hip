@@ -205,6 +205,99 @@ __global__ void __launch_bounds__(64) k_match_radius(const uint16_t* __restrict_
   if (lane == 0) out_count[q0 + q] = total;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused k-NN for k <= 2, one train set, no masks (the frame-to-frame / frame-to-map case): no distance matrix.
+// Workgroup = 64 queries (one per lane, descriptor in registers) x MF_WAVES waves; wave w scans the w-th slice of
+// the train set, whose descriptors are wave-uniform (scalar loads, XOR against SGPRs); per pair 2 x W32 VALU
+// (v_xor + v_bcnt with accumulate) and a 3-instruction top-2 update on packed keys (distance << 22 | train
+// index).  The MF_WAVES partial top-2 lists of a query are merged through LDS.
+// ------------------------------------------------------------------------------------------------
+#define MF_WAVES 16
+#define MF_IDX_BITS 22
+template <int W32>
+__global__ void __launch_bounds__(MF_WAVES * 64) k_match_knn_fused(const uint8_t* __restrict__ query, int q_pitch, int nq,
+                                                                    const uint8_t* __restrict__ train, int t_pitch, int nt,
+                                                                    int k, BriskDMatch* __restrict__ out,
+                                                                    int* __restrict__ out_count) {
+  __shared__ unsigned part[MF_WAVES][2][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 64 + lane;
+  unsigned qv[W32];
+  {
+    const uint8_t* p = query + (long)min(q, nq - 1) * q_pitch;
+#pragma unroll
+    for (int w = 0; w < W32; ++w)  // (byte loads: no alignment assumption on caller rows)
+      qv[w] = (unsigned)p[4 * w] | ((unsigned)p[4 * w + 1] << 8) | ((unsigned)p[4 * w + 2] << 16) | ((unsigned)p[4 * w + 3] << 24);
+  }
+  const int per = (nt + MF_WAVES - 1) / MF_WAVES;
+  const int t0 = __builtin_amdgcn_readfirstlane(wave * per), t1 = min(nt, t0 + per);
+  unsigned b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+  const bool aligned = (((uintptr_t)train | (unsigned)t_pitch) & 3) == 0;
+  if (aligned) {
+    for (int t = t0; t < t1; ++t) {
+      const unsigned* tp = reinterpret_cast<const unsigned*>(train + (long)t * t_pitch);  // wave-uniform address
+      unsigned d = 0;
+#pragma unroll
+      for (int w = 0; w < W32; ++w) d += __popc(qv[w] ^ tp[w]);
+      const unsigned key = (d << MF_IDX_BITS) | (unsigned)t;
+      b2 = min(b2, max(b1, key));
+      b1 = min(b1, key);
+    }
+  } else {
+    for (int t = t0; t < t1; ++t) {
+      const uint8_t* tp = train + (long)t * t_pitch;
+      unsigned d = 0;
+#pragma unroll
+      for (int w = 0; w < W32; ++w) {
+        const unsigned tv = (unsigned)tp[4 * w] | ((unsigned)tp[4 * w + 1] << 8) | ((unsigned)tp[4 * w + 2] << 16) | ((unsigned)tp[4 * w + 3] << 24);
+        d += __popc(qv[w] ^ tv);
+      }
+      const unsigned key = (d << MF_IDX_BITS) | (unsigned)t;
+      b2 = min(b2, max(b1, key));
+      b1 = min(b1, key);
+    }
+  }
+  part[wave][0][lane] = b1;
+  part[wave][1][lane] = b2;
+  __syncthreads();
+  if (wave == 0 && q < nq) {
+    unsigned m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < MF_WAVES; ++w)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned key = part[w][i][lane];
+        m2 = min(m2, max(m1, key));
+        m1 = min(m1, key);
+      }
+    BriskDMatch* orow = out + (long)q * k;
+    BriskDMatch m;
+    m.queryIdx = q; m.imgIdx = 0;
+    m.trainIdx = (int)(m1 & ((1u << MF_IDX_BITS) - 1)); m.distance = (float)(m1 >> MF_IDX_BITS);
+    orow[0] = m;
+    if (k > 1) {
+      m.trainIdx = (int)(m2 & ((1u << MF_IDX_BITS) - 1)); m.distance = (float)(m2 >> MF_IDX_BITS);
+      orow[1] = m;
+    }
+    out_count[q] = k;
+  }
+}
+
+// returns false when the case is not covered (the caller uses the distance-matrix path)
+bool brisk_launch_match_knn_fused(const uint8_t* query, int q_pitch, int nq, const uint8_t* train, int t_pitch, int nt,
+                                  int words32, int k, BriskDMatch* out, int* out_count, hipStream_t s) {
+  if (k < 1 || k > 2 || nt < k || nt >= (1 << MF_IDX_BITS) || nq <= 0) return false;
+  const dim3 grid((nq + 63) / 64), block(MF_WAVES * 64);
+  switch (words32) {
+    case 4: hipLaunchKernelGGL(k_match_knn_fused<4>, grid, block, 0, s, query, q_pitch, nq, train, t_pitch, nt, k, out, out_count); break;
+    case 8: hipLaunchKernelGGL(k_match_knn_fused<8>, grid, block, 0, s, query, q_pitch, nq, train, t_pitch, nt, k, out, out_count); break;
+    case 12: hipLaunchKernelGGL(k_match_knn_fused<12>, grid, block, 0, s, query, q_pitch, nq, train, t_pitch, nt, k, out, out_count); break;
+    case 16: hipLaunchKernelGGL(k_match_knn_fused<16>, grid, block, 0, s, query, q_pitch, nq, train, t_pitch, nt, k, out, out_count); break;
+    default: return false;
+  }
+  return true;
+}
+
 void brisk_launch_match_dist(const uint8_t* query, int q_pitch, int q0, int nqb, const uint8_t* train, int t_pitch, int nt,
                              int words, const uint8_t* mask, long mask_pitch, uint16_t* dist, long dist_pitch,
                              hipStream_t s) {

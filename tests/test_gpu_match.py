@@ -60,6 +60,13 @@ def test_knn_and_radius_vs_oracle(B, dim):
         same_rows(bf.knnMatch(q, k), O.match_knn(q, train, k))
     for r in (0.5, float(dim * 2), float(dim * 3) + 0.5, 1e9):
         same_rows(bf.radiusMatch(q, r), O.match_radius(q, train, r))
+    # a single non-empty train image and k <= 2 take the fused distance + top-2 kernel (plenty of equal distances
+    # here: the (distance, train index) order must hold there too), also when empty images precede it
+    for tr in ([train[0]], [train[1], train[1], train[0], train[1]], [train[3]]):
+        bf1 = B.BruteForceMatcher()
+        bf1.add(tr)
+        for k in (1, 2):
+            same_rows(bf1.knnMatch(q, k), O.match_knn(q, tr, k))
 
 
 def test_masks_topup_and_empty_sets(B):

@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL result gather even with one rank (self-test)")
     ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results become wrong)")
+    ap.add_argument("--pattern-version", type=int, default=2, help="2 = default 66-point pattern (the metric's workload), 1 = legacy 60-point pattern (timing experiments)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,7 +123,7 @@ def main():
     ctx = B.Context(local_rank)
     ctx.set_streams(args.streams)
     ctx.debug_set_flags(args.debug_flags)
-    ext = B.BriskDescriptorExtractor(context=ctx)
+    ext = B.BriskDescriptorExtractor(version=args.pattern_version, context=ctx)
     stream = torch.cuda.current_stream().cuda_stream
     strings = ext.descriptorSize()
 

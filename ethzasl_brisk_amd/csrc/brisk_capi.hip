@@ -115,7 +115,7 @@ static void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G
 
 static void free_buffers(brisk_hip_ctx* c) {
   hipFree(c->B.pyr); hipFree(c->B.smap); hipFree(c->B.cand); hipFree(c->B.blocks); hipFree(c->B.tie_idx); hipFree(c->B.keys);
-  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->B.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale); hipFree(c->D.dperm);
+  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->B.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale); hipFree(c->D.dperm); hipFree(c->D.drec);
   hipFree(c->D.desc); hipFree(c->d_kp_in); hipFree(c->d_n_in);
   c->B = BriskDetectBuffers{};
   c->D = BriskDescribeBuffers{};
@@ -152,6 +152,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMalloc(&c->D.dkp, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
   HIPCHK(c, hipMalloc(&c->D.dscale, (size_t)slots * c->kp_cap * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->D.dperm, (size_t)slots * c->kp_cap * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->D.drec, ((size_t)slots * c->kp_cap + 4) * sizeof(uint4)));
   c->D.desc_pitch = 64;
   HIPCHK(c, hipMalloc(&c->D.desc, (size_t)slots * c->kp_cap * c->D.desc_pitch));
   HIPCHK(c, hipMalloc(&c->d_kp_in, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
@@ -374,6 +375,7 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
     Di.dkp += f0 * Bi.kp_cap;
     Di.dscale += f0 * Bi.kp_cap;
     Di.dperm += f0 * Bi.kp_cap;
+    Di.drec += f0 * Bi.kp_cap;
     Di.desc += f0 * Bi.kp_cap * Di.desc_pitch;
     BriskProfiler* prof = (i == 0) ? &ctx->prof : nullptr;  // per-kernel timing on the first slice's stream
     BriskOverlap ov{};

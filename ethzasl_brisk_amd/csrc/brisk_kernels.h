@@ -38,6 +38,7 @@ struct BriskDescribeBuffers {
   BriskKeyPoint* dkp;  // [slots][kp_cap] filtered keypoints (angle filled in)
   int* dscale;         // [slots][kp_cap]
   int* dperm;          // [slots][kp_cap] processing order of the keypoints (spatially sorted, L2 locality)
+  uint4* drec;         // [slots][kp_cap] the keypoints in processing order: {x, y, angle (float bits), scale | index << 8}
   uint8_t* desc;       // [slots][kp_cap][desc_pitch]
   int desc_pitch;
 };

@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
                                                        const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
-                                                       BriskKeyPoint* dkp, int* dscale, int* dperm, int kp_cap) {
+                                                       BriskKeyPoint* dkp, int* dscale, int* dperm, uint4* drec, int kp_cap) {
   __shared__ int scan[256];
   __shared__ int base;
   __shared__ unsigned pkey[DP_MAXSORT];
@@ -1165,6 +1165,15 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
   } else {
     for (int j = tid; j < m; j += 256) perm[j] = j;
   }
+  // the keypoints again, in processing order, as one 16-byte record each: k_describe reads them with a single
+  // (prefetchable) load instead of the dependent chain order -> keypoint -> scale
+  __syncthreads();
+  for (int r = tid; r < m; r += 256) {
+    const int j = perm[r];
+    const BriskKeyPoint& q = dkp[(long)frame * kp_cap + j];
+    drec[(long)frame * kp_cap + r] = make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.angle),
+                                                 (unsigned)dscale[(long)frame * kp_cap + j] | ((unsigned)j << 8));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1174,10 +1183,126 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
 // ------------------------------------------------------------------------------------------------
 #define DS_WAVES 4
 #define DS_LP_LDS 1024
+
+// ---- SmoothedIntensity split into address / load / combine stages (device only; the arithmetic is that of
+// brisk_smoothed_intensity in brisk_device_describe.h, box branch), so that the gathers of a lane's two pattern
+// points are in flight together and nothing but the gathers sits between a keypoint and its bits.
+struct DsTab {  // scale-dependent part of a pattern point (prefetched one keypoint ahead)
+  float mult, sigma;
+  int scaling, scaling2;
+};
+__device__ __forceinline__ DsTab ds_tab(const BriskPatternDev& P, int scale, int i) {
+  const int si = scale * P.npoints + i;
+  DsTab t;
+  t.mult = P.mult[si];
+  t.sigma = P.sigma[si];
+  const int2 sc = *reinterpret_cast<const int2*>(P.scaling + 2 * si);
+  t.scaling = sc.x; t.scaling2 = sc.y;
+  return t;
+}
+__device__ __forceinline__ BriskSamplePoint ds_point(const DsTab& t, double ux, double uy) {
+  BriskSamplePoint sp;
+  const double m = (double)t.mult;
+  sp.x = (float)(m * ux);
+  sp.y = (float)(m * uy);
+  sp.sigma = t.sigma; sp.scaling = t.scaling; sp.scaling2 = t.scaling2;
+  return sp;
+}
+struct DsPrep {
+  int x_left, y_top, x_right, y_bottom;
+  unsigned A, B, C, D, r_x_1_i, r_y_1_i, r_x1_i, r_y1_i;
+  int scaling, scaling2;
+  bool quirk;
+};
+typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) ds_u32x2;
+struct DsRaw {
+  ds_u32x2 p00, p02, p10, p12, p20, p22, p30, p32;
+  unsigned br, bl;
+};
+// valid == false: a harmless sample at the image origin (the value is discarded)
+__device__ __forceinline__ DsPrep ds_prep(float key_x, float key_y, const BriskSamplePoint& sp, bool valid) {
+  DsPrep p;
+  const float sigma_half = valid ? sp.sigma : 1.0f;
+  const float xf = valid ? sp.x + key_x : 2.0f;
+  const float yf = valid ? sp.y + key_y : 2.0f;
+  p.scaling = sp.scaling; p.scaling2 = valid ? sp.scaling2 : 1;
+  const float x_1 = xf - sigma_half, x1 = xf + sigma_half, y_1 = yf - sigma_half, y1 = yf + sigma_half;
+  p.x_left = (int)(x_1 + 0.5); p.y_top = (int)(y_1 + 0.5); p.x_right = (int)(x1 + 0.5); p.y_bottom = (int)(y1 + 0.5);
+  const float r_x_1 = (float)((float)p.x_left - x_1 + 0.5);
+  const float r_y_1 = (float)((float)p.y_top - y_1 + 0.5);
+  const float r_x1 = (float)(x1 - (float)p.x_right + 0.5);
+  const float r_y1 = (float)(y1 - (float)p.y_bottom + 0.5);
+  const int dx = p.x_right - p.x_left - 1, dy = p.y_bottom - p.y_top - 1;
+  const int scaling = sp.scaling;
+  p.A = (unsigned)(int)((r_x_1 * r_y_1) * scaling);
+  p.B = (unsigned)(int)((r_x1 * r_y_1) * scaling);
+  p.C = (unsigned)(int)((r_x1 * r_y1) * scaling);
+  p.D = (unsigned)(int)((r_x_1 * r_y1) * scaling);
+  p.r_x_1_i = (unsigned)(int)(r_x_1 * scaling);
+  p.r_y_1_i = (unsigned)(int)(r_y_1 * scaling);
+  p.r_x1_i = (unsigned)(int)(r_x1 * scaling);
+  p.r_y1_i = (unsigned)(int)(r_y1 * scaling);
+  p.quirk = (dx + dy > 2);
+  return p;
+}
+__device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, const uint8_t* __restrict__ img, int stride,
+                                        const uint32_t* __restrict__ integral, int istride) {
+  const uint32_t* r0 = integral + (long)p.y_top * istride;
+  const uint32_t* r1 = r0 + istride;
+  const uint32_t* r2 = integral + (long)p.y_bottom * istride;
+  const uint32_t* r3 = r2 + istride;
+  r.p00 = *reinterpret_cast<const ds_u32x2*>(r0 + p.x_left); r.p02 = *reinterpret_cast<const ds_u32x2*>(r0 + p.x_right);
+  r.p10 = *reinterpret_cast<const ds_u32x2*>(r1 + p.x_left); r.p12 = *reinterpret_cast<const ds_u32x2*>(r1 + p.x_right);
+  r.p20 = *reinterpret_cast<const ds_u32x2*>(r2 + p.x_left); r.p22 = *reinterpret_cast<const ds_u32x2*>(r2 + p.x_right);
+  r.p30 = *reinterpret_cast<const ds_u32x2*>(r3 + p.x_left); r.p32 = *reinterpret_cast<const ds_u32x2*>(r3 + p.x_right);
+  // displaced bottom corners of the reference quirk (brisk-descriptor-extractor.cc:453); unconditional loads on a
+  // valid address, used only when the quirk applies
+  const uint8_t* pbot = img + (long)max(p.y_bottom - 1, 0) * stride;
+  r.br = pbot[p.x_right + 1];
+  r.bl = pbot[p.x_left + 1];
+}
+__device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
+  const uint32_t i00 = r.p00.x, i01 = r.p00.y, i02 = r.p02.x, i03 = r.p02.y;
+  const uint32_t i10 = r.p10.x, i11 = r.p10.y, i12 = r.p12.x, i13 = r.p12.y;
+  const uint32_t i20 = r.p20.x, i21 = r.p20.y, i22 = r.p22.x, i23 = r.p22.y;
+  const uint32_t i30 = r.p30.x, i31 = r.p30.y, i32 = r.p32.x, i33 = r.p32.y;
+  const unsigned tl = i11 - i01 - i10 + i00;  // pixel (x_left, y_top)
+  const unsigned tr = i13 - i03 - i12 + i02;  // pixel (x_right, y_top)
+  const unsigned br = p.quirk ? r.br : (i33 - i23 - i32 + i22);
+  const unsigned bl = p.quirk ? r.bl : (i31 - i21 - i30 + i20);
+  const uint32_t top = i12 - i11 - i02 + i01;
+  const uint32_t bottom = i32 - i31 - i22 + i21;
+  const uint32_t left = i21 - i20 - i11 + i10;
+  const uint32_t right = i23 - i22 - i13 + i12;
+  const uint32_t middle = i22 - i21 - i12 + i11;
+  const uint32_t acc = p.A * tl + p.B * tr + p.C * br + p.D * bl + p.r_y_1_i * top + p.r_y1_i * bottom + p.r_x_1_i * left +
+                       p.r_x1_i * right + (unsigned)p.scaling * middle;
+  return (int)acc / p.scaling2;
+}
+
+// smoothed intensities of the lane's two pattern points (i0 = lane, i1 = lane + 64) into values[]
+__device__ __forceinline__ void ds_sample_pass(int* values, const uint8_t* __restrict__ img, int stride,
+                                               const uint32_t* __restrict__ integ, int istride, float kx, float ky,
+                                               const BriskSamplePoint& sa, const BriskSamplePoint& sb, bool va, bool vb,
+                                               int i0, int i1) {
+  if (__any((va && sa.sigma < 0.5f) || (vb && sb.sigma < 0.5f))) {  // bilinear branch of some point (:391-408): rare
+    if (va) values[i0] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, sa);
+    if (vb) values[i1] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, sb);
+    return;
+  }
+  const DsPrep pa = ds_prep(kx, ky, sa, va), pb = ds_prep(kx, ky, sb, vb);
+  DsRaw ra, rb;
+  ds_load(ra, pa, img, stride, integ, istride);
+  ds_load(rb, pb, img, stride, integ, istride);
+  const int xa = ds_combine(pa, ra), xb = ds_combine(pb, rb);
+  if (va) values[i0] = xa;
+  if (vb) values[i1] = xb;
+}
+
 __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
                                                             const uint32_t* __restrict__ integral, int istride,
                                                             long iframe_elems, const BriskFrameCounters* counters,
-                                                            BriskKeyPoint* dkp, const int* dscale, const int* dperm,
+                                                            BriskKeyPoint* dkp, const uint4* __restrict__ drec,
                                                             uint8_t* desc, int kp_cap, int desc_pitch, int bpf, int nframes) {
   __shared__ int values_s[DS_WAVES][BRISK_MAX_POINTS];
   __shared__ int4 lp_s[DS_LP_LDS];                 // long pairs {i, j, wdx, wdy}
@@ -1202,17 +1327,32 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
   const int stride = G.L[0].stride;
   const uint32_t* integ = integral + (long)frame * iframe_elems;
-  for (int jp = block_in_frame * DS_WAVES + wave; jp < n; jp += bpf * DS_WAVES) {
-    const int k = dperm[(long)frame * kp_cap + jp];
-    BriskKeyPoint* kp = &dkp[(long)frame * kp_cap + k];
-    const int scale = dscale[(long)frame * kp_cap + k];
-    const float kx = kp->x, ky = kp->y, kangle = kp->angle;
+  const uint4* rec = drec + (long)frame * kp_cap;
+  const int np = P.npoints;
+  const int i0 = lane, i1 = lane + 64;
+  const bool va = i0 < np, vb = i1 < np;
+  const int i0c = min(i0, np - 1), i1c = min(i1, np - 1);
+  // unrotated pattern offsets of this lane's points: the same for every keypoint's orientation pass
+  const double2 uv0a = reinterpret_cast<const double2*>(P.uv)[i0c], uv0b = reinterpret_cast<const double2*>(P.uv)[i1c];
+  // Software pipeline over the wave's keypoints: the record of keypoint j+2 and the scale-dependent pattern columns of
+  // keypoint j+1 are loaded while keypoint j is sampled, so a keypoint's critical path is
+  //   gathers (orientation) -> rotated offsets uv[theta] -> gathers (descriptor)      : three memory round trips.
+  const int step = bpf * DS_WAVES;
+  int jp = block_in_frame * DS_WAVES + wave;
+  if (jp >= n) return;
+  uint4 rc = rec[jp];
+  uint4 rn = rec[min(jp + step, n - 1)];
+  DsTab ta = ds_tab(P, (int)(rc.w & 0xFF), i0c), tb = ds_tab(P, (int)(rc.w & 0xFF), i1c);
+  for (; jp < n; jp += step) {
+    const uint4 rn2 = rec[min(jp + 2 * step, n - 1)];
+    const DsTab tna = ds_tab(P, (int)(rn.w & 0xFF), i0c), tnb = ds_tab(P, (int)(rn.w & 0xFF), i1c);
+    const int k = (int)(rc.w >> 8);
+    const float kx = __uint_as_float(rc.x), ky = __uint_as_float(rc.y), kangle = __uint_as_float(rc.z);
     int theta = 0;
     if (P.rotation_invariant) {
       if (kangle == -1.0f) {
-        for (int i = lane; i < P.npoints; i += 64) {
-          values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, brisk_pattern_point(P, scale, 0, i));
-        }
+        ds_sample_pass(values, img, stride, integ, istride, kx, ky, ds_point(ta, uv0a.x, uv0a.y), ds_point(tb, uv0b.x, uv0b.y),
+                       va, vb, i0, i1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1237,15 +1377,18 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
           d1 += __shfl_xor(d1, off, 64);
         }
         const float ang = brisk_angle_from_direction(d0, d1);  // every lane, same value
-        if (lane == 0) kp->angle = ang;
+        if (lane == 0) dkp[(long)frame * kp_cap + k].angle = ang;
         theta = brisk_theta_from_angle(ang, true);
         __builtin_amdgcn_wave_barrier();
       } else {
         theta = brisk_theta_from_angle(kangle, false);
       }
     }
-    for (int i = lane; i < P.npoints; i += 64) {
-      values[i] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, brisk_pattern_point(P, scale, theta, i));
+    {
+      const double2* uvt = reinterpret_cast<const double2*>(P.uv) + (long)theta * np;
+      const double2 ua = uvt[i0c], ub = uvt[i1c];
+      ds_sample_pass(values, img, stride, integ, istride, kx, ky, ds_point(ta, ua.x, ua.y), ds_point(tb, ub.x, ub.y), va, vb,
+                     i0, i1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1261,6 +1404,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
       if (lane == 0) *reinterpret_cast<unsigned long long*>(drow + p0 / 8) = m;
     }
     __builtin_amdgcn_wave_barrier();  // values[] is reused by the wave's next keypoint
+    rc = rn; rn = rn2; ta = tna; tb = tnb;
   }
 }
 
@@ -1370,13 +1514,13 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
                        Dd.istride, Dd.iframe_elems, nbands);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
-                     Dd.dscale, Dd.dperm, B.kp_cap);
+                     Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap);
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
   {
-    const int bpf = (G.debug_flags >> 8) ? (G.debug_flags >> 8) : 256;  // blocks per frame = one XCD full of waves (test knob: debug bits 8+)
+    const int bpf = ((G.debug_flags >> 8) & 0xFF) ? (((G.debug_flags >> 8) & 0xFF) * 8) : 128;  // blocks per frame (test knob: debug bits 8-15, x8)
     const int groups = (nframes + 7) / 8;
     hipLaunchKernelGGL(k_describe, dim3(groups * 8 * bpf), dim3(DS_WAVES * 64), 0, s, G, P, B.pyr, Dd.integral, Dd.istride,
-                       Dd.iframe_elems, B.counters, Dd.dkp, Dd.dscale, Dd.dperm, Dd.desc, B.kp_cap, Dd.desc_pitch, bpf, nframes);
+                       Dd.iframe_elems, B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, bpf, nframes);
   }
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);
 }

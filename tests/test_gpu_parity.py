@@ -237,6 +237,36 @@ def test_batch_path_device_resident(B, ctx):
         assert same_kps(kg, ko2) and np.array_equal(dg, do), f
 
 
+def test_batch_path_stream_slices_and_repeated_batches(B):
+    """Batches sliced over internal streams (brisk_hip_set_streams) and back-to-back batches of different sizes on one
+    context (buffers are reused: no state may leak from one batch into the next)."""
+    import torch
+    frames = np.stack([synth.frame_vga(s) for s in range(40)])
+    d = torch.from_numpy(frames).cuda()
+    ext_ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ext_ctx)
+    X = O.Extractor()
+    want = {}
+    for f in (0, 1, 17, 31, 39):
+        ko = O.detect(frames[f], 60, 4)
+        want[f] = (ko,) + X.compute(frames[f], ko)
+    n, h, w = frames.shape
+    stream = torch.cuda.current_stream().cuda_stream
+    for nsub, nb in ((2, 40), (1, 40), (4, 40), (1, 18), (2, 33), (1, 40)):
+        ext_ctx.set_streams(nsub)
+        ext_ctx.detect_describe_batch(ext, d.data_ptr(), nb, w, h, w * h, w, 60, 4, stream)
+        torch.cuda.synchronize()
+        assert ext_ctx.batch_status(nb) == 0
+        for f, (ko, ko2, do) in want.items():
+            if f >= nb:
+                continue
+            kd, _ = ext_ctx.batch_download(f, described=False)
+            kg, dg = ext_ctx.batch_download(f, described=True)
+            assert same_kps(kd, ko), (nsub, nb, f, explain(kd, ko))
+            assert same_kps(kg, ko2) and np.array_equal(dg, do), (nsub, nb, f)
+    ext_ctx.close()
+
+
 def test_full_size_properties_1080p_stream(B, ctx):
     """BASELINE config-2 sizes: properties that need no oracle run per frame - determinism across
     batch slots (same frame twice in one batch gives identical results), output ordering by

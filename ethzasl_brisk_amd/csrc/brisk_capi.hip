@@ -57,6 +57,9 @@ struct brisk_hip_ctx {
   hipStream_t side = nullptr;
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   int overlap = 1;
+  // what the last detect batch left in the score-state map (geometry + frame count), cleared by the next one
+  BriskGeom dirtyG{};
+  int dirty_frames = 0;
   void* d_match = nullptr;  // workspace of brisk_hip_match_knn_device
   size_t match_bytes = 0;
 };
@@ -158,6 +161,10 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMalloc(&c->d_kp_in, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
   HIPCHK(c, hipMalloc(&c->d_n_in, (size_t)slots * sizeof(int)));
   HIPCHK(c, hipMemset(c->B.pyr, 0, (size_t)slots * pyr + 256));
+  // the score-state map is kept all-zero between batches: k_detect writes detections only, the next detect batch
+  // first clears what the previous one left (k_smap_clear)
+  HIPCHK(c, hipMemset(c->B.smap, 0, ((size_t)slots * pyr + 256) * sizeof(uint16_t)));
+  c->dirty_frames = 0;
   c->slots = slots; c->pyr_elems_alloc = pyr; c->iframe_elems_alloc = ifr;
   c->D.istride = istride;
   c->B.istride = istride;
@@ -338,6 +345,11 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
   brisk_prof_begin_call(&ctx->prof);
+  if (do_detect) {
+    if (ctx->dirty_frames > 0) brisk_launch_smap_clear(ctx->dirtyG, ctx->B, ctx->dirty_frames, s);
+    ctx->dirtyG = ctx->G;
+    ctx->dirty_frames = nframes;
+  }
   int nsub = ctx->nsub;
   if (nsub > 8) nsub = 8;
   if (nframes < 16 * nsub) nsub = nframes >= 32 ? 2 : 1;
@@ -560,6 +572,10 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   const int n_in = *n;
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, &n_in, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   if (n_in) HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in, kps, sizeof(BriskKeyPoint) * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->dirty_frames > 0) {  // the clear needs the last detect batch's counters, which are reset below
+    brisk_launch_smap_clear(ctx->dirtyG, ctx->B, ctx->dirty_frames, ctx->stream);
+    ctx->dirty_frames = 0;
+  }
   HIPCHK(ctx, hipMemsetAsync(ctx->B.counters, 0, sizeof(BriskFrameCounters), ctx->stream));
   brisk_launch_layer0_only(ctx->G, ctx->B, 1, ctx->d_stage, (long)img_bytes, pitch, ctx->stream);
   BriskPatternDev P = pat->dev;

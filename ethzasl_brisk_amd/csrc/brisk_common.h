@@ -61,7 +61,9 @@ struct BriskGeom {
   int pyr_elems;       // total elements per frame (sum of stride*h, 256-aligned per layer)
   int threshold;       // AGAST threshold (20..255)
   int single_layer;    // octaves == 0
-  int debug_flags;     // bit0: send every candidate through k_classify_refine_direct (tests the safety net)
+  int debug_flags;     // test knobs: bit0 send every candidate through k_classify_refine_direct (safety-net test);
+                       // bits 8-15 k_describe blocks per frame / 8; bit16 integral image not overlapped; bit17 matcher
+                       // always through the distance matrix
   BriskLayerGeom L[BRISK_MAX_LAYERS];
 };
 

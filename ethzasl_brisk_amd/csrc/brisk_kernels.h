@@ -71,6 +71,8 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                          const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
                          long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof,
                          const BriskOverlap* ov = nullptr);
+// zeroes what the previous batch (geometry Gprev, nframes frames) left in the score-state map
+void brisk_launch_smap_clear(const BriskGeom& Gprev, const BriskDetectBuffers& B, int nframes, hipStream_t s);
 // only stages layer 0 (descriptor-only calls)
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
                               long frame_pitch, int row_pitch, hipStream_t s);

@@ -1,14 +1,18 @@
 // brisk_kernels.hip - hand-written HIP kernels (gfx950 / CDNA4) of the BRISK detect+describe engine.
 //
-// Kernel inventory (one launch handles a whole batch of frames; blockIdx.y = frame):
-//   k_pyramid_level   halfsample / twothirdsample of one pyramid level pair     (HBM-bound)
-//   k_detect          threshold map + adaptive OAST 9_16 test, LDS-tiled        (dominant kernel)
-//   k_classify_refine IsMax2D steps 1-2 + 3-D refinement per candidate          (sparse)
-//   k_tie_resolve     order-faithful replay of the lazy score cache for ties    (sparse, 1 WG/frame)
-//   k_finalize        (layer, y, x) ordering + keypoint output                  (sparse)
-//   k_integral_bandsums / k_integral_final   exclusive 2-D prefix sum (u32)     (HBM-bound)
-//   k_desc_prepare    scale index + border filter + stable compaction           (sparse)
-//   k_describe        pattern sampling, orientation, 384/512 bit tests          (gather / L2-miss bound)
+// Kernel inventory (one launch handles a whole batch of frames; blockIdx.y or a decoded index = frame):
+//   k_smap_clear        zeroes what the previous batch left in the score-state map (sparse)
+//   k_pyramid_even/odd  fused half / two-third sampling chains from 64x64 / 96x96 blocks  (HBM-bound)
+//   k_pyramid_level     one level at a time (layers beyond the fused depth)
+//   k_detect            threshold map + adaptive OAST 9_16 test, LDS-tiled                (dominant kernel, VALU-bound)
+//   k_score_blocks      lane-parallel scores around every candidate (own 5x5, 4x4 above / below)
+//   k_classify_refine   IsMax2D steps 1-2 + 3-D refinement, one lane per candidate (+ _direct safety net)
+//   k_tie_resolve       order-faithful replay of the lazy score cache for ties            (1 WG/frame, latency-bound)
+//   k_finalize          (layer, y, x) ordering + keypoint output
+//   k_integral_final    exclusive 2-D prefix sum (u32) from the band column sums          (HBM-bound, side stream)
+//   k_desc_prepare      scale index + border filter + stable compaction + processing order
+//   k_describe          pattern sampling, orientation, 384/512 bit tests                  (gather / L2-bound)
+// (the Hamming matcher kernels live in brisk_match.hip)
 // No MFMA: the path is byte/integer stencil + gather work.
 #include <hip/hip_runtime.h>
 
@@ -262,14 +266,14 @@ __global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __res
 // k_detect: per-pixel threshold map (37-px disc contrast, brisk-layer.cc:278-598) + contrast-adaptive OAST 9_16
 // segment test (oast9-16.cc:79-100).  Dominant kernel of the pipeline.
 //
-// Tile = 64x32 output pixels per 256-thread workgroup; the (64+8)x(32+6) u8 halo tile is staged in LDS with
-// coalesced dword loads.  Phase A (all pixels): every thread owns 4 columns x 2 rows, pulls its 8x12-byte window
-// out of LDS with 24 dword reads, computes the disc min/max in registers (the horizontal partial extrema of a
-// window row are shared by the two output rows) and applies a cascade of necessary
-// conditions for a 9-of-16 arc (contrast gate, range gate, two adjacent compass points); survivors (a few %) are
-// compacted into an LDS queue with wave ballots.  Phase B (survivors only): one lane per queued pixel runs the
-// closed-form segment test.  Detections go to an LDS result tile that is written out as the smap tile with
-// 8-byte stores; candidates are appended to the frame's list (order is restored later from the (layer,y,x) key).
+// Tile = 64x64 output pixels per 256-thread workgroup; the (64+8)x(64+6) u8 halo tile is staged in LDS with
+// coalesced dword loads issued back to back.  Phase A (all pixels): every thread owns 4 columns x 4 rows, pulls its
+// 10x12-byte window out of LDS with 30 dword reads, computes the disc min/max in registers (the horizontal partial
+// extrema of a window row are shared by the four output rows) and applies a cascade of necessary conditions for a
+// 9-of-16 arc (contrast gate, range gate, two adjacent compass points); survivors (a few %) are compacted into an
+// LDS queue with wave ballots.  Phase B (survivors only): one lane per queued pixel runs the closed-form segment
+// test.  A detection writes its contrast score into the score-state map (all zero otherwise, see k_smap_clear) and
+// appends a candidate to the frame's list (order is restored later from the (layer,y,x) key).
 // grid.x enumerates the tiles of all layers, grid.y = frame.
 // ------------------------------------------------------------------------------------------------
 #define DT_W 64
@@ -288,7 +292,6 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
                                                  uint16_t* __restrict__ smap, BriskCand* __restrict__ cand,
                                                  BriskFrameCounters* __restrict__ counters, int cand_cap) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[DT_LH * DT_LW];
-  __shared__ __attribute__((aligned(16))) uint8_t dres[DT_H * DT_W];  // D of detected pixels, 0 elsewhere
   __shared__ unsigned queue[DT_H * DT_W];                              // idx | D << 16 | b2 << 24
   __shared__ int qcount;
   const int frame = blockIdx.y;
@@ -329,7 +332,6 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       if (i < DT_LH * (DT_LW / 4)) *reinterpret_cast<unsigned*>(&tile[i * 4]) = ((keep >> k) & 1u) ? stg[k] : 0u;
     }
   }
-  for (int i = threadIdx.x; i < DT_H * DT_W / 8; i += 256) *reinterpret_cast<uint2*>(&dres[i * 8]) = make_uint2(0, 0);
   if (threadIdx.x == 0) qcount = 0;
   __syncthreads();
 
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   // output rows that use it:
   //   output row k (gy+k) = max(h3[k], h5[k+1], h7[k+2], h7[k+3], h7[k+4], h5[k+5], h3[k+6])      (same for min)
   const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * DT_R;
-  if (!(G.debug_flags & 128)) {
+  {
     unsigned R[DT_WR][3];
 #pragma unroll
     for (int r = 0; r < DT_WR; ++r) {
@@ -424,16 +426,17 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   __syncthreads();
 
   // ---- phase B: closed-form segment test on the survivors
-  const int nq = (G.debug_flags & 64) ? 0 : qcount;
+  const int nq = qcount;
   for (int i = threadIdx.x; i < nq; i += 256) {
     const unsigned e = queue[i];
     const int idx = e & 0xFFFF, D = (e >> 16) & 0xFF, b2 = e >> 24;
     const int py = idx / DT_W, px = idx % DT_W;
     if (brisk_oast9_16_M(&tile[(py + 3) * DT_LW + px + 4], DT_LW) > b2) {
-      dres[idx] = (uint8_t)D;
+      const int gx = x0 + px, gyy = y0 + py;
+      // the score-state map is all zero between batches (k_smap_clear): only detections are written
+      smap[base + (long)gyy * stride + gx] = (uint16_t)D;
       const int ci = atomicAdd(&counters[frame].ncand, 1);
       if (ci < cand_cap) {
-        const int gx = x0 + px, gyy = y0 + py;
         BriskCand cnd;
         cnd.x = (uint16_t)gx; cnd.y = (uint16_t)gyy; cnd.layer = (uint8_t)l; cnd.D = (uint8_t)D;
         cnd.status = 0; cnd.flags = 0; cnd.fp_x0 = 0; cnd.fp_y0 = 0; cnd.fp_mask = 0; cnd.pad = 0;
@@ -445,18 +448,34 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       }
     }
   }
-  __syncthreads();
+}
 
-  // ---- smap tile: D in the low byte, all state bits cleared
-#pragma unroll
-  for (int rr = 0; rr < DT_R; ++rr) {
-    const int gy = y0 + ly + rr;
-    if (gy < h && x0 + lx < stride && !(G.debug_flags & 32)) {
-      const unsigned d4 = *reinterpret_cast<const unsigned*>(&dres[(ly + rr) * DT_W + lx]);
-      uint2 o;
-      o.x = (d4 & 0xFFu) | ((d4 & 0xFF00u) << 8);
-      o.y = ((d4 >> 16) & 0xFFu) | ((d4 >> 8) & 0xFF0000u);
-      *reinterpret_cast<uint2*>(smap + base + (long)gy * stride + x0 + lx) = o;
+// ------------------------------------------------------------------------------------------------
+// k_smap_clear: restores the "all zero" state of the score-state map after a batch by visiting what the batch
+// wrote: every candidate's own entry (D + state bits) and the 4x4 touch footprint it may have set on the layer
+// above.  Runs at the start of the NEXT batch on the same buffers (so the maps of a finished batch stay readable).
+// A frame whose candidate list overflowed (entries without a record) is cleared completely.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_smap_clear(BriskGeom G, uint16_t* __restrict__ smap, const BriskCand* __restrict__ cand,
+                                                    const BriskFrameCounters* __restrict__ counters, int cand_cap) {
+  const int frame = blockIdx.y;
+  uint16_t* fs = smap + (long)frame * G.pyr_elems;
+  const int ncand = counters[frame].ncand;
+  if (ncand > cand_cap || (counters[frame].overflow & 1)) {
+    uint4* p = reinterpret_cast<uint4*>(fs);  // pyr_elems is a multiple of 256 elements
+    const long n16 = (long)G.pyr_elems * 2 / 16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncand; i += gridDim.x * blockDim.x) {
+    const BriskCand c = cand[(long)frame * cand_cap + i];
+    const int l = c.layer;
+    fs[G.L[l].off + (long)c.y * G.L[l].stride + c.x] = 0;
+    if (c.fp_mask && l + 1 < G.nlayers) {
+      uint16_t* a = fs + G.L[l + 1].off;
+      const int st = G.L[l + 1].stride;
+      for (int b = 0; b < 16; ++b)
+        if (c.fp_mask & (1u << b)) a[(long)(c.fp_y0 + (b >> 2)) * st + c.fp_x0 + (b & 3)] = 0;
     }
   }
 }
@@ -1440,6 +1459,10 @@ void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s) {
   const int c = P->calls % BRISK_PROF_MAX_CALLS;
   (void)hipEventRecord(P->ev[c][slot], s);
   P->used[c][slot] = true;
+}
+
+void brisk_launch_smap_clear(const BriskGeom& Gprev, const BriskDetectBuffers& B, int nframes, hipStream_t s) {
+  if (nframes > 0) hipLaunchKernelGGL(k_smap_clear, dim3(16, nframes), dim3(256), 0, s, Gprev, B.smap, B.cand, B.counters, B.cand_cap);
 }
 
 void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,

@@ -1530,14 +1530,15 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
                            long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov) {
   const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
-  if (ov)  // already running beside the detector's tail (brisk_launch_detect): this stage is only the join
-    (void)hipStreamWaitEvent(s, ov->join, 0);
-  else
+  if (!ov)
     hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, B.bandsum, Dd.integral,
                        Dd.istride, Dd.iframe_elems, nbands);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap);
+  // with `ov` the integral image is already running beside the detector's tail (brisk_launch_detect) and
+  // k_desc_prepare (one workgroup per frame, does not read it): join only in front of the sampling kernel
+  if (ov) (void)hipStreamWaitEvent(s, ov->join, 0);
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
   {
     const int bpf = ((G.debug_flags >> 8) & 0xFF) ? (((G.debug_flags >> 8) & 0xFF) * 8) : 128;  // blocks per frame (test knob: debug bits 8-15, x8)

@@ -157,6 +157,8 @@ def main():
         step()
         if gather:
             gather.run()
+    if gather:
+        gather.finish()                      # the last transfers are part of the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -202,8 +204,8 @@ def main():
         ac, gk, gd = gather.last
         k0, d0 = ctx.batch_download(0, True, strings)
         n0 = int(ac[0, 0].item())
-        assert n0 == len(k0) and np.array_equal(gk[0, 0, :n0].cpu().numpy().view(np.uint32), np.stack([k0[f].view(np.uint32) for f in k0.dtype.names], 1))
-        assert np.array_equal(gd[0, 0, :n0].cpu().numpy(), d0)
+        assert n0 == len(k0) and np.array_equal(gk[0][0, :n0].cpu().numpy().view(np.uint32), np.stack([k0[f].view(np.uint32) for f in k0.dtype.names], 1))
+        assert np.array_equal(gd[0][0, :n0].cpu().numpy(), d0)
         print('gather self-test ok', file=sys.stderr)
     if world > 1 or args.force_gather:
         dist.destroy_process_group()
@@ -230,6 +232,8 @@ class ResultGather:
         self.torch = torch
         self.dev, self.rank, self.world, self.batch, self.strings = dev, rank, world, batch, strings
         self.kpad = 1536
+        self.pg = None
+        self.last = None
         L = ctx._L
         vp = C.c_void_p
         d_det, d_desc_n, d_kd, d_kp, d_desc = vp(), vp(), vp(), vp(), vp()
@@ -254,15 +258,24 @@ class ResultGather:
         return torch.as_tensor(a, device=self.dev)
 
     def run(self):
-        """fixed-size slabs, no host synchronisation inside the timed region"""
+        """fixed-size slabs, no host synchronisation inside the timed region; asynchronous: the transfer of this batch
+        overlaps the next batch's kernels (sharding.PaddedGather), finish() waits for what is still in flight"""
         from ethzasl_brisk_amd import sharding
-        self.last = sharding.gather_results_padded(self.counts, self.kps, self.desc, self.strings, self.kpad, dst=0)
+        if self.pg is None or self.pg.kpad != self.kpad:
+            if self.pg is not None:
+                self.pg.finish()
+            self.pg = sharding.PaddedGather(self.counts, self.kps, self.desc, self.strings, self.kpad, dst=0)
+        self.pg.start()
+
+    def finish(self):
+        if self.pg is not None:
+            self.last = self.pg.finish()
 
     def check_kpad(self):
-        """outside the timed region: the slab size must cover every frame of the batch"""
+        """outside the timed region: the slab size must cover every frame of the batch (rounded up to 128)"""
+        self.finish()
         m = int(self.counts.max().item())
-        if m > self.kpad:
-            self.kpad = min(self.cap, (m + 255) // 256 * 256)
+        self.kpad = min(self.cap, (m + 127) // 128 * 128)
 
 
 if __name__ == "__main__":

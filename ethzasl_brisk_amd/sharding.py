@@ -78,3 +78,65 @@ def gather_results_padded(counts, kps, desc, strings, kpad, dst=0, group=None):
     if rank != dst:
         return None
     return all_counts, torch.stack(gk), torch.stack(gd)
+
+
+class PaddedGather:
+    """The fixed-slab exchange of gather_results_padded as an asynchronous, double-buffered pipeline: start() copies
+    the rank's slabs out of the engine's result buffers (which the next batch overwrites) and launches the collectives
+    with async_op=True, so the transfer of batch i runs on the communicator's stream while batch i+1 is computed;
+    a slot is reused only after its previous transfer has been waited for.  finish() waits for everything in flight
+    and returns the last batch's (counts [world, B], keypoints [world][B, kpad, 7], descriptors [world][B, kpad, strings])
+    on dst, None elsewhere."""
+
+    def __init__(self, counts, kps, desc, strings, kpad, dst=0, group=None, slots=2):
+        self.counts, self.kps, self.desc = counts, kps, desc
+        self.strings, self.kpad, self.dst, self.group = strings, kpad, dst, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.slots = [None] * slots
+        self.i = 0
+        self.last = None
+
+    def _alloc(self):
+        b = self.counts.shape[0]
+        dev = self.counts.device
+        sl = {"c": torch.empty((b,), device=dev, dtype=self.counts.dtype),
+              "k": torch.empty((b, self.kpad, self.kps.shape[2]), device=dev, dtype=self.kps.dtype),
+              "d": torch.empty((b, self.kpad, self.strings), device=dev, dtype=self.desc.dtype),
+              "ac": torch.empty((self.world * b,), device=dev, dtype=self.counts.dtype), "works": [], "kpad": self.kpad}
+        if self.rank == self.dst:
+            sl["gk"] = [torch.empty_like(sl["k"]) for _ in range(self.world)]
+            sl["gd"] = [torch.empty_like(sl["d"]) for _ in range(self.world)]
+        else:
+            sl["gk"] = sl["gd"] = None
+        return sl
+
+    def _wait(self, sl):
+        for w in sl["works"]:
+            w.wait()
+        sl["works"] = []
+
+    def start(self):
+        j = self.i % len(self.slots)
+        sl = self.slots[j]
+        if sl is not None:
+            self._wait(sl)
+        if sl is None or sl["kpad"] != self.kpad:
+            sl = self.slots[j] = self._alloc()
+        sl["c"].copy_(self.counts)
+        sl["k"].copy_(self.kps[:, :self.kpad, :])
+        sl["d"].copy_(self.desc[:, :self.kpad, :self.strings])
+        sl["works"] = [dist.all_gather_into_tensor(sl["ac"], sl["c"], group=self.group, async_op=True),
+                       dist.gather(sl["k"], sl["gk"], dst=self.dst, group=self.group, async_op=True),
+                       dist.gather(sl["d"], sl["gd"], dst=self.dst, group=self.group, async_op=True)]
+        self.last = sl
+        self.i += 1
+
+    def finish(self):
+        for sl in self.slots:
+            if sl is not None:
+                self._wait(sl)
+        sl = self.last
+        if sl is None or self.rank != self.dst:
+            return None
+        return sl["ac"].view(self.world, -1), sl["gk"], sl["gd"]

@@ -59,6 +59,23 @@ def _worker(rank, world, port, q):
             q.put(bool(ok))
         else:
             assert res2 is None
+        # asynchronous double-buffered pipeline (what bench.py runs): three batches back to back, buffers rewritten
+        # between them the way the engine's result buffers are
+        tc, tk, td = torch.from_numpy(c.copy()), torch.from_numpy(k.copy()), torch.from_numpy(d.copy())
+        pg = sharding.PaddedGather(tc, tk, td, strings, cap)
+        for it in range(3):
+            tk.copy_(torch.from_numpy(k) + it)
+            pg.start()
+        res3 = pg.finish()
+        if rank == 0:
+            ac, gk, gd = res3
+            ok = tuple(ac.shape) == (world, batch)
+            for r in range(world):
+                cr, kr, dr = _fake_results(r, batch, cap, pitch)
+                ok &= np.array_equal(ac[r].numpy(), cr) and np.array_equal(gk[r].numpy(), kr[:, :cap] + 2) and np.array_equal(gd[r].numpy(), dr[:, :cap, :strings])
+            q.put(bool(ok))
+        else:
+            assert res3 is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -77,5 +94,6 @@ def test_gather_results_world2_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    assert q.get() is True
     assert q.get() is True
     assert q.get() is True

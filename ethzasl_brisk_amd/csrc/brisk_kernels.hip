@@ -1063,6 +1063,22 @@ __device__ __forceinline__ unsigned ii_wg_scan(unsigned total, unsigned (*wave_t
 }
 
 #define II_MAXCHUNKS 4  // 4 x 2048 columns >= the 8191-pixel width limit of the engine
+// raw dwords that hold pixel columns c0-1 .. c0+2 of one image row (unconditional loads on clamped addresses)
+__device__ __forceinline__ uint2 ii_fetch(const uint8_t* row, int stride, int c0 /* first integral column */) {
+  const int a = min(max(c0 - 4, 0), stride - 4), b = min(c0, stride - 4);
+  return make_uint2(*reinterpret_cast<const unsigned*>(row + a), *reinterpret_cast<const unsigned*>(row + b));
+}
+__device__ __forceinline__ void ii_unpack(uint2 raw, int stride, int w, int c0, unsigned* px) {
+  const unsigned prev = (c0 >= 4 && c0 - 4 < stride) ? raw.x : 0u, cur = (c0 < stride) ? raw.y : 0u;
+  px[0] = (c0 - 1 >= 0 && c0 - 1 < w) ? (prev >> 24) : 0;
+  px[1] = (c0 < w) ? (cur & 0xFF) : 0;
+  px[2] = (c0 + 1 < w) ? ((cur >> 8) & 0xFF) : 0;
+  px[3] = (c0 + 2 < w) ? ((cur >> 16) & 0xFF) : 0;
+}
+
+// NCH = number of 2048-column chunks (template: the running sums and the prefetched row live in registers, and the
+// kernel has to stay at <= 64 VGPRs so that four 512-thread workgroups share a CU)
+template <int NCH>
 __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, const uint8_t* __restrict__ pyr,
                                                                const uint32_t* __restrict__ bandsum,
                                                                uint32_t* __restrict__ integral, int istride, long iframe_elems,
@@ -1073,15 +1089,17 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
   const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
   uint32_t* out = integral + (long)frame * iframe_elems;
   const int y0 = band * II_BAND, y1 = min(h, y0 + II_BAND);
-  const int nchunks = (w + 1 + II_CHUNK - 1) / II_CHUNK;
   int buf = 0;
-  unsigned acc[II_MAXCHUNKS][4];  // running integral values of this thread's columns (row above the current one)
+  unsigned acc[NCH][4];  // running integral values of this thread's columns (row above the current one)
+  // first pixel row of the band: in flight while the carry row is computed
+  uint2 raw[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) raw[ch] = ii_fetch(img + (long)min(y0, h - 1) * stride, stride, ch * II_CHUNK + threadIdx.x * 4);
   // carry row of the band: column sums of the bands above, prefix over the columns (left to right over the chunks)
   {
     unsigned carry = 0;
 #pragma unroll
-    for (int ch = 0; ch < II_MAXCHUNKS; ++ch) {
-      if (ch >= nchunks) break;
+    for (int ch = 0; ch < NCH; ++ch) {
       const int c0 = ch * II_CHUNK + threadIdx.x * 4;
       uint4 C = make_uint4(0, 0, 0, 0);
       if (c0 <= w)
@@ -1102,13 +1120,18 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
     }
   }
   for (int y = y0; y < y1; ++y) {
+    // the next row's pixels are requested before this row's scan (the loop is a chain of barriers otherwise exposed
+    // to one memory round trip per row)
+    uint2 nxt[NCH];
+    const int yn = min(y + 1, y1 - 1);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) nxt[ch] = ii_fetch(img + (long)yn * stride, stride, ch * II_CHUNK + threadIdx.x * 4);
     unsigned carry = 0;
 #pragma unroll
-    for (int ch = 0; ch < II_MAXCHUNKS; ++ch) {
-      if (ch >= nchunks) break;
+    for (int ch = 0; ch < NCH; ++ch) {
       const int c0 = ch * II_CHUNK + threadIdx.x * 4;
       unsigned px[4] = {0, 0, 0, 0};
-      if (c0 <= w) ii_load4(img + (long)y * stride, stride, w, c0, px);
+      if (c0 <= w) ii_unpack(raw[ch], stride, w, c0, px);
       const unsigned s0 = px[0], s1 = s0 + px[1], s2 = s1 + px[2], s3 = s2 + px[3];
       unsigned tot;
       const unsigned o = ii_wg_scan(s3, wave_tot, buf, &tot) + carry;
@@ -1118,7 +1141,18 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
       if (c0 <= w)
         *reinterpret_cast<uint4*>(out + (long)(y + 1) * istride + c0) = make_uint4(acc[ch][0], acc[ch][1], acc[ch][2], acc[ch][3]);
     }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) raw[ch] = nxt[ch];
   }
+}
+
+static void launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
+                            long iframe_elems, int nbands, int nframes, hipStream_t s) {
+  const int nchunks = (G.L[0].w + 1 + II_CHUNK - 1) / II_CHUNK;
+  const dim3 grid(nbands, nframes), block(II_THREADS);
+  if (nchunks <= 1) hipLaunchKernelGGL(k_integral_final<1>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
+  else if (nchunks == 2) hipLaunchKernelGGL(k_integral_final<2>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
+  else hipLaunchKernelGGL(k_integral_final<II_MAXCHUNKS>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1508,8 +1542,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     // earlier it would take the workgroup slots the 1024-thread tie workgroups need (measured: 0.4 -> 1.3 ms).
     const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
     (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
-    hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, ov->side, G, B.pyr, B.bandsum,
-                       ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, nbands);
+    launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, nbands, nframes, ov->side);
     (void)hipEventRecord(ov->join, ov->side);
   }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
@@ -1531,8 +1564,7 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
   const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
   if (!ov)
-    hipLaunchKernelGGL(k_integral_final, dim3(nbands, nframes), dim3(II_THREADS), 0, s, G, B.pyr, B.bandsum, Dd.integral,
-                       Dd.istride, Dd.iframe_elems, nbands);
+    launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, nbands, nframes, s);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap);

@@ -138,3 +138,37 @@ def test_device_resident_knn(B):
     got = out.cpu().numpy().view(B.DMATCH).reshape(500, 2)
     want = O.match_knn(q, [t[:, :48]], 2)
     same_rows([got[i, :c] for i, c in enumerate(cnt.cpu().numpy())], want)
+
+
+def test_pipeline_in_hbm_detect_describe_match(B, golden_ast):
+    """Frames in HBM -> detect + describe batch -> match frame 0 against frame 1 without the descriptors ever leaving
+    the device (brisk_hip_batch_results pointers straight into brisk_hip_match_knn_device); the reference's homography
+    test on the result."""
+    import ctypes as C
+    import torch
+    frames = np.stack([golden_ast[0]["image"], golden_ast[1]["image"]])
+    d = torch.from_numpy(frames).cuda()
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    n, h, w = frames.shape
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.detect_describe_batch(ext, d.data_ptr(), n, w, h, w * h, w, 70, 2, stream)
+    vp = C.c_void_p
+    d_det, d_n, d_kd, d_kp, d_desc = vp(), vp(), vp(), vp(), vp()
+    cstride, cap, pitch = C.c_int(), C.c_int(), C.c_int()
+    ctx.check(ctx._L.brisk_hip_batch_results(ctx._h, C.byref(d_det), C.byref(d_n), C.byref(cstride), C.byref(d_kd), C.byref(d_kp),
+                                             C.byref(d_desc), C.byref(cap), C.byref(pitch)))
+    torch.cuda.synchronize()
+    k0, d0 = ctx.batch_download(0, True)
+    k1, d1 = ctx.batch_download(1, True)
+    out = torch.zeros((len(k0), 1, 4), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(len(k0), dtype=torch.int32, device="cuda")
+    ctx.check(ctx._L.brisk_hip_match_knn_device(ctx._h, d_desc.value, len(k0), pitch.value,
+                                                d_desc.value + cap.value * pitch.value, len(k1), pitch.value, 48, 1,
+                                                out.data_ptr(), cnt.data_ptr(), stream))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(B.DMATCH).reshape(len(k0))
+    same_rows([got[i:i + 1] for i in range(len(k0))], O.match_knn(d0, [d1], 1))
+    best = got[got["distance"] < 50]
+    assert len(best) > 100 and homography_outliers(k0, k1, best) == 0
+    ctx.close()

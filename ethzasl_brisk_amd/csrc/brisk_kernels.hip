@@ -487,7 +487,9 @@ __global__ void __launch_bounds__(256) k_smap_clear(BriskGeom G, uint16_t* __res
 // overlap (the kernel is latency-bound otherwise).
 // ------------------------------------------------------------------------------------------------
 #define SB_WAVES 4
-#define SB_PER_WAVE 4
+#ifndef SB_PER_WAVE
+#define SB_PER_WAVE 3
+#endif
 // ring offsets (dx, dy): 9_16 in the order of brisk_oast9_16_M, 5_8 in the order of brisk_agast5_8_M
 __device__ __forceinline__ constexpr int sb_dx16(int j) { constexpr int t[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3}; return t[j]; }
 __device__ __forceinline__ constexpr int sb_dy16(int j) { constexpr int t[16] = {0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1}; return t[j]; }

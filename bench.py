@@ -186,11 +186,14 @@ def main():
                                "AGAST threshold 80, default 66-point pattern (48-byte descriptors)",
                    "frames_per_step_per_gpu": args.batch, "stream_slices": args.streams, "frames_per_kernel_launch": fpl, "distinct_frames_per_gpu": nd,
                    "mean_keypoints_per_frame": round(mean_kp, 1),
-                   "parallelism": "frames sharded over %d rank(s)%s" % (world, ", RCCL gather of keypoints+descriptors to rank 0 each step" if world > 1 else ""),
+                   "parallelism": "frames sharded over %d rank(s)%s" % (world, ", asynchronous RCCL gather of keypoints+descriptors to rank 0 each step (overlaps the next batch)" if world > 1 else ""),
                    "algorithmic_MB_per_frame": round(per_frame_bytes / 1e6, 3),
                    "pipeline_achieved_GBps": round(per_frame_bytes * fps / 1e9, 2),
                    "pipeline_frac_of_hbm_peak": round(per_frame_bytes * fps / 1e9 / (HBM_PEAK_GBS * world), 5),
-                   "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}},
+                   "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+                   "stage_note": "HIP-event intervals on the launch stream; k_integral_final runs on a second stream beside "
+                                 "k_tie_resolve / k_finalize / k_desc_prepare, so its own entry is only the join and those "
+                                 "three entries include the sharing (kernel durations: profiles/*kernel_stats*)"},
         "roofline": {"bound": "hbm", "kernel": "k_detect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(fpl),
                      "algorithmic_bytes_per_launch": detect_bytes * fpl, "avg_launch_ms": round(det_ms, 4),

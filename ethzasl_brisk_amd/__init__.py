@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
     "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags",
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
-    "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device",
+    "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
 ]
 
 
@@ -90,6 +90,7 @@ def load_library():
     L.brisk_hip_profile_stage_name.argtypes = [C.c_int]
     L.brisk_hip_profile_stage_name.restype = C.c_char_p
     L.brisk_hip_profile_read.argtypes = [vp, vp, ip]
+    L.brisk_hip_set_uniformity.argtypes = [vp, C.c_double, C.c_int]
     L.brisk_hip_match_knn.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
     L.brisk_hip_match_radius.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float,
                                          C.c_int, vp, vp]
@@ -143,6 +144,10 @@ class Context:
         out = np.zeros((h + 1, w + 1), np.uint32)
         self.check(self._L.brisk_hip_debug_integral(self._h, frame, _ptr(out)))
         return out
+
+    def set_uniformity(self, radius, max_keypoints=0x7FFFFFFF):
+        """Optional uniformity enforcement after the detector (0 = off); see brisk_hip_set_uniformity."""
+        self.check(self._L.brisk_hip_set_uniformity(self._h, float(radius), int(max_keypoints)))
 
     def set_streams(self, n):
         self.check(self._L.brisk_hip_set_streams(self._h, n))
@@ -203,10 +208,13 @@ def default_context(device=0):
 class BriskFeatureDetector:
     """Mirror of brisk::BriskFeatureDetector (brisk/include/brisk/brisk-feature-detector.h:51-83)."""
 
-    def __init__(self, thresh, octaves=3, suppressScaleNonmaxima=True, context=None):
+    def __init__(self, thresh, octaves=3, suppressScaleNonmaxima=True, context=None, uniformityRadius=0.0,
+                 maxNumKpt=0x7FFFFFFF):
         self.threshold = int(thresh)
         self.octaves = int(octaves)
         self.m_suppressScaleNonmaxima = bool(suppressScaleNonmaxima)
+        # engine option (not reference behaviour of this class): EnforceKeyPointUniformity as a post-filter
+        self.uniformityRadius, self.maxNumKpt = float(uniformityRadius), int(maxNumKpt)
         self._ctx = context or default_context()
 
     def detect(self, image, mask=None, capacity=16384):
@@ -223,6 +231,7 @@ class BriskFeatureDetector:
         out = np.zeros(capacity, KEYPOINT)
         n = C.c_int()
         c = self._ctx
+        c.set_uniformity(self.uniformityRadius, self.maxNumKpt)
         c.check(c._L.brisk_hip_detect(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
                                       int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0, _ptr(out),
                                       capacity, C.byref(n)))

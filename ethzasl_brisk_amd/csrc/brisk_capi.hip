@@ -60,6 +60,14 @@ struct brisk_hip_ctx {
   // what the last detect batch left in the score-state map (geometry + frame count), cleared by the next one
   BriskGeom dirtyG{};
   int dirty_frames = 0;
+  // optional uniformity enforcement after the detector (brisk_hip_set_uniformity / brisk_hip_detect_uniform)
+  double uni_radius = 0.0;
+  int uni_max = 0x7FFFFFFF;
+  uint8_t* d_occ = nullptr;
+  size_t occ_bytes = 0;
+  BriskKeyPoint* d_uni_tmp = nullptr;
+  int* d_uni_order = nullptr;
+  size_t uni_items = 0;
   void* d_match = nullptr;  // workspace of brisk_hip_match_knn_device
   size_t match_bytes = 0;
 };
@@ -222,6 +230,9 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
   free_buffers(c);
   hipFree(c->d_stage);
   if (c->d_match) hipFree(c->d_match);
+  if (c->d_occ) hipFree(c->d_occ);
+  if (c->d_uni_tmp) hipFree(c->d_uni_tmp);
+  if (c->d_uni_order) hipFree(c->d_uni_order);
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->side_fork); hipEventDestroy(c->side_join); }
   if (c->sub_created) {
     for (int i = 0; i < 8; ++i) { hipStreamDestroy(c->sub[i]); hipEventDestroy(c->join_ev[i]); }
@@ -344,6 +355,24 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
   ctx->G.debug_flags = ctx->debug_flags;
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
+  if (do_detect && ctx->uni_radius > 0.0) {
+    const float scaling = (float)(15.0 / (float)ctx->uni_radius);
+    const int oh = (int)(h * ceil(scaling) + 32), ow = (int)(w * ceil(scaling) + 32);
+    const size_t need = (size_t)(((long)oh * ow + 255) / 256 * 256) * nframes + 64;
+    const size_t items = (size_t)ctx->slots * ctx->kp_cap;
+    if (need > ctx->occ_bytes || items > ctx->uni_items) {
+      HIPCHK(ctx, hipDeviceSynchronize());
+      if (ctx->d_occ) (void)hipFree(ctx->d_occ);
+      if (ctx->d_uni_tmp) (void)hipFree(ctx->d_uni_tmp);
+      if (ctx->d_uni_order) (void)hipFree(ctx->d_uni_order);
+      ctx->d_occ = nullptr; ctx->d_uni_tmp = nullptr; ctx->d_uni_order = nullptr; ctx->occ_bytes = 0; ctx->uni_items = 0;
+      const size_t nb = need > ctx->occ_bytes ? need : ctx->occ_bytes;
+      HIPCHK(ctx, hipMalloc(&ctx->d_occ, nb));
+      HIPCHK(ctx, hipMalloc(&ctx->d_uni_tmp, items * sizeof(BriskKeyPoint)));
+      HIPCHK(ctx, hipMalloc(&ctx->d_uni_order, items * sizeof(int)));
+      ctx->occ_bytes = nb; ctx->uni_items = items;
+    }
+  }
   brisk_prof_begin_call(&ctx->prof);
   if (do_detect) {
     if (ctx->dirty_frames > 0) brisk_launch_smap_clear(ctx->dirtyG, ctx->B, ctx->dirty_frames, s);
@@ -409,6 +438,14 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
     if (do_detect) {
       brisk_launch_detect(ctx->G, ctx->T, Bi, nf, d_frames + f0 * frame_pitch, frame_pitch, row_pitch,
                           d_mask ? d_mask + f0 * mask_frame_pitch : nullptr, mask_frame_pitch, mask_row_pitch, si, prof, ovp);
+    }
+    if (do_detect && ctx->uni_radius > 0.0) {
+      // EnforceKeyPointUniformity as a post-filter of the detected keypoints (brisk_uniformity.hip)
+      const float scaling = (float)(15.0 / (float)ctx->uni_radius);
+      const int oh = (int)(h * ceil(scaling) + 32), ow = (int)(w * ceil(scaling) + 32);
+      const long occ_frame = ((long)oh * ow + 255) / 256 * 256;
+      brisk_launch_uniformity(Bi.kp_out, Bi.counters, ctx->d_uni_order + f0 * Bi.kp_cap, ctx->d_uni_tmp + f0 * Bi.kp_cap,
+                              ctx->d_occ + f0 * occ_frame, occ_frame, ow, Bi.kp_cap, scaling, ctx->uni_max, nf, si);
     }
     if (do_describe) {
       BriskPatternDev P = pat->dev;
@@ -756,6 +793,15 @@ int brisk_hip_match_knn_device(brisk_hip_ctx* ctx, const uint8_t* d_query, int n
   brisk_launch_match_knn(d_dist, dist_pitch, 0, nq, nt, nullptr, 1, nullptr, k,
                          reinterpret_cast<BriskDMatch*>(d_out), d_out_count, st);
   HIPCHK(ctx, hipGetLastError());
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_set_uniformity(brisk_hip_ctx* ctx, double radius, int max_keypoints) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (radius < 0.0 || (radius > 0.0 && radius < 1.0) || max_keypoints < 1) return fail(ctx, BRISK_HIP_ERR_ARG, "uniformity: radius must be 0 (off) or >= 1, max_keypoints >= 1");
+  ctx->uni_radius = radius;
+  ctx->uni_max = max_keypoints;
   return BRISK_HIP_OK;
 }
 

@@ -99,3 +99,7 @@ void brisk_launch_match_radius(const uint16_t* dist, long dist_pitch, int q0, in
 // k <= 2, one train set, no masks: fused distance + top-2 kernel; false = not covered, use the matrix path
 bool brisk_launch_match_knn_fused(const uint8_t* query, int q_pitch, int nq, const uint8_t* train, int t_pitch, int nt,
                                   int words32, int k, BriskDMatch* out, int* out_count, hipStream_t s);
+
+// ---- uniformity enforcement (brisk_uniformity.hip): optional post-filter of the detector's keypoints ----
+void brisk_launch_uniformity(BriskKeyPoint* kp, BriskFrameCounters* counters, int* order, BriskKeyPoint* tmp, uint8_t* occ,
+                             long occ_frame, int ow, int kp_cap, float scaling, int max_keypoints, int nframes, hipStream_t s);

@@ -42,6 +42,14 @@ class BriskFeatureDetector {
   }
 #endif
 
+  // Engine option, not reference behaviour of this class: EnforceKeyPointUniformity
+  // (brisk/include/brisk/internal/uniformity-enforcement-inl.h:44-194; in the reference only the Harris
+  // ScaleSpaceFeatureDetector applies it) as a post-filter of the detected keypoints.  radius = 0 switches it off.
+  void SetUniformityRadius(double radius, size_t maxNumKpt = 0x7FFFFFFF) {
+    m_uniformityRadius = radius;
+    m_maxNumKpt = maxNumKpt > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)maxNumKpt;
+  }
+
   // Reference: brisk-feature-detector.cc:87-92 (scores for provided keypoints).  SURVEY §8(f)#3 "next" row:
   // not implemented on the device path yet.
   void ComputeScale(const agast::Mat& /*image*/, std::vector<agast::KeyPoint>& /*keypoints*/) const {
@@ -56,6 +64,7 @@ class BriskFeatureDetector {
     if (image.empty()) throw std::runtime_error("BriskFeatureDetector: empty image");
     if (image.type() != CV_8UC1) throw std::runtime_error("BriskFeatureDetector: image must be CV_8UC1");
     brisk_hip_ctx* ctx = hip::DefaultContext();
+    hip::Check(ctx, brisk_hip_set_uniformity(ctx, m_uniformityRadius, m_maxNumKpt), "brisk_hip_set_uniformity");
     size_t cap = 16384;
     for (;;) {
       keypoints.resize(cap);
@@ -77,6 +86,8 @@ class BriskFeatureDetector {
     }
   }
   bool m_suppressScaleNonmaxima;
+  double m_uniformityRadius = 0.0;
+  int m_maxNumKpt = 0x7FFFFFFF;
 };
 
 }  // namespace brisk

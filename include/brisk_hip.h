@@ -102,6 +102,16 @@ int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags)
  * caller's stream with events, so the call stays asynchronous and ordered on that stream. */
 int brisk_hip_set_streams(brisk_hip_ctx* ctx, int n);
 
+/* ---- optional post-filter: keypoint uniformity enforcement (BASELINE config 4) ---- */
+/* EnforceKeyPointUniformity (brisk/include/brisk/internal/uniformity-enforcement-inl.h:44-194, mask LUT
+ * scale-space-layer-inl.h:88-97) applied to the detector's keypoints (x, y, response) in every following detect call
+ * of this context (host-buffer and batch): keypoints in descending response order are accepted greedily against an
+ * occupancy image at scale 15 / radius, at most max_keypoints are kept, the output is in acceptance order.
+ * radius = 0 switches it off (default).  In the reference the filter is only wired into the Harris
+ * ScaleSpaceFeatureDetector (scale-space-layer-inl.h:372-375), so this is an engine option, not reference behaviour of
+ * BriskFeatureDetector; equal responses keep their (layer, y, x) order (the reference's std::sort is unstable). */
+int brisk_hip_set_uniformity(brisk_hip_ctx* ctx, double radius, int max_keypoints);
+
 /* ---- Hamming brute-force matcher (the step after the path) ----------------------- */
 /* binary-identical to cv::DMatch */
 typedef struct brisk_hip_dmatch {

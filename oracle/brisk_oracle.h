@@ -88,6 +88,10 @@ bo_dmatch* bo_match_radius(const uint8_t* query, int nq, int q_pitch, int dim, i
                            const int* ntrain, const int* t_pitch, const uint8_t* const* masks, const int* mask_pitch,
                            float max_distance, int* out_count);
 
+/* ---- uniformity enforcement (brisk_oracle_uniformity.c; PARITY UNPINNED for AGAST keypoints, see there) ---- */
+int bo_enforce_uniformity(const bo_keypoint* kps, int n, int rows, int cols, double radius, int max_keypoints,
+                          bo_keypoint* out);
+
 #ifdef __cplusplus
 }
 #endif

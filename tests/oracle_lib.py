@@ -52,6 +52,7 @@ def lib():
         L.bo_extractor_scale_index.argtypes = [vp, C.c_float]
         L.bo_extractor_compute.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
         L.bo_hamming.argtypes = [vp, vp, C.c_int]
+        L.bo_enforce_uniformity.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
         L.bo_match_knn.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         L.bo_match_knn.restype = None
         L.bo_match_radius.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp]
@@ -233,3 +234,10 @@ def match_radius(query, train, max_distance, masks=None):
         rows.append(flat[o:o + cnt[i]])
         o += cnt[i]
     return rows
+
+
+def enforce_uniformity(kps, rows, cols, radius, max_keypoints=0x7FFFFFFF):
+    kps = np.ascontiguousarray(kps, KP)
+    out = np.zeros(max(len(kps), 1), KP)
+    n = lib().bo_enforce_uniformity(_p(kps), len(kps), rows, cols, float(radius), int(max_keypoints), _p(out))
+    return out[:n].copy()

@@ -435,3 +435,43 @@ def test_row_pitch_and_unaligned_buffers(B, ctx, golden_ast):
         assert n2.value == len(ko2) and same_kps(kk[:n2.value], ko2)
         dg = dbuf[1:1 + n2.value * 53].reshape(n2.value, 53)[:, :48]
         assert np.array_equal(dg, do)
+
+
+def test_uniformity_enforcement_config4_and_batch(B):
+    """BASELINE config 4 as named: 4K frame, 6 octaves, uniformity-enforced to ~4 k keypoints (radius 8 px), then
+    described; GPU filter vs the oracle's restatement (itself unpinned, see oracle/brisk_oracle_uniformity.c)."""
+    import torch
+    img = synth.frame_4k(2)
+    ko = O.detect(img, 80, 6)
+    fo = O.enforce_uniformity(ko, img.shape[0], img.shape[1], 8.0)
+    assert len(ko) == 4745 and len(fo) == 4012
+    ctx = B.Context(0)
+    det = B.BriskFeatureDetector(80, 6, context=ctx, uniformityRadius=8.0)
+    kg = det.detect(img, capacity=16384)
+    assert same_kps(kg, fo), explain(kg, fo)
+    ko2, do = O.Extractor().compute(img, fo)
+    kg2, dg = B.BriskDescriptorExtractor(context=ctx).compute(img, kg)
+    assert same_kps(kg2, ko2) and np.array_equal(dg, do)
+    # keypoint budget
+    capped = B.BriskFeatureDetector(80, 6, context=ctx, uniformityRadius=8.0, maxNumKpt=1000).detect(img)
+    assert same_kps(capped, fo[:1000])
+    # off again: the plain detector
+    assert same_kps(B.BriskFeatureDetector(80, 6, context=ctx).detect(img, capacity=16384), ko)
+    # batch path: filter between detection and description, per frame
+    frames = np.stack([synth.frame_vga(s) for s in range(5)])
+    d = torch.from_numpy(frames).cuda()
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    ctx.set_uniformity(12.0, 150)
+    n, h, w = frames.shape
+    ctx.detect_describe_batch(ext, d.data_ptr(), n, w, h, w * h, w, 60, 4, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    X = O.Extractor()
+    for f in range(n):
+        want = O.enforce_uniformity(O.detect(frames[f], 60, 4), h, w, 12.0, 150)
+        kd, _ = ctx.batch_download(f, described=False)
+        assert same_kps(kd, want), (f, explain(kd, want))
+        ko2, do = X.compute(frames[f], want)
+        kg2, dg = ctx.batch_download(f, described=True)
+        assert same_kps(kg2, ko2) and np.array_equal(dg, do), f
+    ctx.set_uniformity(0.0)
+    ctx.close()

@@ -281,3 +281,34 @@ def test_match_oracle_semantics():
              if not (im == 0 and m0[i, j] == 0)]
         d = sorted(x for x in d if x[0] < 200.0)
         assert [(int(m["distance"]), int(m["imgIdx"]), int(m["trainIdx"])) for m in rr[i]] == d
+
+
+# ---- uniformity enforcement (oracle/brisk_oracle_uniformity.c: PARITY UNPINNED, see its header) --------
+
+def test_uniformity_oracle_properties(golden_ast):
+    img = golden_ast[1]["image"]
+    k = O.detect(img, 70, 3)
+    f = O.enforce_uniformity(k, img.shape[0], img.shape[1], 20.0)
+    assert 0 < len(f) < len(k)
+    assert np.all(np.diff(f["response"]) <= 0)                         # acceptance order = descending score
+    kset = {tuple(r) for r in k.view(np.uint32).reshape(len(k), 7)}
+    assert all(tuple(r) in kset for r in f.view(np.uint32).reshape(len(f), 7))   # a subset, fields untouched
+    assert f[0]["response"] == k["response"].max()                      # the best point always survives
+    # hand-checkable cases (radius 15: occupancy at image scale).  The mask centre of an accepted point holds
+    # ceil(0.99 * 255) = 253, so an equally strong point at the same place (255 >= 253) still passes ...
+    two = np.zeros(2, O.KP)
+    two["x"], two["y"], two["response"] = 50.0, 40.0, 100.0
+    assert len(O.enforce_uniformity(two, 100, 120, 15.0)) == 2
+    two["response"][1] = 90.0                                           # ... a weaker one does not ...
+    assert len(O.enforce_uniformity(two, 100, 120, 15.0)) == 1
+    two["x"][1] = 90.0                                                  # ... unless it is outside the 31 x 31 mask
+    assert len(O.enforce_uniformity(two, 100, 120, 15.0)) == 2
+    # the mask centre holds ceil(0.99 * 255) = 253: a point at the same place needs sqrt(sqrt(s / max)) * 255 >= 253
+    two["x"][1] = 50.0
+    two["response"][1] = 100.0 * (253.0 / 255.0) ** 4 * 0.999
+    assert len(O.enforce_uniformity(two, 100, 120, 15.0)) == 1
+    # max_keypoints cuts the descending list
+    assert np.array_equal(O.enforce_uniformity(k, img.shape[0], img.shape[1], 20.0, 50).view(np.uint32),
+                          f[:50].view(np.uint32))
+    # a larger radius keeps fewer points
+    assert len(O.enforce_uniformity(k, img.shape[0], img.shape[1], 40.0)) < len(f)

@@ -56,6 +56,7 @@ def read_set(path):
         e["keypoints"] = np.frombuffer(r.raw(nk * KP_DTYPE.itemsize), dtype=KP_DTYPE).copy()
         desc, typ, esz = r.mat()
         e["descriptors"] = desc
+        e["descriptor_type"] = (typ, esz)
         blobs = {}
         for _ in range(r.u32()):
             k = r.string()
@@ -64,3 +65,39 @@ def read_set(path):
         out.append(e)
     assert r.o == len(r.b), (r.o, len(r.b))
     return out
+
+
+def write_set(path, entries):
+    """Writer for the same format (serialization.cc:46-149, bench-ds.cc:57-94): entries as read_set returns them
+    (path, image, keypoints, descriptors, blobs).  Reading a reference golden file and writing it back is
+    byte-identical (tests/test_oracle_golden.py::test_set_file_round_trip)."""
+    out = bytearray()
+
+    def string(t):
+        b = t.encode("latin1")
+        out.extend(struct.pack("<I", len(b)))
+        out.extend(b)
+
+    def mat(a, typ, esz):
+        a = np.ascontiguousarray(a, np.uint8)
+        rows, cols = (a.shape[0], a.shape[1] // esz) if a.ndim == 2 else (0, 0)
+        out.extend(struct.pack("<iiii", rows, cols, typ, esz))
+        out.extend(a.tobytes())
+
+    out.extend(struct.pack("<I", len(entries)))
+    for e in entries:
+        string(e["path"])
+        mat(e["image"], 0, 1)
+        k = np.ascontiguousarray(e["keypoints"], KP_DTYPE)
+        out.extend(struct.pack("<I", len(k)))
+        out.extend(k.tobytes())
+        typ, esz = e.get("descriptor_type", (0, 1))
+        mat(e["descriptors"], typ, esz)
+        blobs = e.get("blobs", {})
+        out.extend(struct.pack("<I", len(blobs)))
+        for key, val in blobs.items():
+            string(key)
+            out.extend(struct.pack("<I", len(val)))
+            out.extend(val)
+    with open(path, "wb") as f:
+        f.write(bytes(out))

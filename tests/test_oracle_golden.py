@@ -312,3 +312,16 @@ def test_uniformity_oracle_properties(golden_ast):
                           f[:50].view(np.uint32))
     # a larger radius keeps fewer points
     assert len(O.enforce_uniformity(k, img.shape[0], img.shape[1], 40.0)) < len(f)
+
+
+def test_set_file_round_trip(tmp_path):
+    """The `.set` container of the reference's goldens: read -> write is byte-identical, so results of
+    this engine can be handed to the reference's own verification tooling."""
+    import os
+    from setfile import read_set, write_set
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("brisk_verification_ast.set", "brisk_verification_harris.set"):
+        src = os.path.join(here, "golden", name)
+        dst = str(tmp_path / name)
+        write_set(dst, read_set(src))
+        assert open(dst, "rb").read() == open(src, "rb").read()

@@ -2,6 +2,14 @@
 """Averages SQ counters per kernel from one or more rocprofv3 counter_collection.csv files.
 Usage: pmc_sq.py <csv> [<csv> ...] [--kernel k_detect]"""
 import csv
+
+
+def kernel_name(n):
+    """k_foo / void k_foo<1>(...) -> k_foo"""
+    n = n.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("(")[0].split("<")[0]
 import sys
 from collections import defaultdict
 
@@ -17,7 +25,7 @@ while args:
 acc = defaultdict(lambda: defaultdict(list))
 for f in files:
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = kernel_name(r["Kernel_Name"])
         if not k.startswith("k_") or (want and k != want):
             continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

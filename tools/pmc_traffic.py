@@ -9,6 +9,14 @@ HBM bytes per launch for every engine kernel, with the gfx950 corrections of tha
 Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames_per_launch> <w> <h> [out.json]
 """
 import csv
+
+
+def kernel_name(n):
+    """k_foo / void k_foo<1>(...) -> k_foo"""
+    n = n.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("(")[0].split("<")[0]
 import json
 import sys
 from collections import defaultdict
@@ -19,7 +27,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]) * 1024.0)
+        acc[kernel_name(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 

@@ -23,7 +23,7 @@ python3 - "$f" "$out/pmc_fetch_b64.csv" "$w" "$out/pmc_write_b64.csv" <<'PY'
 import csv, sys
 for src, dst in ((sys.argv[1], sys.argv[2]), (sys.argv[3], sys.argv[4])):
     rows = list(csv.DictReader(open(src)))
-    keep = [r for r in rows if r["Kernel_Name"].startswith("k_")]
+    keep = [r for r in rows if r["Kernel_Name"].startswith("k_") or r["Kernel_Name"].startswith("void k_")]
     w = csv.DictWriter(open(dst, "w", newline=""), fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(keep)

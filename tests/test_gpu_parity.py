@@ -341,6 +341,17 @@ def test_capacity_overflow_is_an_error_not_a_truncation(B, golden_ast):
     with pytest.raises(B.BriskHipError) as ei:            # caller's output array too small
         B.BriskFeatureDetector(70, 3).detect(img, capacity=100)
     assert ei.value.code == 4
+    # a context must stay usable after an overflowing frame: the score-state map of that frame holds detections
+    # without a candidate record, which the next batch's clean-up has to wipe completely
+    ctx = B.Context(0, max_candidates=1024, max_keypoints=16384)
+    small = golden_ast[0]["image"][:200, :260]
+    ko = O.detect(np.ascontiguousarray(small), 70, 3)
+    for _ in range(2):
+        with pytest.raises(B.BriskHipError):
+            B.BriskFeatureDetector(70, 3, context=ctx).detect(img)          # > 1024 candidates
+        kg = B.BriskFeatureDetector(70, 3, context=ctx).detect(small)         # fits, same buffers
+        assert same_kps(kg, ko), explain(kg, ko)
+    ctx.close()
 
 
 def test_soak_1080p_batch_vs_oracle(B, ctx):

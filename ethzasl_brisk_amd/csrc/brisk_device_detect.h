@@ -903,6 +903,21 @@ BRISK_HD int brisk_tie_slot_value(const BriskLayerView& L, const bool float_patc
   return (K >= centre) ? K : 0;
 }
 
+// one neighbour of the tie list (o = 0..7 in list order): false iff it is an equal-score neighbour whose smoothed
+// 3x3 sum exceeds the candidate's.  brisk_tie_decide() == all eight of these (the kernel evaluates them on 8 lanes).
+BRISK_HD bool brisk_tie_neighbour_ok(int centre, const int* s /* 8 probe values */, const int* raw /* 25 */, int o) {
+  const int smoothedcenter = 4 * centre + 2 * (s[0] + s[1] + s[2] + s[3]) + s[7] + s[6] + s[4] + s[5];
+  const int k = (int)((0x53410627u >> (4 * o)) & 7u);  // tie list order {7, 2, 6, 0, 1, 4, 3, 5}
+  if (s[k] != centre) return true;
+  const int nx = brisk_probe_dx(k) + 2, ny = brisk_probe_dy(k) + 2;  // position inside the 5x5 block
+  int other = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) other += (dx == 0 ? 2 : 1) * (dy == 0 ? 2 : 1) * raw[(ny + dy) * 5 + nx + dx];
+  return !(other > smoothedcenter);
+}
+
 BRISK_HD bool brisk_tie_decide(int centre, const int* s /* 8 probe values */, const int* raw /* 25 */) {
   // s: W,E,N,S,SW,SE,NE,NW
   const int smoothedcenter = 4 * centre + 2 * (s[0] + s[1] + s[2] + s[3]) + s[7] + s[6] + s[4] + s[5];

@@ -885,8 +885,11 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the eight neighbours of the tie list on eight lanes (a serial walk on one lane costs ~70 dependent LDS reads)
+        const bool nb_ok = (lane >= 8) || brisk_tie_neighbour_ok(centre, &vals[wave][0], &vals[wave][8], lane);
+        const bool pass_all = __all(nb_ok);
         if (lane == 0) {
-          const bool pass = brisk_tie_decide(centre, &vals[wave][0], &vals[wave][8]);
+          const bool pass = pass_all;
           // publish the decision first (other waves spin on it), then the bookkeeping
           __hip_atomic_store(&tstat[j], pass ? (int)BRISK_ST_PASS : (int)BRISK_ST_FAIL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (pass) smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)

@@ -285,6 +285,23 @@ int emul_detect(const uint8_t* img, int w, int h, int threshold, int octaves, un
 
 void emul_free(void* p) { free(p); }
 
+// the kernel evaluates the tie list on 8 lanes (brisk_tie_neighbour_ok); must equal the serial brisk_tie_decide
+int emul_tie_decide_mismatches(unsigned seed, int n) {
+  int bad = 0;
+  unsigned st = seed * 2654435761u + 12345u;
+  for (int it = 0; it < n; ++it) {
+    int s[8], raw[25];
+    st = st * 1664525u + 1013904223u;
+    const int centre = 3 + (int)((st >> 8) % 60);
+    for (int k = 0; k < 8; ++k) { st = st * 1664525u + 1013904223u; const unsigned r = (st >> 10) % 4; s[k] = r == 0 ? centre : r == 1 ? 0 : (int)((st >> 16) % (unsigned)(centre + 1)); }
+    for (int q = 0; q < 25; ++q) { st = st * 1664525u + 1013904223u; raw[q] = ((st >> 9) & 1) ? 0 : (int)((st >> 12) % 80); }
+    bool all_ok = true;
+    for (int o = 0; o < 8; ++o) all_ok = all_ok && brisk_tie_neighbour_ok(centre, s, raw, o);
+    bad += (all_ok != brisk_tie_decide(centre, s, raw));
+  }
+  return bad;
+}
+
 // exhaustive check of the multiply-free threshold scaling used by k_detect; returns the number of mismatches
 int emul_b2_fast_mismatches(void) {
   int bad = 0;

@@ -143,3 +143,10 @@ def test_describe_flags_and_custom_pattern(golden_harris):
 def test_b2_fast_exact():
     """k_detect scales the contrast with an fma instead of (tc * thr) / 100: must be the same integer everywhere."""
     assert E.lib().emul_b2_fast_mismatches() == 0
+
+
+def test_tie_decision_on_eight_lanes_equals_serial():
+    """k_tie_resolve checks the eight tie-list neighbours on eight lanes; same decision as the serial walk."""
+    L = E.lib()
+    L.emul_tie_decide_mismatches.argtypes = [__import__("ctypes").c_uint, __import__("ctypes").c_int]
+    assert L.emul_tie_decide_mismatches(7, 200000) == 0

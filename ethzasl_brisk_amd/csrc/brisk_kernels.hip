@@ -964,7 +964,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
 // k_finalize: keypoints of a frame in (layer, y, x) order.  One workgroup per frame; ranks by
 // counting smaller keys among the valid candidates (a few thousand at most).
 // ------------------------------------------------------------------------------------------------
-#define FN_THREADS 1024
+#define FN_THREADS 512
 __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
                                                           unsigned* keys_scratch, BriskKeyPoint* kp_out, int cand_cap,
                                                           int kp_cap, const uint8_t* mask, long mask_pitch_frame,

@@ -13,6 +13,7 @@
 #include "brisk_kernels.h"
 
 #define UF_THREADS 1024
+#define UF_LDS_POINTS 8192
 
 // L1-bypassing byte read (the workgroup's own earlier stores are at L2)
 __device__ __forceinline__ unsigned uf_load_fresh(const uint8_t* p) {
@@ -60,6 +61,16 @@ __global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __rest
   __syncthreads();
   const float maxScore = K[__hip_atomic_load(&ord[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)].response;
   if (tid == 0) kept_s = 0;
+  // occupancy cell and normalised score of the sorted points, computed in parallel and kept on chip: the sequential
+  // walk below then waits for nothing but the occupancy image itself
+  __shared__ int pcell[UF_LDS_POINTS];     // cy << 16 | cx
+  __shared__ float pnsc[UF_LDS_POINTS];
+  const int nl = min(n, UF_LDS_POINTS);
+  for (int r = tid; r < nl; r += UF_THREADS) {
+    const BriskKeyPoint p = K[__hip_atomic_load(&ord[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    pcell[r] = ((int)(p.y * scaling + 16) << 16) | (int)(p.x * scaling + 16);
+    pnsc[r] = sqrtf(sqrtf(p.response / maxScore)) * 255.0f;
+  }
   __syncthreads();
   // mask value of this thread's cell of the 31 x 31 neighbourhood (scale-space-layer-inl.h:89-97)
   const int my = tid / 31, mx = tid % 31;
@@ -70,18 +81,22 @@ __global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __rest
   }
   for (int r = 0; r < n; ++r) {
     if (tid == 0) {
-      const int idx = __hip_atomic_load(&ord[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const BriskKeyPoint p = K[idx];
-      const int cy = (int)(p.y * scaling + 16);
-      const int cx = (int)(p.x * scaling + 16);
+      int cy, cx;
+      float nsc1;
+      if (r < nl) {
+        cy = pcell[r] >> 16; cx = pcell[r] & 0xFFFF; nsc1 = pnsc[r];
+      } else {
+        const BriskKeyPoint p = K[__hip_atomic_load(&ord[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+        cy = (int)(p.y * scaling + 16); cx = (int)(p.x * scaling + 16);
+        nsc1 = sqrtf(sqrtf(p.response / maxScore)) * 255.0f;
+      }
       const double s0 = (double)uf_load_fresh(&O[(long)cy * ow + cx]);
-      const float nsc1 = sqrtf(sqrtf(p.response / maxScore)) * 255.0f;
       const int acc = !(nsc1 < s0);
       accept_s = acc;
       if (acc) {
         nsc_s = 0.99f * nsc1;
         cy_s = cy; cx_s = cx;
-        T[kept_s] = p;
+        ord[kept_s] = ord[r];   // (kept_s <= r: the accepted prefix of the order array is compacted in place)
         kept_s = kept_s + 1;
       }
     }
@@ -100,6 +115,11 @@ __global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __rest
   }
   __syncthreads();
   const int kept = kept_s;
+  __threadfence();
+  __syncthreads();
+  for (int i = tid; i < kept; i += UF_THREADS) T[i] = K[__hip_atomic_load(&ord[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+  __threadfence();
+  __syncthreads();
   for (int i = tid; i < kept; i += UF_THREADS) K[i] = T[i];
   if (tid == 0) counters[frame].nkp = kept;
 }

@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(64) k_classify_refine_direct(BriskGeom G, uint
 #define TR_WAVES 16
 #define TR_THREADS (TR_WAVES * 64)
 #define TR_WIN 9
-#define TR_MAXSORT 2048
+#define TR_MAXSORT 6144
 #define TR_JACOBI 64
 __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                              BriskFrameCounters* counters, const int* tie_idx,

@@ -1162,13 +1162,14 @@ static void launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32
 
 // ------------------------------------------------------------------------------------------------
 #define DP_MAXSORT 4096
+#define DP_THREADS 512
 // k_desc_prepare: per frame, scale index + border filter (brisk-descriptor-extractor.cc:636-662),
 // stable compaction into dkp (keypoints) / dscale.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
+__global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
                                                        const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
                                                        BriskKeyPoint* dkp, int* dscale, int* dperm, uint4* drec, int kp_cap) {
-  __shared__ int scan[256];
+  __shared__ int scan[DP_THREADS];
   __shared__ int base;
   __shared__ unsigned pkey[DP_MAXSORT];
   const int frame = blockIdx.x, tid = threadIdx.x;
@@ -1176,7 +1177,7 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
   const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;
   if (tid == 0) base = 0;
   __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += 256) {
+  for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
     const int i = i0 + tid;
     int keep = 0, sc = 0;
     BriskKeyPoint kp;
@@ -1187,7 +1188,7 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
     }
     scan[tid] = keep;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
+    for (int off = 1; off < DP_THREADS; off <<= 1) {
       int add = (tid >= off) ? scan[tid - off] : 0;
       __syncthreads();
       scan[tid] += add;
@@ -1199,7 +1200,7 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
       dscale[(long)frame * kp_cap + j] = sc;
     }
     __syncthreads();
-    if (tid == 0) base += scan[255];
+    if (tid == 0) base += scan[DP_THREADS - 1];
     __syncthreads();
   }
   if (tid == 0) counters[frame].ndesc = base;
@@ -1209,24 +1210,24 @@ __global__ void __launch_bounds__(256) k_desc_prepare(BriskGeom G, BriskPatternD
   const int m = base;
   int* perm = dperm + (long)frame * kp_cap;
   if (m <= DP_MAXSORT) {
-    for (int j = tid; j < m; j += 256) {
+    for (int j = tid; j < m; j += DP_THREADS) {
       const BriskKeyPoint& q = dkp[(long)frame * kp_cap + j];
       pkey[j] = ((unsigned)((int)q.y >> 6) << 24) | ((unsigned)((int)q.x & 0x1FFF) << 11) | (unsigned)(j & 0x7FF);
     }
     __syncthreads();
-    for (int j = tid; j < m; j += 256) {
+    for (int j = tid; j < m; j += DP_THREADS) {
       const unsigned kj = pkey[j];
       int r = 0;
       for (int q = 0; q < m; ++q) r += (pkey[q] < kj || (pkey[q] == kj && q < j)) ? 1 : 0;
       perm[r] = j;
     }
   } else {
-    for (int j = tid; j < m; j += 256) perm[j] = j;
+    for (int j = tid; j < m; j += DP_THREADS) perm[j] = j;
   }
   // the keypoints again, in processing order, as one 16-byte record each: k_describe reads them with a single
   // (prefetchable) load instead of the dependent chain order -> keypoint -> scale
   __syncthreads();
-  for (int r = tid; r < m; r += 256) {
+  for (int r = tid; r < m; r += DP_THREADS) {
     const int j = perm[r];
     const BriskKeyPoint& q = dkp[(long)frame * kp_cap + j];
     drec[(long)frame * kp_cap + r] = make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.angle),
@@ -1374,10 +1375,17 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   // 1-D grid of bpf blocks per frame.  All blocks of a frame get the same blockIdx.x % 8, i.e. the same XCD: a
   // frame's integral image (8.3 MB @1080p, gathered ~16 times per 128-B line) then lives in ONE L2 while the frame
   // is being described instead of being pulled through all eight.
-  const int xcd = blockIdx.x & 7;
-  const int jj = blockIdx.x >> 3;
-  const int frame = (jj / bpf) * 8 + xcd;
-  const int block_in_frame = jj % bpf;
+  // (with fewer than 8 frames the affinity would leave XCDs idle: blocks of a frame are then spread over all of them)
+  int frame, block_in_frame;
+  if (nframes >= 8) {
+    const int xcd = blockIdx.x & 7;
+    const int jj = blockIdx.x >> 3;
+    frame = (jj / bpf) * 8 + xcd;
+    block_in_frame = jj % bpf;
+  } else {
+    frame = blockIdx.x / bpf;
+    block_in_frame = blockIdx.x % bpf;
+  }
   if (frame >= nframes) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int* values = values_s[wave];
@@ -1571,16 +1579,18 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
   if (!ov)
     launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, nbands, nframes, s);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
-  hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(256), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
+  hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap);
   // with `ov` the integral image is already running beside the detector's tail (brisk_launch_detect) and
   // k_desc_prepare (one workgroup per frame, does not read it): join only in front of the sampling kernel
   if (ov) (void)hipStreamWaitEvent(s, ov->join, 0);
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
   {
-    const int bpf = ((G.debug_flags >> 8) & 0xFF) ? (((G.debug_flags >> 8) & 0xFF) * 8) : 128;  // blocks per frame (test knob: debug bits 8-15, x8)
+    // blocks per frame (test knob: debug bits 8-15, x8); small batches get enough blocks to cover all CUs
+    const int bpf = ((G.debug_flags >> 8) & 0xFF) ? (((G.debug_flags >> 8) & 0xFF) * 8) : (nframes >= 8 ? 128 : 1024 / nframes);
     const int groups = (nframes + 7) / 8;
-    hipLaunchKernelGGL(k_describe, dim3(groups * 8 * bpf), dim3(DS_WAVES * 64), 0, s, G, P, B.pyr, Dd.integral, Dd.istride,
+    const int nblocks = nframes >= 8 ? groups * 8 * bpf : nframes * bpf;
+    hipLaunchKernelGGL(k_describe, dim3(nblocks), dim3(DS_WAVES * 64), 0, s, G, P, B.pyr, Dd.integral, Dd.istride,
                        Dd.iframe_elems, B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, bpf, nframes);
   }
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);

@@ -503,6 +503,7 @@ static int overflow_to_rc(brisk_hip_ctx* ctx, int flags) {
   if (flags & 1) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "candidate capacity exceeded (brisk_hip_set_capacity)");
   if (flags & 2) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "tie-candidate capacity exceeded (brisk_hip_set_capacity)");
   if (flags & 4) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "keypoint capacity exceeded (brisk_hip_set_capacity)");
+  if (flags & 8) return fail(ctx, BRISK_HIP_ERR_HIP, "tie resolution gave up waiting for a decision (internal error)");
   return BRISK_HIP_OK;
 }
 

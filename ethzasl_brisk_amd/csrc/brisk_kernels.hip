@@ -742,25 +742,25 @@ __global__ void __launch_bounds__(64) k_classify_refine_direct(BriskGeom G, uint
 // waves in contiguous segments; a wave spins until every raster-earlier tie candidate within Chebyshev distance 4 of its
 // candidate is decided (the earliest undecided candidate never waits, so the scheme cannot deadlock), then
 // replays the lazy score cache with one lane per pixel (8 probe values + the 5x5 raw block).
-// Layers with more ties than the sort buffer fall back to a Jacobi relaxation with one thread per candidate.
+// Frames with more ties than the on-chip arrays hold run the same scheme per layer from global scratch, the
+// decisions then travel through the score-state map.
 // ------------------------------------------------------------------------------------------------
 #define TR_WAVES 16
 #define TR_THREADS (TR_WAVES * 64)
 #define TR_WIN 9
 #define TR_MAXSORT 6144
-#define TR_JACOBI 64
 __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                              BriskFrameCounters* counters, const int* tie_idx,
-                                                             const uint8_t* blocks, int cand_cap, int tie_cap) {
+                                                             const uint8_t* blocks, unsigned* gscratch, int cand_cap,
+                                                             int tie_cap) {
   __shared__ uint8_t kp5s[TR_WAVES][32];
-  __shared__ uint16_t win[TR_JACOBI][TR_WIN * TR_WIN + 1];  // per-wave windows (sorted path) / per-thread (fallback)
+  __shared__ uint16_t win[TR_WAVES][TR_WIN * TR_WIN + 1];  // per-wave window of the tie being decided
   __shared__ unsigned skey[TR_MAXSORT];
   __shared__ int sorder[TR_MAXSORT];    // candidate index of the tie with raster rank r
   __shared__ unsigned sxyd[TR_MAXSORT]; // its x | y << 13 | ... (the key) - D is taken from the window
   __shared__ int vals[TR_WAVES][40];
   __shared__ int vals_ci[TR_MAXSORT];   // candidate index of the tie (unsorted order)
   __shared__ uint16_t sfpm[TR_MAXSORT]; // e3 footprint mask of the tie with raster rank r
-  __shared__ int remaining, progressed;
   int* const tstat = reinterpret_cast<int*>(skey);          // after the sort: decision of rank r (0 = pending)
   unsigned* const sfpxy = reinterpret_cast<unsigned*>(vals_ci);  // after the sort: footprint anchor of rank r
   const int frame = blockIdx.x;
@@ -779,6 +779,12 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   __syncthreads();
   const int ntot = lstart[G.nlayers];
   if (ntot == 0) return;
+  // a frame whose candidate or tie list overflowed is reported as an error and its result discarded; its map holds
+  // tie candidates that are in no list, which nobody would ever decide: do not wait for them
+  if (counters[frame].overflow & 3) return;
+  __shared__ int abort_s;
+  if (tid == 0) abort_s = 0;
+  __syncthreads();
   const bool sorted_path = ntot <= TR_MAXSORT;
   if (sorted_path) {
     for (int l = 0; l < G.nlayers; ++l) {
@@ -863,9 +869,10 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
               int st = 0;
               for (int spin = 0; spin < (1 << 22); ++spin) {
                 st = __hip_atomic_load(&tstat[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (st) break;
+                if (st || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                 __builtin_amdgcn_s_sleep(1);
               }
+              if (!st) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
               if (st) v0 = (v0 & ~0x3000u) | ((unsigned)st << 12);
             }
           }
@@ -913,51 +920,89 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       __syncthreads();
       continue;
     }
-    // ---- fallback: Jacobi relaxation, one thread per candidate (first TR_JACOBI threads)
-    for (int iter = 0; iter < (1 << 20); ++iter) {
-      if (tid == 0) { remaining = 0; progressed = 0; }
+    // ---- more ties than the on-chip arrays hold (dense frames): the same in-order scheme with the sorted list of
+    // this layer in global scratch (gkey / gci, rank-sorted through LDS tiles) and the decisions exchanged through
+    // the score-state map itself: a wave re-reads its 9x9 window (L1-bypassing loads) until no raster-earlier tie
+    // in it is pending; decisions are published with device-scope atomics, as in the on-chip path.
+    {
+      unsigned* gkey = gscratch + (long)frame * cand_cap * 2;
+      unsigned* gci = gkey + cand_cap;
+      unsigned* tilek = skey;  // (free in this path)
+      for (int j0 = 0; j0 < n; j0 += TR_THREADS) {
+        const int j = j0 + tid;
+        const int ci = (j < n) ? list[j] : 0;
+        const unsigned myk = (j < n) ? cand[(long)frame * cand_cap + ci].key : 0xFFFFFFFFu;
+        int rank = 0;
+        for (int t0 = 0; t0 < n; t0 += TR_THREADS) {
+          __syncthreads();
+          tilek[tid] = (t0 + tid < n) ? cand[(long)frame * cand_cap + list[t0 + tid]].key : 0xFFFFFFFFu;
+          __syncthreads();
+          const int m = min(TR_THREADS, n - t0);
+          for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
+        }
+        if (j < n) { gkey[rank] = myk; gci[rank] = (unsigned)ci; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
-      if (tid < TR_JACOBI) {
-        for (int j = tid; j < n; j += TR_JACOBI) {
-          BriskCand* c = &cand[(long)frame * cand_cap + list[j]];
-          if (c->status != BRISK_ST_TIE) continue;
-          const int cx = c->x, cy = c->y;
-          uint16_t* wl = win[tid];
-          bool ready = true;
-          for (int dy = -4; dy <= 4; ++dy)
-            for (int dx = -4; dx <= 4; ++dx) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      uint16_t* wl = win[wave];
+      for (int j = wave; j < n; j += TR_WAVES) {
+        const unsigned key = __hip_atomic_load(&gkey[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ci = (int)__hip_atomic_load(&gci[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
+        if (lane < 25) kp5s[wave][lane] = blocks[((long)frame * cand_cap + ci) * 64 + lane];
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+          bool pending = false;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int e = lane + 64 * t;
+            if (e < TR_WIN * TR_WIN) {
+              const int dy = e / TR_WIN - 4, dx = e % TR_WIN - 4;
               const int qx = cx + dx, qy = cy + dy;
               unsigned v = 0;
               if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
-              wl[(dy + 4) * TR_WIN + dx + 4] = (uint16_t)v;
-              if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) ready = false;
+              wl[e] = (uint16_t)v;
+              if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) pending = true;
             }
-          if (!ready) { atomicAdd(&remaining, 1); continue; }
-          const bool pass = brisk_tie_eval<false>(L, float_patch, touch2x2, cx, cy, wl, cx - 4, cy - 4, TR_WIN,
-                                                 blocks + ((long)frame * cand_cap + list[j]) * 64);
-          if (pass) {
-            if (c->fp_mask && l + 1 < G.nlayers) {
-              const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
-              for (int b = 0; b < 16; ++b)
-                if (c->fp_mask & (1u << b))
-                  smap_or(La.smap, (long)(c->fp_y0 + (b >> 2)) * La.stride + c->fp_x0 + (b & 3), BRISK_SM_TOUCH);
-            }
-            c->status = BRISK_ST_PASS;
-            smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);
-          } else {
-            c->status = BRISK_ST_FAIL;
-            smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);
           }
-          atomicAdd(&progressed, 1);
+          if (!__any(pending) || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+          if (spin == (1 << 20)) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+          __builtin_amdgcn_s_sleep(2);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
+        {
+          const int slot = (lane < 8) ? lane : (lane >= 32 && lane < 57) ? lane - 24 : -1;
+          if (slot >= 0)
+            vals[wave][slot] = brisk_tie_slot_value<false>(L, float_patch, touch2x2, cx, cy, centre, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool nb_ok = (lane >= 8) || brisk_tie_neighbour_ok(centre, &vals[wave][0], &vals[wave][8], lane);
+        const bool pass = __all(nb_ok);
+        if (lane == 0) {
+          BriskCand* c = &cand[(long)frame * cand_cap + ci];
+          // bookkeeping first, the decision last: whoever sees the new status may rely on the touches
+          if (pass && c->fp_mask && l + 1 < G.nlayers) {
+            const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
+            for (int b = 0; b < 16; ++b)
+              if (c->fp_mask & (1u << b))
+                smap_or(La.smap, (long)(c->fp_y0 + (b >> 2)) * La.stride + c->fp_x0 + (b & 3), BRISK_SM_TOUCH);
+          }
+          c->status = pass ? BRISK_ST_PASS : BRISK_ST_FAIL;
+          if (pass) smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
+          else smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);       // TIE (10b) -> FAIL (11b)
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __threadfence();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      const int rem = remaining, prog = progressed;
-      __syncthreads();
-      if (rem == 0 || prog == 0) break;
     }
   }
+  if (tid == 0 && abort_s) atomicOr(&counters[frame].overflow, 8);  // a wait ran into its bound: reported as an error
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1621,7 +1666,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   brisk_prof_mark(prof, BRISK_STG_TIES, s);
   if (ov) (void)hipEventRecord(ov->fork, s);
   hipLaunchKernelGGL(k_tie_resolve, dim3(nframes), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                     B.blocks, B.cand_cap, B.tie_cap);
+                     B.blocks, B.keys, B.cand_cap, B.tie_cap);
   if (ov) {
     // The integral image only needs layer 0 and the band sums (k_pyramid_even) and is HBM-bound; tie resolution
     // (one workgroup per frame, a chain of dependent decisions) and the final ordering are latency-bound and leave

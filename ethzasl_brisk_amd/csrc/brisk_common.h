@@ -91,7 +91,8 @@ struct BriskFrameCounters {
   int ndesc;                        // keypoints surviving the descriptor border filter
   int overflow;                     // bit0 cand overflow, bit1 tie overflow, bit2 keypoint overflow
   int nredo;                        // candidates deferred to k_classify_refine_direct
-  int pad[3];
+  int nvalid_large;                 // > 0: k_finalize left the ordering of this many keypoints to k_finalize_large
+  int pad[2];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)

@@ -1012,29 +1012,17 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
 #define FN_THREADS 512
 #define FN_BUCKETS 2048
 #define FN_SMALL 3072   // up to this many keypoints: rank by counting smaller keys (tiled through LDS)
-// Ordering in O(n): the key is (layer, y, x), so a counting sort over (layer, row) buckets puts every keypoint into
-// its row's range and the position inside the range is the number of smaller x of the same row (rows hold a
-// handful of keypoints).  scratch2: 2 * (number of valid candidates) words (the tie lists are free by now).
 __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
-                                                          unsigned* keys_scratch, unsigned* scratch2, long scratch2_stride,
-                                                          BriskKeyPoint* kp_out, int cand_cap, int kp_cap,
-                                                          const uint8_t* mask, long mask_pitch_frame, int mask_row_pitch) {
+                                                          unsigned* keys_scratch, BriskKeyPoint* kp_out, int cand_cap,
+                                                          int kp_cap, const uint8_t* mask, long mask_pitch_frame,
+                                                          int mask_row_pitch) {
   __shared__ int nvalid;
-  __shared__ int bstart[FN_BUCKETS + 1];
-  __shared__ int bfill[FN_BUCKETS];
-  __shared__ int rbase[BRISK_MAX_LAYERS + 1];
-  __shared__ int wsum[FN_THREADS / 64];
+  __shared__ unsigned tilek[FN_THREADS];
   const int frame = blockIdx.x, tid = threadIdx.x;
   const int n = min(counters[frame].ncand, cand_cap);
   const BriskCand* C = cand + (long)frame * cand_cap;
   unsigned* keys = keys_scratch + (long)frame * cand_cap * 2;  // [key][cand index]
-  unsigned* tmp = scratch2 + (long)frame * scratch2_stride;    // the same pairs grouped by bucket
-  if (tid == 0) {
-    nvalid = 0;
-    int acc = 0;
-    for (int l = 0; l < G.nlayers; ++l) { rbase[l] = acc; acc += G.L[l].h; }
-    rbase[G.nlayers] = acc;
-  }
+  if (tid == 0) nvalid = 0;
   __syncthreads();
   for (int i = tid; i < n; i += FN_THREADS) {
     const BriskCand& c = C[i];
@@ -1049,41 +1037,65 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
       keys[2 * j + 1] = (unsigned)i;
     }
   }
-  __threadfence();
+  __threadfence_block();
   __syncthreads();
   const int nv = nvalid;
-  if (nv <= FN_SMALL) {  // the usual case: fewer memory round trips than the counting sort below
-    unsigned* tilek = reinterpret_cast<unsigned*>(bfill);
-    for (int j0 = 0; j0 < nv; j0 += FN_THREADS) {
-      const int j = j0 + tid;
-      const unsigned myk = (j < nv) ? keys[2 * j] : 0xFFFFFFFFu;
-      int rank = 0;
-      for (int t0 = 0; t0 < nv; t0 += FN_THREADS) {
-        __syncthreads();
-        tilek[tid] = (t0 + tid < nv) ? keys[2 * (t0 + tid)] : 0xFFFFFFFFu;
-        __syncthreads();
-        const int m = min(FN_THREADS, nv - t0);
-        for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
-      }
-      if (j < nv && rank < kp_cap) {
-        const BriskCand& c = C[keys[2 * j + 1]];
-        BriskKeyPoint kp;
-        kp.x = c.kx; kp.y = c.ky; kp.size = c.ksize; kp.angle = -1.0f; kp.response = c.kresp;
-        kp.octave = G.single_layer ? 0 : c.layer; kp.class_id = -1;
-        kp_out[(long)frame * kp_cap + rank] = kp;
-      }
-    }
-    if (tid == 0) {
-      counters[frame].nkp = min(nv, kp_cap);
-      if (nv > kp_cap) atomicOr(&counters[frame].overflow, 4);
-    }
+  if (nv > FN_SMALL) {  // dense frame: the O(n) ordering of k_finalize_large takes over
+    if (tid == 0) counters[frame].nvalid_large = nv;
     return;
   }
-  // many keypoints: counting sort over (layer, row) buckets
-  int shift = 0;
-  while ((rbase[G.nlayers] >> shift) >= FN_BUCKETS) ++shift;  // several rows per bucket if the pyramid has more rows
+  for (int j0 = 0; j0 < nv; j0 += FN_THREADS) {
+    const int j = j0 + tid;
+    const unsigned myk = (j < nv) ? keys[2 * j] : 0xFFFFFFFFu;
+    int rank = 0;
+    for (int t0 = 0; t0 < nv; t0 += FN_THREADS) {
+      __syncthreads();
+      tilek[tid] = (t0 + tid < nv) ? keys[2 * (t0 + tid)] : 0xFFFFFFFFu;
+      __syncthreads();
+      const int m = min(FN_THREADS, nv - t0);
+      for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
+    }
+    if (j < nv && rank < kp_cap) {
+      const BriskCand& c = C[keys[2 * j + 1]];
+      BriskKeyPoint kp;
+      kp.x = c.kx; kp.y = c.ky; kp.size = c.ksize; kp.angle = -1.0f; kp.response = c.kresp;
+      kp.octave = G.single_layer ? 0 : c.layer; kp.class_id = -1;
+      kp_out[(long)frame * kp_cap + rank] = kp;
+    }
+  }
+  if (tid == 0) {
+    counters[frame].nkp = min(nv, kp_cap);
+    if (nv > kp_cap) atomicOr(&counters[frame].overflow, 4);
+  }
+}
+
+// Ordering of dense frames (more than FN_SMALL keypoints) in O(n): the key is (layer, y, x), so a counting sort over
+// (layer, row) buckets puts every keypoint into its row's range and the position inside the range is the number of
+// smaller x of the same row (rows hold a handful of keypoints).  Exits at once for the other frames.
+// scratch2: 2 * (number of valid candidates) words per frame (the tie lists are free by now).
+__global__ void __launch_bounds__(FN_THREADS) k_finalize_large(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
+                                                                const unsigned* keys_scratch, unsigned* scratch2,
+                                                                long scratch2_stride, BriskKeyPoint* kp_out, int cand_cap,
+                                                                int kp_cap) {
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  const int nv = counters[frame].nvalid_large;
+  if (nv <= 0) return;
+  __shared__ int bstart[FN_BUCKETS + 1];
+  __shared__ int bfill[FN_BUCKETS];
+  __shared__ int rbase[BRISK_MAX_LAYERS + 1];
+  __shared__ int wsum[FN_THREADS / 64];
+  const BriskCand* C = cand + (long)frame * cand_cap;
+  const unsigned* keys = keys_scratch + (long)frame * cand_cap * 2;  // [key][cand index] from k_finalize
+  unsigned* tmp = scratch2 + (long)frame * scratch2_stride;          // the same pairs grouped by bucket
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < G.nlayers; ++l) { rbase[l] = acc; acc += G.L[l].h; }
+    rbase[G.nlayers] = acc;
+  }
   for (int b = tid; b < FN_BUCKETS; b += FN_THREADS) { bstart[b] = 0; bfill[b] = 0; }
   __syncthreads();
+  int shift = 0;
+  while ((rbase[G.nlayers] >> shift) >= FN_BUCKETS) ++shift;  // several rows per bucket if the pyramid has more rows
   for (int j = tid; j < nv; j += FN_THREADS) {
     const unsigned key = keys[2 * j];
     atomicAdd(&bstart[(rbase[key >> 26] + (int)((key >> 13) & 0x1FFF)) >> shift], 1);
@@ -1679,9 +1691,10 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     (void)hipEventRecord(ov->join, ov->side);
   }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
-  hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys,
-                     reinterpret_cast<unsigned*>(B.tie_idx), (long)BRISK_MAX_LAYERS * B.tie_cap, B.kp_out, B.cand_cap, B.kp_cap,
-                     mask, mask_frame_pitch, mask_row_pitch);
+  hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,
+                     B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);
+  hipLaunchKernelGGL(k_finalize_large, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys,
+                     reinterpret_cast<unsigned*>(B.tie_idx), (long)BRISK_MAX_LAYERS * B.tie_cap, B.kp_out, B.cand_cap, B.kp_cap);
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
 }
 

@@ -1165,18 +1165,6 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize_large(BriskGeom G, cons
 #define II_BAND 64
 #define II_CHUNK (II_THREADS * 4)
 
-// pixels 4t-1 .. 4t+2 of a row (0 outside [0, w))
-__device__ __forceinline__ void ii_load4(const uint8_t* row, int stride, int w, int c0 /* first integral column */,
-                                         unsigned* px) {
-  unsigned prev = 0, cur = 0;
-  if (c0 >= 4 && c0 - 4 < stride) prev = *reinterpret_cast<const unsigned*>(row + c0 - 4);
-  if (c0 < stride) cur = *reinterpret_cast<const unsigned*>(row + c0);
-  px[0] = (c0 - 1 >= 0 && c0 - 1 < w) ? (prev >> 24) : 0;
-  px[1] = (c0 < w) ? (cur & 0xFF) : 0;
-  px[2] = (c0 + 1 < w) ? ((cur >> 8) & 0xFF) : 0;
-  px[3] = (c0 + 2 < w) ? ((cur >> 16) & 0xFF) : 0;
-}
-
 // exclusive offset of `total` among the workgroup's threads (thread order) + the workgroup total
 __device__ __forceinline__ unsigned ii_wg_scan(unsigned total, unsigned (*wave_tot)[II_THREADS / 64], int buf, unsigned* wg_total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -215,6 +215,16 @@ def test_integral_kernel_wide_and_tall(B, ctx):
         B.BriskDescriptorExtractor().compute(img, k)
         got = ctx.debug_integral(0, shape[1], shape[0])
         assert np.array_equal(got.astype(np.int64), O.integral(img).astype(np.int64) & 0xFFFFFFFF), shape
+    # the widest image the engine takes (four column chunks), tall and bright enough for the 32-bit sums to wrap
+    # around like the reference's int arithmetic does
+    img = rng.integers(200, 256, (2400, 8191), dtype=np.uint8)
+    k = np.zeros(1, B.KEYPOINT)
+    k["x"], k["y"], k["size"], k["angle"] = 4000, 1000, 12, -1
+    B.BriskDescriptorExtractor().compute(img, k)
+    got = ctx.debug_integral(0, 8191, 2400)
+    want = np.zeros((2401, 8192), np.uint64)
+    want[1:, 1:] = img.astype(np.uint64).cumsum(0).cumsum(1)
+    assert want.max() > 2 ** 32 and np.array_equal(got.astype(np.uint64), want & 0xFFFFFFFF)
 
 
 def test_batch_path_device_resident(B, ctx):

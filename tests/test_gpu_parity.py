@@ -107,6 +107,7 @@ CASES = [
     ("single_layer", lambda: synth.frame_vga(4), 50, 0),
     ("one_octave", lambda: synth.frame_vga(5), 50, 1),
     ("1080p_cfg2_thr80_o4", lambda: synth.frame_1080p(0), 80, 4),  # BASELINE config 2
+    ("large_5003x3001_thr80_o8", lambda: synth.gen(5003, 3001, 9, 2000), 80, 8),   # 16 layers, odd sizes, > 4K
 ]
 
 

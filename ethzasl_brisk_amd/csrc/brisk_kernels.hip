@@ -822,9 +822,36 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     const bool float_patch = last || G.single_layer;
     const bool touch2x2 = last && !G.single_layer;
     const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
-    if (sorted_path) {
+    // dense frame (the one-off sort of all layers does not fit on chip) but this layer alone does: sort just this
+    // layer into the on-chip arrays and run the on-chip scheme on it
+    const bool lds_layer = sorted_path || n <= TR_MAXSORT;
+    if (!sorted_path && lds_layer) {
+      __syncthreads();
+      for (int j = tid; j < n; j += TR_THREADS) {
+        const int ci = list[j];
+        vals_ci[j] = ci;
+        skey[j] = cand[(long)frame * cand_cap + ci].key;
+      }
+      __syncthreads();
+      for (int j = tid; j < n; j += TR_THREADS) {
+        const unsigned k = skey[j];
+        int r = 0;
+        for (int q = 0; q < n; ++q) r += (skey[q] < k) ? 1 : 0;
+        sorder[r] = vals_ci[j];
+        sxyd[r] = k;
+      }
+      __syncthreads();
+      for (int r = tid; r < n; r += TR_THREADS) {
+        const BriskCand* c = &cand[(long)frame * cand_cap + sorder[r]];
+        sfpxy[r] = (unsigned)(uint16_t)c->fp_x0 | ((unsigned)(uint16_t)c->fp_y0 << 16);
+        sfpm[r] = c->fp_mask;
+        tstat[r] = 0;
+      }
+      __syncthreads();
+    }
+    if (lds_layer) {
       uint16_t* wl = win[wave];
-      const int lbeg = lstart[l], lend = lstart[l + 1];
+      const int lbeg = sorted_path ? lstart[l] : 0, lend = lbeg + n;
       // Round-robin over the raster-sorted ties: neighbouring ties (which depend on each other) run on different
       // waves back to back.  The only thing a tie needs from raster-earlier ties of its 9x9 window is their
       // decision, which is exchanged through LDS (tstat); the window itself and the 5x5 score block of a wave's

@@ -277,8 +277,11 @@ class ResultGather:
     def check_kpad(self):
         """outside the timed region: the slab size must cover every frame of the batch (rounded up to 128)"""
         self.finish()
-        m = int(self.counts.max().item())
-        self.kpad = min(self.cap, (m + 127) // 128 * 128)
+        m = self.counts.max().to(self.torch.int64).reshape(1)
+        if self.world > 1:  # every rank must cut slabs of the same shape
+            import torch.distributed as dist
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        self.kpad = min(self.cap, (int(m.item()) + 127) // 128 * 128)
 
 
 if __name__ == "__main__":

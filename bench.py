@@ -124,7 +124,12 @@ def main():
     ctx.set_streams(args.streams)
     ctx.debug_set_flags(args.debug_flags)
     ext = B.BriskDescriptorExtractor(version=args.pattern_version, context=ctx)
-    stream = torch.cuda.current_stream().cuda_stream
+    # everything below runs on ONE explicit torch stream: the engine's launches, the slab copies of the gather and
+    # (through torch.distributed's stream synchronisation) the RCCL transfers are ordered on it.  (The legacy NULL
+    # stream would make the engine fall back to its own non-blocking stream, which torch's work is not ordered with.)
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
     strings = ext.descriptorSize()
 
     # result buffers as torch views (for the multi-GPU gather)
@@ -203,12 +208,23 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(list(host[:16]))
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if gather is not None and args.force_gather:
+        # self-test on content the previous steps did not produce (a stale or half-written slab would show)
+        frames2 = frames.flip(0).contiguous()
+        ctx.detect_describe_batch(ext, frames2.data_ptr(), args.batch, W, H, W * H, W, THRESHOLD, OCTAVES, stream)
+        gather.run()
+        gather.finish()
+        torch.cuda.synchronize()
     if gather is not None and rank == 0 and args.force_gather:
         ac, gk, gd = gather.last
         k0, d0 = ctx.batch_download(0, True, strings)
         n0 = int(ac[0, 0].item())
         assert n0 == len(k0) and np.array_equal(gk[0][0, :n0].cpu().numpy().view(np.uint32), np.stack([k0[f].view(np.uint32) for f in k0.dtype.names], 1))
         assert np.array_equal(gd[0][0, :n0].cpu().numpy(), d0)
+        fl = args.batch - 1                      # a frame whose content differs from the timed steps' frame at that slot
+        kl, dl = ctx.batch_download(fl, True, strings)
+        nl = int(ac[0, fl].item())
+        assert nl == len(kl) and np.array_equal(gd[0][fl, :nl].cpu().numpy(), dl)
         print('gather self-test ok', file=sys.stderr)
     if world > 1 or args.force_gather:
         dist.destroy_process_group()

@@ -80,7 +80,9 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
 /* ---- device-resident batch path (frames already in HBM; results stay in HBM) ----------------- */
 /* d_frames: nframes images, frame f at d_frames + f*frame_pitch, row pitch row_pitch.  Runs
  * detect (threshold, octaves) then describe (pat) for every frame on `stream` (hipStream_t, may be
- * NULL = the context's stream).  Asynchronous: synchronise the stream before reading results. */
+ * NULL = the context's stream, a non-blocking stream that is NOT ordered with the legacy default stream: pass
+ * your own stream if other work has to be ordered with the batch).  Asynchronous: synchronise the stream before
+ * reading results. */
 int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames,
                                     int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
                                     int octaves, void* stream);

@@ -497,3 +497,39 @@ def test_uniformity_enforcement_config4_and_batch(B):
         assert same_kps(kg2, ko2) and np.array_equal(dg, do), f
     ctx.set_uniformity(0.0)
     ctx.close()
+
+
+def test_c_abi_argument_validation(B, ctx):
+    """Bad arguments come back as error codes with a message, never as a crash or a silent result."""
+    L = B.load_library()
+    img = np.zeros((64, 64), np.uint8)
+    out = np.zeros(16, B.KEYPOINT)
+    n = C.c_int(-1)
+
+    def detect(w=64, h=64, stride=64, thr=70, octaves=3, imgp=img.ctypes.data, outp=out.ctypes.data, cap=16):
+        return L.brisk_hip_detect(ctx._h, imgp, w, h, stride, thr, octaves, 1, None, 0, outp, cap, C.byref(n))
+
+    assert detect() == 0 and n.value == 0
+    assert detect(w=0) == 1 and detect(h=-3) == 1 and detect(w=8192) == 1          # BRISK_HIP_ERR_ARG
+    assert detect(stride=32) == 1
+    assert detect(octaves=9) == 1 and detect(octaves=-1) == 1
+    assert detect(thr=19) == 5 and detect(thr=256) == 5                              # BRISK_HIP_ERR_THRESHOLD
+    assert detect(imgp=None) == 1 and detect(outp=None) == 1 and detect(cap=-1) == 1
+    assert L.brisk_hip_last_error(ctx._h)                                            # a message is always there
+    assert L.brisk_hip_detect(None, img.ctypes.data, 64, 64, 64, 70, 3, 1, None, 0, out.ctypes.data, 16, C.byref(n)) == 1
+    ext = B.BriskDescriptorExtractor()
+    desc = np.zeros((4, 48), np.uint8)
+    kp = np.zeros(4, B.KEYPOINT)
+    m = C.c_int(4)
+    assert L.brisk_hip_describe(ctx._h, ext._h, img.ctypes.data, 64, 64, 64, kp.ctypes.data, C.byref(m), desc.ctypes.data, 16, 1, 1) == 1  # pitch < 48
+    m = C.c_int(-1)
+    assert L.brisk_hip_describe(ctx._h, ext._h, img.ctypes.data, 64, 64, 64, kp.ctypes.data, C.byref(m), desc.ctypes.data, 48, 1, 1) == 1
+    assert L.brisk_hip_set_capacity(ctx._h, 10, 10) == 1
+    assert L.brisk_hip_set_uniformity(ctx._h, 0.5, 10) == 1 and L.brisk_hip_set_uniformity(ctx._h, 10.0, 0) == 1
+    assert L.brisk_hip_set_uniformity(ctx._h, 0.0, 1) == 0
+    h = C.c_void_p()
+    assert L.brisk_hip_pattern_create(ctx._h, 3, 1.0, C.byref(h)) != 0              # only versions 1 and 2 exist
+    assert L.brisk_hip_pattern_create_from_text(ctx._h, b"not a pattern", 1.0, C.byref(h)) != 0
+    # the context still works
+    k = B.BriskFeatureDetector(70, 3).detect(synth.frame_vga(1))
+    assert len(k) > 100

@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """bench.py - frames/sec detect+describe @1080p on N MI355X GPUs (BASELINE.json metric).
 
-A "step" is one pass of the hot path (pyramid -> AGAST detect -> NMS/refine -> integral -> describe) over one
-batch of synthetic 1080p frames that already sit in HBM (BASELINE config 2: Appendix-C recipe, 4 octaves,
-threshold 80, ~1k keypoints/frame).  Frames shard over ranks (one process per GPU, no data-path collective in the
-detect/describe path itself); with N > 1 every step ends with the RCCL gather of the packed keypoints+descriptors
-to rank 0 that BASELINE config 3 describes.  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path (pyramid -> AGAST detect -> NMS/refine -> describe) over one batch of synthetic
+1080p frames that already sit in HBM (BASELINE config 2: Appendix-C recipe, 4 octaves, threshold 80, ~1k keypoints per
+frame).  The batch of a step is `--batch x --inner` frames (default 256 x 32 = 8192 per GPU): the engine takes it in
+chunks of `--batch` frames through one workspace, so that a step is ~0.1-0.2 s of GPU work and the timed region
+lasts seconds (clocks settled), while the per-chunk time stays comparable between rounds (`config.ms_per_chunk`).
+
+Launch: `python bench.py --gpus N ...` starts N ranks itself (fresh child processes, one per GPU, before anything has
+touched the GPU) unless it already runs under a launcher (RANK set, e.g. `python -m torch.distributed.run`).  Frames
+shard over ranks with no data-path collective; with N > 1 every chunk ends with the asynchronous RCCL gather of the
+keypoints + descriptors to rank 0 that BASELINE config 3 describes.  Default is weak scaling (fixed frames per GPU);
+`--frames 512` is config 3 literally: 512 frames split by sharding.shard_frames (strong scaling).
+`--dry --backend gloo` runs the same launcher / rendezvous / sharding / gather / timing plumbing on CPU tensors without
+the engine (CI without a GPU: tests/test_bench_launcher.py).
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -21,103 +31,250 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 W, H, OCTAVES, THRESHOLD = 1920, 1080, 4, 80
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable with a float4 copy
+METRIC = "frames/sec detect+describe @1080p (1/2/4/8 GPU); % HBM roofline"
 
 
-def algorithmic_bytes(w, h, octaves, kp):
-    """SURVEY §8(d) stage model.  Returns (total per frame, detect-kernel bytes per frame)."""
+def layer_sizes(w, h, octaves):
     sizes = [(w, h)]
     if octaves:
         sizes.append((2 * (w // 3), 2 * (h // 3)))
         for i in range(2, 2 * octaves):
             sizes.append((sizes[i - 2][0] // 2, sizes[i - 2][1] // 2))
-    px = [a * b for a, b in sizes]
+    return sizes
+
+
+def algorithmic_bytes(w, h, octaves, kp):
+    """SURVEY §8(d) stage model (every stage reads its inputs once and writes its outputs once), bytes per frame.
+    Returned per kernel group of the engine: the groups partition the model's S1..S5 (sum == the survey's total)."""
+    px = [a * b for a, b in layer_sizes(w, h, octaves)]
     P = sum(px)
     parents = sum(px[0 if i == 1 else i - 2] for i in range(1, len(px)))
-    s1 = parents + (P - px[0])
-    s2 = 2 * P
-    s3 = P + 28 * kp
-    s4 = px[0] + 4 * (w + 1) * (h + 1)
-    s5 = kp * 8524
-    return s1 + s2 + s3 + s4 + s5, s2
+    groups = {
+        "pyramid": parents + (P - px[0]),          # S1
+        "detect": 2 * P,                           # S2: threshold map + detection + score
+        "nms": P + 28 * kp,                        # S3: NMS / refinement
+        "integral": px[0] + 4 * (w + 1) * (h + 1),  # S4
+        "describe": kp * 8524,                     # S5: K (2*66*(4*1+12*4) + 2*792 + 48 + 28)
+    }
+    return groups
 
 
-def cpu_baseline(frames, seconds_budget=20.0):
-    """Oracle (CPU port of the reference path) on a bounded sample of the same workload, one process per core."""
-    import multiprocessing as mp
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
-    sample = frames[:max(cores, 4)]
-    t0 = time.time()
-    _cpu_one(sample[0])                      # single-thread time for one frame
-    t1 = time.time() - t0
-    reps = max(1, int(seconds_budget / max(t1, 1e-3) / 2))
-    work = [sample[i % len(sample)] for i in range(min(cores * reps, cores * 8))]
-    ctx = mp.get_context("fork")
-    t0 = time.time()
-    with ctx.Pool(cores) as pool:
-        counts = pool.map(_cpu_one, work, chunksize=1)
-    dt = time.time() - t0
-    return {"value": round(len(work) / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "single_thread_fps": round(1.0 / t1, 3),
-            "sample": "%d synthetic 1080p frames (same recipe/params), oracle detect+describe, %d processes; "
-                      "mean %d keypoints/frame" % (len(work), cores, int(np.mean(counts)))}
-
-
-_EXT = None
-
-
-def _cpu_one(img):
-    global _EXT
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (CPU port of the reference path) on the GPU box's host cores.  The worker processes are
+# forked BEFORE this process loads torch / HIP, build their own extractor and frames, and then wait; the measurement
+# itself is a steady-state window (every worker loops over its frames until the deadline), so process start-up, table
+# construction and frame generation are outside the timed interval.
+# ------------------------------------------------------------------------------------------------------------------
+def _cpu_worker(idx, conn, nframes):
+    import numpy as np  # noqa: F401
     import oracle_lib as O
-    if _EXT is None:
-        _EXT = O.Extractor()
-    k = O.detect(img, THRESHOLD, OCTAVES)
-    k2, _ = _EXT.compute(img, k)
-    return len(k2)
+    import synth
+    ext = O.Extractor()
+    frames = [synth.frame_1080p(500000 + idx * 16 + i) for i in range(nframes)]
+
+    def one(img):
+        k = O.detect(img, THRESHOLD, OCTAVES)
+        k2, _ = ext.compute(img, k)
+        return len(k2)
+
+    one(frames[0])  # warm-up (page faults, lazy binding)
+    conn.send(("ready", idx))
+    while True:
+        msg = conn.recv()
+        if msg[0] == "quit":
+            return
+        seconds = msg[1]
+        n = 0
+        kp = 0
+        t0 = time.perf_counter()
+        while True:
+            kp += one(frames[n % len(frames)])
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                break
+        conn.send(("done", n, dt, kp))
+
+
+class CpuBaseline:
+    def __init__(self, max_workers=256, frames_per_worker=3):
+        import multiprocessing as mp
+        self.cores = max(1, min(len(os.sched_getaffinity(0)), max_workers))
+        ctx = mp.get_context("fork")
+        self.procs, self.conns = [], []
+        for i in range(self.cores):
+            a, b = ctx.Pipe()
+            p = ctx.Process(target=_cpu_worker, args=(i, b, frames_per_worker), daemon=True)
+            p.start()
+            b.close()
+            self.procs.append(p)
+            self.conns.append(a)
+
+    def _window(self, conns, seconds):
+        for c in conns:
+            c.send(("go", seconds))
+        res = [c.recv() for c in conns]
+        fps = [r[1] / r[2] for r in res]
+        frames = sum(r[1] for r in res)
+        kps = sum(r[3] for r in res)
+        return fps, frames, kps
+
+    def measure(self, single_seconds=3.0, all_seconds=8.0):
+        for c in self.conns:  # every worker has built its tables and frames
+            assert c.recv()[0] == "ready"
+        fps1, n1, _ = self._window(self.conns[:1], single_seconds)
+        fps, n, kps = self._window(self.conns, all_seconds)
+        for c in self.conns:
+            c.send(("quit",))
+        for p in self.procs:
+            p.join(timeout=10)
+        model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        agg = sum(fps)
+        return {"value": round(agg, 2), "unit": "frames/s", "cores": self.cores, "kind": "port",
+                "single_thread_fps": round(fps1[0], 3), "per_core_fps_all_busy": round(agg / self.cores, 3),
+                "cpu_model": model,
+                "sample": "oracle detect+describe on synthetic 1080p frames (same recipe/params), one process per core "
+                          "(%d), steady-state window of %.0f s after start-up (tables, frames, one warm-up frame outside "
+                          "the window): %d frames, mean %d keypoints/frame; single-thread window %.0f s alone: %d frames"
+                          % (self.cores, all_seconds, n, kps // max(n, 1), single_seconds, n1)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh child ranks, started before this process touches torch / HIP
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    children = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "BRISK_BENCH_CHILD": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                         stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = children[0].communicate()
+    rcs = [children[0].returncode] + [c.wait() for c in children[1:]]
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %r\n" % (rcs,))
+        sys.exit(1)
+    lines = [ln for ln in out0.decode().splitlines() if ln.strip().startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
+        sys.exit(1)
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+
+
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per engine call (chunk) per GPU")
+    ap.add_argument("--inner", type=int, default=32, help="chunks per step: a step is batch x inner frames per GPU")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="BASELINE config 3: this many frames in total per step, split over the ranks by "
+                         "sharding.shard_frames (strong scaling); 0 = weak scaling with --batch x --inner per GPU")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per GPU (ring)")
+    ap.add_argument("--streams", type=int, default=1, help="internal stream slices per chunk (1..8)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --dry)")
+    ap.add_argument("--dry", action="store_true", help="no engine, no GPU: launcher / sharding / gather / timing plumbing only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-fed (host frames) measurement")
+    ap.add_argument("--force-gather", action="store_true", help="run the RCCL result gather even with one rank (self-test)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results become wrong)")
+    ap.add_argument("--pattern-version", type=int, default=2)
+    return ap.parse_args(argv)
 
 
 def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args.gpus, argv)
     # Exactly ONE line may reach stdout (the JSON).  Libraries (RCCL prints a version banner at exit) write to the
     # C-level stdout, so fd 1 is pointed at stderr for the whole run and the JSON is written to the saved fd.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
-    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames per GPU (ring)")
-    ap.add_argument("--streams", type=int, default=1, help="internal stream slices per batch (1..8)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-gather", action="store_true", help="run the RCCL result gather even with one rank (self-test)")
-    ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results become wrong)")
-    ap.add_argument("--pattern-version", type=int, default=2, help="2 = default 66-point pattern (the metric's workload), 1 = legacy 60-point pattern (timing experiments)")
-    args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
 
+    # the CPU baseline workers are forked before torch / HIP exist in this process (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry:
+        cpu = CpuBaseline()
+
+    import numpy as np
     import torch
     import torch.distributed as dist
-    import synth
-    import ethzasl_brisk_amd as B
+    from ethzasl_brisk_amd import sharding
 
-    if world > 1 or args.force_gather:
+    use_dist = world > 1 or args.force_gather
+    ctl = None  # gloo control group: barriers, timing reduction and the collective "keep the gather?" decision
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dry:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        ctl = dist.new_group(backend="gloo")
+        assert dist.get_world_size() == args.gpus
+
+    # ---- work split
+    if args.frames:
+        mine = sharding.shard_frames(args.frames, rank, world)
+        chunk = len(mine)
+        chunk_max = max(len(sharding.shard_frames(args.frames, r, world)) for r in range(world))
+        inner = 1
+        scaling = "strong"
+        frames_per_step_total = args.frames
+    else:
+        mine = list(range(args.batch))
+        chunk = chunk_max = args.batch
+        inner = args.inner
+        scaling = "weak"
+        frames_per_step_total = args.batch * args.inner * world
+    assert chunk > 0, "rank without frames"
+
+    if args.dry:
+        return dry_run(args, rank, world, chunk, chunk_max, inner, scaling, frames_per_step_total, ctl, real_stdout)
+
+    import synth
+    import ethzasl_brisk_amd as B
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    # ---- synthetic frame ring, resident in HBM before the timed region
-    nd = max(1, min(args.distinct, args.batch))
-    host = np.stack([synth.frame_1080p(rank * 100000 + i) for i in range(nd)])
+    # ---- synthetic frame ring, resident in HBM before the timed region (frame seed = global frame index)
+    nd = max(1, min(args.distinct, chunk))
+    seeds = [(mine[i] if args.frames else rank * 100000 + i) for i in range(nd)]
+    host = np.stack([synth.frame_1080p(s) for s in seeds])
     ring = torch.from_numpy(host).to(dev)
-    idx = torch.arange(args.batch, device=dev) % nd
-    frames = ring[idx].contiguous()          # [batch, H, W] u8 in HBM
+    idx = torch.arange(chunk, device=dev) % nd
+    frames = ring[idx].contiguous()          # [chunk, H, W] u8 in HBM
     del ring
 
     ctx = B.Context(local_rank)
@@ -125,141 +282,261 @@ def main():
     ctx.debug_set_flags(args.debug_flags)
     ext = B.BriskDescriptorExtractor(version=args.pattern_version, context=ctx)
     # everything below runs on ONE explicit torch stream: the engine's launches, the slab copies of the gather and
-    # (through torch.distributed's stream synchronisation) the RCCL transfers are ordered on it.  (The legacy NULL
-    # stream would make the engine fall back to its own non-blocking stream, which torch's work is not ordered with.)
+    # (through torch.distributed's stream synchronisation) the RCCL transfers are ordered on it.
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
     strings = ext.descriptorSize()
 
-    # result buffers as torch views (for the multi-GPU gather)
-    def step():
-        ctx.detect_describe_batch(ext, frames.data_ptr(), args.batch, W, H, W * H, W, THRESHOLD, OCTAVES, stream)
+    def run_chunk():
+        ctx.detect_describe_batch(ext, frames.data_ptr(), chunk, W, H, W * H, W, THRESHOLD, OCTAVES, stream)
 
     gather = None
     gather_note = ""
-    if world > 1 or args.force_gather:
-        step()                               # allocates the engine's result buffers
+    if use_dist:
+        run_chunk()                          # allocates the engine's result buffers
         torch.cuda.synchronize()
-        gather = ResultGather(ctx, args.batch, strings, dev, rank, world)
+        gather = ResultGather(ctx, chunk, strings, dev, rank, world, chunk_max)
 
-    try:
-        for _ in range(args.warmup):
-            step()
+    def step():
+        for _ in range(inner):
+            run_chunk()
             if gather:
                 gather.run()
+
+    ok = 1
+    try:
+        for _ in range(max(args.warmup, 1) if gather else args.warmup):
+            step()
         torch.cuda.synchronize()
-    except Exception as e:                   # a failing collective must not take the throughput measurement with it
+    except Exception as e:
         if gather is None or args.force_gather:
             raise
-        print("result gather failed in warm-up (%r): measuring without it" % (e,), file=sys.stderr)
-        gather = None
-        gather_note = " [RCCL gather failed in warm-up and was left out: %s]" % type(e).__name__
-        torch.cuda.synchronize()
-    assert ctx.batch_status(args.batch) == 0 or args.debug_flags
+        print("rank %d: result gather failed in warm-up (%r)" % (rank, e), file=sys.stderr)
+        ok = 0
+    if ctl is not None:
+        # the decision is collective and taken on the gloo control group: either every rank keeps the gather or none
+        # does.  A broken RCCL communicator is never reused (barriers and the timing reduction run on gloo).
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
+        if int(flag.item()) == 0 and gather is not None:
+            gather = None
+            gather_note = " [RCCL gather failed in warm-up on some rank and was left out on all ranks]"
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                sys.exit(3)
+    assert ctx.batch_status(chunk) == 0 or args.debug_flags
     if gather:
-        gather.check_kpad()
-    kps0, _ = ctx.batch_download(0, True, strings)
-    mean_kp = float(np.mean([len(ctx.batch_download(f, True, strings)[0]) for f in range(min(args.batch, 8))]))
+        gather.check_kpad(ctl)
+        run_chunk()
+        gather.run()                         # slabs of the final size exist before the timed region
+        gather.finish()
+        torch.cuda.synchronize()
+    mean_kp = float(np.mean([len(ctx.batch_download(f, True, strings)[0]) for f in range(min(chunk, 8))]))
 
     ctx.profile_enable(True)
-    if world > 1:
-        dist.barrier()
+    if ctl is not None:
+        dist.barrier(group=ctl)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if gather:
-            gather.run()
     if gather:
         gather.finish()                      # the last transfers are part of the timed region
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if ctl is not None:
+        dist.barrier(group=ctl)
     dt = time.perf_counter() - t0
     stage_ms, ncalls = ctx.profile_read()
-    fpl = ctx.profile_frames_per_launch() or args.batch   # frames per timed kernel launch (one stream slice)
+    fpl = ctx.profile_frames_per_launch() or chunk   # frames per timed kernel launch (one stream slice)
     ctx.profile_enable(False)
 
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if ctl is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         dt = float(t.item())
 
-    total_frames = args.batch * args.steps * world
+    total_frames = frames_per_step_total * args.steps
     fps = total_frames / dt
-    per_frame_bytes, detect_bytes = algorithmic_bytes(W, H, OCTAVES, int(round(mean_kp)))
-    det_ms = stage_ms.get("k_detect", 0.0)
-    achieved = (detect_bytes * fpl) / (det_ms * 1e-3) / 1e9 if det_ms > 0 else 0.0
+    groups = algorithmic_bytes(W, H, OCTAVES, int(round(mean_kp)))
+    per_frame_bytes = sum(groups.values())
+    traffic = load_traffic(ctx)
+    kgroups = kernel_groups(stage_ms, groups, fpl, traffic)
+    dom = max(kgroups, key=lambda k: kgroups[k]["ms"])
     out = {
-        "metric": "frames/sec detect+describe @1080p (1/2/4/8 GPU); % HBM roofline",
+        "metric": METRIC,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "1080p synthetic textured stream (SURVEY App. C recipe, 300 rects), 4 octaves, "
                                "AGAST threshold 80, default 66-point pattern (48-byte descriptors)",
-                   "frames_per_step_per_gpu": args.batch, "stream_slices": args.streams, "frames_per_kernel_launch": fpl, "distinct_frames_per_gpu": nd,
+                   "frames_per_step_per_gpu": chunk * inner, "frames_per_step_total": frames_per_step_total,
+                   "chunk_frames": chunk, "chunks_per_step": inner,
+                   "ms_per_chunk": round(dt / args.steps / inner * 1e3, 4),
+                   "timed_region_s": round(dt, 3),
+                   "stream_slices": args.streams, "frames_per_kernel_launch": fpl, "distinct_frames_per_gpu": nd,
                    "mean_keypoints_per_frame": round(mean_kp, 1),
-                   "parallelism": "frames sharded over %d rank(s)%s" % (world, (", asynchronous RCCL gather of keypoints+descriptors to rank 0 each step (overlaps the next batch)" if (world > 1 and gather) else "") + gather_note),
+                   "parallelism": "frames sharded over %d rank(s)%s" % (world, (", asynchronous RCCL gather of keypoints+descriptors to rank 0 after every chunk (overlaps the next chunk)" if (world > 1 and gather) else "") + gather_note),
                    "algorithmic_MB_per_frame": round(per_frame_bytes / 1e6, 3),
                    "pipeline_achieved_GBps": round(per_frame_bytes * fps / 1e9, 2),
                    "pipeline_frac_of_hbm_peak": round(per_frame_bytes * fps / 1e9 / (HBM_PEAK_GBS * world), 5),
-                   "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-                   "stage_note": "HIP-event intervals on the launch stream; k_integral_final runs on a second stream beside "
-                                 "k_tie_resolve / k_finalize / k_desc_prepare, so its own entry is only the join and those "
-                                 "three entries include the sharing (kernel durations: profiles/*kernel_stats*)"},
-        "roofline": {"bound": "hbm", "kernel": "k_detect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(fpl),
-                     "algorithmic_bytes_per_launch": detect_bytes * fpl, "avg_launch_ms": round(det_ms, 4),
-                     "launches_timed": ncalls},
+                   "stage_ms_per_chunk": {k: round(v, 4) for k, v in stage_ms.items()},
+                   "kernel_groups": kgroups,
+                   "stage_note": "HIP-event intervals on the launch stream of one chunk (average over the timed "
+                                 "region); kernel_groups: algorithmic bytes of SURVEY 8(d) per group x frames per launch / "
+                                 "interval; hbm_bytes from the committed rocprofv3 PMC passes when they belong to this "
+                                 "kernel revision, else null"},
+        "roofline": dict(kgroups[dom], bound="hbm", kernel=dom, peak=HBM_PEAK_GBS, unit="GB/s",
+                         launches_timed=ncalls),
     }
+    out["roofline"]["achieved"] = out["roofline"].pop("GBps")
+    out["roofline"]["traffic"] = out["roofline"].pop("hbm_bytes")
+    out["roofline"]["algorithmic_bytes_per_launch"] = out["roofline"].pop("alg_bytes")
+    out["roofline"]["avg_launch_ms"] = out["roofline"].pop("ms")
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(list(host[:16]))
+        if world == 1 and not args.no_host_fed and hasattr(ctx, "detect_describe_batch_host"):
+            out["config"]["pcie_fed"] = host_fed(ctx, ext, host, chunk, strings)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu.measure()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if gather is not None and args.force_gather:
-        # self-test on content the previous steps did not produce (a stale or half-written slab would show)
-        frames2 = frames.flip(0).contiguous()
-        ctx.detect_describe_batch(ext, frames2.data_ptr(), args.batch, W, H, W * H, W, THRESHOLD, OCTAVES, stream)
-        gather.run()
-        gather.finish()
-        torch.cuda.synchronize()
-    if gather is not None and rank == 0 and args.force_gather:
+        gather_selftest(ctx, ext, frames, chunk, strings, stream, gather, rank)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def kernel_groups(stage_ms, groups, fpl, traffic):
+    """{group: {alg_bytes, ms, GBps, frac, hbm_bytes}} per launch (fpl frames), from the engine's per-stage HIP-event
+    intervals.  Stage names -> groups of SURVEY 8(d)."""
+    stage_of = {"pyramid": ["k_pyramid"], "detect": ["k_detect"],
+                "nms": ["k_classify_refine", "k_tie_resolve", "k_finalize"],
+                "integral": ["k_integral_final"], "describe": ["k_desc_prepare", "k_describe"]}
+    out = {}
+    for g, stages in stage_of.items():
+        ms = sum(stage_ms.get(s, 0.0) for s in stages)
+        alg = groups[g] * fpl
+        gb = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        hb = None
+        if traffic and g in traffic.get("groups", {}):
+            hb = round(traffic["groups"][g] * fpl / traffic["frames_per_launch"])
+        out[g] = {"alg_bytes": alg, "ms": round(ms, 4), "GBps": round(gb, 2), "frac": round(gb / HBM_PEAK_GBS, 5),
+                  "hbm_bytes": hb}
+    return out
+
+
+def load_traffic(ctx):
+    """HBM bytes per kernel group from the committed rocprofv3 PMC passes (profiles/traffic.json, made by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs); only used when it was measured on this kernel
+    revision (brisk_hip_kernel_revision), otherwise None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        d = json.load(open(p))
+        rev = ctx.kernel_revision() if hasattr(ctx, "kernel_revision") else None
+        if d.get("kernel_revision") != rev:
+            return None
+        return d
+    except Exception:
+        return None
+
+
+def host_fed(ctx, ext, host, chunk, strings, seconds=1.5):
+    """PCIe-fed rate: frames start in pinned HOST memory, the engine's host-batch entry moves them in
+    chunks over a copy stream while the previous chunk computes.  Never `value`: reported next to it."""
+    import numpy as np
+    import torch
+    n = min(chunk, 256)
+    src = torch.from_numpy(np.ascontiguousarray(host[np.arange(n) % len(host)])).pin_memory()
+    ctx.detect_describe_batch_host(ext, src.data_ptr(), n, W, H, W * H, W, THRESHOLD, OCTAVES)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        ctx.detect_describe_batch_host(ext, src.data_ptr(), n, W, H, W * H, W, THRESHOLD, OCTAVES)
+        reps += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"fps": round(reps * n / dt, 1), "frames_per_call": n,
+            "note": "frames in pinned host memory, H2D on a copy stream overlapped with compute; results stay in HBM"}
+
+
+def gather_selftest(ctx, ext, frames, chunk, strings, stream, gather, rank):
+    import numpy as np
+    import torch
+    # content the previous steps did not produce (a stale or half-written slab would show)
+    frames2 = frames.flip(0).contiguous()
+    ctx.detect_describe_batch(ext, frames2.data_ptr(), chunk, W, H, W * H, W, THRESHOLD, OCTAVES, stream)
+    gather.run()
+    gather.finish()
+    torch.cuda.synchronize()
+    if rank == 0:
         ac, gk, gd = gather.last
         k0, d0 = ctx.batch_download(0, True, strings)
         n0 = int(ac[0, 0].item())
         assert n0 == len(k0) and np.array_equal(gk[0][0, :n0].cpu().numpy().view(np.uint32), np.stack([k0[f].view(np.uint32) for f in k0.dtype.names], 1))
         assert np.array_equal(gd[0][0, :n0].cpu().numpy(), d0)
-        fl = args.batch - 1                      # a frame whose content differs from the timed steps' frame at that slot
+        fl = chunk - 1                      # a frame whose content differs from the timed steps' frame at that slot
         kl, dl = ctx.batch_download(fl, True, strings)
         nl = int(ac[0, fl].item())
         assert nl == len(kl) and np.array_equal(gd[0][fl, :nl].cpu().numpy(), dl)
         print('gather self-test ok', file=sys.stderr)
-    if world > 1 or args.force_gather:
+
+
+def dry_run(args, rank, world, chunk, chunk_max, inner, scaling, frames_per_step_total, ctl, real_stdout):
+    """The N-rank plumbing without the engine: every rank fabricates result buffers on the CPU, the steps run the same
+    PaddedGather pipeline, barriers and max-over-ranks timing; value is 0 (nothing was measured)."""
+    import torch
+    import torch.distributed as dist
+    from ethzasl_brisk_amd import sharding
+    cap, strings, pitch = 32, 48, 64
+    g = torch.Generator().manual_seed(rank)
+    counts = torch.randint(0, cap + 1, (chunk,), generator=g, dtype=torch.int32)
+    kps = torch.randn((chunk, cap, 7), generator=g)
+    desc = torch.randint(0, 256, (chunk, cap, pitch), generator=g, dtype=torch.uint8)
+    pg = sharding.PaddedGather(counts, kps, desc, strings, cap, dst=0, frames_max=chunk_max) if world > 1 else None
+    if ctl is not None:
+        dist.barrier(group=ctl)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for _ in range(inner):
+            if pg:
+                pg.start()
+    last = pg.finish() if pg else None
+    if ctl is not None:
+        dist.barrier(group=ctl)
+    dt = time.perf_counter() - t0
+    if ctl is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+        dt = float(t.item())
+    if rank == 0:
+        if last is not None:
+            ac, gk, gd = last
+            assert ac.shape == (world, chunk_max) and len(gk) == world and torch.equal(ac[0][:chunk], counts)
+        out = {"metric": METRIC, "value": 0.0, "unit": "frames/s", "n_gpus": dist.get_world_size() if world > 1 else 1,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
+               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "dry": True,
+               "config": {"workload": "DRY RUN: launcher / sharding / gather plumbing on CPU tensors, no engine",
+                          "frames_per_step_total": frames_per_step_total, "chunk_frames": chunk, "chunks_per_step": inner,
+                          "shard_sizes": [len(sharding.shard_frames(args.frames, r, world)) for r in range(world)] if args.frames else None,
+                          "backend": args.backend}}
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1:
         dist.destroy_process_group()
-
-
-def load_traffic(frames_per_launch):
-    """HBM bytes per k_detect launch from the committed rocprofv3 PMC passes (profiles/traffic_k_detect.json, made by
-    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs), scaled to this run's frames per launch; or None."""
-    p = os.path.join(ROOT, "profiles", "traffic_k_detect.json")
-    try:
-        d = json.load(open(p))
-        return round(d["hbm_bytes_per_launch"] * frames_per_launch / d["frames_per_launch"])
-    except Exception:
-        return None
 
 
 class ResultGather:
     """RCCL gather of the packed per-frame results to rank 0 (BASELINE config 3).  Counts first (all_gather),
     then one gather of fixed-size padded slabs sized to the largest rank's payload."""
 
-    def __init__(self, ctx, batch, strings, dev, rank, world):
+    def __init__(self, ctx, batch, strings, dev, rank, world, frames_max=None):
         import ctypes as C
         import torch
         self.torch = torch
         self.dev, self.rank, self.world, self.batch, self.strings = dev, rank, world, batch, strings
         self.kpad = 1536
+        self.frames_max = frames_max or batch
         self.pg = None
         self.last = None
         L = ctx._L
@@ -286,26 +563,26 @@ class ResultGather:
         return torch.as_tensor(a, device=self.dev)
 
     def run(self):
-        """fixed-size slabs, no host synchronisation inside the timed region; asynchronous: the transfer of this batch
-        overlaps the next batch's kernels (sharding.PaddedGather), finish() waits for what is still in flight"""
+        """fixed-size slabs, no host synchronisation inside the timed region; asynchronous: the transfer of this chunk
+        overlaps the next chunk's kernels (sharding.PaddedGather), finish() waits for what is still in flight"""
         from ethzasl_brisk_amd import sharding
         if self.pg is None or self.pg.kpad != self.kpad:
             if self.pg is not None:
                 self.pg.finish()
-            self.pg = sharding.PaddedGather(self.counts, self.kps, self.desc, self.strings, self.kpad, dst=0)
+            self.pg = sharding.PaddedGather(self.counts, self.kps, self.desc, self.strings, self.kpad, dst=0, frames_max=self.frames_max)
         self.pg.start()
 
     def finish(self):
         if self.pg is not None:
             self.last = self.pg.finish()
 
-    def check_kpad(self):
+    def check_kpad(self, ctl):
         """outside the timed region: the slab size must cover every frame of the batch (rounded up to 128)"""
         self.finish()
-        m = self.counts.max().to(self.torch.int64).reshape(1)
+        m = self.counts.max().to(self.torch.int64).reshape(1).cpu()
         if self.world > 1:  # every rank must cut slabs of the same shape
             import torch.distributed as dist
-            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=ctl)
         self.kpad = min(self.cap, (int(m.item()) + 127) // 128 * 128)
 
 

@@ -86,11 +86,15 @@ class PaddedGather:
     with async_op=True, so the transfer of batch i runs on the communicator's stream while batch i+1 is computed;
     a slot is reused only after its previous transfer has been waited for.  finish() waits for everything in flight
     and returns the last batch's (counts [world, B], keypoints [world][B, kpad, 7], descriptors [world][B, kpad, strings])
-    on dst, None elsewhere."""
+    on dst, None elsewhere (B = frames_max, the largest shard; a rank's surplus rows have count 0)."""
 
-    def __init__(self, counts, kps, desc, strings, kpad, dst=0, group=None, slots=2):
+    def __init__(self, counts, kps, desc, strings, kpad, dst=0, group=None, slots=2, frames_max=None):
         self.counts, self.kps, self.desc = counts, kps, desc
         self.strings, self.kpad, self.dst, self.group = strings, kpad, dst, group
+        # ranks may own shards of different sizes (512 frames over 3 ranks): every rank cuts slabs for `frames_max`
+        # frames (the largest shard), the frames it does not own stay at count 0
+        self.bmax = int(frames_max) if frames_max else int(counts.shape[0])
+        assert self.bmax >= counts.shape[0]
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.slots = [None] * slots
@@ -98,11 +102,11 @@ class PaddedGather:
         self.last = None
 
     def _alloc(self):
-        b = self.counts.shape[0]
+        b = self.bmax
         dev = self.counts.device
-        sl = {"c": torch.empty((b,), device=dev, dtype=self.counts.dtype),
-              "k": torch.empty((b, self.kpad, self.kps.shape[2]), device=dev, dtype=self.kps.dtype),
-              "d": torch.empty((b, self.kpad, self.strings), device=dev, dtype=self.desc.dtype),
+        sl = {"c": torch.zeros((b,), device=dev, dtype=self.counts.dtype),
+              "k": torch.zeros((b, self.kpad, self.kps.shape[2]), device=dev, dtype=self.kps.dtype),
+              "d": torch.zeros((b, self.kpad, self.strings), device=dev, dtype=self.desc.dtype),
               "ac": torch.empty((self.world * b,), device=dev, dtype=self.counts.dtype), "works": [], "kpad": self.kpad}
         if self.rank == self.dst:
             sl["gk"] = [torch.empty_like(sl["k"]) for _ in range(self.world)]
@@ -123,9 +127,10 @@ class PaddedGather:
             self._wait(sl)
         if sl is None or sl["kpad"] != self.kpad:
             sl = self.slots[j] = self._alloc()
-        sl["c"].copy_(self.counts)
-        sl["k"].copy_(self.kps[:, :self.kpad, :])
-        sl["d"].copy_(self.desc[:, :self.kpad, :self.strings])
+        b = self.counts.shape[0]
+        sl["c"][:b].copy_(self.counts)
+        sl["k"][:b].copy_(self.kps[:, :self.kpad, :])
+        sl["d"][:b].copy_(self.desc[:, :self.kpad, :self.strings])
         sl["works"] = [dist.all_gather_into_tensor(sl["ac"], sl["c"], group=self.group, async_op=True),
                        dist.gather(sl["k"], sl["gk"], dst=self.dst, group=self.group, async_op=True),
                        dist.gather(sl["d"], sl["gd"], dst=self.dst, group=self.group, async_op=True)]

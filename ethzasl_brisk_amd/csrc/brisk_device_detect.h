@@ -189,6 +189,73 @@ BRISK_HD int brisk_b2_fast(int tc, float k) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pre-gate of k_detect: a cheap NECESSARY condition for a detection, evaluated for two horizontally
+// adjacent pixels at once in packed 16-bit lanes (v_pk_* on the device, plain C on the host).
+//   * a 9-of-16 arc contains two adjacent compass points, i.e. one of {N, S} and one of {W, E} (ring radius 3);
+//   * the disc contrast t (37 px, brisk-layer.cc:278-598) is at least the range t5 of {c, N, S, W, E}, all of
+//     which lie in the disc, and the adaptive threshold b2 = clamp(t, 10, 230) * thr / 100 (oast9-16.cc:79-100)
+//     is monotone in t, so b2 >= b2' := (clamp(t5, 10, 230) * K) >> s with K / 2^s <= thr / 100.
+// A detection therefore implies  min(max(dN, dS), max(dW, dE)) > b2'  (bright arc) or
+// max(min(dN, dS), min(dW, dE)) < -b2'  (dark arc), d* = compass pixel - centre.  About 1.3 % of the pixels of
+// the benchmark frames pass; only those get the exact 37-pixel contrast and the segment test.
+// ---------------------------------------------------------------------------------------------
+struct BriskPregate {
+  uint32_t K;      // multiplier in both 16-bit lanes
+  uint32_t shift;  // shift in both 16-bit lanes
+};
+BRISK_HD BriskPregate brisk_pregate_make(int thr) {
+  int s = 8;
+  while (s > 0 && 230 * ((thr << s) / 100) > 65535) --s;
+  const uint32_t K = (uint32_t)((thr << s) / 100);
+  BriskPregate g;
+  g.K = K | (K << 16);
+  g.shift = (uint32_t)s | ((uint32_t)s << 16);
+  return g;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef short brisk_v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short brisk_v2u __attribute__((ext_vector_type(2)));
+#define BRISK_PK_S(x) __builtin_bit_cast(brisk_v2s, (uint32_t)(x))
+#define BRISK_PK_U(x) __builtin_bit_cast(brisk_v2u, (uint32_t)(x))
+__device__ __forceinline__ uint32_t brisk_pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (brisk_v2s)(BRISK_PK_S(a) - BRISK_PK_S(b))); }
+__device__ __forceinline__ uint32_t brisk_pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(BRISK_PK_S(a), BRISK_PK_S(b))); }
+__device__ __forceinline__ uint32_t brisk_pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(BRISK_PK_S(a), BRISK_PK_S(b))); }
+__device__ __forceinline__ uint32_t brisk_pk_mul(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (brisk_v2u)(BRISK_PK_U(a) * BRISK_PK_U(b))); }
+__device__ __forceinline__ uint32_t brisk_pk_shr(uint32_t a, uint32_t s) { return __builtin_bit_cast(uint32_t, (brisk_v2u)(BRISK_PK_U(a) >> BRISK_PK_U(s))); }
+#else
+#define BRISK_PK_LANES(expr)                                                              \
+  const int a0 = (int16_t)(a & 0xFFFFu), a1 = (int16_t)(a >> 16);                         \
+  const int b0 = (int16_t)(b & 0xFFFFu), b1 = (int16_t)(b >> 16);                         \
+  (void)a0; (void)a1; (void)b0; (void)b1;                                                 \
+  return expr;
+static inline uint32_t brisk_pk_pack(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+static inline uint32_t brisk_pk_sub(uint32_t a, uint32_t b) { BRISK_PK_LANES(brisk_pk_pack(a0 - b0, a1 - b1)) }
+static inline uint32_t brisk_pk_max(uint32_t a, uint32_t b) { BRISK_PK_LANES(brisk_pk_pack(a0 > b0 ? a0 : b0, a1 > b1 ? a1 : b1)) }
+static inline uint32_t brisk_pk_min(uint32_t a, uint32_t b) { BRISK_PK_LANES(brisk_pk_pack(a0 < b0 ? a0 : b0, a1 < b1 ? a1 : b1)) }
+static inline uint32_t brisk_pk_mul(uint32_t a, uint32_t b) { return brisk_pk_pack((int)(((a & 0xFFFFu) * (b & 0xFFFFu)) & 0xFFFFu), (int)(((a >> 16) * (b >> 16)) & 0xFFFFu)); }
+static inline uint32_t brisk_pk_shr(uint32_t a, uint32_t s) { return brisk_pk_pack((int)((a & 0xFFFFu) >> (s & 0xFFFFu)), (int)((a >> 16) >> (s >> 16))); }
+#endif
+
+// c, n, s, w, e: centre and compass pixels (ring radius 3) of two pixels, one per 16-bit lane (values 0..255).
+// Returns 1 in the lane of a pixel that passes the pre-gate, 0 otherwise.
+BRISK_HD uint32_t brisk_pregate_pair(uint32_t c, uint32_t n, uint32_t s, uint32_t w, uint32_t e, const BriskPregate& g) {
+  const uint32_t dN = brisk_pk_sub(n, c), dS = brisk_pk_sub(s, c), dW = brisk_pk_sub(w, c), dE = brisk_pk_sub(e, c);
+  const uint32_t mxNS = brisk_pk_max(dN, dS), mnNS = brisk_pk_min(dN, dS);
+  const uint32_t mxWE = brisk_pk_max(dW, dE), mnWE = brisk_pk_min(dW, dE);
+  const uint32_t vb = brisk_pk_min(mxNS, mxWE);   // > b2: two adjacent compass points brighter
+  const uint32_t vd = brisk_pk_max(mnNS, mnWE);   // < -b2: two adjacent compass points darker
+  const uint32_t hi = brisk_pk_max(brisk_pk_max(mxNS, mxWE), 0u), lo = brisk_pk_min(brisk_pk_min(mnNS, mnWE), 0u);
+  const uint32_t t5 = brisk_pk_sub(hi, lo);       // range of {c, N, S, W, E} <= disc contrast
+  const uint32_t lower = (uint32_t)BRISK_LOWER_THRESHOLD * 0x10001u, upper = (uint32_t)BRISK_UPPER_THRESHOLD * 0x10001u;
+  const uint32_t tc = brisk_pk_min(brisk_pk_max(t5, lower), upper);
+  const uint32_t b2p = brisk_pk_shr(brisk_pk_mul(tc, g.K), g.shift);
+  const uint32_t ev = brisk_pk_max(vb, brisk_pk_sub(0u, vd));
+  const uint32_t f = brisk_pk_sub(ev, b2p);       // > 0 <=> passes
+  return brisk_pk_min(brisk_pk_max(f, 0u), 0x10001u);
+}
+
 // Per-pixel detection (agast/src/oast9-16.cc:79-100 + SURVEY F5): returns D (= thrmap value) if
 // (x,y) is an AGAST point at threshold thr, else 0.  Caller guarantees 3 <= x <= w-4, 3 <= y <= h-4.
 BRISK_HD int brisk_detect_px(const uint8_t* p, int s, int thr) {

@@ -264,35 +264,48 @@ __global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __res
 
 // ------------------------------------------------------------------------------------------------
 // k_detect: per-pixel threshold map (37-px disc contrast, brisk-layer.cc:278-598) + contrast-adaptive OAST 9_16
-// segment test (oast9-16.cc:79-100).  Dominant kernel of the pipeline.
+// segment test (oast9-16.cc:79-100).
 //
 // Tile = 64x64 output pixels per 256-thread workgroup; the (64+8)x(64+6) u8 halo tile is staged in LDS with
-// coalesced dword loads issued back to back.  Phase A (all pixels): every thread owns 4 columns x 4 rows, pulls its
-// 10x12-byte window out of LDS with 30 dword reads, computes the disc min/max in registers (the horizontal partial
-// extrema of a window row are shared by the four output rows) and applies a cascade of necessary conditions for a
-// 9-of-16 arc (contrast gate, range gate, two adjacent compass points); survivors (a few %) are compacted into an
-// LDS queue with wave ballots.  Phase B (survivors only): one lane per queued pixel runs the closed-form segment
-// test.  A detection writes its contrast score into the score-state map (all zero otherwise, see k_smap_clear) and
-// appends a candidate to the frame's list (order is restored later from the (layer,y,x) key).
+// coalesced dword loads issued back to back (row pitch 80 bytes: the four row groups of a wave start 80 dwords
+// apart, so the window reads of a wave are bank-conflict free).
+// Phase A (all pixels, dense): the pre-gate brisk_pregate_pair - a necessary condition for a detection that needs
+// only the centre and the four compass pixels of the ring - on two pixels per instruction (packed 16-bit lanes;
+// byte pairs are pulled out of the window dwords with v_perm_b32).  Every thread owns 4 columns x 4 rows; the
+// pixels that pass (about 1 %) are compacted into an LDS queue: per-thread bit mask, wave prefix sum of the
+// counts (DPP), one LDS atomic per wave.
+// Phase B (survivors only, one lane each): exact 37-pixel disc contrast -> adaptive threshold -> closed-form
+// segment test on the ring (a subset of the disc pixels already in registers).  A detection writes its contrast
+// score into the score-state map (all zero otherwise, see k_smap_clear) and appends a candidate to the frame's
+// list (order is restored later from the (layer,y,x) key).
 // grid.x enumerates the tiles of all layers, grid.y = frame.
 // ------------------------------------------------------------------------------------------------
-#define DT_W 64
-#define DT_R BRISK_DETECT_ROWS_PER_THREAD
+#define DT_W BRISK_DETECT_TILE_W
 #define DT_H BRISK_DETECT_TILE_H
-#define DT_LW (DT_W + 8)
+#define DT_R BRISK_DETECT_ROWS_PER_THREAD
+#define DT_PITCH 80                                   // LDS row pitch (bytes)
+#define DT_ROWDW ((DT_W + 8) / 4)                     // data dwords per tile row
 #define DT_LH (DT_H + 6)
 #define DT_WR (DT_R + 6)                              // window rows per thread
-#define DT_NLD ((DT_LH * (DT_LW / 4) + 255) / 256)    // staging dwords per thread
-static_assert(DT_H == 16 * DT_R, "256 threads = 16 column groups x 16 row groups");
+#define DT_NLD ((DT_LH * DT_ROWDW + 255) / 256)       // staging dwords per thread
+static_assert(DT_H == 16 * DT_R && DT_W == 64, "256 threads = 16 column groups x 16 row groups");
 
-// byte i (-4..7, relative to the thread's first pixel) of a 3-dword row window
-#define DT_B(w0, w1, w2, i) ((int)((((i) < 0) ? ((w0) >> (8 * ((i) + 4))) : ((i) < 4) ? ((w1) >> (8 * (i))) : ((w2) >> (8 * ((i)-4)))) & 0xFFu))
+// inclusive prefix sum over the 64 lanes of a wave (DPP row shifts + row broadcasts, no LDS)
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
 
 __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, const uint8_t* __restrict__ pyr,
                                                  uint16_t* __restrict__ smap, BriskCand* __restrict__ cand,
                                                  BriskFrameCounters* __restrict__ counters, int cand_cap) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[DT_LH * DT_LW];
-  __shared__ unsigned queue[DT_H * DT_W];                              // idx | D << 16 | b2 << 24
+  __shared__ __attribute__((aligned(16))) uint8_t tile[DT_LH * DT_PITCH];
+  __shared__ uint16_t queue[DT_H * DT_W];                              // tile-local pixel index py * 64 + px
   __shared__ int qcount;
   const int frame = blockIdx.y;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so blocks with equal blockIdx.x % 8
@@ -312,127 +325,117 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   const int thr = G.threshold;
 
   // stage halo tile: rows y0-3 .. y0+DT_H+2, columns x0-4 .. x0+DT_W+3 (dword granularity).  All loads of a thread
-  // are issued before the first LDS write (one memory round trip per workgroup instead of one per load): the
-  // loads are unconditional on clamped addresses, out-of-image dwords are zeroed on the way to LDS.
+  // are issued before the first LDS write (one memory round trip per workgroup instead of one per load) on clamped
+  // addresses.  What lands in the tile for positions outside the image is irrelevant: no valid centre (3 px inside
+  // the border) reads it, and phase B rejects the invalid centres phase A may let through.
   {
     unsigned stg[DT_NLD];
-    unsigned keep = 0;
 #pragma unroll
     for (int k = 0; k < DT_NLD; ++k) {
-      const int i = min((int)threadIdx.x + k * 256, DT_LH * (DT_LW / 4) - 1);
-      const int r = i / (DT_LW / 4), c4 = i % (DT_LW / 4);
-      const int gy = y0 - 3 + r, gx = x0 - 4 + c4 * 4;
-      if (gy >= 0 && gy < h && gx >= 0 && gx < stride) keep |= 1u << k;
-      const int cy = min(max(gy, 0), h - 1), cx = min(max(gx, 0), stride - 4);
+      const int i = min((int)threadIdx.x + k * 256, DT_LH * DT_ROWDW - 1);
+      const int r = i / DT_ROWDW, c4 = i % DT_ROWDW;
+      const int cy = min(max(y0 - 3 + r, 0), h - 1), cx = min(max(x0 - 4 + c4 * 4, 0), stride - 4);
       stg[k] = *reinterpret_cast<const unsigned*>(img + (long)cy * stride + cx);
     }
 #pragma unroll
     for (int k = 0; k < DT_NLD; ++k) {
       const int i = threadIdx.x + k * 256;
-      if (i < DT_LH * (DT_LW / 4)) *reinterpret_cast<unsigned*>(&tile[i * 4]) = ((keep >> k) & 1u) ? stg[k] : 0u;
+      const int r = i / DT_ROWDW, c4 = i % DT_ROWDW;
+      if (i < DT_LH * DT_ROWDW) *reinterpret_cast<unsigned*>(&tile[r * DT_PITCH + c4 * 4]) = stg[k];
     }
   }
   if (threadIdx.x == 0) qcount = 0;
   __syncthreads();
 
-  // ---- phase A: 4 columns x DT_R rows per thread.  Window rows 0..DT_R+5 = image rows gy-3 .. gy+DT_R+2; the
-  // horizontal partial extrema (widths 3, 5, 7 around each of the 4 columns) of a window row are shared by all the
-  // output rows that use it:
-  //   output row k (gy+k) = max(h3[k], h5[k+1], h7[k+2], h7[k+3], h7[k+4], h5[k+5], h3[k+6])      (same for min)
+  // ---- phase A: 4 columns x DT_R rows per thread.  Window rows 0..DT_R+5 = image rows gy-3 .. gy+DT_R+2, three
+  // dwords each = image columns gx-4 .. gx+7.  Pairs of horizontally adjacent pixels as packed 16-bit lanes:
+  //   C*  the pixels themselves (they are centre for output row r-3, N for r, S for r-6),
+  //   W*/E*  the pixels 3 to the left / right of them (centre rows only).
   const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * DT_R;
+  const int lane = threadIdx.x & 63;
   {
+    const BriskPregate pg = brisk_pregate_make(thr);
     unsigned R[DT_WR][3];
 #pragma unroll
     for (int r = 0; r < DT_WR; ++r) {
-      const unsigned* p = reinterpret_cast<const unsigned*>(&tile[(ly + r) * DT_LW + lx]);
+      const unsigned* p = reinterpret_cast<const unsigned*>(&tile[(ly + r) * DT_PITCH + lx]);
       R[r][0] = p[0]; R[r][1] = p[1]; R[r][2] = p[2];
     }
-    int X3[DT_WR][4], N3[DT_WR][4], X5[DT_WR][4], N5[DT_WR][4], X7[DT_WR][4], N7[DT_WR][4];
+    unsigned CA[DT_WR], CB[DT_WR];
 #pragma unroll
     for (int r = 0; r < DT_WR; ++r) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int a = DT_B(R[r][0], R[r][1], R[r][2], j - 1), b = DT_B(R[r][0], R[r][1], R[r][2], j), c = DT_B(R[r][0], R[r][1], R[r][2], j + 1);
-        X3[r][j] = max(max(a, b), c);
-        N3[r][j] = min(min(a, b), c);
-        if (r >= 1 && r <= DT_WR - 2) {
-          const int d = DT_B(R[r][0], R[r][1], R[r][2], j - 2), e = DT_B(R[r][0], R[r][1], R[r][2], j + 2);
-          X5[r][j] = max(max(X3[r][j], d), e);
-          N5[r][j] = min(min(N3[r][j], d), e);
-        } else { X5[r][j] = 0; N5[r][j] = 0; }
-        if (r >= 2 && r <= DT_WR - 3) {
-          const int f = DT_B(R[r][0], R[r][1], R[r][2], j - 3), g = DT_B(R[r][0], R[r][1], R[r][2], j + 3);
-          X7[r][j] = max(max(X5[r][j], f), g);
-          N7[r][j] = min(min(N5[r][j], f), g);
-        } else { X7[r][j] = 0; N7[r][j] = 0; }
-      }
+      CA[r] = __builtin_amdgcn_perm(0u, R[r][1], 0x0c010c00u);   // (col 0, col 1)
+      CB[r] = __builtin_amdgcn_perm(0u, R[r][1], 0x0c030c02u);   // (col 2, col 3)
     }
-    // Gates as straight-line code on WAVE MASKS: every comparison is one v_cmp whose 64-bit lane mask is combined
-    // with scalar and/or (no exec-mask branches, no boolean VGPRs); the combined mask is the compaction ballot.
-    const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
-    const float kthr = brisk_b2_factor(thr);
-    const int lane = threadIdx.x & 63;
+    unsigned m = 0;  // bit 2*rr + (j >> 1) + 16 * (j & 1): pixel (row rr, column j) of the thread passes
 #pragma unroll
-    for (int half = 0; half < DT_R / 2; ++half) {  // two output rows per compaction round
-      unsigned long long mk[8];
-      unsigned entry_k[8];
-      int total = 0;
-#pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        const int rr = half * 2 + r2;
-        const int gy = y0 + ly + rr;
-        const bool row_ok = (gy >= 3) && (gy <= h - 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int gx = x0 + lx + j;
-          int mx = max(max(X3[rr][j], X5[rr + 1][j]), X7[rr + 2][j]);
-          mx = max(max(mx, X7[rr + 3][j]), X7[rr + 4][j]);
-          mx = max(max(mx, X5[rr + 5][j]), X3[rr + 6][j]);
-          int mn = min(min(N3[rr][j], N5[rr + 1][j]), N7[rr + 2][j]);
-          mn = min(min(mn, N7[rr + 3][j]), N7[rr + 4][j]);
-          mn = min(min(mn, N5[rr + 5][j]), N3[rr + 6][j]);
-          const int tt = mx - mn;
-          const int tc = min(max(tt, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
-          const int b2 = brisk_b2_fast(tc, kthr);  // == (tc * thr) / 100 without quarter-rate integer multiplies
-          const int c = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j);
-          const int cb = c + b2, c_b = c - b2;
-          // a 9-of-16 arc contains two adjacent compass points (W, N, E, S)
-          const int pw = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j - 3), pe = DT_B(R[rr + 3][0], R[rr + 3][1], R[rr + 3][2], j + 3);
-          const int pn = DT_B(R[rr][0], R[rr][1], R[rr][2], j), ps = DT_B(R[rr + 6][0], R[rr + 6][1], R[rr + 6][2], j);
-          const unsigned long long m_in = __ballot(row_ok && gx >= 3 && gx <= w - 4 && tt >= cmp);
-          const unsigned long long m_rng = __ballot(mx > cb) | __ballot(mn < c_b);
-          const unsigned long long bw = __ballot(pw > cb), bn = __ballot(pn > cb), be = __ballot(pe > cb), bs = __ballot(ps > cb);
-          const unsigned long long dw = __ballot(pw < c_b), dn = __ballot(pn < c_b), de = __ballot(pe < c_b), ds = __ballot(ps < c_b);
-          // two adjacent compass points of one polarity: (N or S) and (W or E)
-          const unsigned long long m = m_in & m_rng & (((bn | bs) & (bw | be)) | ((dn | ds) & (dw | de)));
-          mk[r2 * 4 + j] = m;
-          total += __popcll(m);
-          // (b2 < 255 for every survivor: the range gate cannot pass otherwise, so 8 bits hold it)
-          entry_k[r2 * 4 + j] = (unsigned)((ly + rr) * DT_W + lx + j) | ((unsigned)tt << 16) | ((unsigned)b2 << 24);
-        }
-      }
-      if (total) {  // compaction: one LDS atomic per wave for 8 pixel slots
-        int qb = 0;
-        if (lane == 0) qb = atomicAdd(&qcount, total);
-        qb = __builtin_amdgcn_readfirstlane(qb);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if ((mk[k] >> lane) & 1ull) queue[qb + __popcll(mk[k] & ((1ull << lane) - 1ull))] = entry_k[k];
-          qb += __popcll(mk[k]);
-        }
+    for (int rr = 0; rr < DT_R; ++rr) {
+      const int ci = rr + 3;
+      const unsigned WA = __builtin_amdgcn_perm(0u, R[ci][0], 0x0c020c01u);        // (col -3, col -2)
+      const unsigned WB = __builtin_amdgcn_perm(R[ci][1], R[ci][0], 0x0c040c03u);  // (col -1, col 0)
+      const unsigned EA = __builtin_amdgcn_perm(R[ci][2], R[ci][1], 0x0c040c03u);  // (col 3, col 4)
+      const unsigned EB = __builtin_amdgcn_perm(0u, R[ci][2], 0x0c020c01u);        // (col 5, col 6)
+      const unsigned gA = brisk_pregate_pair(CA[ci], CA[rr], CA[rr + 6], WA, EA, pg);
+      const unsigned gB = brisk_pregate_pair(CB[ci], CB[rr], CB[rr + 6], WB, EB, pg);
+      m |= gA << (2 * rr);
+      m |= gB << (2 * rr + 1);
+    }
+    // compaction: wave prefix sum of the per-thread counts, one LDS atomic per wave
+    const int cnt = __popc(m);
+    const int incl = wave_inclusive_scan(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total) {
+      int qb = 0;
+      if (lane == 0) qb = atomicAdd(&qcount, total);
+      qb = __builtin_amdgcn_readfirstlane(qb);
+      int pos = qb + incl - cnt;
+      while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        const int k = bit & 15, half = bit >> 4;
+        queue[pos++] = (uint16_t)((ly + (k >> 1)) * DT_W + lx + ((k & 1) << 1) + half);
       }
     }
   }
   __syncthreads();
 
-  // ---- phase B: closed-form segment test on the survivors
+  // ---- phase B: exact contrast + closed-form segment test on the survivors (one lane each)
   const int nq = qcount;
+  const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
+  const float kthr = brisk_b2_factor(thr);
   for (int i = threadIdx.x; i < nq; i += 256) {
-    const unsigned e = queue[i];
-    const int idx = e & 0xFFFF, D = (e >> 16) & 0xFF, b2 = e >> 24;
+    const int idx = queue[i];
     const int py = idx / DT_W, px = idx % DT_W;
-    if (brisk_oast9_16_M(&tile[(py + 3) * DT_LW + px + 4], DT_LW) > b2) {
-      const int gx = x0 + px, gyy = y0 + py;
+    const int gx = x0 + px, gyy = y0 + py;
+    if (gx < 3 || gyy < 3 || gx > w - 4 || gyy > h - 4) continue;
+    const uint8_t* p = &tile[(py + 3) * DT_PITCH + px + 4];
+    // the 37 disc pixels, row by row (half widths 1, 2, 3, 3, 3, 2, 1)
+    int v[7][7];
+#pragma unroll
+    for (int dy = -3; dy <= 3; ++dy) {
+      const int hw = (dy == -3 || dy == 3) ? 1 : (dy == -2 || dy == 2) ? 2 : 3;
+#pragma unroll
+      for (int dx = -3; dx <= 3; ++dx) v[dy + 3][dx + 3] = (dx >= -hw && dx <= hw) ? (int)p[dy * DT_PITCH + dx] : -1;
+    }
+    int mx = 0, mn = 255;
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 7; ++dx)
+        if (v[dy][dx] >= 0) { mx = max(mx, v[dy][dx]); mn = min(mn, v[dy][dx]); }
+    const int tt = mx - mn;
+    if (tt < cmp) continue;
+    const int tc = min(max(tt, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
+    const int b2 = brisk_b2_fast(tc, kthr);  // == (tc * thr) / 100 without quarter-rate integer multiplies
+    const int c = v[3][3];
+    if (mx - c <= b2 && c - mn <= b2) continue;  // no ring pixel can differ by more than b2
+    int d[16];  // ring order of brisk_oast9_16_M (agast/include/agast/oast9-16.h:99-116)
+    d[0] = v[3][0] - c;  d[1] = v[2][0] - c;  d[2] = v[1][1] - c;  d[3] = v[0][2] - c;
+    d[4] = v[0][3] - c;  d[5] = v[0][4] - c;  d[6] = v[1][5] - c;  d[7] = v[2][6] - c;
+    d[8] = v[3][6] - c;  d[9] = v[4][6] - c;  d[10] = v[5][5] - c; d[11] = v[6][4] - c;
+    d[12] = v[6][3] - c; d[13] = v[6][2] - c; d[14] = v[5][1] - c; d[15] = v[4][0] - c;
+    if (brisk_oast9_16_M_from_d(d) > b2) {
+      const int D = tt;
       // the score-state map is all zero between batches (k_smap_clear): only detections are written
       smap[base + (long)gyy * stride + gx] = (uint16_t)D;
       const int ci = atomicAdd(&counters[frame].ncand, 1);

@@ -312,6 +312,45 @@ int emul_b2_fast_mismatches(void) {
   return bad;
 }
 
+// k_detect phase A: the packed pre-gate must be a NECESSARY condition of brisk_detect_px.  Walks an image exactly as
+// the kernel pairs the pixels (two horizontally adjacent centres per call) and returns the number of detections the
+// pre-gate would have dropped (must be 0); *survivors receives the number of pixels that pass it.
+int emul_pregate_missed(const uint8_t* img, int w, int h, int stride, int thr, long* survivors) {
+  const BriskPregate pg = brisk_pregate_make(thr);
+  int missed = 0;
+  long pass = 0;
+  auto px = [&](int x, int y) -> uint32_t { return img[(long)y * stride + x]; };
+  for (int y = 3; y <= h - 4; ++y)
+    for (int x = 3; x <= w - 4; x += 2) {
+      const int x1 = (x + 1 <= w - 4) ? x + 1 : x;  // second lane of the pair (duplicate of the first at the edge)
+      auto pair = [&](int dx, int dy) { return px(x + dx, y + dy) | (px(x1 + dx, y + dy) << 16); };
+      const uint32_t g = brisk_pregate_pair(pair(0, 0), pair(0, -3), pair(0, 3), pair(-3, 0), pair(3, 0), pg);
+      const int lanes[2] = {x, x1};
+      for (int k = 0; k < 2; ++k) {
+        if (k == 1 && x1 == x) break;
+        const bool gate = ((g >> (16 * k)) & 0xFFFFu) != 0;
+        pass += gate;
+        if (!gate && brisk_detect_px(img + (long)y * stride + lanes[k], stride, thr)) ++missed;
+      }
+    }
+  if (survivors) *survivors = pass;
+  return missed;
+}
+// the pre-gate's lower bound of the adaptive threshold: (tc * K) >> s <= (tc * thr) / 100 and no 16-bit overflow
+int emul_pregate_bound_violations(void) {
+  int bad = 0;
+  for (int thr = 1; thr <= 255; ++thr) {
+    const BriskPregate pg = brisk_pregate_make(thr);
+    const unsigned K = pg.K & 0xFFFFu, s = pg.shift & 0xFFFFu;
+    if ((pg.K >> 16) != K || (pg.shift >> 16) != s) ++bad;
+    for (unsigned tc = 10; tc <= 230; ++tc) {
+      if (tc * K > 65535u) ++bad;
+      if ((int)((tc * K) >> s) > (int)(tc * thr) / 100) ++bad;
+    }
+  }
+  return bad;
+}
+
 // closed-form scores vs the oracle's bisection (per pixel)
 int emul_oast_Kp(const uint8_t* p, int stride) { return brisk_Kp_from_M(brisk_oast9_16_M(p, stride)); }
 int emul_agast58_Kp(const uint8_t* p, int stride) { return brisk_Kp_from_M(brisk_agast5_8_M(p, stride)); }

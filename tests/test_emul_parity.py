@@ -150,3 +150,27 @@ def test_tie_decision_on_eight_lanes_equals_serial():
     L = E.lib()
     L.emul_tie_decide_mismatches.argtypes = [__import__("ctypes").c_uint, __import__("ctypes").c_int]
     assert L.emul_tie_decide_mismatches(7, 200000) == 0
+
+
+def test_pregate_is_a_necessary_condition():
+    """k_detect phase A (packed 16-bit pre-gate on the compass pixels) must never drop a pixel that
+    brisk_detect_px (the exact per-pixel detection) accepts: synthetic frames, pure noise, saturated blocks, all
+    threshold regimes; and its threshold bound must hold for every (threshold, contrast)."""
+    import ctypes as C
+    L = E.lib()
+    L.emul_pregate_missed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
+    assert L.emul_pregate_bound_violations() == 0
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    blocks = (np.kron(rng.integers(0, 2, (30, 40)), np.ones((8, 8))) * 255).astype(np.uint8)
+    soft = np.clip(blocks.astype(np.int32) // 2 + rng.integers(-20, 21, blocks.shape), 0, 255).astype(np.uint8)
+    for img in (synth.frame_vga(1), synth.gen(333, 201, 3, 40), noise, blocks, soft):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape
+        for thr in (1, 5, 20, 40, 80, 130, 255):
+            n = C.c_long(0)
+            assert L.emul_pregate_missed(img.ctypes.data, w, h, w, thr, C.byref(n)) == 0, (img.shape, thr)
+    n = C.c_long(0)
+    img = np.ascontiguousarray(synth.frame_vga(1))
+    L.emul_pregate_missed(img.ctypes.data, 640, 480, 640, 80, C.byref(n))
+    assert n.value < 0.05 * 640 * 480          # the gate is selective (a few % of the pixels pass)

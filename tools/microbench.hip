@@ -3,7 +3,6 @@
 //  (1) clk per wave-instruction of the integer VALU ops k_detect is built from, at 1..8 waves per SIMD
 //      (one workgroup per CU, 4*W waves, every wave runs an unrolled stream of independent instructions;
 //      cycles from s_memtime, so the result does not depend on the DVFS clock)
-//  (2) v_cmp -> SGPR -> s_and/s_or chains (the "gates as wave masks" idiom)
 //  (3) LDS window reads with the row pitch of the k_detect tile (72 vs 80 bytes)
 //  (4) the box's own streaming ceiling: float4 copy / read-only pass over 2 GiB
 // Prints one JSON object.
@@ -95,22 +94,6 @@ DEF_OP(33, "v_pk_min_u16 %0, %0, %1")
 DEF_OP(34, "v_pk_max_i16 %0, %0, %1")
 DEF_OP(35, "v_pk_add_u16 %0, %0, %1")
 DEF_OP(36, "v_pk_sub_i16 %0, %0, %1")
-DEF_OP(37, "v_pk_sub_u16 %0, %0, %1 clamp")
-DEF_OP(38, "v_pk_mul_lo_u16 %0, %0, %1")
-DEF_OP(39, "v_pk_lshrrev_b16 %0, 1, %0")
-DEF_OP(40, "v_pk_max_f16 %0, %0, %1")
-DEF_OP(41, "v_pk_min_f16 %0, %0, %1")
-DEF_OP(42, "v_pk_add_f16 %0, %0, %1")
-DEF_OP(43, "v_pk_fma_f16 %0, %0, %1, %2")
-DEF_OP(44, "v_max_u16 %0, %0, %1")
-DEF_OP(45, "v_max_f16 %0, %0, %1")
-DEF_OP(46, "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
-DEF_OP(47, "v_max_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
-DEF_OP(48, "v_cmp_gt_i32 vcc, %0, %1")
-DEF_OP(49, "v_cmp_gt_i32 s[20:21], %0, %1")
-DEF_OP(50, "v_cmp_gt_i32 s[20:21], %0, %1\n s_and_b64 s[22:23], s[22:23], s[20:21]")
-DEF_OP(51, "s_and_b64 s[22:23], s[22:23], s[20:21]")
-DEF_OP(52, "v_max3_i32 %0, %0, %1, %2\n v_max3_i32 %0, %0, %1, %2\n v_cmp_gt_i32 s[20:21], %0, %1\n s_and_b64 s[22:23], s[22:23], s[20:21]")
 
 typedef void (*op_kernel_t)(unsigned long long*, int*, int);
 struct OpDesc { const char* name; op_kernel_t fn; int ninstr; };
@@ -152,22 +135,6 @@ static const OpDesc g_ops[] = {
     {"v_pk_max_i16", k_op_34, 1},
     {"v_pk_add_u16", k_op_35, 1},
     {"v_pk_sub_i16", k_op_36, 1},
-    {"v_pk_sub_u16_clamp", k_op_37, 1},
-    {"v_pk_mul_lo_u16", k_op_38, 1},
-    {"v_pk_lshrrev_b16", k_op_39, 1},
-    {"v_pk_max_f16", k_op_40, 1},
-    {"v_pk_min_f16", k_op_41, 1},
-    {"v_pk_add_f16", k_op_42, 1},
-    {"v_pk_fma_f16", k_op_43, 1},
-    {"v_max_u16", k_op_44, 1},
-    {"v_max_f16", k_op_45, 1},
-    {"v_add_u32_dpp_row_shr1", k_op_46, 1},
-    {"v_max_u32_sdwa_b1", k_op_47, 1},
-    {"v_cmp_gt_i32_vcc", k_op_48, 1},
-    {"v_cmp_gt_i32_sgpr", k_op_49, 1},
-    {"v_cmp+s_and", k_op_50, 2},
-    {"s_and_b64", k_op_51, 1},
-    {"2max3+cmp+s_and", k_op_52, 4},
 };
 
 // LDS window reads as in k_detect phase A: thread (cg = t & 15, rg = t >> 4) reads 3 dwords of 10 rows

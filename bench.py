@@ -97,10 +97,32 @@ def _cpu_worker(idx, conn, nframes):
         conn.send(("done", n, dt, kp))
 
 
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (cpu.max) - on the GPU
+    boxes 256 hardware threads are visible but the container's quota is 16 CPUs."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 class CpuBaseline:
     def __init__(self, max_workers=256, frames_per_worker=3):
         import multiprocessing as mp
-        self.cores = max(1, min(len(os.sched_getaffinity(0)), max_workers))
+        self.visible = len(os.sched_getaffinity(0))
+        self.cores = max(1, min(usable_cores(), max_workers))
         ctx = mp.get_context("fork")
         self.procs, self.conns = [], []
         for i in range(self.cores):
@@ -140,7 +162,7 @@ class CpuBaseline:
         agg = sum(fps)
         return {"value": round(agg, 2), "unit": "frames/s", "cores": self.cores, "kind": "port",
                 "single_thread_fps": round(fps1[0], 3), "per_core_fps_all_busy": round(agg / self.cores, 3),
-                "cpu_model": model,
+                "cpu_model": model, "hardware_threads_visible": self.visible,
                 "sample": "oracle detect+describe on synthetic 1080p frames (same recipe/params), one process per core "
                           "(%d), steady-state window of %.0f s after start-up (tables, frames, one warm-up frame outside "
                           "the window): %d frames, mean %d keypoints/frame; single-thread window %.0f s alone: %d frames"
@@ -395,6 +417,12 @@ def main():
     out["roofline"]["algorithmic_bytes_per_launch"] = out["roofline"].pop("alg_bytes")
     out["roofline"]["avg_launch_ms"] = out["roofline"].pop("ms")
     if rank == 0:
+        try:
+            cp, rd = ctx.stream_ceiling(1 << 30)
+            out["config"]["box_streaming_ceiling_GBps"] = {"float4_copy_read_plus_write": round(cp, 1),
+                                                           "float4_read_only": round(rd, 1)}
+        except Exception as e:  # reported, never fatal for the measurement
+            out["config"]["box_streaming_ceiling_GBps"] = "failed: %r" % (e,)
         if world == 1 and not args.no_host_fed and hasattr(ctx, "detect_describe_batch_host"):
             out["config"]["pcie_fed"] = host_fed(ctx, ext, host, chunk, strings)
         if cpu is not None:

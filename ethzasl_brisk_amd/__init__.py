@@ -29,6 +29,8 @@ ABI_SYMBOLS = [
     "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags",
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
     "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
+    "brisk_hip_reserve", "brisk_hip_detect_uniform", "brisk_hip_detect_describe_batch_host", "brisk_hip_stream_ceiling",
+    "brisk_hip_kernel_revision",
 ]
 
 
@@ -95,6 +97,14 @@ def load_library():
     L.brisk_hip_match_radius.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float,
                                          C.c_int, vp, vp]
     L.brisk_hip_match_knn_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.brisk_hip_reserve.argtypes = [vp, C.c_int, C.c_int]
+    L.brisk_hip_detect_uniform.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
+                                           C.c_double, C.c_int, vp, C.c_int, ip]
+    L.brisk_hip_detect_describe_batch_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
+                                                       C.c_int]
+    L.brisk_hip_stream_ceiling.argtypes = [vp, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.brisk_hip_kernel_revision.argtypes = []
+    L.brisk_hip_kernel_revision.restype = C.c_char_p
     _lib = L
     return L
 
@@ -177,6 +187,23 @@ class Context:
                                                            frame_pitch, row_pitch, threshold, octaves,
                                                            C.c_void_p(stream) if stream else None))
 
+    def detect_describe_batch_host(self, pattern, h_frames_ptr, nframes, w, h, frame_pitch, row_pitch, threshold, octaves):
+        """frames in (pinned) HOST memory: sliced H2D copies on a copy stream overlapped with compute"""
+        self.check(self._L.brisk_hip_detect_describe_batch_host(self._h, pattern._h, C.c_void_p(h_frames_ptr), nframes, w,
+                                                                h, frame_pitch, row_pitch, threshold, octaves))
+
+    def reserve(self, min_candidates, min_keypoints):
+        self.check(self._L.brisk_hip_reserve(self._h, int(min_candidates), int(min_keypoints)))
+
+    def stream_ceiling(self, nbytes=1 << 30):
+        """(copy GB/s counting read + write, read-only GB/s) of the engine's float4 streaming kernels on this box"""
+        a, b = C.c_double(), C.c_double()
+        self.check(self._L.brisk_hip_stream_ceiling(self._h, nbytes, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def kernel_revision(self):
+        return self._L.brisk_hip_kernel_revision().decode()
+
     def detect_batch(self, d_frames_ptr, nframes, w, h, frame_pitch, row_pitch, threshold, octaves, stream=None):
         self.check(self._L.brisk_hip_detect_batch(self._h, C.c_void_p(d_frames_ptr), nframes, w, h, frame_pitch,
                                                   row_pitch, threshold, octaves, C.c_void_p(stream) if stream else None))
@@ -231,10 +258,9 @@ class BriskFeatureDetector:
         out = np.zeros(capacity, KEYPOINT)
         n = C.c_int()
         c = self._ctx
-        c.set_uniformity(self.uniformityRadius, self.maxNumKpt)
-        c.check(c._L.brisk_hip_detect(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
-                                      int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0, _ptr(out),
-                                      capacity, C.byref(n)))
+        c.check(c._L.brisk_hip_detect_uniform(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
+                                              int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0,
+                                              self.uniformityRadius, self.maxNumKpt, _ptr(out), capacity, C.byref(n)))
         return out[:n.value].copy()
 
 

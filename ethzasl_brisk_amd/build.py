@@ -24,6 +24,16 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
+def kernel_revision():
+    """Short hash of everything that defines the device code (committed PMC data names the revision it measured)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h", ".inc")) and f != "brisk_capi.hip":
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
@@ -31,7 +41,7 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     extra = os.environ.get("BRISK_HIPCC_EXTRA", "").split()  # tuning experiments only (e.g. -DBRISK_DETECT_ROWS_PER_THREAD=2)
-    cmd = [hipcc] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + extra + ['-DBRISK_KERNEL_REV="%s"' % kernel_revision(), "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,7 +1,9 @@
 // brisk_capi.hip - implementation of the C ABI declared in include/brisk_hip.h.
 // Host side only: context / workspace management, pyramid geometry, H2D/D2H staging, kernel launches.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -16,7 +18,7 @@
 static_assert(sizeof(brisk_hip_keypoint) == 28 && sizeof(BriskKeyPoint) == 28, "cv::KeyPoint layout");
 
 struct brisk_hip_pattern {
-  brisk_hip_ctx* ctx;
+  int device;  // device the tables live on (usable from every context of that device)
   BriskPatternHost host;
   BriskPatternDev dev;  // device pointers
   void* blob;           // single device allocation backing dev.*
@@ -70,7 +72,28 @@ struct brisk_hip_ctx {
   size_t uni_items = 0;
   void* d_match = nullptr;  // workspace of brisk_hip_match_knn_device
   size_t match_bytes = 0;
+  // Calls share one workspace but may be issued on different streams: every call that uses the workspace first makes
+  // its stream wait for the end of the previous one (event recorded at the end of each call).
+  hipEvent_t done_ev = nullptr;
+  bool done_valid = false;
+  // host-fed batches: two device staging buffers filled over a copy stream while the previous slice computes
+  uint8_t* d_hstage[2] = {nullptr, nullptr};
+  size_t hstage_bytes = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copied_ev[2] = {nullptr, nullptr}, consumed_ev[2] = {nullptr, nullptr};
 };
+
+// the workspace is reused by every call: order this call's stream behind the previous call's work
+static int workspace_acquire(brisk_hip_ctx* c, hipStream_t s) {
+  if (c->done_valid && hipStreamWaitEvent(s, c->done_ev, 0) != hipSuccess) return BRISK_HIP_ERR_HIP;
+  return BRISK_HIP_OK;
+}
+static int workspace_release(brisk_hip_ctx* c, hipStream_t s) {
+  if (!c->done_ev && hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) return BRISK_HIP_ERR_HIP;
+  if (hipEventRecord(c->done_ev, s) != hipSuccess) return BRISK_HIP_ERR_HIP;
+  c->done_valid = true;
+  return BRISK_HIP_OK;
+}
 
 #define HIPCHK(ctx, call)                                                                       \
   do {                                                                                          \
@@ -230,9 +253,17 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
   free_buffers(c);
   hipFree(c->d_stage);
   if (c->d_match) hipFree(c->d_match);
+  if (c->done_ev) hipEventDestroy(c->done_ev);
+  for (int i = 0; i < 2; ++i) {
+    if (c->d_hstage[i]) hipFree(c->d_hstage[i]);
+    if (c->copied_ev[i]) hipEventDestroy(c->copied_ev[i]);
+    if (c->consumed_ev[i]) hipEventDestroy(c->consumed_ev[i]);
+  }
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   if (c->d_occ) hipFree(c->d_occ);
   if (c->d_uni_tmp) hipFree(c->d_uni_tmp);
   if (c->d_uni_order) hipFree(c->d_uni_order);
+  brisk_prof_destroy(&c->prof);
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->side_fork); hipEventDestroy(c->side_join); }
   if (c->sub_created) {
     for (int i = 0; i < 8; ++i) { hipStreamDestroy(c->sub[i]); hipEventDestroy(c->join_ev[i]); }
@@ -251,6 +282,17 @@ int brisk_hip_set_capacity(brisk_hip_ctx* ctx, int max_candidates, int max_keypo
   ctx->cand_cap = max_candidates;
   ctx->kp_cap = max_keypoints;
   ctx->tie_cap = max_candidates / 4 > 1024 ? max_candidates / 4 : 1024;
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_reserve(brisk_hip_ctx* ctx, int min_candidates, int min_keypoints) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (min_candidates > ctx->cand_cap) {
+    ctx->cand_cap = min_candidates;
+    if (min_candidates / 4 > ctx->tie_cap) ctx->tie_cap = min_candidates / 4;
+  }
+  if (min_keypoints > ctx->kp_cap) ctx->kp_cap = min_keypoints;
   return BRISK_HIP_OK;
 }
 
@@ -291,7 +333,7 @@ static int pattern_finish(brisk_hip_ctx* ctx, brisk_hip_pattern* p, bool ok, con
     delete p;
     return BRISK_HIP_ERR_PATTERN;
   }
-  p->ctx = ctx;
+  p->device = ctx->device;
   p->blob = nullptr;
   const int rc = upload_pattern(ctx, p);
   if (rc != BRISK_HIP_OK) {
@@ -326,7 +368,7 @@ int brisk_hip_pattern_create_from_text(brisk_hip_ctx* ctx, const char* ptn_text,
 
 void brisk_hip_pattern_destroy(brisk_hip_pattern* p) {
   if (!p) return;
-  if (p->ctx) hipSetDevice(p->ctx->device);
+  hipSetDevice(p->device);
   if (p->blob) hipFree(p->blob);
   delete p;
 }
@@ -343,21 +385,31 @@ int brisk_hip_pattern_tables(const brisk_hip_pattern* p, float* scale_list, int*
 }
 
 // ---- batch (device-resident) path ------------------------------------------------------------------
-static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes, int w, int h,
-                     long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* d_mask,
-                     long mask_frame_pitch, int mask_row_pitch, hipStream_t s, bool do_detect, bool do_describe) {
-  int rc = check_detect_args(ctx, w, h, threshold, octaves);
+struct BatchArgs {
+  const brisk_hip_pattern* pat;
+  int w, h, threshold, octaves;
+  long frame_pitch;
+  int row_pitch;
+  const uint8_t* d_mask;
+  long mask_frame_pitch;
+  int mask_row_pitch;
+  bool do_detect, do_describe;
+  double uni_radius;  // uniformity enforcement of this call (0 = off)
+  int uni_max;
+};
+
+// geometry, workspace, restoring the all-zero score-state map, profiler bookkeeping: once per batch, on stream s
+static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipStream_t s) {
+  int rc = check_detect_args(ctx, A.w, A.h, A.threshold, A.octaves);
   if (rc) return rc;
-  if (!d_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
-    return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  make_geometry(w, h, threshold, octaves, &ctx->G, &ctx->T);
+  make_geometry(A.w, A.h, A.threshold, A.octaves, &ctx->G, &ctx->T);
   ctx->G.debug_flags = ctx->debug_flags;
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
-  if (do_detect && ctx->uni_radius > 0.0) {
-    const float scaling = (float)(15.0 / (float)ctx->uni_radius);
-    const int oh = (int)(h * ceil(scaling) + 32), ow = (int)(w * ceil(scaling) + 32);
+  if (A.do_detect && A.uni_radius > 0.0) {
+    const float scaling = (float)(15.0 / (float)A.uni_radius);
+    const int oh = (int)(A.h * ceil(scaling) + 32), ow = (int)(A.w * ceil(scaling) + 32);
     const size_t need = (size_t)(((long)oh * ow + 255) / 256 * 256) * nframes + 64;
     const size_t items = (size_t)ctx->slots * ctx->kp_cap;
     if (need > ctx->occ_bytes || items > ctx->uni_items) {
@@ -366,19 +418,98 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
       if (ctx->d_uni_tmp) (void)hipFree(ctx->d_uni_tmp);
       if (ctx->d_uni_order) (void)hipFree(ctx->d_uni_order);
       ctx->d_occ = nullptr; ctx->d_uni_tmp = nullptr; ctx->d_uni_order = nullptr; ctx->occ_bytes = 0; ctx->uni_items = 0;
-      const size_t nb = need > ctx->occ_bytes ? need : ctx->occ_bytes;
-      HIPCHK(ctx, hipMalloc(&ctx->d_occ, nb));
+      HIPCHK(ctx, hipMalloc(&ctx->d_occ, need));
       HIPCHK(ctx, hipMalloc(&ctx->d_uni_tmp, items * sizeof(BriskKeyPoint)));
       HIPCHK(ctx, hipMalloc(&ctx->d_uni_order, items * sizeof(int)));
-      ctx->occ_bytes = nb; ctx->uni_items = items;
+      ctx->occ_bytes = need; ctx->uni_items = items;
     }
   }
+  rc = workspace_acquire(ctx, s);
+  if (rc) return fail(ctx, rc, "hipStreamWaitEvent failed");
   brisk_prof_begin_call(&ctx->prof);
-  if (do_detect) {
+  if (A.do_detect) {
     if (ctx->dirty_frames > 0) brisk_launch_smap_clear(ctx->dirtyG, ctx->B, ctx->dirty_frames, s);
     ctx->dirtyG = ctx->G;
     ctx->dirty_frames = nframes;
   }
+  return BRISK_HIP_OK;
+}
+
+// frames [f0, f0 + nf) of the batch: d_frames points at frame f0's image, results go to frame slots f0...
+static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_frames, long f0, int nf, hipStream_t si,
+                       BriskProfiler* prof, bool overlap_integral) {
+  const int nbands = (A.h + 63) / 64;
+  BriskDetectBuffers Bi = ctx->B;
+  Bi.pyr += f0 * ctx->G.pyr_elems;
+  Bi.smap += f0 * ctx->G.pyr_elems;
+  Bi.cand += f0 * Bi.cand_cap;
+  Bi.blocks += f0 * Bi.cand_cap * 64;
+  Bi.tie_idx += f0 * BRISK_MAX_LAYERS * Bi.tie_cap;
+  Bi.keys += f0 * Bi.cand_cap * 2;
+  Bi.counters += f0;
+  Bi.kp_out += f0 * Bi.kp_cap;
+  Bi.bandsum += f0 * nbands * Bi.istride;
+  BriskDescribeBuffers Di = ctx->D;
+  Di.integral += f0 * Di.iframe_elems;
+  Di.dkp += f0 * Bi.kp_cap;
+  Di.dscale += f0 * Bi.kp_cap;
+  Di.dperm += f0 * Bi.kp_cap;
+  Di.drec += f0 * Bi.kp_cap;
+  Di.desc += f0 * Bi.kp_cap * Di.desc_pitch;
+  BriskOverlap ov{};
+  const BriskOverlap* ovp = nullptr;
+  if (A.do_detect && A.do_describe && overlap_integral && ctx->overlap && !(ctx->debug_flags & 0x10000)) {
+    if (!ctx->side) {
+      // lowest priority: the detector's latency-bound kernels get their workgroups placed first, the
+      // bandwidth-bound integral kernel fills what they leave
+      int least = 0, greatest = 0;
+      HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
+      HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+      HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+    }
+    ov.side = ctx->side; ov.fork = ctx->side_fork; ov.join = ctx->side_join; ov.Dd = &Di;
+    ovp = &ov;
+  }
+  if (A.do_detect) {
+    brisk_launch_detect(ctx->G, ctx->T, Bi, nf, d_frames, A.frame_pitch, A.row_pitch,
+                        A.d_mask ? A.d_mask + f0 * A.mask_frame_pitch : nullptr, A.mask_frame_pitch, A.mask_row_pitch, si, prof, ovp);
+  }
+  if (A.do_detect && A.uni_radius > 0.0) {
+    // EnforceKeyPointUniformity as a post-filter of the detected keypoints (brisk_uniformity.hip)
+    const float scaling = (float)(15.0 / (float)A.uni_radius);
+    const int oh = (int)(A.h * ceil(scaling) + 32), ow = (int)(A.w * ceil(scaling) + 32);
+    const long occ_frame = ((long)oh * ow + 255) / 256 * 256;
+    brisk_launch_uniformity(Bi.kp_out, Bi.counters, ctx->d_uni_order + f0 * Bi.kp_cap, ctx->d_uni_tmp + f0 * Bi.kp_cap,
+                            ctx->d_occ + f0 * occ_frame, occ_frame, ow, Bi.kp_cap, scaling, A.uni_max, nf, si);
+  }
+  if (A.do_describe) {
+    BriskPatternDev P = A.pat->dev;
+    brisk_launch_describe(ctx->G, P, Bi, Di, nf, Bi.kp_out, &Bi.counters[0].nkp, sizeof(BriskFrameCounters), si, prof, ovp);
+  }
+  return BRISK_HIP_OK;
+}
+
+static int batch_end(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipStream_t s) {
+  if (ctx->prof.on) ctx->prof.calls++;
+  HIPCHK(ctx, hipGetLastError());
+  ctx->last_nframes = nframes;
+  ctx->last_has_desc = A.do_describe;
+  const int rc = workspace_release(ctx, s);
+  if (rc) return fail(ctx, rc, "hipEventRecord failed");
+  return BRISK_HIP_OK;
+}
+
+static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes, int w, int h,
+                     long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* d_mask,
+                     long mask_frame_pitch, int mask_row_pitch, hipStream_t s, bool do_detect, bool do_describe,
+                     double uni_radius = -1.0, int uni_max = 0) {
+  if (!d_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
+    return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
+  BatchArgs A{pat, w, h, threshold, octaves, frame_pitch, row_pitch, d_mask, mask_frame_pitch, mask_row_pitch, do_detect,
+              do_describe, uni_radius < 0.0 ? ctx->uni_radius : uni_radius, uni_radius < 0.0 ? ctx->uni_max : uni_max};
+  int rc = batch_begin(ctx, A, nframes, s);
+  if (rc) return rc;
   int nsub = ctx->nsub;
   if (nsub > 8) nsub = 8;
   if (nframes < 16 * nsub) nsub = nframes >= 32 ? 2 : 1;
@@ -391,7 +522,6 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
     ctx->sub_created = true;
   }
   if (nsub > 1) HIPCHK(ctx, hipEventRecord(ctx->fork_ev, s));
-  const int nbands = (h + 63) / 64;
   for (int i = 0; i < nsub; ++i) {
     const long f0 = (long)nframes * i / nsub, f1 = (long)nframes * (i + 1) / nsub;
     const int nf = (int)(f1 - f0);
@@ -401,66 +531,81 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
       si = ctx->sub[i];
       HIPCHK(ctx, hipStreamWaitEvent(si, ctx->fork_ev, 0));
     }
-    BriskDetectBuffers Bi = ctx->B;
-    Bi.pyr += f0 * ctx->G.pyr_elems;
-    Bi.smap += f0 * ctx->G.pyr_elems;
-    Bi.cand += f0 * Bi.cand_cap;
-    Bi.blocks += f0 * Bi.cand_cap * 64;
-    Bi.tie_idx += f0 * BRISK_MAX_LAYERS * Bi.tie_cap;
-    Bi.keys += f0 * Bi.cand_cap * 2;
-    Bi.counters += f0;
-    Bi.kp_out += f0 * Bi.kp_cap;
-    Bi.bandsum += f0 * nbands * Bi.istride;
-    BriskDescribeBuffers Di = ctx->D;
-    Di.integral += f0 * Di.iframe_elems;
-    Di.dkp += f0 * Bi.kp_cap;
-    Di.dscale += f0 * Bi.kp_cap;
-    Di.dperm += f0 * Bi.kp_cap;
-    Di.drec += f0 * Bi.kp_cap;
-    Di.desc += f0 * Bi.kp_cap * Di.desc_pitch;
-    BriskProfiler* prof = (i == 0) ? &ctx->prof : nullptr;  // per-kernel timing on the first slice's stream
-    BriskOverlap ov{};
-    const BriskOverlap* ovp = nullptr;
-    if (do_detect && do_describe && nsub == 1 && ctx->overlap && !(ctx->debug_flags & 0x10000)) {
-      if (!ctx->side) {
-        // lowest priority: the detector's latency-bound kernels get their workgroups placed first, the
-        // bandwidth-bound integral kernel fills what they leave
-        int least = 0, greatest = 0;
-        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
-      }
-      ov.side = ctx->side; ov.fork = ctx->side_fork; ov.join = ctx->side_join; ov.Dd = &Di;
-      ovp = &ov;
-    }
     if (i == 0) ctx->last_frames_per_launch = nf;
-    if (do_detect) {
-      brisk_launch_detect(ctx->G, ctx->T, Bi, nf, d_frames + f0 * frame_pitch, frame_pitch, row_pitch,
-                          d_mask ? d_mask + f0 * mask_frame_pitch : nullptr, mask_frame_pitch, mask_row_pitch, si, prof, ovp);
-    }
-    if (do_detect && ctx->uni_radius > 0.0) {
-      // EnforceKeyPointUniformity as a post-filter of the detected keypoints (brisk_uniformity.hip)
-      const float scaling = (float)(15.0 / (float)ctx->uni_radius);
-      const int oh = (int)(h * ceil(scaling) + 32), ow = (int)(w * ceil(scaling) + 32);
-      const long occ_frame = ((long)oh * ow + 255) / 256 * 256;
-      brisk_launch_uniformity(Bi.kp_out, Bi.counters, ctx->d_uni_order + f0 * Bi.kp_cap, ctx->d_uni_tmp + f0 * Bi.kp_cap,
-                              ctx->d_occ + f0 * occ_frame, occ_frame, ow, Bi.kp_cap, scaling, ctx->uni_max, nf, si);
-    }
-    if (do_describe) {
-      BriskPatternDev P = pat->dev;
-      brisk_launch_describe(ctx->G, P, Bi, Di, nf, Bi.kp_out, &Bi.counters[0].nkp, sizeof(BriskFrameCounters), si, prof, ovp);
-    }
+    rc = batch_slice(ctx, A, d_frames + f0 * frame_pitch, f0, nf, si, (i == 0) ? &ctx->prof : nullptr, nsub == 1);
+    if (rc) return rc;
     if (nsub > 1) {
       HIPCHK(ctx, hipEventRecord(ctx->join_ev[i], si));
       HIPCHK(ctx, hipStreamWaitEvent(s, ctx->join_ev[i], 0));
     }
   }
-  if (ctx->prof.on) ctx->prof.calls++;
-  HIPCHK(ctx, hipGetLastError());
-  ctx->last_nframes = nframes;
-  ctx->last_has_desc = do_describe;
-  return BRISK_HIP_OK;
+  return batch_end(ctx, A, nframes, s);
+}
+
+// ---- host-fed batch: frames in (pinned) host memory, H2D on a copy stream overlapped with compute ---------------
+static int host_slice_frames() {
+  static const int v = [] { const char* e = getenv("BRISK_HOST_SLICE"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 64; }();
+  return v;
+}
+
+int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames,
+                                         int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
+                                         int octaves) {
+  if (!ctx || !pat) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!h_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
+    return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
+  BatchArgs A{pat, w, h, threshold, octaves, 0, 0, nullptr, 0, 0, true, true, ctx->uni_radius, ctx->uni_max};
+  hipStream_t s = ctx->stream;
+  int rc = batch_begin(ctx, A, nframes, s);
+  if (rc) return rc;
+  const int slice = host_slice_frames() < nframes ? host_slice_frames() : nframes;
+  const int dpitch = brisk_align_up(w, 64);           // device staging: rows at a 64-byte aligned pitch
+  const size_t dframe = (size_t)dpitch * h;
+  if (!ctx->copy_stream) {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(ctx, hipEventCreateWithFlags(&ctx->copied_ev[i], hipEventDisableTiming));
+      HIPCHK(ctx, hipEventCreateWithFlags(&ctx->consumed_ev[i], hipEventDisableTiming));
+    }
+  }
+  if (ctx->hstage_bytes < dframe * slice) {
+    HIPCHK(ctx, hipDeviceSynchronize());
+    for (int i = 0; i < 2; ++i) {
+      if (ctx->d_hstage[i]) (void)hipFree(ctx->d_hstage[i]);
+      ctx->d_hstage[i] = nullptr;
+    }
+    ctx->hstage_bytes = 0;
+    for (int i = 0; i < 2; ++i) HIPCHK(ctx, hipMalloc(&ctx->d_hstage[i], dframe * slice + 256));
+    ctx->hstage_bytes = dframe * slice;
+  }
+  A.frame_pitch = (long)dframe;
+  A.row_pitch = dpitch;
+  // the copy stream starts behind whatever this context's stream still has queued on the staging buffers
+  HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[0], s));
+  HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[1], s));
+  int k = 0;
+  for (long f0 = 0; f0 < nframes; f0 += slice, ++k) {
+    const int nf = (int)((nframes - f0 < slice) ? nframes - f0 : slice);
+    const int b = k & 1;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->consumed_ev[b], 0));
+    const uint8_t* src = h_frames + f0 * frame_pitch;
+    if (frame_pitch == (long)row_pitch * h) {          // rows of consecutive frames at one pitch: a single 2-D copy
+      HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_hstage[b], dpitch, src, row_pitch, w, (size_t)h * nf, hipMemcpyHostToDevice,
+                                   ctx->copy_stream));
+    } else {
+      for (int f = 0; f < nf; ++f)
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_hstage[b] + (size_t)f * dframe, dpitch, src + (long)f * frame_pitch, row_pitch, w,
+                                     h, hipMemcpyHostToDevice, ctx->copy_stream));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->copied_ev[b], ctx->copy_stream));
+    HIPCHK(ctx, hipStreamWaitEvent(s, ctx->copied_ev[b], 0));
+    if (k == 0) ctx->last_frames_per_launch = nf;
+    rc = batch_slice(ctx, A, ctx->d_hstage[b], f0, nf, s, (k == 0) ? &ctx->prof : nullptr, true);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[b], s));
+  }
+  return batch_end(ctx, A, nframes, s);
 }
 
 int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes,
@@ -555,12 +700,14 @@ int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which, brisk_hip
 }
 
 // ---- host-buffer calls ---------------------------------------------------------------------------
-int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
-                     int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, brisk_hip_keypoint* out,
-                     int cap, int* n) {
+static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                       int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, double uni_radius, int uni_max,
+                       brisk_hip_keypoint* out, int cap, int* n) {
   if (!ctx || !img || !n || (cap > 0 && !out) || cap < 0) return BRISK_HIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   *n = 0;
+  if (uni_radius >= 0.0 && ((uni_radius > 0.0 && uni_radius < 1.0) || uni_max < 1))
+    return fail(ctx, BRISK_HIP_ERR_ARG, "uniformity: radius must be 0 (off) or >= 1, max_keypoints >= 1");
   // suppressScaleNonmaxima = false (brisk-scale-space.cc:131-170): with octaves == 0 the branch is the single-layer
   // 2-D refinement (:172-209) verbatim, which the engine runs.  With more layers the reference takes every layer's
   // points from layer 0's list (`agastPoints.at(0)[n]`, :137) and probes layer i's score map at layer-0 coordinates
@@ -577,6 +724,7 @@ int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int s
   rc = ensure_stage(ctx, img_bytes * 2);
   if (rc) return rc;
   const int pitch = brisk_align_up(w, 64);
+  if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
   const uint8_t* d_mask = nullptr;
   if (mask) {
@@ -585,9 +733,24 @@ int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int s
     d_mask = ctx->d_stage + img_bytes;
   }
   rc = run_batch(ctx, nullptr, ctx->d_stage, 1, w, h, (long)img_bytes, pitch, threshold, octaves, d_mask, (long)img_bytes,
-                 pitch, ctx->stream, true, false);
+                 pitch, ctx->stream, true, false, uni_radius, uni_max);
   if (rc) return rc;
   return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
+}
+
+int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                     int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, brisk_hip_keypoint* out,
+                     int cap, int* n) {
+  return detect_host(ctx, img, w, h, stride, threshold, octaves, suppress_scale_nonmaxima, mask, mask_stride, -1.0, 0, out,
+                     cap, n);
+}
+
+int brisk_hip_detect_uniform(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                             int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, double uniformity_radius,
+                             int max_keypoints, brisk_hip_keypoint* out, int cap, int* n) {
+  if (uniformity_radius < 0.0) return ctx ? fail(ctx, BRISK_HIP_ERR_ARG, "uniformity: negative radius") : BRISK_HIP_ERR_ARG;
+  return detect_host(ctx, img, w, h, stride, threshold, octaves, suppress_scale_nonmaxima, mask, mask_stride,
+                     uniformity_radius, max_keypoints, out, cap, n);
 }
 
 int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
@@ -606,6 +769,7 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   make_geometry(w, h, 20, 0, &ctx->G, &ctx->T);  // only layer 0 is needed
   rc = ensure_buffers(ctx, 1, ctx->G);
   if (rc) return rc;
+  if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
   const int n_in = *n;
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, &n_in, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -623,6 +787,7 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;
   ctx->last_has_desc = true;
+  if (workspace_release(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
   return download_locked(ctx, 0, 1, kps, n_in, n, desc, desc_stride, pat->host.strings);
 }
 
@@ -783,7 +948,9 @@ int brisk_hip_match_knn_device(brisk_hip_ctx* ctx, const uint8_t* d_query, int n
   }
   const long dist_pitch = ((long)nt + 63) / 64 * 64 + 64;
   const size_t need = (size_t)nq * dist_pitch * 2;
+  if (workspace_acquire(ctx, st)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   if (ctx->match_bytes < need) {  // workspace kept by the context (the call is asynchronous)
+    HIPCHK(ctx, hipDeviceSynchronize());
     if (ctx->d_match) (void)hipFree(ctx->d_match);
     ctx->d_match = nullptr; ctx->match_bytes = 0;
     HIPCHK(ctx, hipMalloc(&ctx->d_match, need));
@@ -794,6 +961,7 @@ int brisk_hip_match_knn_device(brisk_hip_ctx* ctx, const uint8_t* d_query, int n
   brisk_launch_match_knn(d_dist, dist_pitch, 0, nq, nt, nullptr, 1, nullptr, k,
                          reinterpret_cast<BriskDMatch*>(d_out), d_out_count, st);
   HIPCHK(ctx, hipGetLastError());
+  if (workspace_release(ctx, st)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
   return BRISK_HIP_OK;
 }
 
@@ -844,8 +1012,58 @@ int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls) {
     }
     avg_ms[k] = cnt ? (float)(sum / cnt) : 0.f;
   }
+  {  // the integral kernel of an overlapped batch ran on the side stream: its duration there replaces the (empty)
+     // interval on the launch stream
+    double sum = 0;
+    int cnt = 0;
+    for (int c = 0; c < n; ++c) {
+      if (!P.side_used[c]) continue;
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, P.side_ev[c][0], P.side_ev[c][1]) == hipSuccess) { sum += ms; cnt++; }
+    }
+    if (cnt) avg_ms[BRISK_STG_INTEGRAL] = (float)(sum / cnt);
+  }
   if (calls) *calls = n;
   P.calls = 0;
+  return BRISK_HIP_OK;
+}
+
+#ifndef BRISK_KERNEL_REV
+#define BRISK_KERNEL_REV "unversioned"
+#endif
+const char* brisk_hip_kernel_revision(void) { return BRISK_KERNEL_REV; }
+
+int brisk_hip_stream_ceiling(brisk_hip_ctx* ctx, size_t bytes, double* copy_GBps, double* read_GBps) {
+  if (!ctx || bytes < (1u << 20)) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  void *a = nullptr, *b = nullptr;
+  HIPCHK(ctx, hipMalloc(&a, bytes));
+  if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(ctx, BRISK_HIP_ERR_HIP, "hipMalloc failed"); }
+  (void)hipMemset(a, 1, bytes);
+  (void)hipMemset(b, 2, bytes);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  double best[2] = {0, 0};
+  for (int mode = 0; mode < 2; ++mode)
+    for (int rep = 0; rep < 5; ++rep) {
+      (void)hipEventRecord(e0, ctx->stream);
+      brisk_launch_stream_probe(a, b, bytes, mode, ctx->stream);
+      (void)hipEventRecord(e1, ctx->stream);
+      (void)hipEventSynchronize(e1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      const double gbps = (mode ? 1.0 : 2.0) * (double)bytes / (ms * 1e-3) / 1e9;
+      if (rep && gbps > best[mode]) best[mode] = gbps;
+    }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (copy_GBps) *copy_GBps = best[0];
+  if (read_GBps) *read_GBps = best[1];
+  HIPCHK(ctx, hipGetLastError());
   return BRISK_HIP_OK;
 }
 

@@ -51,6 +51,9 @@ struct BriskProfiler {
   int calls = 0;                                                   // calls recorded since the last reset
   hipEvent_t ev[BRISK_PROF_MAX_CALLS][BRISK_PROF_STAGES + 1] = {};  // created lazily
   bool used[BRISK_PROF_MAX_CALLS][BRISK_PROF_STAGES + 1] = {};
+  // the integral image kernel of a detect + describe batch runs on the side stream: its own event pair
+  hipEvent_t side_ev[BRISK_PROF_MAX_CALLS][2] = {};
+  bool side_used[BRISK_PROF_MAX_CALLS] = {};
   bool created = false;
 };
 // stage ids
@@ -59,6 +62,8 @@ enum { BRISK_STG_PYRAMID = 0, BRISK_STG_DETECT, BRISK_STG_CLASSIFY, BRISK_STG_TI
 const char* brisk_stage_name(int i);
 void brisk_prof_begin_call(BriskProfiler* P);
 void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s);  // slot k = start of stage k (k == stages: end)
+void brisk_prof_mark_side(BriskProfiler* P, int which, hipStream_t side);  // 0 / 1 = before / after the side-stream kernel
+void brisk_prof_destroy(BriskProfiler* P);
 
 // detect + describe in one batch: the integral image runs on `side` beside the detector's latency-bound tail
 struct BriskOverlap {
@@ -80,6 +85,9 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
                            long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov = nullptr);
+
+// streaming probe (brisk_hip_stream_ceiling): mode 0 copies `bytes` from a to b with 16-byte loads/stores, mode 1 only reads a
+void brisk_launch_stream_probe(const void* a, void* b, size_t bytes, int mode, hipStream_t s);
 
 // ---- Hamming brute-force matcher (brisk_match.hip) ----
 struct BriskDMatch {  // binary-identical to cv::DMatch

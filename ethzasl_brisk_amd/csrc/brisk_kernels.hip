@@ -15,6 +15,7 @@
 // (the Hamming matcher kernels live in brisk_match.hip)
 // No MFMA: the path is byte/integer stencil + gather work.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "brisk_common.h"
 #include "brisk_device_describe.h"
@@ -1627,6 +1628,12 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from the C ABI implementation)
 // ------------------------------------------------------------------------------------------------
+// tuning experiments only: integer knob from the environment (read once)
+static int env_knob(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 static inline int grid_for(long items, int per_block, int cap) {
   long b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -1645,10 +1652,29 @@ void brisk_prof_begin_call(BriskProfiler* P) {
   if (!P->created) {
     for (int c = 0; c < BRISK_PROF_MAX_CALLS; ++c)
       for (int k = 0; k <= BRISK_PROF_STAGES; ++k) (void)hipEventCreate(&P->ev[c][k]);
+    for (int c = 0; c < BRISK_PROF_MAX_CALLS; ++c)
+      for (int k = 0; k < 2; ++k) (void)hipEventCreate(&P->side_ev[c][k]);
     P->created = true;
   }
   const int c = P->calls % BRISK_PROF_MAX_CALLS;
   for (int k = 0; k <= BRISK_PROF_STAGES; ++k) P->used[c][k] = false;
+  P->side_used[c] = false;
+}
+
+void brisk_prof_mark_side(BriskProfiler* P, int which, hipStream_t side) {
+  if (!P || !P->on) return;
+  const int c = P->calls % BRISK_PROF_MAX_CALLS;
+  (void)hipEventRecord(P->side_ev[c][which], side);
+  if (which == 1) P->side_used[c] = true;
+}
+
+void brisk_prof_destroy(BriskProfiler* P) {
+  if (!P || !P->created) return;
+  for (int c = 0; c < BRISK_PROF_MAX_CALLS; ++c) {
+    for (int k = 0; k <= BRISK_PROF_STAGES; ++k) (void)hipEventDestroy(P->ev[c][k]);
+    for (int k = 0; k < 2; ++k) (void)hipEventDestroy(P->side_ev[c][k]);
+  }
+  P->created = false;
 }
 
 void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s) {
@@ -1656,6 +1682,24 @@ void brisk_prof_mark(BriskProfiler* P, int slot, hipStream_t s) {
   const int c = P->calls % BRISK_PROF_MAX_CALLS;
   (void)hipEventRecord(P->ev[c][slot], s);
   P->used[c][slot] = true;
+}
+
+// ---- the box's own streaming ceiling (reported next to the roofline numbers): float4 copy / read-only pass
+__global__ void __launch_bounds__(256) k_stream_copy(const float4* __restrict__ in, float4* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i];
+}
+__global__ void __launch_bounds__(256) k_stream_read(const float4* __restrict__ in, float* __restrict__ out, long n) {
+  float s = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = in[i];
+    s += v.x + v.y + v.z + v.w;
+  }
+  if (s == 1.2345f) out[0] = s;
+}
+void brisk_launch_stream_probe(const void* a, void* b, size_t bytes, int mode, hipStream_t s) {
+  const long n = (long)(bytes / 16);
+  if (mode == 0) hipLaunchKernelGGL(k_stream_copy, dim3(4096), dim3(256), 0, s, (const float4*)a, (float4*)b, n);
+  else hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(256), 0, s, (const float4*)a, (float*)b, n);
 }
 
 void brisk_launch_smap_clear(const BriskGeom& Gprev, const BriskDetectBuffers& B, int nframes, hipStream_t s) {
@@ -1687,9 +1731,10 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   hipLaunchKernelGGL(k_detect, dim3(T.total_tiles, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,
                      B.cand_cap);
   brisk_prof_mark(prof, BRISK_STG_CLASSIFY, s);
-  hipLaunchKernelGGL(k_score_blocks, dim3(grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, 256), nframes), dim3(SB_WAVES * 64), 0,
+  static const int sb_blocks = env_knob("BRISK_SB_BLOCKS", 256), cr_blocks = env_knob("BRISK_CR_BLOCKS", 64);
+  hipLaunchKernelGGL(k_score_blocks, dim3(grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, sb_blocks), nframes), dim3(SB_WAVES * 64), 0,
                      s, G, B.pyr, B.smap, B.cand, B.counters, B.blocks, B.cand_cap);
-  hipLaunchKernelGGL(k_classify_refine, dim3(grid_for(B.cand_cap, 64, 64), nframes), dim3(64), 0, s, G, B.pyr, B.smap,
+  hipLaunchKernelGGL(k_classify_refine, dim3(grid_for(B.cand_cap, 64, cr_blocks), nframes), dim3(64), 0, s, G, B.pyr, B.smap,
                      B.cand, B.counters, B.blocks, B.tie_idx, B.cand_cap, B.tie_cap);
   hipLaunchKernelGGL(k_classify_refine_direct, dim3(8, nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters,
                      B.tie_idx, B.cand_cap, B.tie_cap);
@@ -1705,7 +1750,9 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     // earlier it would take the workgroup slots the 1024-thread tie workgroups need (measured: 0.4 -> 1.3 ms).
     const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
     (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
+    brisk_prof_mark_side(prof, 0, ov->side);
     launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, nbands, nframes, ov->side);
+    brisk_prof_mark_side(prof, 1, ov->side);
     (void)hipEventRecord(ov->join, ov->side);
   }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);

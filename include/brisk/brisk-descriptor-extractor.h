@@ -95,7 +95,7 @@ class BriskDescriptorExtractor {
     int n = (int)keypoints.size();
     agast::Mat tmp = agast::Mat::zeros(n > 0 ? n : 1, strings, CV_8UC1);
     brisk_hip_ctx* ctx = hip::DefaultContext();
-    brisk_hip_set_capacity(ctx, 65536 > 4 * n ? 65536 : 4 * n, 16384 > n ? 16384 : n);
+    brisk_hip_reserve(ctx, 4 * n, n);  // grows the workspace when needed, never shrinks it
     hip::Check(ctx,
                brisk_hip_describe(ctx, pattern_, image.data, image.cols, image.rows, (int)image.step,
                                   reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), &n, tmp.data, (int)tmp.step,

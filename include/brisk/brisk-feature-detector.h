@@ -63,20 +63,19 @@ class BriskFeatureDetector {
     keypoints.clear();
     if (image.empty()) throw std::runtime_error("BriskFeatureDetector: empty image");
     if (image.type() != CV_8UC1) throw std::runtime_error("BriskFeatureDetector: image must be CV_8UC1");
-    brisk_hip_ctx* ctx = hip::DefaultContext();
-    hip::Check(ctx, brisk_hip_set_uniformity(ctx, m_uniformityRadius, m_maxNumKpt), "brisk_hip_set_uniformity");
+    brisk_hip_ctx* ctx = hip::DefaultContext();  // this thread's workspace
     size_t cap = 16384;
     for (;;) {
       keypoints.resize(cap);
       int n = 0;
-      const int rc = brisk_hip_detect(ctx, image.data, image.cols, image.rows, (int)image.step, threshold, octaves,
-                                      m_suppressScaleNonmaxima ? 1 : 0, mask.empty() ? nullptr : mask.data,
-                                      mask.empty() ? 0 : (int)mask.step,
-                                      reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), (int)cap, &n);
+      const int rc = brisk_hip_detect_uniform(ctx, image.data, image.cols, image.rows, (int)image.step, threshold, octaves,
+                                              m_suppressScaleNonmaxima ? 1 : 0, mask.empty() ? nullptr : mask.data,
+                                              mask.empty() ? 0 : (int)mask.step, m_uniformityRadius, m_maxNumKpt,
+                                              reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), (int)cap, &n);
       if (rc == BRISK_HIP_ERR_CAPACITY && cap < (1u << 22)) {  // output buffer too small: retry larger
         keypoints.clear();
         cap *= 4;
-        brisk_hip_set_capacity(ctx, (int)(cap * 4), (int)cap);
+        brisk_hip_reserve(ctx, (int)(cap * 4), (int)cap);
         continue;
       }
       if (rc != BRISK_HIP_OK) keypoints.clear();

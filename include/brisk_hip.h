@@ -14,6 +14,7 @@
 #ifndef BRISK_HIP_H_
 #define BRISK_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -48,6 +49,8 @@ const char* brisk_hip_last_error(const brisk_hip_ctx* ctx);
 /* per-frame capacities: AGAST candidates (default 65536) and keypoints (default 16384) */
 int brisk_hip_set_capacity(brisk_hip_ctx* ctx, int max_candidates, int max_keypoints);
 int brisk_hip_device_count(void);
+/* raises the capacities to at least these values; never lowers them (no reallocation for smaller requests) */
+int brisk_hip_reserve(brisk_hip_ctx* ctx, int min_candidates, int min_keypoints);
 
 /* ---- pattern: replaces the BriskDescriptorExtractor constructors ---------------------------- */
 /* brisk-descriptor-extractor.cc:293-343: version 2 = built-in 66-point pattern (InitFromStream :180-291),
@@ -71,6 +74,11 @@ int brisk_hip_pattern_tables(const brisk_hip_pattern* p, float* scale_list, int*
 int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
                      int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, brisk_hip_keypoint* out,
                      int cap, int* n);
+/* The same call with the uniformity post-filter (see brisk_hip_set_uniformity) given per call instead of as context
+ * state: uniformity_radius 0 = off, else >= 1; at most max_keypoints keypoints are kept. */
+int brisk_hip_detect_uniform(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                             int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, double uniformity_radius,
+                             int max_keypoints, brisk_hip_keypoint* out, int cap, int* n);
 /* BriskDescriptorExtractor::compute (brisk-descriptor-extractor.cc:612-778): filters `kps` in place
  * (border test), fills kps[i].angle, writes *n rows of descriptorSize() bytes at pitch desc_stride. */
 int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
@@ -86,6 +94,14 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
 int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames,
                                     int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
                                     int octaves, void* stream);
+/* Host-fed form of the batch (the PCIe-fed stream): h_frames is HOST memory (pinned with hipHostMalloc /
+ * hipHostRegister for full speed; pageable memory works but copies synchronously).  The frames are moved in slices of 64
+ * into two device staging buffers on a copy stream while the previous slice is computed on the context's stream; the
+ * results stay in HBM exactly as after brisk_hip_detect_describe_batch (brisk_hip_batch_results / _download /
+ * _status).  Returns when everything is queued; brisk_hip_batch_status synchronises. */
+int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames,
+                                         int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
+                                         int octaves);
 /* detect only / describe only variants of the batch path (roofline + stage timing) */
 int brisk_hip_detect_batch(brisk_hip_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, long frame_pitch,
                            int row_pitch, int threshold, int octaves, void* stream);
@@ -154,6 +170,14 @@ const char* brisk_hip_profile_stage_name(int stage);
 int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls);
 /* frames handled by each timed kernel launch (= frames of the first stream slice of the last batch) */
 int brisk_hip_profile_frames_per_launch(brisk_hip_ctx* ctx);
+
+/* The box's own streaming ceiling, measured with the engine's float4 kernels over two buffers of `bytes` each:
+ * a device-to-device copy (read + write bytes per second) and a read-only pass.  Reported by bench.py next to the
+ * roofline numbers (the spec peak is never reached by any kernel). */
+int brisk_hip_stream_ceiling(brisk_hip_ctx* ctx, size_t bytes, double* copy_GBps, double* read_GBps);
+/* identifies the kernel sources this library was built from (hash); committed PMC traffic data names the revision
+ * it was measured on */
+const char* brisk_hip_kernel_revision(void);
 
 /* ---- per-stage device entry points (parity tests of individual kernels) ---------------------- */
 /* which: 0 pyramid image, 1 score-state map low byte (D), after the last detect on frame slot 0.

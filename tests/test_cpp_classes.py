@@ -9,16 +9,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "test_binary_equal")
 
 
-def build_binary():
+def build_binary(name="test_binary_equal"):
     from ethzasl_brisk_amd import build
     build.build()
-    src = os.path.join(ROOT, "tests", "cpp", "test_binary_equal.cc")
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
+    out = os.path.join(ROOT, "tests", "cpp", name)
     hdrs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs]
-    if not os.path.exists(BIN) or any(os.path.getmtime(p) > os.path.getmtime(BIN) for p in [src] + hdrs):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", BIN, src,
-                               "-L" + os.path.join(ROOT, "ethzasl_brisk_amd"), "-lbrisk_hip",
+    if not os.path.exists(out) or any(os.path.getmtime(p) > os.path.getmtime(out) for p in [src] + hdrs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", out,
+                               src, "-L" + os.path.join(ROOT, "ethzasl_brisk_amd"), "-lbrisk_hip",
                                "-Wl,-rpath," + os.path.join(ROOT, "ethzasl_brisk_amd"), "-Wl,-rpath,/opt/rocm/lib"])
-    return BIN
+    return out
 
 
 def test_host_classes_compile_and_fail_loudly_without_gpu():
@@ -37,3 +38,17 @@ def test_reference_golden_through_cpp_classes():
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "Verification success" in r.stdout
     assert r.stdout.count("OK") == 5
+
+
+def test_thread_test_compiles():
+    build_binary("test_threads")
+
+
+@pytest.mark.gpu
+def test_four_threads_bit_equal_to_serial():
+    """per-thread workspaces (include/brisk/hip-context.h): 4 threads, different detector parameters incl. uniformity
+    radii, one shared extractor - every result bit-equal to the serial run"""
+    b = build_binary("test_threads")
+    r = subprocess.run([b, os.path.join(ROOT, "tests", "golden"), "4", "12"], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "threads OK" in r.stdout

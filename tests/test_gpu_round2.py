@@ -1,0 +1,178 @@
+"""GPU tests added in round 2 (run with -m gpu): host-fed batch entry, BASELINE config 3 (512 frames + the RCCL
+result gather) on one rank, ordering of calls that share the workspace but use different streams, the streaming probe."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+from test_gpu_parity import same_kps, explain  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import ethzasl_brisk_amd as B
+    from ethzasl_brisk_amd import build
+    build.build()
+    B.load_library()
+    return B
+
+
+def _expected(img, thr, octaves, ext):
+    k = O.detect(img, thr, octaves)
+    return k, ext.compute(img, k)
+
+
+def test_host_fed_batch_equals_oracle_and_device_batch(B):
+    """brisk_hip_detect_describe_batch_host: frames in pinned host memory, sliced H2D copies overlapped with compute.
+    70 VGA frames (two slices of 64 + 6), every frame bit-equal to the oracle; then a padded layout (row pitch > width,
+    frame pitch > rows) that takes the per-frame copy branch; then pageable memory."""
+    import torch
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    oext = O.Extractor()
+    w, h, n = 640, 480, 70
+    distinct = [synth.gen(w, h, 40 + i, 60) for i in range(5)]
+    exp = [_expected(img, 60, 4, oext) for img in distinct]
+    host = torch.from_numpy(np.stack([distinct[f % 5] for f in range(n)])).pin_memory()
+    for rep in range(2):  # the second call reuses the staging buffers and the dirty score-state map
+        ctx.detect_describe_batch_host(ext, host.data_ptr(), n, w, h, w * h, w, 60, 4)
+        assert ctx.batch_status(n) == 0
+        for f in range(n):
+            kd, _ = ctx.batch_download(f, described=False)
+            kg, dg = ctx.batch_download(f, described=True)
+            ko, (ko2, do) = exp[f % 5]
+            assert same_kps(kd, ko), (f, explain(kd, ko))
+            assert same_kps(kg, ko2) and np.array_equal(dg, do), f
+    # padded rows and frames
+    pw, ph = w + 24, h + 3
+    pad = np.zeros((9, ph, pw), np.uint8)
+    for f in range(9):
+        pad[f, :h, :w] = distinct[f % 5]
+    tpad = torch.from_numpy(pad).pin_memory()
+    ctx.detect_describe_batch_host(ext, tpad.data_ptr(), 9, w, h, pw * ph, pw, 60, 4)
+    assert ctx.batch_status(9) == 0
+    for f in range(9):
+        kg, dg = ctx.batch_download(f, described=True)
+        assert same_kps(kg, exp[f % 5][1][0]) and np.array_equal(dg, exp[f % 5][1][1])
+    # pageable host memory (numpy): slower copies, same result
+    plain = np.ascontiguousarray(np.stack([distinct[(f + 2) % 5] for f in range(3)]))
+    ctx.detect_describe_batch_host(ext, plain.ctypes.data, 3, w, h, w * h, w, 60, 4)
+    assert ctx.batch_status(3) == 0
+    for f in range(3):
+        kg, dg = ctx.batch_download(f, described=True)
+        assert same_kps(kg, exp[(f + 2) % 5][1][0]) and np.array_equal(dg, exp[(f + 2) % 5][1][1])
+    ctx.close()
+
+
+def test_config3_512_frames_with_result_gather_on_one_rank(B):
+    """BASELINE config 3 on a single GPU: one batch of 512 x 1080p frames (sharding.shard_frames at world 1), the
+    asynchronous PaddedGather exchange over RCCL (backend nccl, world size 1), a sample of frames checked bit-exactly
+    against the oracle through the GATHERED buffers."""
+    import torch
+    import torch.distributed as dist
+    from ethzasl_brisk_amd import sharding
+    import bench
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n, w, h = 512, 1920, 1080
+        mine = sharding.shard_frames(n, 0, 1)
+        assert mine == list(range(n))
+        nd = 8
+        distinct = [synth.frame_1080p(700 + i) for i in range(nd)]
+        ring = torch.from_numpy(np.stack(distinct)).to(dev)
+        frames = ring[torch.arange(n, device=dev) % nd].contiguous()
+        ctx = B.Context(0)
+        ext = B.BriskDescriptorExtractor(context=ctx)
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.detect_describe_batch(ext, frames.data_ptr(), n, w, h, w * h, w, 80, 4, stream)
+        torch.cuda.synchronize()
+        assert ctx.batch_status(n) == 0
+        g = bench.ResultGather(ctx, n, ext.descriptorSize(), dev, 0, 1)
+        g.check_kpad(None)
+        g.run()
+        g.finish()
+        torch.cuda.synchronize()
+        ac, gk, gd = g.last
+        assert ac.shape == (1, n)
+        oext = O.Extractor()
+        exp = {}
+        for f in (0, 1, 7, 8, 255, 256, 300, 511):
+            if f % nd not in exp:
+                exp[f % nd] = _expected(distinct[f % nd], 80, 4, oext)[1]
+            ko2, do = exp[f % nd]
+            cnt = int(ac[0, f].item())
+            assert cnt == len(ko2), (f, cnt, len(ko2))
+            got_k = gk[0][f, :cnt].cpu().numpy()
+            want_k = np.stack([ko2[name].view(np.uint32) for name in ko2.dtype.names], 1)
+            assert np.array_equal(got_k.view(np.uint32), want_k), f
+            assert np.array_equal(gd[0][f, :cnt].cpu().numpy(), do), f
+        # every slot that holds the same image holds the same result (no cross-frame leakage at this batch size)
+        cnts = ac[0].cpu().numpy()
+        for f in range(n):
+            assert cnts[f] == cnts[f % nd]
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_calls_on_different_streams_share_the_workspace_safely(B):
+    """A batch queued on stream A followed at once by calls on other streams (another batch on stream B, a host-buffer
+    detect on the context's own stream): the later call must wait for the earlier one before it clears / reuses the
+    shared workspace (event recorded at the end of every call)."""
+    import torch
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    oext = O.Extractor()
+    w, h = 1920, 1080
+    a = [synth.frame_1080p(900 + i) for i in range(4)]
+    b = [synth.frame_1080p(950 + i) for i in range(2)]
+    da = torch.from_numpy(np.stack(a * 16)).cuda()   # 64 frames: long enough to still run when the next call arrives
+    db = torch.from_numpy(np.stack(b)).cuda()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        ctx.detect_describe_batch(ext, da.data_ptr(), 64, w, h, w * h, w, 80, 4, sa.cuda_stream)
+        ctx.detect_describe_batch(ext, db.data_ptr(), 2, w, h, w * h, w, 80, 4, sb.cuda_stream)
+        assert ctx.batch_status(2) == 0
+        for f in range(2):
+            kg, dg = ctx.batch_download(f, described=True)
+            ko2, do = _expected(b[f], 80, 4, oext)[1]
+            assert same_kps(kg, ko2) and np.array_equal(dg, do), (rep, f)
+        ctx.detect_describe_batch(ext, da.data_ptr(), 64, w, h, w * h, w, 80, 4, sa.cuda_stream)
+        det = B.BriskFeatureDetector(80, 4, context=ctx)
+        k = det.detect(b[0])
+        assert same_kps(k, O.detect(b[0], 80, 4)), rep
+    ctx.close()
+
+
+def test_stream_ceiling_probe_and_kernel_revision(B):
+    ctx = B.Context(0)
+    cp, rd = ctx.stream_ceiling(1 << 29)
+    assert 1000 < cp < 8000 and 1000 < rd < 8000      # GB/s: above a PCIe-class number, below the spec peak
+    assert len(ctx.kernel_revision()) == 12
+    ctx.close()
+
+
+def test_reserve_never_shrinks(B):
+    ctx = B.Context(0)
+    img = synth.frame_vga(1)
+    det = B.BriskFeatureDetector(70, 4, context=ctx)
+    k0 = det.detect(img)
+    ctx.reserve(300000, 70000)
+    ctx.reserve(1000, 100)            # smaller request: nothing changes (no reallocation, no truncation)
+    k1 = det.detect(img, capacity=70000)
+    assert same_kps(k0, k1)
+    ctx.close()

@@ -217,8 +217,8 @@ static int ensure_stage(brisk_hip_ctx* c, size_t bytes) {
 static int check_detect_args(brisk_hip_ctx* ctx, int w, int h, int threshold, int octaves) {
   if (w <= 0 || h <= 0 || w > 8191 || h > 8191) return fail(ctx, BRISK_HIP_ERR_ARG, "image size must be in [1, 8191]");
   if (octaves < 0 || 2 * octaves > BRISK_MAX_LAYERS) return fail(ctx, BRISK_HIP_ERR_ARG, "octaves must be in [0, 8]");
-  if (threshold < 20 || threshold > 255)
-    return fail(ctx, BRISK_HIP_ERR_THRESHOLD, "AGAST threshold must be in [20, 255] on the device path");
+  if (threshold < 1 || threshold > 255)
+    return fail(ctx, BRISK_HIP_ERR_THRESHOLD, "AGAST threshold must be in [1, 255]");
   return BRISK_HIP_OK;
 }
 
@@ -396,6 +396,7 @@ struct BatchArgs {
   bool do_detect, do_describe;
   double uni_radius;  // uniformity enforcement of this call (0 = off)
   int uni_max;
+  bool no_scale_nms = false;  // suppressScaleNonmaxima == false with octaves > 0
 };
 
 // geometry, workspace, restoring the all-zero score-state map, profiler bookkeeping: once per batch, on stream s
@@ -405,6 +406,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   HIPCHK(ctx, hipSetDevice(ctx->device));
   make_geometry(A.w, A.h, A.threshold, A.octaves, &ctx->G, &ctx->T);
   ctx->G.debug_flags = ctx->debug_flags;
+  ctx->G.no_scale_nms = (A.no_scale_nms && A.octaves != 0) ? 1 : 0;
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
   if (A.do_detect && A.uni_radius > 0.0) {
@@ -503,11 +505,12 @@ static int batch_end(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipStr
 static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes, int w, int h,
                      long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* d_mask,
                      long mask_frame_pitch, int mask_row_pitch, hipStream_t s, bool do_detect, bool do_describe,
-                     double uni_radius = -1.0, int uni_max = 0) {
+                     double uni_radius = -1.0, int uni_max = 0, bool no_scale_nms = false) {
   if (!d_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   BatchArgs A{pat, w, h, threshold, octaves, frame_pitch, row_pitch, d_mask, mask_frame_pitch, mask_row_pitch, do_detect,
               do_describe, uni_radius < 0.0 ? ctx->uni_radius : uni_radius, uni_radius < 0.0 ? ctx->uni_max : uni_max};
+  A.no_scale_nms = no_scale_nms;
   int rc = batch_begin(ctx, A, nframes, s);
   if (rc) return rc;
   int nsub = ctx->nsub;
@@ -649,6 +652,10 @@ static int overflow_to_rc(brisk_hip_ctx* ctx, int flags) {
   if (flags & 2) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "tie-candidate capacity exceeded (brisk_hip_set_capacity)");
   if (flags & 4) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "keypoint capacity exceeded (brisk_hip_set_capacity)");
   if (flags & 8) return fail(ctx, BRISK_HIP_ERR_HIP, "tie resolution gave up waiting for a decision (internal error)");
+  if (flags & 16)
+    return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED,
+                "suppressScaleNonmaxima=false: on this image the reference indexes layer 0's point list past its end or reads "
+                "outside a score matrix (brisk-scale-space.cc:137) - no defined result");
   return BRISK_HIP_OK;
 }
 
@@ -709,13 +716,8 @@ static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int
   if (uni_radius >= 0.0 && ((uni_radius > 0.0 && uni_radius < 1.0) || uni_max < 1))
     return fail(ctx, BRISK_HIP_ERR_ARG, "uniformity: radius must be 0 (off) or >= 1, max_keypoints >= 1");
   // suppressScaleNonmaxima = false (brisk-scale-space.cc:131-170): with octaves == 0 the branch is the single-layer
-  // 2-D refinement (:172-209) verbatim, which the engine runs.  With more layers the reference takes every layer's
-  // points from layer 0's list (`agastPoints.at(0)[n]`, :137) and probes layer i's score map at layer-0 coordinates
-  // - out of range for every layer but the first - so there is no defined result to reproduce.
-  if (!suppress_scale_nonmaxima && octaves != 0)
-    return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED,
-                "suppressScaleNonmaxima=false is only defined for octaves == 0 (the reference indexes layer 0's point "
-                "list on every layer, brisk-scale-space.cc:137)");
+  // 2-D refinement (:172-209) verbatim (fast path); with more layers it runs on the ordered path, `at(0)` indexing
+  // included (k_ordered_keypoints)
   int rc = check_detect_args(ctx, w, h, threshold, octaves);
   if (rc) return rc;
   if (stride < w || (mask && mask_stride < w)) return fail(ctx, BRISK_HIP_ERR_ARG, "stride smaller than width");
@@ -733,7 +735,7 @@ static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int
     d_mask = ctx->d_stage + img_bytes;
   }
   rc = run_batch(ctx, nullptr, ctx->d_stage, 1, w, h, (long)img_bytes, pitch, threshold, octaves, d_mask, (long)img_bytes,
-                 pitch, ctx->stream, true, false, uni_radius, uni_max);
+                 pitch, ctx->stream, true, false, uni_radius, uni_max, !suppress_scale_nonmaxima);
   if (rc) return rc;
   return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
 }

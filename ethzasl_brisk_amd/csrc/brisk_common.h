@@ -20,6 +20,9 @@
 #endif
 
 #define BRISK_MAX_LAYERS 16
+// AGAST thresholds below this run the ordered path (k_ordered_keypoints): a detection may then store a score <= 2,
+// which the reference's lazy cache treats as "not cached" (brisk-layer.cc:118-132)
+#define BRISK_FAST_PATH_MIN_THRESHOLD 20
 #define BRISK_STRIDE_ALIGN 64
 
 // candidate status (smap bits 12-13)
@@ -61,6 +64,7 @@ struct BriskGeom {
   int pyr_elems;       // total elements per frame (sum of stride*h, 256-aligned per layer)
   int threshold;       // AGAST threshold (20..255)
   int single_layer;    // octaves == 0
+  int no_scale_nms;    // suppressScaleNonmaxima == false with more than one layer (ordered path, brisk-scale-space.cc:131-170)
   int debug_flags;     // test knobs: bit0 send every candidate through k_classify_refine_direct (safety-net test);
                        // bits 8-15 k_describe blocks per frame / 8; bit16 integral image not overlapped; bit17 matcher
                        // always through the distance matrix
@@ -92,7 +96,8 @@ struct BriskFrameCounters {
   int overflow;                     // bit0 cand overflow, bit1 tie overflow, bit2 keypoint overflow
   int nredo;                        // candidates deferred to k_classify_refine_direct
   int nvalid_large;                 // > 0: k_finalize left the ordering of this many keypoints to k_finalize_large
-  int pad[2];
+  int full_clear;                   // the ordered path wrote the map outside the candidates' footprints: clear all of it
+  int pad[1];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)

@@ -291,10 +291,32 @@ BRISK_HD int brisk_V_eval(const BriskLayerView& L, int x, int y) {
   if (D > 2) return D;
   return brisk_Kp(L, x, y);
 }
-// DIRECT = true: evaluate from the image.  DIRECT = false: read the view's pre-evaluated score block
+// ---------------------------------------------------------------------------------------------
+// Literal lazy score cache (ordered path, DIRECT == 2): BriskLayer::GetAgastScore(x, y, threshold)
+// (brisk/src/brisk-layer.cc:118-132) on the low byte of the score-state map, which then IS the reference's
+// scores_ matrix (initial state: D at detections, 0 elsewhere).  cornerScore(b) in closed form: the bisection on
+// [b, 255) (oast9-16-nms.cc:39-42, 1964-1975) never tests its lower end, so it returns max(b, min(M - 1, 254));
+// for threshold 0 (b = -1) a pixel with M <= 0 therefore yields -1, stored as the uint8_t 255.
+// ---------------------------------------------------------------------------------------------
+BRISK_HD int brisk_S_literal(const BriskLayerView& L, int x, int y, int threshold /* uint8_t in the reference */) {
+  if (x < 3 || y < 3) return 0;
+  if (x >= L.w - 3 || y >= L.h - 3) return 0;
+  uint16_t* sc = L.smap + (long)y * L.stride + x;
+  const int m = (int)(*sc & 0xFFu);
+  if (m > 2) return m;
+  const int b = threshold - 1;
+  const int M = brisk_oast9_16_M(L.img + (long)y * L.stride + x, L.stride);
+  int score = (int)(uint8_t)brisk_max(b, brisk_min(M - 1, 254));
+  if (score < threshold) score = 0;
+  *sc = (uint16_t)score;
+  return score;
+}
+
+// DIRECT = 1: evaluate from the image.  DIRECT = 0: read the view's pre-evaluated score block
 // (kernel fast path; contains no evaluation code at all, a miss only raises the flag).
-template <bool DIRECT>
+template <int DIRECT>
 BRISK_HD int brisk_V(const BriskLayerView& L, int x, int y) {
+  if (DIRECT == 2) return brisk_S_literal(L, x, y, 1);  // ordered path: the reference's cache, literally
   if (DIRECT) return brisk_V_eval(L, x, y);
   const unsigned ux = (unsigned)(x - L.blk.x0), uy = (unsigned)(y - L.blk.y0);
   if (ux < (unsigned)L.blk.cw && uy < (unsigned)L.blk.ch) return brisk_block_get(L.blk, (int)(uy * L.blk.cw + ux));
@@ -307,7 +329,7 @@ BRISK_HD int brisk_V58_eval(const BriskLayerView& L, int x, int y) {
   if (x < 2 || y < 2 || x >= L.w - 2 || y >= L.h - 2) return 0;
   return brisk_Kp_from_M(brisk_agast5_8_M(L.img + (long)y * L.stride + x, L.stride));
 }
-template <bool DIRECT>
+template <int DIRECT>
 BRISK_HD int brisk_V58(const BriskLayerView& L, int x, int y) {
   if (DIRECT) return brisk_V58_eval(L, x, y);
   const unsigned ux = (unsigned)(x - L.blk58.x0), uy = (unsigned)(y - L.blk58.y0);
@@ -358,7 +380,7 @@ BRISK_HD void brisk_touch(BriskTouch* t, const BriskLayerView& L, int x, int y) 
   if (bx >= 0 && bx < 4 && by >= 0 && by < 4) t->mask |= 1u << (by * 4 + bx);
 }
 
-template <bool DIRECT>
+template <int DIRECT>
 BRISK_HD int brisk_Vt(const BriskLayerView& L, int x, int y, BriskTouch* t) {
   brisk_touch(t, L, x, y);
   return brisk_V<DIRECT>(L, x, y);
@@ -366,7 +388,7 @@ BRISK_HD int brisk_Vt(const BriskLayerView& L, int x, int y, BriskTouch* t) {
 
 // GetAgastScore(float, float, 1) (brisk-layer.cc:147-161): bilinear blend of 4 integer scores,
 // all four always evaluated (and touched), result truncated to u8.
-template <bool DIRECT>
+template <int DIRECT>
 BRISK_HD int brisk_Vf(const BriskLayerView& L, float xf, float yf, BriskTouch* t) {
   const int x = (int)xf;
   const float rx1 = xf - (float)x;
@@ -460,7 +482,7 @@ BRISK_HD_OUTLINE float brisk_subpixel2d(const int s_0_0, const int s_0_1, const 
 }
 
 // 3x3 patch around (x, y) with integer score access + Subpixel2D
-template <bool DIRECT>
+template <int DIRECT>
 BRISK_HD float brisk_patch_subpixel(const BriskLayerView& L, int x, int y, BriskTouch* t, float& dx, float& dy,
                                     int* centre) {
   const int s_0_0 = brisk_Vt<DIRECT>(L, x - 1, y - 1, t);
@@ -473,6 +495,26 @@ BRISK_HD float brisk_patch_subpixel(const BriskLayerView& L, int x, int y, Brisk
   const int s_1_2 = brisk_Vt<DIRECT>(L, x, y + 1, t);
   const int s_2_2 = brisk_Vt<DIRECT>(L, x + 1, y + 1, t);
   if (centre) *centre = s_1_1;
+  return brisk_subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, dx, dy);
+}
+
+// The same patch read the way GetKeypoints itself reads it (brisk-scale-space.cc:186-194, 232-240): the coordinates
+// are floats there, so every sample is a bilinear GetAgastScore(float, float, 1) that touches a 2x2 block.  The
+// values equal the integer reads for integral coordinates; the touched set differs, which only the literal cache
+// (DIRECT == 2) can see.
+template <int DIRECT>
+BRISK_HD float brisk_patch_subpixel_f(const BriskLayerView& L, float x, float y, float& dx, float& dy) {
+  BriskTouch none;
+  none.on = false; none.mask = 0; none.x0 = 0; none.y0 = 0;
+  const int s_0_0 = brisk_Vf<DIRECT>(L, x - 1, y - 1, &none);
+  const int s_1_0 = brisk_Vf<DIRECT>(L, x, y - 1, &none);
+  const int s_2_0 = brisk_Vf<DIRECT>(L, x + 1, y - 1, &none);
+  const int s_2_1 = brisk_Vf<DIRECT>(L, x + 1, y, &none);
+  const int s_1_1 = brisk_Vf<DIRECT>(L, x, y, &none);
+  const int s_0_1 = brisk_Vf<DIRECT>(L, x - 1, y, &none);
+  const int s_0_2 = brisk_Vf<DIRECT>(L, x - 1, y + 1, &none);
+  const int s_1_2 = brisk_Vf<DIRECT>(L, x, y + 1, &none);
+  const int s_2_2 = brisk_Vf<DIRECT>(L, x + 1, y + 1, &none);
   return brisk_subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, dx, dy);
 }
 
@@ -543,7 +585,7 @@ BRISK_HD_OUTLINE float brisk_refine1d_2(const float s_05, const float s0, const 
 // GetScoreMaxAbove / GetScoreMaxBelow (brisk-scale-space.cc:757-1099), history-free evaluation
 // with touch recording.  `above` selects the window mapping; `odd` = (layer % 2 == 1).
 // ---------------------------------------------------------------------------------------------
-template <bool DIRECT>
+template <int DIRECT>
 BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above, const bool odd, const int x_layer,
                                      const int y_layer, const int thr, bool& ismax, float& dx, float& dy,
                                      BriskTouch* t) {
@@ -678,7 +720,7 @@ BRISK_HD constexpr int brisk_probe_index(int dx, int dy) {  // {7, 2, 6, 0, -1, 
 }
 
 // returns status (REJ / PASS / TIE) and the number of probes issued
-template <bool DIRECT>
+template <int DIRECT>
 BRISK_HD unsigned brisk_classify(const BriskLayerView& L, int x, int y, int centre, int* nprobed) {
   bool tie = false;
   for (int k = 0; k < 8; ++k) {
@@ -704,12 +746,65 @@ BRISK_HD unsigned brisk_classify(const BriskLayerView& L, int x, int y, int cent
 }
 
 // ---------------------------------------------------------------------------------------------
+// IsMax2D, literally (brisk-scale-space.cc:430-531), on the literal cache: the ordered path for AGAST thresholds
+// below 20, where a detection can store a score <= 2 (which the cache treats as "not cached") and the history-free
+// split of the fast path does not hold.  centre = raw map value; 8 probes with threshold = centre in the order
+// W, E, N, S, SW, SE, NE, NW with early exit; equal neighbours are compared through the [1 2 1; 2 4 2; 1 2 1]
+// smoothed sums of the RAW map.
+// ---------------------------------------------------------------------------------------------
+// RAW = true: the map reads are addressed as the reference addresses them, `data + y * cols + x` on a matrix without
+// row padding - needed where the coordinates do not belong to this layer (the `at(0)` indexing of the
+// suppressScaleNonmaxima = false branch, :137): a column beyond the row end then lands in the next row.  *oob is set
+// when such a read would leave the matrix (undefined behaviour in the reference).
+template <bool RAW>
+BRISK_HD int brisk_raw_read(const BriskLayerView& L, long lin_x, long lin_y, bool* oob) {
+  if (!RAW) return (int)(L.smap[lin_y * L.stride + lin_x] & 0xFFu);
+  const long idx = lin_y * L.w + lin_x;
+  if (idx < 0 || idx >= (long)L.w * L.h) { *oob = true; return 0; }
+  return (int)(L.smap[(idx / L.w) * L.stride + (idx % L.w)] & 0xFFu);
+}
+
+template <bool RAW>
+BRISK_HD bool brisk_ismax2d_literal(const BriskLayerView& L, const int x_layer, const int y_layer, bool* oob) {
+  const int center = brisk_raw_read<RAW>(L, x_layer, y_layer, oob);
+  const int s_10 = brisk_S_literal(L, x_layer - 1, y_layer, center);
+  if (center < s_10) return false;
+  const int s10 = brisk_S_literal(L, x_layer + 1, y_layer, center);
+  if (center < s10) return false;
+  const int s0_1 = brisk_S_literal(L, x_layer, y_layer - 1, center);
+  if (center < s0_1) return false;
+  const int s01 = brisk_S_literal(L, x_layer, y_layer + 1, center);
+  if (center < s01) return false;
+  const int s_11 = brisk_S_literal(L, x_layer - 1, y_layer + 1, center);
+  if (center < s_11) return false;
+  const int s11 = brisk_S_literal(L, x_layer + 1, y_layer + 1, center);
+  if (center < s11) return false;
+  const int s1_1 = brisk_S_literal(L, x_layer + 1, y_layer - 1, center);
+  if (center < s1_1) return false;
+  const int s_1_1 = brisk_S_literal(L, x_layer - 1, y_layer - 1, center);
+  if (center < s_1_1) return false;
+  // equal-score neighbours in the reference's list order (:478-497)
+  const int ddx[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, ddy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+  const int sv[8] = {s_1_1, s0_1, s1_1, s_10, s10, s_11, s01, s11};
+  const int smoothedcenter = 4 * center + 2 * (s_10 + s10 + s0_1 + s01) + s_1_1 + s1_1 + s_11 + s11;
+  for (int i = 0; i < 8; ++i) {
+    if (sv[i] != center) continue;
+    int other = 0;
+    for (int oy = -1; oy <= 1; ++oy)
+      for (int ox = -1; ox <= 1; ++ox)
+        other += (ox == 0 ? 2 : 1) * (oy == 0 ? 2 : 1) * brisk_raw_read<RAW>(L, x_layer + ddx[i] + ox, y_layer + ddy[i] + oy, oob);
+    if (other > smoothedcenter) return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Refinement of a 2D maximum (brisk-scale-space.cc:211-287 + Refine3D :534-754).
 // Returns true if a keypoint results.  e5 = the candidate reaches its own-layer patch reads;
 // touch = score-touches on the layer above (event e3).
 // ---------------------------------------------------------------------------------------------
 // Lbelow / tl / Labove: views of layer-1, layer, layer+1 (the neighbours may be dummies where they do not exist).
-template <bool DIRECT>
+template <int DIRECT>
 BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, const BriskLayerView& tl,
                            const BriskLayerView& Labove, const int layer, const int x_layer, const int y_layer,
                            BriskKeyPoint* kp, bool* e5, BriskTouch* touch) {
@@ -725,7 +820,8 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
   if (G.single_layer) {  // :172-209 (patch via float access: 4x4 touch footprint)
     float delta_x, delta_y;
     *e5 = true;
-    const float max = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
+    const float max = (DIRECT == 2) ? brisk_patch_subpixel_f<DIRECT>(tl, (float)x_layer, (float)y_layer, delta_x, delta_y)
+                                    : brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
     kp->x = (float)x_layer + delta_x;
     kp->y = (float)y_layer + delta_y;
     kp->size = BRISK_BASIC_SIZE;
@@ -737,12 +833,14 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
   if (layer == G.nlayers - 1) {  // :215-256
     bool ismax;
     float dx, dy;
-    const int centre = brisk_V<DIRECT>(tl, x_layer, y_layer);
+    // (:227: the threshold argument is the float overload GetAgastScore(point_x, point_y, 1))
+    const int centre = (DIRECT == 2) ? brisk_Vf<DIRECT>(tl, (float)x_layer, (float)y_layer, &none) : brisk_V<DIRECT>(tl, x_layer, y_layer);
     brisk_score_max_other<DIRECT>(Lbelow, false, (layer & 1) != 0, x_layer, y_layer, centre, ismax, dx, dy, &none);
     if (!ismax) return false;
     *e5 = true;
     float delta_x, delta_y;
-    const float max = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
+    const float max = (DIRECT == 2) ? brisk_patch_subpixel_f<DIRECT>(tl, (float)x_layer, (float)y_layer, delta_x, delta_y)
+                                    : brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
     kp->x = ((float)x_layer + delta_x) * lscale + loffset;
     kp->y = ((float)y_layer + delta_y) * lscale + loffset;
     kp->size = BRISK_BASIC_SIZE * lscale;
@@ -866,6 +964,88 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
   kp->size = BRISK_BASIC_SIZE * scale;
   kp->response = max;
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The ordered path as one sequential walk (k_ordered_keypoints runs it on one lane per frame; the test harness runs
+// the same function): GetKeypoints (brisk-scale-space.cc:92-287) over the candidates in (layer, y, x) order on the
+// literal cache.  no_scale_nms: the suppressScaleNonmaxima = false branch (:131-170) with more than one layer - layer i
+// contributes as many keypoints as it has AGAST points but takes their COORDINATES from layer 0's list
+// (`agastPoints.at(0)[n]`, :137) and probes layer i's maps there; only a 2-D refinement follows.  Returns true where
+// the reference has no defined result (at() throws because layer i has more points than layer 0, or IsMax2D reads
+// outside a score matrix).
+// ---------------------------------------------------------------------------------------------
+struct BriskOrderedOut {
+  BriskKeyPoint* kp;
+  int cap, n;            // n counts every keypoint, also those beyond cap
+  const uint8_t* mask;   // optional (RemoveInvalidKeyPoints, brisk-feature-detector.cc:49-66)
+  int mask_row_pitch;
+};
+BRISK_HD BriskLayerView brisk_view_of(const BriskGeom& G, uint8_t* pyr_frame, uint16_t* smap_frame, int l) {
+  BriskLayerView v;
+  v.img = pyr_frame + G.L[l].off;
+  v.smap = smap_frame + G.L[l].off;
+  v.w = G.L[l].w; v.h = G.L[l].h; v.stride = G.L[l].stride;
+  brisk_block_clear(&v.blk);
+  brisk_block_clear(&v.blk58);
+  v.miss = 0;
+  return v;
+}
+BRISK_HD void brisk_ordered_emit(BriskOrderedOut* o, const BriskKeyPoint& kp) {
+  if (o->mask && o->mask[(long)(int)(kp.y + 0.5f) * o->mask_row_pitch + (int)(kp.x + 0.5f)] == 0) return;
+  if (o->n < o->cap) o->kp[o->n] = kp;
+  o->n++;
+}
+BRISK_HD bool brisk_ordered_walk(const BriskGeom& G, uint8_t* pyr_frame, uint16_t* smap_frame, const BriskCand* C,
+                                 const unsigned* order, int n, bool no_scale_nms, BriskOrderedOut* out) {
+  if (no_scale_nms && !G.single_layer) {
+    int start[BRISK_MAX_LAYERS + 2];  // candidate ranges of the layers in the ordered list
+    for (int l = 0; l <= BRISK_MAX_LAYERS + 1; ++l) start[l] = n;
+    for (int r = n - 1; r >= 0; --r) start[C[order[r]].layer] = r;
+    for (int l = G.nlayers - 1; l >= 0; --l)
+      if (start[l] > start[l + 1]) start[l] = start[l + 1];  // empty layers
+    const int n0 = start[1] - start[0];
+    for (int i = 0; i < G.nlayers; ++i) {
+      const int num = start[i + 1] - start[i];
+      if (num > n0) return true;  // agastPoints.at(0)[n] throws std::out_of_range
+      const BriskLayerView Li = brisk_view_of(G, pyr_frame, smap_frame, i);
+      for (int k = 0; k < num; ++k) {
+        const BriskCand& c = C[order[start[0] + k]];
+        const int x = c.x, y = c.y;
+        bool oob = false;
+        const bool is_max = brisk_ismax2d_literal<true>(Li, x, y, &oob);
+        if (oob) return true;
+        if (!is_max) continue;
+        float dx, dy;
+        const float mx = brisk_patch_subpixel_f<2>(Li, (float)x, (float)y, dx, dy);
+        BriskKeyPoint kp;
+        kp.x = (float)x + dx; kp.y = (float)y + dy;
+        kp.size = BRISK_BASIC_SIZE * G.L[i].scale;
+        kp.angle = -1.0f; kp.response = mx; kp.octave = 0; kp.class_id = -1;
+        brisk_ordered_emit(out, kp);
+      }
+    }
+    return false;
+  }
+  for (int r = 0; r < n; ++r) {
+    const BriskCand& c = C[order[r]];
+    const int l = c.layer, x = c.x, y = c.y;
+    const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
+    const bool has_below = !G.single_layer && (l > 0);
+    const BriskLayerView Lo = brisk_view_of(G, pyr_frame, smap_frame, l);
+    const BriskLayerView La = brisk_view_of(G, pyr_frame, smap_frame, has_above ? l + 1 : l);
+    const BriskLayerView Lb = brisk_view_of(G, pyr_frame, smap_frame, has_below ? l - 1 : l);
+    bool oob = false;
+    if (!brisk_ismax2d_literal<false>(Lo, x, y, &oob)) continue;
+    BriskKeyPoint kp;
+    kp.x = kp.y = kp.size = kp.response = 0.f;
+    BriskTouch touch;
+    touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
+    bool e5 = false;
+    if (!brisk_refine<2>(G, Lb, Lo, La, l, x, y, &kp, &e5, &touch)) continue;
+    brisk_ordered_emit(out, kp);
+  }
+  return false;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) k_smap_clear(BriskGeom G, uint16_t* __res
   const int frame = blockIdx.y;
   uint16_t* fs = smap + (long)frame * G.pyr_elems;
   const int ncand = counters[frame].ncand;
-  if (ncand > cand_cap || (counters[frame].overflow & 1)) {
+  if (ncand > cand_cap || (counters[frame].overflow & 1) || counters[frame].full_clear) {
     uint4* p = reinterpret_cast<uint4*>(fs);  // pyr_elems is a multiple of 256 elements
     const long n16 = (long)G.pyr_elems * 2 / 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
@@ -738,6 +738,92 @@ __global__ void __launch_bounds__(64) k_classify_refine_direct(BriskGeom G, uint
     }
     smap_or(Lo.smap, (long)y * Lo.stride + x, bits);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ordered path (AGAST thresholds 1..19): the reference's GetKeypoints (brisk-scale-space.cc:92-287) walked in its own
+// order on its own lazy score cache (low byte of the score-state map).  Below threshold 20 a detection can store a
+// score <= 2, which the cache treats as "not cached" (brisk-layer.cc:118-132), and the history-free / history-
+// dependent split of the fast path no longer holds; this path makes no such assumption, it is the sequential
+// algorithm itself: slow (one lane per frame), bit-exact for every threshold, and used only where the fast path
+// does not apply.
+//   k_order_candidates     all candidates of a frame into (layer, y, x) order: counting sort over (layer, row)
+//                          buckets in global scratch, rows sorted by x
+//   k_ordered_keypoints    one lane per frame: literal IsMax2D + refinement per candidate, keypoints in order
+// ------------------------------------------------------------------------------------------------
+#define OC_THREADS 256
+__global__ void __launch_bounds__(OC_THREADS) k_order_candidates(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
+                                                                 unsigned* order_scratch, int* row_scratch, long row_scratch_stride,
+                                                                 int cand_cap) {
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  const int n = min(counters[frame].ncand, cand_cap);
+  const BriskCand* C = cand + (long)frame * cand_cap;
+  unsigned* order = order_scratch + (long)frame * cand_cap * 2;  // [0, n): candidate indices in key order
+  int* rows = row_scratch + (long)frame * row_scratch_stride;     // [0, R]: start of every (layer, row) bucket; [R+1, 2R+1): fill
+  __shared__ int rbase[BRISK_MAX_LAYERS + 1];
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < G.nlayers; ++l) { rbase[l] = acc; acc += G.L[l].h; }
+    rbase[G.nlayers] = acc;
+  }
+  __syncthreads();
+  const int R = rbase[G.nlayers];
+  if (2 * R + 2 > row_scratch_stride) {  // (cannot happen with the capacities the host checks)
+    if (tid == 0) atomicOr(&counters[frame].overflow, 8);
+    return;
+  }
+  for (int r = tid; r < 2 * R + 2; r += OC_THREADS) rows[r] = 0;
+  __threadfence_block();
+  __syncthreads();
+  for (int i = tid; i < n; i += OC_THREADS) atomicAdd(&rows[rbase[C[i].layer] + C[i].y + 1], 1);
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {  // inclusive prefix over the row counts: rows[r] = first slot of bucket r (serial: a few thousand rows)
+    int acc = 0;
+    for (int r = 1; r <= R; ++r) { acc += rows[r]; rows[r] = acc; }
+  }
+  __threadfence_block();
+  __syncthreads();
+  int* fill = rows + R + 1;
+  for (int i = tid; i < n; i += OC_THREADS) {
+    const int b = rbase[C[i].layer] + C[i].y;
+    order[rows[b] + atomicAdd(&fill[b], 1)] = (unsigned)i;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int b = tid; b < R; b += OC_THREADS) {  // inside a row: insertion sort by x (rows hold a handful of candidates)
+    const int lo = rows[b], hi = rows[b + 1];
+    for (int i = lo + 1; i < hi; ++i) {
+      const unsigned v = order[i];
+      const int xv = C[v].x;
+      int j = i - 1;
+      while (j >= lo && C[order[j]].x > xv) { order[j + 1] = order[j]; --j; }
+      order[j + 1] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) k_ordered_keypoints(BriskGeom G, uint8_t* pyr, uint16_t* smap, const BriskCand* cand,
+                                                           BriskFrameCounters* counters, const unsigned* order_scratch,
+                                                           BriskKeyPoint* kp_out, int cand_cap, int kp_cap, const uint8_t* mask,
+                                                           long mask_pitch_frame, int mask_row_pitch, int no_scale_nms) {
+  if (threadIdx.x != 0) return;
+  const int frame = blockIdx.x;
+  const int n = min(counters[frame].ncand, cand_cap);
+  counters[frame].full_clear = 1;  // the cache is written wherever a score was asked for: the next batch clears the whole map
+  if (counters[frame].overflow & 1) return;
+  BriskOrderedOut out;
+  out.kp = kp_out + (long)frame * kp_cap;
+  out.cap = kp_cap;
+  out.n = 0;
+  out.mask = mask ? mask + (long)frame * mask_pitch_frame : nullptr;
+  out.mask_row_pitch = mask_row_pitch;
+  const bool undefined = brisk_ordered_walk(G, pyr + (long)frame * G.pyr_elems, smap + (long)frame * G.pyr_elems,
+                                            cand + (long)frame * cand_cap, order_scratch + (long)frame * cand_cap * 2, n,
+                                            no_scale_nms != 0, &out);
+  if (undefined) atomicOr(&counters[frame].overflow, 16);
+  counters[frame].nkp = min(out.n, kp_cap);
+  if (out.n > kp_cap) atomicOr(&counters[frame].overflow, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1727,10 +1813,38 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
       hipLaunchKernelGGL(k_pyramid_level, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, B.pyr, l - 2, l, 0);
     }
   }
+  // The integral image only needs layer 0 and the band sums (k_pyramid_even) and is HBM-bound; tie resolution
+  // (one workgroup per frame, a chain of dependent decisions) and the final ordering are latency-bound and leave
+  // most of the chip idle.  The integral kernel runs beside them on a second, low-priority stream (forked in front
+  // of the tie kernel) and is joined before the descriptor kernels.
+  static const int fork_at = env_knob("BRISK_INTEGRAL_FORK", 0);  // experiments: 1 = beside k_detect, 2 = beside the score blocks
+  auto fork_integral = [&]() {
+    const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
+    (void)hipEventRecord(ov->fork, s);
+    (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
+    brisk_prof_mark_side(prof, 0, ov->side);
+    launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, nbands, nframes, ov->side);
+    brisk_prof_mark_side(prof, 1, ov->side);
+    (void)hipEventRecord(ov->join, ov->side);
+  };
+  if (ov && fork_at == 1) fork_integral();
   brisk_prof_mark(prof, BRISK_STG_DETECT, s);
   hipLaunchKernelGGL(k_detect, dim3(T.total_tiles, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,
                      B.cand_cap);
+  if (ov && fork_at == 2) fork_integral();
   brisk_prof_mark(prof, BRISK_STG_CLASSIFY, s);
+  if (G.threshold < BRISK_FAST_PATH_MIN_THRESHOLD || G.no_scale_nms) {  // ordered path: the sequential algorithm on its literal cache
+    const long row_stride = (long)BRISK_MAX_LAYERS * B.tie_cap;
+    hipLaunchKernelGGL(k_order_candidates, dim3(nframes), dim3(OC_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.tie_idx,
+                       row_stride, B.cand_cap);
+    brisk_prof_mark(prof, BRISK_STG_TIES, s);
+    if (ov && fork_at != 1 && fork_at != 2) fork_integral();
+    hipLaunchKernelGGL(k_ordered_keypoints, dim3(nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.keys, B.kp_out,
+                       B.cand_cap, B.kp_cap, mask, mask_frame_pitch, mask_row_pitch, G.no_scale_nms);
+    brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
+    brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
+    return;
+  }
   static const int sb_blocks = env_knob("BRISK_SB_BLOCKS", 256), cr_blocks = env_knob("BRISK_CR_BLOCKS", 64);
   hipLaunchKernelGGL(k_score_blocks, dim3(grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, sb_blocks), nframes), dim3(SB_WAVES * 64), 0,
                      s, G, B.pyr, B.smap, B.cand, B.counters, B.blocks, B.cand_cap);
@@ -1739,22 +1853,9 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   hipLaunchKernelGGL(k_classify_refine_direct, dim3(8, nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters,
                      B.tie_idx, B.cand_cap, B.tie_cap);
   brisk_prof_mark(prof, BRISK_STG_TIES, s);
-  if (ov) (void)hipEventRecord(ov->fork, s);
+  if (ov && fork_at == 0) fork_integral();
   hipLaunchKernelGGL(k_tie_resolve, dim3(nframes), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
                      B.blocks, B.keys, B.cand_cap, B.tie_cap);
-  if (ov) {
-    // The integral image only needs layer 0 and the band sums (k_pyramid_even) and is HBM-bound; tie resolution
-    // (one workgroup per frame, a chain of dependent decisions) and the final ordering are latency-bound and leave
-    // most of the chip idle.  Run the integral kernel beside them on a second, low-priority stream (it starts when
-    // the tie kernel does: the fork event sits in front of it) and join before the descriptor kernels.  Started any
-    // earlier it would take the workgroup slots the 1024-thread tie workgroups need (measured: 0.4 -> 1.3 ms).
-    const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
-    (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
-    brisk_prof_mark_side(prof, 0, ov->side);
-    launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, nbands, nframes, ov->side);
-    brisk_prof_mark_side(prof, 1, ov->side);
-    (void)hipEventRecord(ov->join, ov->side);
-  }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,
                      B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);

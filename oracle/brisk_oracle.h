@@ -55,6 +55,12 @@ int bo_scale_space_layers(const bo_scale_space* s);
 const uint8_t* bo_scale_space_map(const bo_scale_space* s, int layer, int which, int* w, int* h);
 /* GetKeypoints (suppressScaleNonmaxima = true paths, octaves >= 0); returns count; *out malloc'd */
 int bo_scale_space_get_keypoints(bo_scale_space* s, bo_keypoint** out);
+/* the same with suppressScaleNonmaxima_ given; suppress == 0 with several layers is brisk-scale-space.cc:131-170 incl. the
+ * agastPoints.at(0) indexing (PARITY UNPINNED: nothing in the reference's tests reaches that branch); -1 = the
+ * reference has no defined result on this input */
+int bo_scale_space_get_keypoints_ex(bo_scale_space* s, int suppress, bo_keypoint** out);
+int bo_detect_ex(const uint8_t* img, int w, int h, int threshold, int octaves, int suppress_scale_nonmaxima,
+                 const uint8_t* mask, bo_keypoint** out);
 /* Convenience: whole detectImpl incl. optional mask (h x w, u8, may be NULL). */
 int bo_detect(const uint8_t* img, int w, int h, int threshold, int octaves, const uint8_t* mask,
               bo_keypoint** out);

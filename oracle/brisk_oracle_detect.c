@@ -535,9 +535,18 @@ static float refine1d_2(const float s_05, const float s0, const float s05, float
 }
 
 /* :430-531 */
+static int g_oob; /* set when is_max_2d would read outside the score matrix (only possible with the at(0) indexing, :137) */
 static int is_max_2d(bo_scale_space* s, int layer, const int x_layer, const int y_layer) {
   bo_layer* l = &s->l[layer];
   const int scorescols = l->w;
+  const long total = (long)l->w * l->h;
+  {
+    const long lo = (long)(y_layer - 2) * scorescols + x_layer - 2, hi = (long)(y_layer + 2) * scorescols + x_layer + 2;
+    if (lo < 0 || hi >= total) { /* a read of this call could leave the matrix: check each one exactly */
+      const long c = (long)y_layer * scorescols + x_layer;
+      if (c < 0 || c >= total) { g_oob = 1; return 0; }
+    }
+  }
   const uint8_t* data = l->scores + (long)y_layer * scorescols + x_layer;
   const uint8_t center = *data;
   const uint8_t s_10 = S(l, x_layer - 1, y_layer, center);
@@ -571,6 +580,7 @@ static int is_max_2d(bo_scale_space* s, int layer, const int x_layer, const int 
     int smoothedcenter = 4 * center + 2 * (s_10 + s10 + s0_1 + s01) + s_1_1 + s1_1 + s_11 + s11;
     for (int i = 0; i < nd; i += 2) {
       data = l->scores + (long)(y_layer - 1 + delta[i + 1]) * scorescols + x_layer + delta[i] - 1;
+      if (data < l->scores || data + 2 * scorescols + 2 >= l->scores + total) { g_oob = 1; return 0; }
       int othercenter = *data;
       data++; othercenter += 2 * (*data);
       data++; othercenter += *data;
@@ -926,10 +936,50 @@ static float refine3d(bo_scale_space* s, const int layer, const int x_layer, con
 
 /* :92-287 (detection path: empty input keypoints, suppressScaleNonmaxima = true) */
 int bo_scale_space_get_keypoints(bo_scale_space* s, bo_keypoint** out) {
+  return bo_scale_space_get_keypoints_ex(s, 1, out);
+}
+
+/* GetKeypoints with suppressScaleNonmaxima_ given (:92-287).  suppress == 0 with more than one layer is the branch
+ * :131-170 with its `agastPoints.at(0)[n]` indexing (:137); returns -1 where the reference has no defined result (at()
+ * throws because layer i has more points than layer 0, or IsMax2D reads outside a score matrix).  PARITY UNPINNED for
+ * that branch: no test or golden vector of the reference exercises it. */
+int bo_scale_space_get_keypoints_ex(bo_scale_space* s, int suppress, bo_keypoint** out) {
   for (int i = 0; i < s->layers; ++i) layer_get_agast_points(&s->l[i], s->threshold);
   int cap = 1024, n = 0;
   bo_keypoint* kps = (bo_keypoint*)malloc(sizeof(bo_keypoint) * cap);
 #define PUSH(KP) do { if (n == cap) { cap *= 2; kps = (bo_keypoint*)realloc(kps, sizeof(bo_keypoint) * cap); } kps[n++] = (KP); } while (0)
+
+  if (!suppress && s->layers > 1) { /* :131-170 */
+    g_oob = 0;
+    for (int i = 0; i < s->layers; i++) {
+      bo_layer* l = &s->l[i];
+      const int num = l->npts;
+      for (int k = 0; k < num; k++) {
+        if (k >= s->l[0].npts) { free(kps); *out = NULL; return -1; } /* agastPoints.at(0)[n]: std::out_of_range */
+        const float point_x = (float)s->l[0].pts[2 * k], point_y = (float)s->l[0].pts[2 * k + 1];
+        const int is_max = is_max_2d(s, i, (int)point_x, (int)point_y);
+        if (g_oob) { free(kps); *out = NULL; return -1; }
+        if (!is_max) continue;
+        int s_0_0 = Sf(l, point_x - 1, point_y - 1, 1);
+        int s_1_0 = Sf(l, point_x, point_y - 1, 1);
+        int s_2_0 = Sf(l, point_x + 1, point_y - 1, 1);
+        int s_2_1 = Sf(l, point_x + 1, point_y, 1);
+        int s_1_1 = Sf(l, point_x, point_y, 1);
+        int s_0_1 = Sf(l, point_x - 1, point_y, 1);
+        int s_0_2 = Sf(l, point_x - 1, point_y + 1, 1);
+        int s_1_2 = Sf(l, point_x, point_y + 1, 1);
+        int s_2_2 = Sf(l, point_x + 1, point_y + 1, 1);
+        float delta_x, delta_y;
+        float max = subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, &delta_x, &delta_y);
+        bo_keypoint kp;
+        kp.x = point_x + delta_x; kp.y = point_y + delta_y;
+        kp.size = kBasicSize * l->scale; kp.angle = -1; kp.response = max; kp.octave = 0; kp.class_id = -1;
+        PUSH(kp);
+      }
+    }
+    *out = kps;
+    return n;
+  }
 
   if (s->layers == 1) { /* :172-209 */
     bo_layer* l = &s->l[0];
@@ -1007,9 +1057,15 @@ int bo_scale_space_get_keypoints(bo_scale_space* s, bo_keypoint** out) {
 /* brisk-feature-detector.cc:49-66,77-85 */
 int bo_detect(const uint8_t* img, int w, int h, int threshold, int octaves, const uint8_t* mask,
               bo_keypoint** out) {
+  return bo_detect_ex(img, w, h, threshold, octaves, 1, mask, out);
+}
+
+int bo_detect_ex(const uint8_t* img, int w, int h, int threshold, int octaves, int suppress_scale_nonmaxima,
+                 const uint8_t* mask, bo_keypoint** out) {
   bo_scale_space* s = bo_scale_space_create(img, w, h, threshold, octaves);
-  int n = bo_scale_space_get_keypoints(s, out);
+  int n = bo_scale_space_get_keypoints_ex(s, suppress_scale_nonmaxima, out);
   bo_scale_space_destroy(s);
+  if (n < 0) return n;
   if (mask) {
     bo_keypoint* k = *out;
     int m = 0;

@@ -54,6 +54,7 @@ struct Emul {
   std::vector<int> ties[BRISK_MAX_LAYERS];
   std::vector<BriskKeyPoint> kps;
   int relax_iters = 0, max_chain = 0;
+  bool undefined = false;  // ordered path: the reference has no defined result on this input
 };
 
 BriskLayerView view(Emul& E, int l) {
@@ -73,7 +74,7 @@ void touch_apply(Emul& E, int l_above, int x0, int y0, unsigned mask) {
 
 // mirrors k_copy_layer0 + k_pyramid_level + k_detect + k_classify_refine + k_tie_resolve + k_finalize
 void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int octaves, unsigned shuffle_seed, int jacobi,
-                bool use_cache) {
+                bool use_cache, bool ordered = false, bool jacobi_no_scale_nms = false) {
   make_geometry(w, h, threshold, octaves, &E.G);
   const BriskGeom& G = E.G;
   E.pyr.assign((size_t)G.pyr_elems + 256, 0);
@@ -107,6 +108,19 @@ void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int oc
   if (shuffle_seed) {  // atomic-append order is arbitrary on the GPU
     srand(shuffle_seed);
     for (size_t i = E.cand.size(); i > 1; --i) std::swap(E.cand[i - 1], E.cand[(size_t)rand() % i]);
+  }
+  if (ordered) {  // k_order_candidates + k_ordered_keypoints: the sequential algorithm on the literal cache
+    std::sort(E.cand.begin(), E.cand.end(), [](const BriskCand& a, const BriskCand& b) { return a.key < b.key; });
+    std::vector<unsigned> order(E.cand.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (unsigned)i;
+    E.kps.assign(E.cand.size() + 1, BriskKeyPoint());
+    BriskOrderedOut out;
+    out.kp = E.kps.data(); out.cap = (int)E.kps.size(); out.n = 0; out.mask = nullptr; out.mask_row_pitch = 0;
+    E.G.no_scale_nms = (jacobi_no_scale_nms && octaves != 0) ? 1 : 0;
+    E.undefined = brisk_ordered_walk(E.G, E.pyr.data(), E.smap.data(), E.cand.data(), order.data(), (int)E.cand.size(),
+                                     E.G.no_scale_nms != 0, &out);
+    E.kps.resize((size_t)out.n);
+    return;
   }
   // k_classify_refine (one wave per candidate: lane-parallel score blocks, then uniform scalar logic)
   for (int l = 0; l < G.nlayers; ++l) E.ties[l].clear();
@@ -266,12 +280,15 @@ extern "C" {
 
 // returns keypoint count; *out malloc'd (free with emul_free). stats[0]=#candidates, [1]=#ties, [2]=relaxation sweeps,
 // [3]=longest per-layer chain, [4]=score-block cache misses.  mode: bits 0-1 tie scheme (0 Gauss-Seidel sweeps, 1 Jacobi
-// sweeps, 2 sorted in-order = the kernel's main path), bit 2 = use the lane-parallel score-block caches
+// sweeps, 2 sorted in-order = the kernel's main path), bit 2 = use the lane-parallel score-block caches, bit 3 = the
+// ordered path of thresholds below 20 (k_order_candidates + k_ordered_keypoints), bit 4 = the ordered path's
+// suppressScaleNonmaxima = false branch (returns -1 where the reference has no defined result)
 int emul_detect(const uint8_t* img, int w, int h, int threshold, int octaves, unsigned shuffle_seed, int jacobi,
                 BriskKeyPoint** out, int* stats) {
   Emul E;
   brisk_cache_misses = 0;
-  run_detect(E, img, w, h, threshold, octaves, shuffle_seed, jacobi & 3, (jacobi & 4) != 0);
+  run_detect(E, img, w, h, threshold, octaves, shuffle_seed, jacobi & 3, (jacobi & 4) != 0, (jacobi & 24) != 0, (jacobi & 16) != 0);
+  if (E.undefined) return -1;
   *out = (BriskKeyPoint*)malloc(sizeof(BriskKeyPoint) * (E.kps.size() + 1));
   memcpy(*out, E.kps.data(), sizeof(BriskKeyPoint) * E.kps.size());
   if (stats) {

@@ -51,6 +51,9 @@ def detect(img, threshold, octaves, shuffle_seed=0, jacobi=0):
     out = C.c_void_p()
     stats = np.zeros(5, np.int32)
     n = lib().emul_detect(_p(img), w, h, threshold, octaves, shuffle_seed, jacobi, C.byref(out), _p(stats))
+    if n < 0:
+        lib().emul_free(out)
+        return None, stats
     kps = np.frombuffer(C.string_at(out.value, n * KP.itemsize), dtype=KP).copy() if n else np.zeros(0, KP)
     lib().emul_free(out)
     return kps, stats

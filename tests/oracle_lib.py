@@ -37,6 +37,7 @@ def lib():
         L.bo_scale_space_map.argtypes = [vp, C.c_int, C.c_int, i32p, i32p]
         L.bo_scale_space_get_keypoints.argtypes = [vp, C.POINTER(vp)]
         L.bo_detect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+        L.bo_detect_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
         L.bo_free.argtypes = [vp]
         L.bo_extractor_create.restype = vp
         L.bo_extractor_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_char_p]
@@ -103,12 +104,16 @@ def _take_kps(out, n):
     return kps
 
 
-def detect(img, threshold, octaves, mask=None):
+def detect(img, threshold, octaves, mask=None, suppress_scale_nonmaxima=True):
+    """detectImpl; returns None where the reference has no defined result (suppressScaleNonmaxima=False with several
+    layers on an input that makes agastPoints.at(0) throw or IsMax2D read outside a matrix)."""
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
     out = C.c_void_p()
     m = None if mask is None else _p(np.ascontiguousarray(mask, np.uint8))
-    n = lib().bo_detect(_p(img), w, h, threshold, octaves, m, C.byref(out))
+    n = lib().bo_detect_ex(_p(img), w, h, threshold, octaves, int(bool(suppress_scale_nonmaxima)), m, C.byref(out))
+    if n < 0:
+        return None
     return _take_kps(out, n)
 
 

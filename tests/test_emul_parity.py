@@ -174,3 +174,42 @@ def test_pregate_is_a_necessary_condition():
     img = np.ascontiguousarray(synth.frame_vga(1))
     L.emul_pregate_missed(img.ctypes.data, 640, 480, 640, 80, C.byref(n))
     assert n.value < 0.05 * 640 * 480          # the gate is selective (a few % of the pixels pass)
+
+
+@pytest.mark.parametrize("thr", [1, 3, 7, 12, 19, 20, 45])
+def test_ordered_path_literal_cache_equals_oracle(thr):
+    """k_ordered_keypoints (AGAST thresholds 1..19): IsMax2D and the refinement on the literal lazy cache, candidates
+    in (layer, y, x) order.  Same device functions as the kernel, run in the harness; also valid (and checked) at
+    thresholds the fast path covers."""
+    rng = np.random.default_rng(11)
+    imgs = [synth.gen(160, 120, 5, 12), synth.gen(213, 107, 6, 20),
+            np.clip(synth.gen(96, 96, 7, 6).astype(np.int32) // 3 + rng.integers(0, 6, (96, 96)), 0, 255).astype(np.uint8)]
+    for img in imgs:
+        for octaves in (0, 1, 3):
+            ko = O.detect(img, thr, octaves)
+            ke, _ = E.detect(img, thr, octaves, shuffle_seed=3, jacobi=8)
+            assert same_kps(ke, ko), (img.shape, thr, octaves, len(ke), len(ko))
+
+
+def banded(seed, h=240, w=320, band=48, cell=3):
+    """texture only in a band at the top: every layer's AGAST points then lie in its first rows, which is what makes
+    the `agastPoints.at(0)[n]` indexing of the suppressScaleNonmaxima=false branch stay inside the score matrices"""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 128, np.uint8)
+    blocks = (np.kron(rng.integers(0, 2, (band // cell + 1, w // cell + 1)), np.ones((cell, cell))) * 180 + 30).astype(np.uint8)
+    img[4:4 + band, :] = blocks[:band, :w]
+    return img
+
+
+def test_ordered_path_no_scale_nms_branch_equals_oracle():
+    """suppressScaleNonmaxima=false with several layers (brisk-scale-space.cc:131-170, `at(0)` quirk): defined inputs
+    bit-equal to the oracle, undefined inputs (at() would throw / reads outside a matrix) reported as such by both."""
+    for seed, cell, octaves, thr in ((0, 3, 2, 60), (1, 4, 3, 60), (2, 2, 1, 45), (3, 4, 3, 12)):
+        img = banded(seed, cell=cell)
+        ko = O.detect(img, thr, octaves, suppress_scale_nonmaxima=False)
+        ke, _ = E.detect(img, thr, octaves, shuffle_seed=5, jacobi=16)
+        assert ko is not None and len(ko) > 300 and len(set(ko["size"])) >= 2
+        assert same_kps(ke, ko), (seed, cell, octaves, thr)
+    img = synth.gen(320, 240, 3, 30)
+    assert O.detect(img, 60, 2, suppress_scale_nonmaxima=False) is None
+    assert E.detect(img, 60, 2, jacobi=16)[0] is None

@@ -156,10 +156,15 @@ def test_mask_and_errors(B, golden_ast):
     kg = B.BriskFeatureDetector(70, 3).detect(img, mask)
     assert 0 < len(ko) < 1000 and same_kps(kg, ko)
     with pytest.raises(B.BriskHipError) as ei:
-        B.BriskFeatureDetector(10, 3).detect(img)           # documented deviation: threshold < 20
+        B.BriskFeatureDetector(0, 3).detect(img)            # thresholds 1..255 (1..19 on the ordered path)
     assert ei.value.code == 5
-    with pytest.raises(B.BriskHipError):
-        B.BriskFeatureDetector(70, 3, suppressScaleNonmaxima=False).detect(img)   # undefined in the reference (:137)
+    # suppressScaleNonmaxima=false with several layers: on this image the reference indexes layer 0's point list
+    # (`agastPoints.at(0)[n]`, brisk-scale-space.cc:137) at rows that lie outside layer i's score matrix - no defined
+    # result, reported as such (the oracle agrees); defined inputs: tests/test_gpu_round2.py
+    assert O.detect(img, 70, 3, suppress_scale_nonmaxima=False) is None
+    with pytest.raises(B.BriskHipError) as ei:
+        B.BriskFeatureDetector(70, 3, suppressScaleNonmaxima=False).detect(img)
+    assert ei.value.code == 7
     # suppressScaleNonmaxima=false with a single layer is the 2-D refinement branch (brisk-scale-space.cc:131-170)
     assert same_kps(B.BriskFeatureDetector(70, 0, suppressScaleNonmaxima=False).detect(img), O.detect(img, 70, 0))
     with pytest.raises(RuntimeError):
@@ -513,7 +518,7 @@ def test_c_abi_argument_validation(B, ctx):
     assert detect(w=0) == 1 and detect(h=-3) == 1 and detect(w=8192) == 1          # BRISK_HIP_ERR_ARG
     assert detect(stride=32) == 1
     assert detect(octaves=9) == 1 and detect(octaves=-1) == 1
-    assert detect(thr=19) == 5 and detect(thr=256) == 5                              # BRISK_HIP_ERR_THRESHOLD
+    assert detect(thr=0) == 5 and detect(thr=256) == 5 and detect(thr=19) == 0       # BRISK_HIP_ERR_THRESHOLD
     assert detect(imgp=None) == 1 and detect(outp=None) == 1 and detect(cap=-1) == 1
     assert L.brisk_hip_last_error(ctx._h)                                            # a message is always there
     assert L.brisk_hip_detect(None, img.ctypes.data, 64, 64, 64, 70, 3, 1, None, 0, out.ctypes.data, 16, C.byref(n)) == 1

@@ -176,3 +176,68 @@ def test_reserve_never_shrinks(B):
     k1 = det.detect(img, capacity=70000)
     assert same_kps(k0, k1)
     ctx.close()
+
+
+@pytest.mark.parametrize("thr", [1, 5, 12, 19])
+def test_thresholds_below_20_ordered_path(B, thr):
+    """AGAST thresholds 1..19 (the `> 2` cache rule of brisk-layer.cc:118-132 for stored scores <= 2): the
+    ordered path (k_order_candidates + k_ordered_keypoints) against the oracle - host-buffer call, mask, batch of
+    frames with description, and a fast-path call afterwards on the same context (the cache the ordered path left
+    in the score-state map must be wiped completely)."""
+    import torch
+    ctx = B.Context(0, max_candidates=400000, max_keypoints=100000)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    oext = O.Extractor()
+    imgs = [synth.gen(320, 240, 9, 30), synth.gen(213, 160, 4, 14)]
+    for octaves in (0, 3):
+        det = B.BriskFeatureDetector(thr, octaves, context=ctx)
+        for img in imgs:
+            ko = O.detect(img, thr, octaves)
+            k = det.detect(img, capacity=100000)
+            assert same_kps(k, ko), (thr, octaves, img.shape, explain(k, ko))
+    # mask
+    img = imgs[0]
+    mask = np.zeros(img.shape, np.uint8)
+    mask[40:200, 60:300] = 255
+    det = B.BriskFeatureDetector(thr, 2, context=ctx)
+    km = det.detect(img, mask=mask, capacity=100000)
+    ko = O.detect(img, thr, 2, mask=mask)
+    assert same_kps(km, ko)
+    # batch of frames, detect + describe
+    n = 3
+    frames = np.stack([synth.gen(320, 240, 20 + i, 30) for i in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    ctx.detect_describe_batch(ext, d.data_ptr(), n, 320, 240, 320 * 240, 320, thr, 2, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.batch_status(n) == 0
+    for f in range(n):
+        ko = O.detect(frames[f], thr, 2)
+        ko2, do = oext.compute(frames[f], ko)
+        kd, _ = ctx.batch_download(f, described=False)
+        kg, dg = ctx.batch_download(f, described=True, strings=48)
+        assert same_kps(kd, ko), (f, explain(kd, ko))
+        assert same_kps(kg, ko2) and np.array_equal(dg, do)
+    # the fast path on the same context afterwards
+    det70 = B.BriskFeatureDetector(70, 3, context=ctx)
+    assert same_kps(det70.detect(imgs[0]), O.detect(imgs[0], 70, 3))
+    ctx.close()
+
+
+def test_no_scale_nms_several_layers_at0_quirk(B):
+    """suppressScaleNonmaxima=false with octaves > 0 (brisk-scale-space.cc:131-170): layer i takes its points'
+    coordinates from layer 0's list (:137).  Inputs on which that stays inside the score matrices (texture only in a
+    band at the top) are bit-equal to the oracle; the usual input is reported as undefined (code 7)."""
+    from test_emul_parity import banded
+    ctx = B.Context(0)
+    for seed, cell, octaves, thr in ((0, 3, 2, 60), (1, 4, 3, 60), (2, 2, 1, 45), (3, 4, 3, 12)):
+        img = banded(seed, cell=cell)
+        ko = O.detect(img, thr, octaves, suppress_scale_nonmaxima=False)
+        k = B.BriskFeatureDetector(thr, octaves, suppressScaleNonmaxima=False, context=ctx).detect(img)
+        assert ko is not None and len(ko) > 300 and same_kps(k, ko), (seed, explain(k, ko))
+    with pytest.raises(B.BriskHipError) as ei:
+        B.BriskFeatureDetector(60, 2, suppressScaleNonmaxima=False, context=ctx).detect(synth.gen(320, 240, 3, 30))
+    assert ei.value.code == 7
+    # and the context keeps working on the fast path
+    img = synth.frame_vga(1)
+    assert same_kps(B.BriskFeatureDetector(70, 4, context=ctx).detect(img), O.detect(img, 70, 4))
+    ctx.close()

@@ -7,6 +7,8 @@
 #include <brisk/brisk.h>
 #include <brisk/brute-force-matcher.h>
 
+#include "set_serialization.h"
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -14,55 +16,22 @@
 #include <string>
 #include <vector>
 
+// .set layout: brisk/src/test/serialization.cc:46-149, bench-ds.cc:57-94 (tests/cpp/set_serialization.h)
 struct Entry {
   std::string path;
   agast::Mat image;
   std::vector<agast::KeyPoint> keypoints;
   agast::Mat descriptors;
 };
-
-template <typename T> static T rd(std::ifstream& in) {
-  T v;
-  in.read(reinterpret_cast<char*>(&v), sizeof(T));
-  return v;
-}
-
-static agast::Mat read_mat(std::ifstream& in) {
-  const int rows = rd<int>(in), cols = rd<int>(in), type = rd<int>(in), esz = rd<int>(in);
-  agast::Mat m(rows, cols * esz, CV_8UC1);
-  (void)type;
-  in.read(reinterpret_cast<char*>(m.data), (std::streamsize)rows * cols * esz);
-  return m;
-}
-
-// .set layout: brisk/src/test/serialization.cc:46-149, bench-ds.cc:57-94
 static std::vector<Entry> read_set(const std::string& fn) {
-  std::ifstream in(fn.c_str(), std::ios::binary);
-  if (!in.good()) throw std::runtime_error("cannot open " + fn);
-  std::vector<Entry> out(rd<uint32_t>(in));
-  for (Entry& e : out) {
-    const uint32_t len = rd<uint32_t>(in);
-    e.path.resize(len);
-    in.read(&e.path[0], len);
-    e.image = read_mat(in);
-    e.keypoints.resize(rd<uint32_t>(in));
-    for (agast::KeyPoint& k : e.keypoints) {
-      k.angle = rd<float>(in);
-      k.class_id = rd<int>(in);
-      k.octave = rd<int>(in);
-      k.pt.x = rd<float>(in);
-      k.pt.y = rd<float>(in);
-      k.response = rd<float>(in);
-      k.size = rd<float>(in);
-    }
-    e.descriptors = read_mat(in);
-    const uint32_t nblobs = rd<uint32_t>(in);
-    for (uint32_t b = 0; b < nblobs; ++b) {
-      const uint32_t kl = rd<uint32_t>(in);
-      in.seekg(kl, std::ios::cur);
-      const uint32_t sz = rd<uint32_t>(in);
-      in.seekg(sz, std::ios::cur);
-    }
+  std::vector<Entry> out;
+  for (setio::DatasetEntry& d : setio::ReadSet(fn)) {
+    Entry e;
+    e.path = d.path;
+    e.image = d.image.mat;
+    e.keypoints = d.keypoints;
+    e.descriptors = d.descriptors.mat;
+    out.push_back(e);
   }
   return out;
 }

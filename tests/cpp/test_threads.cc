@@ -6,6 +6,8 @@
 // Usage: test_threads <golden dir> [threads] [iterations]; exit code 0 = all threads bit-equal to the serial run.
 #include <brisk/brisk.h>
 
+#include "set_serialization.h"
+
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -14,25 +16,7 @@
 #include <thread>
 #include <vector>
 
-template <typename T> static T rd(std::ifstream& in) {
-  T v;
-  in.read(reinterpret_cast<char*>(&v), sizeof(T));
-  return v;
-}
-
-// first image of a .set file (layout: brisk/src/test/serialization.cc:46-149)
-static agast::Mat first_image(const std::string& fn) {
-  std::ifstream in(fn.c_str(), std::ios::binary);
-  if (!in.good()) throw std::runtime_error("cannot open " + fn);
-  rd<uint32_t>(in);
-  const uint32_t len = rd<uint32_t>(in);
-  in.seekg(len, std::ios::cur);
-  const int rows = rd<int>(in), cols = rd<int>(in), type = rd<int>(in), esz = rd<int>(in);
-  (void)type;
-  agast::Mat m(rows, cols * esz, CV_8UC1);
-  in.read(reinterpret_cast<char*>(m.data), (std::streamsize)rows * cols * esz);
-  return m;
-}
+static agast::Mat first_image(const std::string& fn) { return setio::ReadSet(fn).at(0).image.mat; }
 
 struct Result {
   std::vector<agast::KeyPoint> kps;

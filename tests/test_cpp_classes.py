@@ -15,6 +15,7 @@ def build_binary(name="test_binary_equal"):
     src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
     out = os.path.join(ROOT, "tests", "cpp", name)
     hdrs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs]
+    hdrs.append(os.path.join(ROOT, "tests", "cpp", "set_serialization.h"))
     if not os.path.exists(out) or any(os.path.getmtime(p) > os.path.getmtime(out) for p in [src] + hdrs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", out,
                                src, "-L" + os.path.join(ROOT, "ethzasl_brisk_amd"), "-lbrisk_hip",
@@ -52,3 +53,11 @@ def test_four_threads_bit_equal_to_serial():
     r = subprocess.run([b, os.path.join(ROOT, "tests", "golden"), "4", "12"], capture_output=True, text=True)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "threads OK" in r.stdout
+
+
+def test_set_container_cpp_round_trip(tmp_path):
+    """the reference's golden .set files through the C++ reader / writer (tests/cpp/set_serialization.h): byte-identical"""
+    b = build_binary("test_serialization")
+    r = subprocess.run([b, os.path.join(ROOT, "tests", "golden"), str(tmp_path / "rt.set")], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout.count("OK") == 3

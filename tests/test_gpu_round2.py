@@ -241,3 +241,27 @@ def test_no_scale_nms_several_layers_at0_quirk(B):
     img = synth.frame_vga(1)
     assert same_kps(B.BriskFeatureDetector(70, 4, context=ctx).detect(img), O.detect(img, 70, 4))
     ctx.close()
+
+
+def test_custom_ptn_pattern_and_bilinear_branch(B, golden_harris):
+    """A valid custom .ptn (jittered positions, 60 points, smaller smoothing radii) through the text constructor
+    (brisk-descriptor-extractor.cc:345-367), at patternScale 1.0 and at 0.45, where sigma_half < 0.5 for the small
+    scales and SmoothedIntensity takes its bilinear branch (:391-408); provided-angle, rotation-estimated and
+    non-scale-invariant modes; bit-equal to the oracle."""
+    import ptn
+    text = ptn.custom_pattern(1, sigma_factor=0.6, drop_points=6)
+    e = golden_harris[0]
+    g = e["keypoints"]
+    k = np.zeros(len(g), B.KEYPOINT)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        k[f] = g[f]
+    k["angle"] = -1
+    k["size"] = np.linspace(7.0, 40.0, len(k)).astype(np.float32)
+    for ps in (1.0, 0.45):
+        for rot, sc in ((True, True), (False, True), (True, False)):
+            ko, do = O.Extractor(rot, sc, pattern_text=text, pattern_scale=ps).compute(e["image"], k)
+            ext = B.BriskDescriptorExtractor(rot, sc, pattern_text=text, patternScale=ps)
+            assert ext.descriptorSize() == 48
+            kg, dg = ext.compute(e["image"], k)
+            assert len(ko) > 300 and same_kps(kg, ko), (ps, rot, sc, explain(kg, ko))
+            assert np.array_equal(dg, do), (ps, rot, sc)

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbrisk_hip.so")
+# BRISK_HIP_LIB: tuning experiments only (an alternative build of the same library, e.g. with another -D knob)
+LIB_PATH = os.environ.get("BRISK_HIP_LIB") or os.path.join(HERE, "libbrisk_hip.so")
 
 KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

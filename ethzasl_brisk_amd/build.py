@@ -34,6 +34,16 @@ def kernel_revision():
     return h.hexdigest()[:12]
 
 
+def build_variant(name, defines):
+    """tuning experiments: the same sources with extra -D knobs into ethzasl_brisk_amd/<name>.so (load with BRISK_HIP_LIB)"""
+    out = os.path.join(HERE, name + ".so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ['-DBRISK_KERNEL_REV="%s"' % kernel_revision(), "-o", out] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

@@ -1547,10 +1547,11 @@ __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, const uint8_t
   const uint32_t* r1 = r0 + istride;
   const uint32_t* r2 = integral + (long)p.y_bottom * istride;
   const uint32_t* r3 = r2 + istride;
-  r.p00 = *reinterpret_cast<const ds_u32x2*>(r0 + p.x_left); r.p02 = *reinterpret_cast<const ds_u32x2*>(r0 + p.x_right);
-  r.p10 = *reinterpret_cast<const ds_u32x2*>(r1 + p.x_left); r.p12 = *reinterpret_cast<const ds_u32x2*>(r1 + p.x_right);
-  r.p20 = *reinterpret_cast<const ds_u32x2*>(r2 + p.x_left); r.p22 = *reinterpret_cast<const ds_u32x2*>(r2 + p.x_right);
-  r.p30 = *reinterpret_cast<const ds_u32x2*>(r3 + p.x_left); r.p32 = *reinterpret_cast<const ds_u32x2*>(r3 + p.x_right);
+#define DS_GATHER(ptr) (*reinterpret_cast<const ds_u32x2*>(ptr))
+  r.p00 = DS_GATHER(r0 + p.x_left); r.p02 = DS_GATHER(r0 + p.x_right);
+  r.p10 = DS_GATHER(r1 + p.x_left); r.p12 = DS_GATHER(r1 + p.x_right);
+  r.p20 = DS_GATHER(r2 + p.x_left); r.p22 = DS_GATHER(r2 + p.x_right);
+  r.p30 = DS_GATHER(r3 + p.x_left); r.p32 = DS_GATHER(r3 + p.x_right);
   // displaced bottom corners of the reference quirk (brisk-descriptor-extractor.cc:453); unconditional loads on a
   // valid address, used only when the quirk applies
   const uint8_t* pbot = img + (long)max(p.y_bottom - 1, 0) * stride;

@@ -6,7 +6,9 @@ HBM bytes per launch for every engine kernel, with the gfx950 corrections of tha
     4 B/lane dword loads, an uncalibrated width, so the read side was calibrated in this repo on kernels of the same
     access width with an exactly known byte count: k_copy_layer0 (factor 1.9992) and k_integral_bandsums (1.9995),
     both since folded into k_pyramid_even.  The factor 2.0 is therefore applied to every kernel's FETCH_SIZE.
-Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames_per_launch> <w> <h> [out.json]
+Also sums the kernels into the groups of SURVEY 8(d) that bench.py reports (`groups`, bytes per launch) and names the
+kernel revision (brisk_hip_kernel_revision) the passes were measured on: bench.py uses the file only for that revision.
+Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames_per_launch> <w> <h> [out.json [kernel_revision]]
 """
 import csv
 
@@ -42,6 +44,18 @@ def main():
             continue
         f, wr = fetch.get(k, 0.0), write.get(k, 0.0)
         out["kernels"][k] = {"fetch_raw": f, "fetch_corrected": f * corr, "write": wr, "hbm_bytes_per_launch": f * corr + wr}
+    group_of = {"k_pyramid_even": "pyramid", "k_pyramid_odd": "pyramid", "k_pyramid_level": "pyramid", "k_detect": "detect",
+                "k_score_blocks": "nms", "k_classify_refine": "nms", "k_classify_refine_direct": "nms", "k_tie_resolve": "nms",
+                "k_finalize": "nms", "k_finalize_large": "nms", "k_smap_clear": "nms", "k_order_candidates": "nms",
+                "k_ordered_keypoints": "nms", "k_nms": "nms", "k_integral_final": "integral", "k_desc_prepare": "describe",
+                "k_describe": "describe"}
+    groups = {}
+    for k, v in out["kernels"].items():
+        g = group_of.get(k)
+        if g:
+            groups[g] = groups.get(g, 0.0) + v["hbm_bytes_per_launch"]
+    out["groups"] = groups
+    out["kernel_revision"] = sys.argv[7] if len(sys.argv) > 7 else None
     out["hbm_bytes_per_launch"] = out["kernels"]["k_detect"]["hbm_bytes_per_launch"]
     txt = json.dumps(out, indent=1)
     if len(sys.argv) > 6:

@@ -3,7 +3,7 @@
 # Collects what profiles/ holds for a round into gpurun_out/<tag>/:
 #   kernel_stats_b256.csv    rocprofv3 --kernel-trace --stats of the default bench command
 #   pmc_fetch_b64.csv / pmc_write_b64.csv   separate PMC passes (FETCH_SIZE, WRITE_SIZE) of a 64-frame run, engine kernels only
-#   traffic_k_detect.json    tools/pmc_traffic.py on those two passes
+#   traffic.json             tools/pmc_traffic.py on those two passes (per kernel and per group, tagged with the kernel revision)
 #   sq_counters.txt          SQ occupancy / stall / instruction counters per kernel (tools/pmc_sq.sh)
 #   bench.json               the bench line of an un-profiled default run
 tag=$1
@@ -11,10 +11,10 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/bench.py > $out/bench.json 2> $out/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/ks.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --steps 2 --warmup 1 --inner 8 > $out/ks.log 2>&1
 cp $(find $out/ks -name "*kernel_stats.csv" | head -1) $out/kernel_stats_b256.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c -d $out/pmc_$c -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --batch 64 --steps 2 --warmup 1 > $out/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c -d $out/pmc_$c -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --batch 64 --inner 2 --steps 2 --warmup 1 > $out/pmc_$c.log 2>&1
 done
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
@@ -28,7 +28,8 @@ for src, dst in ((sys.argv[1], sys.argv[2]), (sys.argv[3], sys.argv[4])):
     w.writeheader()
     w.writerows(keep)
 PY
-python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $out/pmc_fetch_b64.csv $out/pmc_write_b64.csv 64 1920 1080 $out/traffic_k_detect.json > /dev/null
+rev=$(python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import ethzasl_brisk_amd as B; print(B.load_library().brisk_hip_kernel_revision().decode())")
+python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $out/pmc_fetch_b64.csv $out/pmc_write_b64.csv 64 1920 1080 $out/traffic.json $rev > /dev/null
 cd $GRAFT_REPO_ROOT && bash tools/pmc_sq.sh $tag/sq > /dev/null 2>&1
 cp $out/sq/summary_all.txt $out/sq_counters.txt
 rm -rf $out/ks $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/sq

@@ -56,6 +56,23 @@ __device__ __forceinline__ unsigned smap_load_fresh(const uint16_t* smap, long i
   return (idx & 1) ? (v >> 16) : (v & 0xFFFFu);
 }
 
+// XCD-affine frame mapping for kernels whose blocks gather sparsely inside one frame: workgroups are dealt round-robin
+// over the 8 XCDs, so with a 1-D grid all blocks with equal blockIdx.x % 8 share an XCD (and its L2).  Every frame gets
+// `bpf` blocks on ONE residue: the lines its neighbouring candidates / keypoints share are then fetched into one L2
+// instead of up to eight.  (With fewer than 8 frames the affinity would idle XCDs: plain mapping.)
+__device__ __forceinline__ bool xcd_frame_block(int nframes, int bpf, int* frame, int* block_in_frame) {
+  if (nframes >= 8) {
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    *frame = (jj / bpf) * 8 + xcd;
+    *block_in_frame = jj % bpf;
+  } else {
+    *frame = blockIdx.x / bpf;
+    *block_in_frame = blockIdx.x % bpf;
+  }
+  return *frame < nframes;
+}
+static inline int xcd_grid(int nframes, int bpf) { return nframes >= 8 ? (nframes + 7) / 8 * 8 * bpf : nframes * bpf; }
+
 // ------------------------------------------------------------------------------------------------
 // k_pyramid_level: builds destination layer `dl` from source layer `sl` (mode 0 half, 1 two-third).
 // One thread produces 4 horizontally adjacent output pixels (one dword store).
@@ -100,6 +117,29 @@ struct TileRef {  // view of an LDS tile that covers image pixels [x0, x0+tw) x 
 // pointer such that ptr[r * stride + c] addresses absolute pixel (c, r) of the tiled layer
 __device__ __forceinline__ const uint8_t* tile_origin(const TileRef& t) { return t.p - (long)t.y0 * t.tw - t.x0; }
 
+// one level of a fused chain: a (tw x tw) tile at absolute origin (ox, oy) of the destination layer from the LDS tile
+// `so` (addressed with absolute source coordinates, row pitch stw) of a source layer of width sw.  Four horizontally
+// adjacent outputs per thread: one dword store to the pyramid (and to the next LDS tile) instead of four byte stores;
+// tile origins are multiples of 8, layer offsets / strides multiples of 64.
+template <bool TWOTHIRD>
+__device__ __forceinline__ void pyramid_tile_level(const uint8_t* so, int stw, int sw, uint8_t* __restrict__ dst, int dstride,
+                                                   int dw, int dh, int ox, int oy, int tw, uint8_t* dl) {
+  const int qw = tw >> 2;
+  for (int i = threadIdx.x; i < tw * qw; i += 256) {
+    const int r = i / qw, c = (i % qw) * 4;
+    const int gx = ox + c, gy = oy + r;
+    unsigned v = 0;
+    if (gy < dh) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (gx + q < dw)
+          v |= (unsigned)(TWOTHIRD ? brisk_twothird_px(so, stw, sw, gx + q, gy) : brisk_half_px(so, stw, sw, gx + q, gy)) << (8 * q);
+      if (gx < dstride) *reinterpret_cast<unsigned*>(dst + (long)gy * dstride + gx) = v;
+    }
+    if (dl) *reinterpret_cast<unsigned*>(&dl[r * tw + c]) = v;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t* __restrict__ frames, long frame_pitch,
                                                        int row_pitch, uint8_t* __restrict__ pyr, int nlevels, int tiles_x,
                                                        int tiles_y, uint32_t* __restrict__ bandsum, int istride) {
@@ -115,9 +155,16 @@ __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t
   const uint8_t* src = frames + (long)frame * frame_pitch;
   uint8_t* P = pyr + (long)frame * G.pyr_elems;
   const bool aligned = ((row_pitch | (uintptr_t)src) & 3) == 0;
-  // stage the 64x64 source block (zero outside the image) and write the layer-0 copy.  The four dword loads of a
-  // thread are issued back to back (unconditional, on a safe address when the dword is not fully inside the row)
-  {
+  // stage the 64x64 source block (zero outside the image) and write the layer-0 copy.  Interior blocks of 16-byte
+  // aligned frames: one 16-byte load and store per thread (a row of the block = 4 lanes).  Otherwise four dword loads
+  // per thread, issued back to back (unconditional, on a safe address when the dword is not fully inside the row).
+  const bool wide = (((unsigned)row_pitch | (uintptr_t)src) & 15) == 0 && by + 64 <= h && bx + 64 <= w;
+  if (wide) {
+    const int r = threadIdx.x >> 2, c16 = (threadIdx.x & 3) * 16;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (long)(by + r) * row_pitch + bx + c16);
+    *reinterpret_cast<uint4*>(P + G.L[0].off + (long)(by + r) * G.L[0].stride + bx + c16) = v;
+    *reinterpret_cast<uint4*>(&t0[r * 64 + c16]) = v;
+  } else {
     const long safe_off = -(long)((uintptr_t)src & 3);
     unsigned stg[4];
 #pragma unroll
@@ -172,18 +219,8 @@ __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t
     const int tw = 64 >> k;
     const int ox = bx >> k, oy = by >> k;
     const int dw = G.L[l].w, dh = G.L[l].h, dstride = G.L[l].stride;
-    const uint8_t* so = tile_origin(srct);
     uint8_t* dl = dst_lds[k - 1];
-    for (int i = threadIdx.x; i < tw * tw; i += 256) {
-      const int r = i / tw, c = i % tw;
-      const int gx = ox + c, gy = oy + r;
-      uint8_t v = 0;
-      if (gx < dw && gy < dh) {
-        v = brisk_half_px(so, srct.tw, sw, gx, gy);
-        P[G.L[l].off + (long)gy * dstride + gx] = v;
-      }
-      if (dl) dl[r * tw + c] = v;
-    }
+    pyramid_tile_level<false>(tile_origin(srct), srct.tw, sw, P + G.L[l].off, dstride, dw, dh, ox, oy, tw, dl);
     __syncthreads();
     srct.p = dl; srct.x0 = ox; srct.y0 = oy; srct.tw = tw;
     sw = dw;
@@ -201,7 +238,19 @@ __global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __res
   uint8_t* P = pyr + (long)frame * G.pyr_elems;
   const int w = G.L[0].w, h = G.L[0].h, s0 = G.L[0].stride;
   const uint8_t* src = P + G.L[0].off;
-  {  // stage the 96x96 source block: nine dword loads per thread, issued back to back on clamped addresses
+  if (by + 96 <= h && bx + 96 <= s0) {  // interior block: 16-byte loads (a block row = 6 lanes), issued back to back
+    uint4 stg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = min((int)threadIdx.x + k * 256, 96 * 6 - 1);
+      stg[k] = *reinterpret_cast<const uint4*>(src + (long)(by + i / 6) * s0 + bx + (i % 6) * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < 96 * 6) *reinterpret_cast<uint4*>(&t0[i * 16]) = stg[k];
+    }
+  } else {  // stage the 96x96 source block: nine dword loads per thread, issued back to back on clamped addresses
     unsigned stg[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -222,17 +271,7 @@ __global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __res
     const int ox = bx / 3 * 2, oy = by / 3 * 2;
     const int dw = G.L[1].w, dh = G.L[1].h, dstride = G.L[1].stride;
     const TileRef st = {t0, bx, by, 96};
-    const uint8_t* so = tile_origin(st);
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-      const int r = i >> 6, c = i & 63;
-      const int gx = ox + c, gy = oy + r;
-      uint8_t v = 0;
-      if (gx < dw && gy < dh) {
-        v = brisk_twothird_px(so, 96, w, gx, gy);
-        P[G.L[1].off + (long)gy * dstride + gx] = v;
-      }
-      t1[r * 64 + c] = v;
-    }
+    pyramid_tile_level<true>(tile_origin(st), 96, w, P + G.L[1].off, dstride, dw, dh, ox, oy, 64, t1);
   }
   __syncthreads();
   TileRef srct = {t1, bx / 3 * 2, by / 3 * 2, 64};
@@ -245,18 +284,8 @@ __global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __res
     const int tw = 64 >> k;
     const int ox = srct.x0 >> 1, oy = srct.y0 >> 1;
     const int dw = G.L[l].w, dh = G.L[l].h, dstride = G.L[l].stride;
-    const uint8_t* so = tile_origin(srct);
     uint8_t* dl = dst_lds[k - 1];
-    for (int i = threadIdx.x; i < tw * tw; i += 256) {
-      const int r = i / tw, c = i % tw;
-      const int gx = ox + c, gy = oy + r;
-      uint8_t v = 0;
-      if (gx < dw && gy < dh) {
-        v = brisk_half_px(so, srct.tw, sw, gx, gy);
-        P[G.L[l].off + (long)gy * dstride + gx] = v;
-      }
-      if (dl) dl[r * tw + c] = v;
-    }
+    pyramid_tile_level<false>(tile_origin(srct), srct.tw, sw, P + G.L[l].off, dstride, dw, dh, ox, oy, tw, dl);
     __syncthreads();
     srct.p = dl; srct.x0 = ox; srct.y0 = oy; srct.tw = tw;
     sw = dw;
@@ -509,8 +538,9 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
                                                                 const uint16_t* __restrict__ smap,
                                                                 const BriskCand* __restrict__ cand,
                                                                 const BriskFrameCounters* __restrict__ counters,
-                                                                uint8_t* __restrict__ blocks, int cand_cap) {
-  const int frame = blockIdx.y;
+                                                                uint8_t* __restrict__ blocks, int cand_cap, int nframes, int bpf) {
+  int frame, bx;
+  if (!xcd_frame_block(nframes, bpf, &frame, &bx)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = min(counters[frame].ncand, cand_cap);
   const uint8_t* fimg = pyr + (long)frame * G.pyr_elems;
@@ -521,7 +551,7 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
   __shared__ __attribute__((aligned(16))) uint8_t patch[SB_WAVES][SB_PER_WAVE][3][SB_PROWS][16];
   if (threadIdx.x < BRISK_MAX_LAYERS) lgeo[threadIdx.x] = make_int4(G.L[threadIdx.x].w, G.L[threadIdx.x].h, G.L[threadIdx.x].stride, G.L[threadIdx.x].off);
   __syncthreads();
-  for (int base = (blockIdx.x * SB_WAVES + wave) * SB_PER_WAVE; base < n; base += gridDim.x * SB_WAVES * SB_PER_WAVE) {
+  for (int base = (bx * SB_WAVES + wave) * SB_PER_WAVE; base < n; base += bpf * SB_WAVES * SB_PER_WAVE) {
     // -- round trip 1: the candidate headers (x, y, layer) of the wave's SB_PER_WAVE candidates
     uint2 hdr[SB_PER_WAVE];
 #pragma unroll
@@ -626,10 +656,11 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_classify_refine(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                          BriskFrameCounters* counters, const uint8_t* blocks, int* tie_idx,
-                                                         int cand_cap, int tie_cap) {
-  const int frame = blockIdx.y;
+                                                         int cand_cap, int tie_cap, int nframes, int bpf) {
+  int frame, bx;
+  if (!xcd_frame_block(nframes, bpf, &frame, &bx)) return;
   const int n = min(counters[frame].ncand, cand_cap);
-  for (int mine = blockIdx.x * blockDim.x + threadIdx.x; mine < n; mine += gridDim.x * blockDim.x) {
+  for (int mine = bx * blockDim.x + threadIdx.x; mine < n; mine += bpf * blockDim.x) {
     BriskCand* c = &cand[(long)frame * cand_cap + mine];
     const int x = c->x, y = c->y, l = c->layer, D = c->D;
     const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
@@ -1846,11 +1877,14 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
     return;
   }
-  static const int sb_blocks = env_knob("BRISK_SB_BLOCKS", 256), cr_blocks = env_knob("BRISK_CR_BLOCKS", 64);
-  hipLaunchKernelGGL(k_score_blocks, dim3(grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, sb_blocks), nframes), dim3(SB_WAVES * 64), 0,
-                     s, G, B.pyr, B.smap, B.cand, B.counters, B.blocks, B.cand_cap);
-  hipLaunchKernelGGL(k_classify_refine, dim3(grid_for(B.cand_cap, 64, cr_blocks), nframes), dim3(64), 0, s, G, B.pyr, B.smap,
-                     B.cand, B.counters, B.blocks, B.tie_idx, B.cand_cap, B.tie_cap);
+  static const int sb_blocks = env_knob("BRISK_SB_BLOCKS", 32), cr_blocks = env_knob("BRISK_CR_BLOCKS", 16);
+  {
+    const int sb_bpf = grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, sb_blocks), cr_bpf = grid_for(B.cand_cap, 64, cr_blocks);
+    hipLaunchKernelGGL(k_score_blocks, dim3(xcd_grid(nframes, sb_bpf)), dim3(SB_WAVES * 64), 0, s, G, B.pyr, B.smap, B.cand,
+                       B.counters, B.blocks, B.cand_cap, nframes, sb_bpf);
+    hipLaunchKernelGGL(k_classify_refine, dim3(xcd_grid(nframes, cr_bpf)), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters,
+                       B.blocks, B.tie_idx, B.cand_cap, B.tie_cap, nframes, cr_bpf);
+  }
   hipLaunchKernelGGL(k_classify_refine_direct, dim3(8, nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters,
                      B.tie_idx, B.cand_cap, B.tie_cap);
   brisk_prof_mark(prof, BRISK_STG_TIES, s);

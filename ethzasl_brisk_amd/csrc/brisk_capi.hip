@@ -466,7 +466,8 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
       // bandwidth-bound integral kernel fills what they leave
       int least = 0, greatest = 0;
       HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-      HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
+      const char* pe = getenv("BRISK_SIDE_PRIO");  // tuning experiments: 0 = default priority for the side stream
+      HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, (pe && atoi(pe) == 0) ? 0 : least));
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
     }

@@ -239,7 +239,7 @@ static inline uint32_t brisk_pk_shr(uint32_t a, uint32_t s) { return brisk_pk_pa
 #endif
 
 // c, n, s, w, e: centre and compass pixels (ring radius 3) of two pixels, one per 16-bit lane (values 0..255).
-// Returns 1 in the lane of a pixel that passes the pre-gate, 0 otherwise.
+// Returns bit 15 of the lane (0x8000) set for a pixel that passes the pre-gate, the lane zero otherwise.
 BRISK_HD uint32_t brisk_pregate_pair(uint32_t c, uint32_t n, uint32_t s, uint32_t w, uint32_t e, const BriskPregate& g) {
   const uint32_t dN = brisk_pk_sub(n, c), dS = brisk_pk_sub(s, c), dW = brisk_pk_sub(w, c), dE = brisk_pk_sub(e, c);
   const uint32_t mxNS = brisk_pk_max(dN, dS), mnNS = brisk_pk_min(dN, dS);
@@ -252,8 +252,9 @@ BRISK_HD uint32_t brisk_pregate_pair(uint32_t c, uint32_t n, uint32_t s, uint32_
   const uint32_t tc = brisk_pk_min(brisk_pk_max(t5, lower), upper);
   const uint32_t b2p = brisk_pk_shr(brisk_pk_mul(tc, g.K), g.shift);
   const uint32_t ev = brisk_pk_max(vb, brisk_pk_sub(0u, vd));
-  const uint32_t f = brisk_pk_sub(ev, b2p);       // > 0 <=> passes
-  return brisk_pk_min(brisk_pk_max(f, 0u), 0x10001u);
+  // passes <=> ev > b2' <=> b2' - ev < 0: the lane's sign bit (one subtraction and one 32-bit AND; a 0 / 1 result
+  // would cost a compare and a select per lane)
+  return brisk_pk_sub(b2p, ev) & 0x80008000u;
 }
 
 // Per-pixel detection (agast/src/oast9-16.cc:79-100 + SURVEY F5): returns D (= thrmap value) if

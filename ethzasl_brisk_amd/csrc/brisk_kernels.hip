@@ -360,18 +360,23 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   // the border) reads it, and phase B rejects the invalid centres phase A may let through.
   {
     unsigned stg[DT_NLD];
+    // dword i = threadIdx.x + 256 k of the tile: (row, dword in row) advances by (256 / DT_ROWDW, 256 % DT_ROWDW) per k
+    const int r0 = threadIdx.x / DT_ROWDW, c0 = threadIdx.x % DT_ROWDW;
+    int r = r0, c = c0;
 #pragma unroll
     for (int k = 0; k < DT_NLD; ++k) {
-      const int i = min((int)threadIdx.x + k * 256, DT_LH * DT_ROWDW - 1);
-      const int r = i / DT_ROWDW, c4 = i % DT_ROWDW;
-      const int cy = min(max(y0 - 3 + r, 0), h - 1), cx = min(max(x0 - 4 + c4 * 4, 0), stride - 4);
+      const int rr = min(r, DT_LH - 1);  // (the last round's surplus threads reload the last row)
+      const int cy = min(max(y0 - 3 + rr, 0), h - 1), cx = min(max(x0 - 4 + c * 4, 0), stride - 4);
       stg[k] = *reinterpret_cast<const unsigned*>(img + (long)cy * stride + cx);
+      r += 256 / DT_ROWDW; c += 256 % DT_ROWDW;
+      if (c >= DT_ROWDW) { c -= DT_ROWDW; ++r; }
     }
+    r = r0; c = c0;
 #pragma unroll
     for (int k = 0; k < DT_NLD; ++k) {
-      const int i = threadIdx.x + k * 256;
-      const int r = i / DT_ROWDW, c4 = i % DT_ROWDW;
-      if (i < DT_LH * DT_ROWDW) *reinterpret_cast<unsigned*>(&tile[r * DT_PITCH + c4 * 4]) = stg[k];
+      if (r < DT_LH) *reinterpret_cast<unsigned*>(&tile[r * DT_PITCH + c * 4]) = stg[k];
+      r += 256 / DT_ROWDW; c += 256 % DT_ROWDW;
+      if (c >= DT_ROWDW) { c -= DT_ROWDW; ++r; }
     }
   }
   if (threadIdx.x == 0) qcount = 0;
@@ -397,7 +402,9 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       CA[r] = __builtin_amdgcn_perm(0u, R[r][1], 0x0c010c00u);   // (col 0, col 1)
       CB[r] = __builtin_amdgcn_perm(0u, R[r][1], 0x0c030c02u);   // (col 2, col 3)
     }
-    unsigned m = 0;  // bit 2*rr + (j >> 1) + 16 * (j & 1): pixel (row rr, column j) of the thread passes
+    // pass flags of the thread's 16 pixels: every pair's two sign bits (15 and 31) are shifted in from the top, so
+    // pair k = 2 * rr + (j >> 1) ends at bits 8 + k (column j even) and 24 + k (column j odd)
+    unsigned m = 0;
 #pragma unroll
     for (int rr = 0; rr < DT_R; ++rr) {
       const int ci = rr + 3;
@@ -407,8 +414,8 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       const unsigned EB = __builtin_amdgcn_perm(0u, R[ci][2], 0x0c020c01u);        // (col 5, col 6)
       const unsigned gA = brisk_pregate_pair(CA[ci], CA[rr], CA[rr + 6], WA, EA, pg);
       const unsigned gB = brisk_pregate_pair(CB[ci], CB[rr], CB[rr + 6], WB, EB, pg);
-      m |= gA << (2 * rr);
-      m |= gB << (2 * rr + 1);
+      m = (m >> 1) | gA;
+      m = (m >> 1) | gB;
     }
     // compaction: wave prefix sum of the per-thread counts, one LDS atomic per wave
     const int cnt = __popc(m);
@@ -422,7 +429,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       while (m) {
         const int bit = __ffs(m) - 1;
         m &= m - 1;
-        const int k = bit & 15, half = bit >> 4;
+        const int k = (bit & 15) - 8, half = bit >> 4;
         queue[pos++] = (uint16_t)((ly + (k >> 1)) * DT_W + lx + ((k & 1) << 1) + half);
       }
     }

@@ -385,7 +385,18 @@ def main():
     per_frame_bytes = sum(groups.values())
     traffic = load_traffic(ctx)
     kgroups = kernel_groups(stage_ms, groups, fpl, traffic)
-    dom = max(kgroups, key=lambda k: kgroups[k]["ms"])
+    # the dominant KERNEL (largest HIP-event interval of a single stage) carries the roofline object; its algorithmic
+    # bytes are those of its SURVEY 8(d) stage
+    group_of_stage = {"k_pyramid": "pyramid", "k_detect": "detect", "k_classify_refine": "nms", "k_tie_resolve": "nms",
+                      "k_finalize": "nms", "k_integral_final": "integral", "k_desc_prepare": "describe", "k_describe": "describe"}
+    dom_stage = max(stage_ms, key=lambda k: stage_ms[k])
+    dom = group_of_stage[dom_stage]
+    dom_ms = stage_ms[dom_stage]
+    dom_alg = groups[dom] * fpl
+    dom_gb = dom_alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    dom_traffic = None
+    if traffic and dom_stage in traffic.get("kernels", {}):
+        dom_traffic = round(traffic["kernels"][dom_stage]["hbm_bytes_per_launch"] * fpl / traffic["frames_per_launch"])
     out = {
         "metric": METRIC,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -409,13 +420,13 @@ def main():
                                  "region); kernel_groups: algorithmic bytes of SURVEY 8(d) per group x frames per launch / "
                                  "interval; hbm_bytes from the committed rocprofv3 PMC passes when they belong to this "
                                  "kernel revision, else null"},
-        "roofline": dict(kgroups[dom], bound="hbm", kernel=dom, peak=HBM_PEAK_GBS, unit="GB/s",
-                         launches_timed=ncalls),
+        "roofline": {"bound": "hbm", "kernel": dom_stage, "achieved": round(dom_gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(dom_gb / HBM_PEAK_GBS, 5), "traffic": dom_traffic,
+                     "algorithmic_bytes_per_launch": dom_alg, "avg_launch_ms": round(dom_ms, 4), "launches_timed": ncalls,
+                     "note": ("k_describe is bound by outstanding cache-line requests x latency (gathers), not by HBM "
+                              "bandwidth: DESIGN.md 5, profiles/r02_describe_tcp_counters.txt; " if dom_stage == "k_describe" else "")
+                             + "every kernel group: config.kernel_groups"},
     }
-    out["roofline"]["achieved"] = out["roofline"].pop("GBps")
-    out["roofline"]["traffic"] = out["roofline"].pop("hbm_bytes")
-    out["roofline"]["algorithmic_bytes_per_launch"] = out["roofline"].pop("alg_bytes")
-    out["roofline"]["avg_launch_ms"] = out["roofline"].pop("ms")
     if rank == 0:
         try:
             cp, rd = ctx.stream_ceiling(1 << 30)

@@ -22,6 +22,13 @@
 #include "brisk_device_detect.h"
 #include "brisk_kernels.h"
 
+// tuning experiments only: integer knob from the environment (read once)
+static int env_knob(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
@@ -1430,7 +1437,8 @@ static void launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32
                             long iframe_elems, int nbands, int nframes, hipStream_t s) {
   const int nchunks = (G.L[0].w + 1 + II_CHUNK - 1) / II_CHUNK;
   const dim3 grid(nbands, nframes), block(II_THREADS);
-  if (nchunks <= 1) hipLaunchKernelGGL(k_integral_final<1>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
+  static const int pad_lds = env_knob("BRISK_II_LDS", 0);  // tuning experiments: dynamic LDS bytes = fewer workgroups per CU
+  if (nchunks <= 1) hipLaunchKernelGGL(k_integral_final<1>, grid, block, pad_lds, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
   else if (nchunks == 2) hipLaunchKernelGGL(k_integral_final<2>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
   else hipLaunchKernelGGL(k_integral_final<II_MAXCHUNKS>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
 }
@@ -1515,7 +1523,9 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
 // workgroup barriers.  Lane i samples pattern point i (points 64.. take a second round), the long pairs are
 // reduced with integer wave reductions (order independent), the short-pair bits are packed with 64-wide ballots.
 // ------------------------------------------------------------------------------------------------
+#ifndef DS_WAVES
 #define DS_WAVES 4
+#endif
 #define DS_LP_LDS 1024
 
 // ---- SmoothedIntensity split into address / load / combine stages (device only; the arithmetic is that of
@@ -1753,12 +1763,6 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from the C ABI implementation)
 // ------------------------------------------------------------------------------------------------
-// tuning experiments only: integer knob from the environment (read once)
-static int env_knob(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 static inline int grid_for(long items, int per_block, int cap) {
   long b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -1884,7 +1888,10 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
     return;
   }
-  static const int sb_blocks = env_knob("BRISK_SB_BLOCKS", 32), cr_blocks = env_knob("BRISK_CR_BLOCKS", 16);
+  // blocks per frame: few for large batches (every block then walks several rounds of its frame's candidates on one
+  // XCD), many for small ones (a single frame must spread over the chip)
+  static const int sb_knob = env_knob("BRISK_SB_BLOCKS", 0), cr_knob = env_knob("BRISK_CR_BLOCKS", 0);
+  const int sb_blocks = sb_knob ? sb_knob : (nframes >= 64 ? 32 : 256), cr_blocks = cr_knob ? cr_knob : (nframes >= 64 ? 16 : 64);
   {
     const int sb_bpf = grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, sb_blocks), cr_bpf = grid_for(B.cand_cap, 64, cr_blocks);
     hipLaunchKernelGGL(k_score_blocks, dim3(xcd_grid(nframes, sb_bpf)), dim3(SB_WAVES * 64), 0, s, G, B.pyr, B.smap, B.cand,

@@ -50,8 +50,9 @@ class BriskFeatureDetector {
     m_maxNumKpt = maxNumKpt > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)maxNumKpt;
   }
 
-  // Reference: brisk-feature-detector.cc:87-92 (scores for provided keypoints).  SURVEY §8(f)#3 "next" row:
-  // not implemented on the device path yet.
+  // Reference: brisk-feature-detector.cc:87-92 (scores for provided keypoints).  Not built: nothing in
+  // the reference calls it, and for ordinary inputs it reads score / image rows past the layer matrices
+  // (brisk-layer.cc:110-115 with float offsets), so there is no defined result to reproduce.
   void ComputeScale(const agast::Mat& /*image*/, std::vector<agast::KeyPoint>& /*keypoints*/) const {
     throw std::runtime_error("BriskFeatureDetector::ComputeScale is not implemented by the MI355X engine");
   }

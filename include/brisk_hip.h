@@ -27,9 +27,9 @@ enum {
   BRISK_HIP_ERR_NO_DEVICE = 2,  /* no usable HIP device */
   BRISK_HIP_ERR_HIP = 3,        /* a HIP runtime call failed */
   BRISK_HIP_ERR_CAPACITY = 4,   /* more candidates / keypoints than the configured capacity */
-  BRISK_HIP_ERR_THRESHOLD = 5,  /* AGAST threshold outside [20, 255] (deviations) */
+  BRISK_HIP_ERR_THRESHOLD = 5,  /* AGAST threshold outside [1, 255] (1..19 run the ordered path) */
   BRISK_HIP_ERR_PATTERN = 6,    /* malformed pattern (reference: CHECK_EQ(noShortPairs_, 384), :286) */
-  BRISK_HIP_ERR_UNSUPPORTED = 7 /* mode not implemented on the device path */
+  BRISK_HIP_ERR_UNSUPPORTED = 7 /* no defined result in the reference on this input (see brisk_hip_detect), or an unsupported size */
 };
 
 /* Binary-identical to cv::KeyPoint {Point2f pt; float size, angle, response; int octave, class_id;} */
@@ -42,7 +42,10 @@ typedef struct brisk_hip_ctx brisk_hip_ctx;          /* device workspace + strea
 typedef struct brisk_hip_pattern brisk_hip_pattern;  /* sampling pattern tables (extractor) */
 
 /* ---- context ------------------------------------------------------------------------------- */
-/* device: HIP device ordinal.  Buffers are sized lazily for the largest (w, h, octaves, batch) seen. */
+/* device: HIP device ordinal.  Buffers are sized lazily for the largest (w, h, octaves, batch) seen.  The calls of one
+ * context are serialised (mutex) and share one workspace: every call orders its stream behind the previous call's work,
+ * whichever stream that ran on.  For concurrency use one context per host thread (what include/brisk/hip-context.h
+ * does); pattern handles are plain device tables and may be shared by all contexts of a device. */
 int brisk_hip_create(int device, brisk_hip_ctx** out);
 void brisk_hip_destroy(brisk_hip_ctx* ctx);
 const char* brisk_hip_last_error(const brisk_hip_ctx* ctx);
@@ -68,8 +71,11 @@ int brisk_hip_pattern_tables(const brisk_hip_pattern* p, float* scale_list, int*
 /* ---- host-buffer calls: what the two host classes forward to --------------------------------- */
 /* BriskFeatureDetector::detectImpl (brisk-feature-detector.cc:77-85): clears/overwrites `out`.
  * img: h x w u8, row pitch `stride` bytes.  mask: optional h x w u8 (0 = drop keypoint), or NULL.
- * suppress_scale_nonmaxima = 0 is accepted with octaves == 0 only (brisk-scale-space.cc:131-170 is then the
- * single-layer refinement; with more layers the reference reads layer 0's point list on every layer, :137).
+ * threshold: 1..255 (20..255 on the fast path; below 20 the sequential ordered path, bit-exact but slow).
+ * suppress_scale_nonmaxima = 0 (brisk-scale-space.cc:131-170): with octaves == 0 the single-layer 2-D refinement; with
+ * more layers the reference takes every layer's point coordinates from layer 0's list (`agastPoints.at(0)[n]`, :137) -
+ * reproduced on the ordered path; where that indexing leaves layer 0's list or a score matrix (the usual case for
+ * ordinary images: undefined behaviour in the reference) the call fails with BRISK_HIP_ERR_UNSUPPORTED.
  * out: capacity `cap` keypoints; *n receives the count (BRISK_HIP_ERR_CAPACITY if cap is too small). */
 int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
                      int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, brisk_hip_keypoint* out,

@@ -49,6 +49,8 @@ void bo_integral_image8(const uint8_t* img, int w, int h, int32_t* out);
 typedef struct bo_scale_space bo_scale_space;
 /* BriskScaleSpace(octaves, suppress) + ConstructPyramid(image, threshold) */
 bo_scale_space* bo_scale_space_create(const uint8_t* img, int w, int h, int threshold, int octaves);
+/* ConstructPyramid(image, threshold, overwrite_lower_thres) */
+bo_scale_space* bo_scale_space_create_ex(const uint8_t* img, int w, int h, int threshold, int octaves, int lower_threshold);
 void bo_scale_space_destroy(bo_scale_space* s);
 int bo_scale_space_layers(const bo_scale_space* s);
 /* which: 0 image, 1 score map (lazy cache state), 2 threshold map */
@@ -64,6 +66,11 @@ int bo_detect_ex(const uint8_t* img, int w, int h, int threshold, int octaves, i
 /* Convenience: whole detectImpl incl. optional mask (h x w, u8, may be NULL). */
 int bo_detect(const uint8_t* img, int w, int h, int threshold, int octaves, const uint8_t* mask,
               bo_keypoint** out);
+/* BriskFeatureDetector::ComputeScale (brisk-feature-detector.cc:87-92, brisk-scale-space.cc:104-123): scores / scales
+ * for provided keypoints; PARITY UNPINNED (nothing in the reference exercises it); -1 = the reference has no defined
+ * result on this input (see the function).  *out malloc'd. */
+int bo_compute_scale(const uint8_t* img, int w, int h, int threshold, int octaves, int suppress_scale_nonmaxima,
+                     const bo_keypoint* in, int n_in, bo_keypoint** out);
 void bo_free(void* p);
 
 /* ---- extractor: brisk/src/brisk-descriptor-extractor.cc ---- */

@@ -341,11 +341,16 @@ static const int kMinDrop = 15;        /* :49 */
 
 /* :54-90 with BriskLayer ctors brisk-layer.cc:53-95 */
 bo_scale_space* bo_scale_space_create(const uint8_t* img, int w, int h, int threshold, int octaves) {
+  return bo_scale_space_create_ex(img, w, h, threshold, octaves, 10); /* kDefaultLowerThreshold :50-51 */
+}
+
+/* ConstructPyramid(image, threshold, overwrite_lower_thres) (:64-90) */
+bo_scale_space* bo_scale_space_create_ex(const uint8_t* img, int w, int h, int threshold, int octaves, int lower_threshold) {
   bo_scale_space* s = (bo_scale_space*)calloc(1, sizeof(*s));
   s->layers = (octaves == 0) ? 1 : 2 * octaves;
   s->threshold = threshold;
   s->l = (bo_layer*)calloc((size_t)s->layers, sizeof(bo_layer));
-  const int upper = 230, lower = 10; /* :50-51 */
+  const int upper = 230, lower = lower_threshold; /* :50-51 */
   bo_layer* L0 = &s->l[0];
   L0->w = w; L0->h = h;
   L0->img = (uint8_t*)malloc((size_t)w * h + 64);
@@ -1076,6 +1081,154 @@ int bo_detect_ex(const uint8_t* img, int w, int h, int threshold, int octaves, i
     n = m;
   }
   return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* BriskFeatureDetector::ComputeScale (brisk-feature-detector.cc:87-92): ConstructPyramid(image, threshold, 0) +   */
+/* GetKeypoints with a non-empty keypoint list (brisk-scale-space.cc:104-123 and the branches that follow with      */
+/* perform_2d_nonMax == false).  PARITY UNPINNED: nothing in the reference calls or tests this entry.                */
+/* Returns -1 where the reference has no defined result: GetAgastPoints addresses the maps with                      */
+/* int(x_float + y_float * cols) (brisk-layer.cc:110-115) and cornerScore then reads the ring around that pixel by   */
+/* linear offsets - past the image for points of a layer's last rows; or agastPoints.at(0)[n] throws (:137).         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { bo_keypoint* k; int n, cap; } kp_list;
+static void kp_push(kp_list* L, bo_keypoint kp) {
+  if (L->n == L->cap) { L->cap = L->cap ? 2 * L->cap : 64; L->k = (bo_keypoint*)realloc(L->k, sizeof(bo_keypoint) * L->cap); }
+  L->k[L->n++] = kp;
+}
+
+int bo_compute_scale(const uint8_t* img, int w, int h, int threshold, int octaves, int suppress_scale_nonmaxima,
+                     const bo_keypoint* in, int n_in, bo_keypoint** out) {
+  bo_scale_space* s = bo_scale_space_create_ex(img, w, h, threshold, octaves, 0);
+  if (n_in == 0) { /* empty list: plain detection on the lower-threshold-0 pyramid (no mask filter in ComputeScale) */
+    int n = bo_scale_space_get_keypoints_ex(s, suppress_scale_nonmaxima, out);
+    bo_scale_space_destroy(s);
+    return n;
+  }
+  kp_list* lists = (kp_list*)calloc((size_t)s->layers, sizeof(kp_list));
+  kp_list res = {0, 0, 0};
+  int undefined = 0;
+  for (int i = 0; i < s->layers && !undefined; ++i) { /* :99-126 */
+    bo_layer* l = &s->l[i];
+    for (int k = 0; k < n_in; ++k) {
+      bo_keypoint kp = in[k];
+      kp.x = ((float)in[k].x) / l->scale - l->offset;
+      kp.y = ((float)in[k].y) / l->scale - l->offset;
+      if (kp.x < 3 || kp.y < 3 || kp.x > l->w - 3 || kp.y > l->h - 3) continue;
+      Sf(l, kp.x, kp.y, 0); /* "calculates and stores the score of this keypoint in the score map" */
+      kp_push(&lists[i], kp);
+    }
+    if (lists[i].n == 0) { /* GetAgastPoints on an empty list detects (brisk-layer.cc:103-105), lower threshold 0 */
+      layer_get_agast_points(l, threshold);
+      for (int k = 0; k < l->npts; ++k) {
+        bo_keypoint kp;
+        kp.x = (float)l->pts[2 * k]; kp.y = (float)l->pts[2 * k + 1];
+        kp.size = 0; kp.angle = -1; kp.response = 0; kp.octave = 0; kp.class_id = -1; /* agast::KeyPoint h; (oast9-16.cc:48) */
+        kp_push(&lists[i], kp);
+      }
+    } else { /* brisk-layer.cc:106-116 with float coordinates */
+      const long total = (long)l->w * l->h;
+      for (int k = 0; k < lists[i].n; ++k) {
+        const int offs = lists[i].k[k].x + lists[i].k[k].y * l->w; /* float + float * int -> float -> int */
+        if (offs - 3 * l->w - 1 < 0 || offs + 3 * l->w + 1 >= total) { undefined = 1; break; } /* ring leaves the image */
+        const int thr = l->thrmap[offs];
+        l->scores[offs] = (uint8_t)bo_oast9_16_corner_score(l->img + offs, l->w, thr);
+      }
+    }
+  }
+#define EMIT(KP) kp_push(&res, (KP))
+  if (!undefined && !suppress_scale_nonmaxima && s->layers > 1) { /* :131-170, perform_2d_nonMax == false */
+    for (int i = 0; i < s->layers && !undefined; i++) {
+      bo_layer* l = &s->l[i];
+      for (int k = 0; k < lists[i].n; k++) {
+        if (k >= lists[0].n) { undefined = 1; break; }
+        const bo_keypoint keypoint = lists[0].k[k];
+        const float point_x = keypoint.x, point_y = keypoint.y;
+        int s_0_0 = Sf(l, point_x - 1, point_y - 1, 1);
+        int s_1_0 = Sf(l, point_x, point_y - 1, 1);
+        int s_2_0 = Sf(l, point_x + 1, point_y - 1, 1);
+        int s_2_1 = Sf(l, point_x + 1, point_y, 1);
+        int s_1_1 = Sf(l, point_x, point_y, 1);
+        int s_0_1 = Sf(l, point_x - 1, point_y, 1);
+        int s_0_2 = Sf(l, point_x - 1, point_y + 1, 1);
+        int s_1_2 = Sf(l, point_x, point_y + 1, 1);
+        int s_2_2 = Sf(l, point_x + 1, point_y + 1, 1);
+        float delta_x, delta_y;
+        float max = subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, &delta_x, &delta_y);
+        bo_keypoint kp = keypoint;
+        kp.x = point_x + delta_x; kp.y = point_y + delta_y;
+        kp.size = kBasicSize * l->scale; kp.angle = -1; kp.response = max; kp.octave = 0;
+        EMIT(kp);
+      }
+    }
+  } else if (!undefined && s->layers == 1) { /* :172-209 */
+    bo_layer* l = &s->l[0];
+    for (int k = 0; k < lists[0].n; k++) {
+      const bo_keypoint keypoint = lists[0].k[k];
+      const float point_x = keypoint.x, point_y = keypoint.y;
+      int s_0_0 = Sf(l, point_x - 1, point_y - 1, 1);
+      int s_1_0 = Sf(l, point_x, point_y - 1, 1);
+      int s_2_0 = Sf(l, point_x + 1, point_y - 1, 1);
+      int s_2_1 = Sf(l, point_x + 1, point_y, 1);
+      int s_1_1 = Sf(l, point_x, point_y, 1);
+      int s_0_1 = Sf(l, point_x - 1, point_y, 1);
+      int s_0_2 = Sf(l, point_x - 1, point_y + 1, 1);
+      int s_1_2 = Sf(l, point_x, point_y + 1, 1);
+      int s_2_2 = Sf(l, point_x + 1, point_y + 1, 1);
+      float delta_x, delta_y;
+      float max = subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, &delta_x, &delta_y);
+      bo_keypoint kp = keypoint;
+      kp.x = point_x + delta_x; kp.y = point_y + delta_y;
+      kp.size = kBasicSize; kp.angle = -1; kp.response = max; kp.octave = 0;
+      EMIT(kp);
+    }
+  } else if (!undefined) { /* :211-287 */
+    for (int i = 0; i < s->layers; i++) {
+      bo_layer* l = &s->l[i];
+      for (int k = 0; k < lists[i].n; k++) {
+        const bo_keypoint keypoint = lists[i].k[k];
+        const float point_x = keypoint.x, point_y = keypoint.y;
+        if (i == s->layers - 1) {
+          int ismax;
+          float dx, dy;
+          get_score_max_below(s, i, (int)point_x, (int)point_y, Sf(l, point_x, point_y, 1), &ismax, &dx, &dy);
+          if (!ismax) continue;
+          int s_0_0 = Sf(l, point_x - 1, point_y - 1, 1);
+          int s_1_0 = Sf(l, point_x, point_y - 1, 1);
+          int s_2_0 = Sf(l, point_x + 1, point_y - 1, 1);
+          int s_2_1 = Sf(l, point_x + 1, point_y, 1);
+          int s_1_1 = Sf(l, point_x, point_y, 1);
+          int s_0_1 = Sf(l, point_x - 1, point_y, 1);
+          int s_0_2 = Sf(l, point_x - 1, point_y + 1, 1);
+          int s_1_2 = Sf(l, point_x, point_y + 1, 1);
+          int s_2_2 = Sf(l, point_x + 1, point_y + 1, 1);
+          float delta_x, delta_y;
+          float max = subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, &delta_x, &delta_y);
+          bo_keypoint kp = keypoint;
+          kp.x = (point_x + delta_x) * l->scale + l->offset;
+          kp.y = (point_y + delta_y) * l->scale + l->offset;
+          kp.size = kBasicSize * l->scale; kp.angle = -1; kp.response = max; kp.octave = i;
+          EMIT(kp);
+        } else {
+          int ismax;
+          float x, y, scale;
+          float score = refine3d(s, i, (int)point_x, (int)point_y, &x, &y, &scale, &ismax);
+          if (!ismax) continue;
+          bo_keypoint kp = keypoint;
+          kp.x = x; kp.y = y; kp.size = kBasicSize * scale; kp.angle = -1; kp.response = score; kp.octave = i;
+          EMIT(kp);
+        }
+      }
+    }
+  }
+#undef EMIT
+  for (int i = 0; i < s->layers; ++i) free(lists[i].k);
+  free(lists);
+  bo_scale_space_destroy(s);
+  if (undefined) { free(res.k); *out = NULL; return -1; }
+  if (!res.k) res.k = (bo_keypoint*)malloc(sizeof(bo_keypoint));
+  *out = res.k;
+  return res.n;
 }
 
 void bo_free(void* p) { free(p); }

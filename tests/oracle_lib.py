@@ -39,6 +39,7 @@ def lib():
         L.bo_detect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
         L.bo_detect_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
         L.bo_free.argtypes = [vp]
+        L.bo_compute_scale.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
         L.bo_extractor_create.restype = vp
         L.bo_extractor_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_char_p]
         L.bo_extractor_destroy.argtypes = [vp]
@@ -112,6 +113,19 @@ def detect(img, threshold, octaves, mask=None, suppress_scale_nonmaxima=True):
     out = C.c_void_p()
     m = None if mask is None else _p(np.ascontiguousarray(mask, np.uint8))
     n = lib().bo_detect_ex(_p(img), w, h, threshold, octaves, int(bool(suppress_scale_nonmaxima)), m, C.byref(out))
+    if n < 0:
+        return None
+    return _take_kps(out, n)
+
+
+def compute_scale(img, keypoints, threshold, octaves, suppress_scale_nonmaxima=True):
+    """BriskFeatureDetector::ComputeScale; None where the reference has no defined result."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    k = np.ascontiguousarray(keypoints, KP)
+    out = C.c_void_p()
+    n = lib().bo_compute_scale(_p(img), w, h, threshold, octaves, int(bool(suppress_scale_nonmaxima)),
+                               _p(k) if len(k) else None, len(k), C.byref(out))
     if n < 0:
         return None
     return _take_kps(out, n)

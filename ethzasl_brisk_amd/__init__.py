@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
     "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
     "brisk_hip_reserve", "brisk_hip_detect_uniform", "brisk_hip_detect_describe_batch_host", "brisk_hip_stream_ceiling",
-    "brisk_hip_kernel_revision",
+    "brisk_hip_kernel_revision", "brisk_hip_compute_scale",
 ]
 
 
@@ -101,6 +101,8 @@ def load_library():
     L.brisk_hip_reserve.argtypes = [vp, C.c_int, C.c_int]
     L.brisk_hip_detect_uniform.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                            C.c_double, C.c_int, vp, C.c_int, ip]
+    L.brisk_hip_compute_scale.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp,
+                                          C.c_int, ip]
     L.brisk_hip_detect_describe_batch_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
                                                        C.c_int]
     L.brisk_hip_stream_ceiling.argtypes = [vp, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -262,6 +264,26 @@ class BriskFeatureDetector:
         c.check(c._L.brisk_hip_detect_uniform(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
                                               int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0,
                                               self.uniformityRadius, self.maxNumKpt, _ptr(out), capacity, C.byref(n)))
+        return out[:n.value].copy()
+
+
+    def ComputeScale(self, image, keypoints, capacity=None):
+        """ComputeScale (brisk-feature-detector.cc:87-92): returns the keypoints GetKeypoints produces for the provided
+        ones (the reference replaces the vector's contents)."""
+        img = np.ascontiguousarray(image)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise ValueError("image must be a 2-D uint8 array (CV_8UC1)")
+        h, w = img.shape
+        k = np.ascontiguousarray(keypoints, KEYPOINT)
+        layers = 1 if self.octaves == 0 else 2 * self.octaves
+        cap = capacity or (len(k) * layers + 65536)
+        c = self._ctx
+        c.reserve(65536, max(len(k), cap))
+        out = np.zeros(cap, KEYPOINT)
+        n = C.c_int()
+        c.check(c._L.brisk_hip_compute_scale(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
+                                             int(self.m_suppressScaleNonmaxima), _ptr(k) if len(k) else None, len(k),
+                                             _ptr(out), cap, C.byref(n)))
         return out[:n.value].copy()
 
 

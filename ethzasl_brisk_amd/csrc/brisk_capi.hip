@@ -117,6 +117,7 @@ static void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G
   G->w = w;
   G->h = h;
   G->threshold = threshold;
+  G->lower_threshold = BRISK_LOWER_THRESHOLD;
   int off = 0;
   for (int l = 0; l < G->nlayers; ++l) {
     BriskLayerGeom& L = G->L[l];
@@ -397,6 +398,7 @@ struct BatchArgs {
   double uni_radius;  // uniformity enforcement of this call (0 = off)
   int uni_max;
   bool no_scale_nms = false;  // suppressScaleNonmaxima == false with octaves > 0
+  int lower_threshold = BRISK_LOWER_THRESHOLD;  // 0: ComputeScale's pyramid (brisk-feature-detector.cc:90)
 };
 
 // geometry, workspace, restoring the all-zero score-state map, profiler bookkeeping: once per batch, on stream s
@@ -407,6 +409,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   make_geometry(A.w, A.h, A.threshold, A.octaves, &ctx->G, &ctx->T);
   ctx->G.debug_flags = ctx->debug_flags;
   ctx->G.no_scale_nms = (A.no_scale_nms && A.octaves != 0) ? 1 : 0;
+  ctx->G.lower_threshold = A.lower_threshold;
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
   if (A.do_detect && A.uni_radius > 0.0) {
@@ -506,12 +509,14 @@ static int batch_end(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipStr
 static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes, int w, int h,
                      long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* d_mask,
                      long mask_frame_pitch, int mask_row_pitch, hipStream_t s, bool do_detect, bool do_describe,
-                     double uni_radius = -1.0, int uni_max = 0, bool no_scale_nms = false) {
+                     double uni_radius = -1.0, int uni_max = 0, bool no_scale_nms = false,
+                     int lower_threshold = BRISK_LOWER_THRESHOLD) {
   if (!d_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   BatchArgs A{pat, w, h, threshold, octaves, frame_pitch, row_pitch, d_mask, mask_frame_pitch, mask_row_pitch, do_detect,
               do_describe, uni_radius < 0.0 ? ctx->uni_radius : uni_radius, uni_radius < 0.0 ? ctx->uni_max : uni_max};
   A.no_scale_nms = no_scale_nms;
+  A.lower_threshold = lower_threshold;
   int rc = batch_begin(ctx, A, nframes, s);
   if (rc) return rc;
   int nsub = ctx->nsub;
@@ -655,8 +660,9 @@ static int overflow_to_rc(brisk_hip_ctx* ctx, int flags) {
   if (flags & 8) return fail(ctx, BRISK_HIP_ERR_HIP, "tie resolution gave up waiting for a decision (internal error)");
   if (flags & 16)
     return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED,
-                "suppressScaleNonmaxima=false: on this image the reference indexes layer 0's point list past its end or reads "
-                "outside a score matrix (brisk-scale-space.cc:137) - no defined result");
+                "no defined result in the reference on this input: suppressScaleNonmaxima=false indexes layer 0's point list "
+                "past its end or reads outside a score matrix (brisk-scale-space.cc:137), or ComputeScale addresses the maps of "
+                "a point in a layer's last rows beyond the image (brisk-layer.cc:110-115)");
   return BRISK_HIP_OK;
 }
 
@@ -754,6 +760,49 @@ int brisk_hip_detect_uniform(brisk_hip_ctx* ctx, const uint8_t* img, int w, int 
   if (uniformity_radius < 0.0) return ctx ? fail(ctx, BRISK_HIP_ERR_ARG, "uniformity: negative radius") : BRISK_HIP_ERR_ARG;
   return detect_host(ctx, img, w, h, stride, threshold, octaves, suppress_scale_nonmaxima, mask, mask_stride,
                      uniformity_radius, max_keypoints, out, cap, n);
+}
+
+int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                            int suppress_scale_nonmaxima, const brisk_hip_keypoint* in, int n_in, brisk_hip_keypoint* out,
+                            int cap, int* n) {
+  if (!ctx || !img || !n || n_in < 0 || (n_in > 0 && !in) || (cap > 0 && !out) || cap < 0) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *n = 0;
+  int rc = check_detect_args(ctx, w, h, threshold, octaves);
+  if (rc) return rc;
+  if (stride < w) return fail(ctx, BRISK_HIP_ERR_ARG, "stride smaller than width");
+  if (n_in > ctx->kp_cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "more keypoints than the configured capacity");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int pitch = brisk_align_up(w, 64);
+  const size_t img_bytes = (size_t)pitch * h;
+  rc = ensure_stage(ctx, img_bytes * 2);
+  if (rc) return rc;
+  if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
+  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  if (n_in == 0) {
+    // an empty list makes GetKeypoints detect (brisk-scale-space.cc:104): plain detection on the pyramid ComputeScale
+    // builds (lowerThreshold_ = 0, brisk-feature-detector.cc:90), without the mask filter
+    rc = run_batch(ctx, nullptr, ctx->d_stage, 1, w, h, (long)img_bytes, pitch, threshold, octaves, nullptr, 0, 0, ctx->stream,
+                   true, false, 0.0, 0x7FFFFFFF, !suppress_scale_nonmaxima, 0);
+    if (rc) return rc;
+    return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
+  }
+  make_geometry(w, h, threshold, octaves, &ctx->G, &ctx->T);
+  ctx->G.debug_flags = ctx->debug_flags;
+  ctx->G.lower_threshold = 0;
+  rc = ensure_buffers(ctx, 1, ctx->G);
+  if (rc) return rc;
+  if (ctx->dirty_frames > 0) brisk_launch_smap_clear(ctx->dirtyG, ctx->B, ctx->dirty_frames, ctx->stream);
+  ctx->dirtyG = ctx->G;
+  ctx->dirty_frames = 1;  // (the kernel marks the frame for a complete clear: the walk writes the cache anywhere)
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in, in, sizeof(BriskKeyPoint) * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
+  brisk_launch_compute_scale(ctx->G, ctx->B, ctx->d_stage, pitch, ctx->d_kp_in, n_in, suppress_scale_nonmaxima ? 1 : 0,
+                             ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  ctx->last_nframes = 1;
+  ctx->last_has_desc = false;
+  if (workspace_release(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
+  return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
 }
 
 int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,

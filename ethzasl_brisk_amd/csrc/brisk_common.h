@@ -64,6 +64,7 @@ struct BriskGeom {
   int pyr_elems;       // total elements per frame (sum of stride*h, 256-aligned per layer)
   int threshold;       // AGAST threshold (20..255)
   int single_layer;    // octaves == 0
+  int lower_threshold; // lowerThreshold_ of the layers (10; 0 in ComputeScale, brisk-feature-detector.cc:90): ordered path if != 10
   int no_scale_nms;    // suppressScaleNonmaxima == false with more than one layer (ordered path, brisk-scale-space.cc:131-170)
   int debug_flags;     // test knobs: bit0 send every candidate through k_classify_refine_direct (safety-net test);
                        // bits 8-15 k_describe blocks per frame / 8; bit16 integral image not overlapped; bit17 matcher

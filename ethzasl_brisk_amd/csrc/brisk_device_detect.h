@@ -203,14 +203,16 @@ BRISK_HD int brisk_b2_fast(int tc, float k) {
 struct BriskPregate {
   uint32_t K;      // multiplier in both 16-bit lanes
   uint32_t shift;  // shift in both 16-bit lanes
+  uint32_t lower;  // lowerThreshold_ in both 16-bit lanes
 };
-BRISK_HD BriskPregate brisk_pregate_make(int thr) {
+BRISK_HD BriskPregate brisk_pregate_make(int thr, int lower_threshold = BRISK_LOWER_THRESHOLD) {
   int s = 8;
   while (s > 0 && 230 * ((thr << s) / 100) > 65535) --s;
   const uint32_t K = (uint32_t)((thr << s) / 100);
   BriskPregate g;
   g.K = K | (K << 16);
   g.shift = (uint32_t)s | ((uint32_t)s << 16);
+  g.lower = (uint32_t)lower_threshold * 0x10001u;
   return g;
 }
 
@@ -248,8 +250,8 @@ BRISK_HD uint32_t brisk_pregate_pair(uint32_t c, uint32_t n, uint32_t s, uint32_
   const uint32_t vd = brisk_pk_max(mnNS, mnWE);   // < -b2: two adjacent compass points darker
   const uint32_t hi = brisk_pk_max(brisk_pk_max(mxNS, mxWE), 0u), lo = brisk_pk_min(brisk_pk_min(mnNS, mnWE), 0u);
   const uint32_t t5 = brisk_pk_sub(hi, lo);       // range of {c, N, S, W, E} <= disc contrast
-  const uint32_t lower = (uint32_t)BRISK_LOWER_THRESHOLD * 0x10001u, upper = (uint32_t)BRISK_UPPER_THRESHOLD * 0x10001u;
-  const uint32_t tc = brisk_pk_min(brisk_pk_max(t5, lower), upper);
+  const uint32_t upper = (uint32_t)BRISK_UPPER_THRESHOLD * 0x10001u;
+  const uint32_t tc = brisk_pk_min(brisk_pk_max(t5, g.lower), upper);
   const uint32_t b2p = brisk_pk_shr(brisk_pk_mul(tc, g.K), g.shift);
   const uint32_t ev = brisk_pk_max(vb, brisk_pk_sub(0u, vd));
   // passes <=> ev > b2' <=> b2' - ev < 0: the lane's sign bit (one subtraction and one 32-bit AND; a 0 / 1 result
@@ -259,13 +261,13 @@ BRISK_HD uint32_t brisk_pregate_pair(uint32_t c, uint32_t n, uint32_t s, uint32_
 
 // Per-pixel detection (agast/src/oast9-16.cc:79-100 + SURVEY F5): returns D (= thrmap value) if
 // (x,y) is an AGAST point at threshold thr, else 0.  Caller guarantees 3 <= x <= w-4, 3 <= y <= h-4.
-BRISK_HD int brisk_detect_px(const uint8_t* p, int s, int thr) {
+BRISK_HD int brisk_detect_px(const uint8_t* p, int s, int thr, int lower = BRISK_LOWER_THRESHOLD) {
   int mn, mx;
   brisk_disc_minmax(p, s, &mn, &mx);
   const int t = mx - mn;
-  const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
+  const int cmp = (thr * lower) / 100;
   if (t < cmp) return 0;
-  const int tc = brisk_min(brisk_max(t, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
+  const int tc = brisk_min(brisk_max(t, lower), BRISK_UPPER_THRESHOLD);
   const int b2 = (tc * thr) / 100;
   // necessary condition: some ring pixel must differ from the centre by more than b2
   const int c = p[0];
@@ -808,7 +810,11 @@ BRISK_HD bool brisk_ismax2d_literal(const BriskLayerView& L, const int x_layer, 
 template <int DIRECT>
 BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, const BriskLayerView& tl,
                            const BriskLayerView& Labove, const int layer, const int x_layer, const int y_layer,
-                           BriskKeyPoint* kp, bool* e5, BriskTouch* touch) {
+                           BriskKeyPoint* kp, bool* e5, BriskTouch* touch, const float* fxy = nullptr) {
+  // fxy: the candidate's float coordinates where they are not integral (provided keypoints, ComputeScale; literal mode
+  // only).  GetKeypoints keeps them as floats for its own patch reads and the output, and truncates them where it calls
+  // Refine3D / GetScoreMaxBelow (int parameters).
+  const float fx = fxy ? fxy[0] : (float)x_layer, fy = fxy ? fxy[1] : (float)y_layer;
   const float lscale = G.L[layer].scale, loffset = G.L[layer].offset;
   BriskTouch none;
   none.on = false; none.mask = 0; none.x0 = 0; none.y0 = 0;
@@ -821,10 +827,10 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
   if (G.single_layer) {  // :172-209 (patch via float access: 4x4 touch footprint)
     float delta_x, delta_y;
     *e5 = true;
-    const float max = (DIRECT == 2) ? brisk_patch_subpixel_f<DIRECT>(tl, (float)x_layer, (float)y_layer, delta_x, delta_y)
+    const float max = (DIRECT == 2) ? brisk_patch_subpixel_f<DIRECT>(tl, fx, fy, delta_x, delta_y)
                                     : brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
-    kp->x = (float)x_layer + delta_x;
-    kp->y = (float)y_layer + delta_y;
+    kp->x = fx + delta_x;
+    kp->y = fy + delta_y;
     kp->size = BRISK_BASIC_SIZE;
     kp->response = max;
     kp->octave = 0;
@@ -835,15 +841,15 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
     bool ismax;
     float dx, dy;
     // (:227: the threshold argument is the float overload GetAgastScore(point_x, point_y, 1))
-    const int centre = (DIRECT == 2) ? brisk_Vf<DIRECT>(tl, (float)x_layer, (float)y_layer, &none) : brisk_V<DIRECT>(tl, x_layer, y_layer);
+    const int centre = (DIRECT == 2) ? brisk_Vf<DIRECT>(tl, fx, fy, &none) : brisk_V<DIRECT>(tl, x_layer, y_layer);
     brisk_score_max_other<DIRECT>(Lbelow, false, (layer & 1) != 0, x_layer, y_layer, centre, ismax, dx, dy, &none);
     if (!ismax) return false;
     *e5 = true;
     float delta_x, delta_y;
-    const float max = (DIRECT == 2) ? brisk_patch_subpixel_f<DIRECT>(tl, (float)x_layer, (float)y_layer, delta_x, delta_y)
+    const float max = (DIRECT == 2) ? brisk_patch_subpixel_f<DIRECT>(tl, fx, fy, delta_x, delta_y)
                                     : brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x, delta_y, nullptr);
-    kp->x = ((float)x_layer + delta_x) * lscale + loffset;
-    kp->y = ((float)y_layer + delta_y) * lscale + loffset;
+    kp->x = (fx + delta_x) * lscale + loffset;
+    kp->y = (fy + delta_y) * lscale + loffset;
     kp->size = BRISK_BASIC_SIZE * lscale;
     kp->response = max;
     return true;
@@ -1045,6 +1051,157 @@ BRISK_HD bool brisk_ordered_walk(const BriskGeom& G, uint8_t* pyr_frame, uint16_
     bool e5 = false;
     if (!brisk_refine<2>(G, Lb, Lo, La, l, x, y, &kp, &e5, &touch)) continue;
     brisk_ordered_emit(out, kp);
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ComputeScale (brisk-feature-detector.cc:87-92): GetKeypoints with a non-empty keypoint list
+// (brisk-scale-space.cc:104-123 and the branches behind it with perform_2d_nonMax == false) on a pyramid built with
+// lowerThreshold_ = 0, walked sequentially on the literal cache like brisk_ordered_walk.
+//   * per layer the provided points at (x / scale - offset) as floats, admitted inside [3, cols - 3] x [3, rows - 3];
+//     each is score-touched through the bilinear overload with threshold 0 (:121);
+//   * GetAgastPoints (brisk-layer.cc:99-117): a layer with no admitted point detects (lower threshold 0); otherwise
+//     the maps are addressed with int(x_float + y_float * cols) - a LINEAR index into matrices without row padding -
+//     and scores_[offs] = cornerScore(b = thrmap_[offs]) with the ring read at linear offsets around that pixel;
+//   * then the refinement branches, without IsMax2D, with the float coordinates where GetKeypoints keeps them.
+// Returns true where the reference has no defined result (the ring of such a pixel leaves the image, or
+// agastPoints.at(0)[n] throws); *cap_exceeded when the scratch list of a detecting layer is too small.
+// ---------------------------------------------------------------------------------------------
+BRISK_HD int brisk_img_linear(const BriskLayerView& L, long idx) { return L.img[(idx / L.w) * L.stride + (idx % L.w)]; }
+
+BRISK_HD int brisk_M_linear(const BriskLayerView& L, long offs) {
+  const long s = L.w;
+  const int c = brisk_img_linear(L, offs);
+  int d[16];
+  d[0] = brisk_img_linear(L, offs - 3) - c;          d[1] = brisk_img_linear(L, offs - 3 - s) - c;
+  d[2] = brisk_img_linear(L, offs - 2 - 2 * s) - c;  d[3] = brisk_img_linear(L, offs - 1 - 3 * s) - c;
+  d[4] = brisk_img_linear(L, offs - 3 * s) - c;      d[5] = brisk_img_linear(L, offs + 1 - 3 * s) - c;
+  d[6] = brisk_img_linear(L, offs + 2 - 2 * s) - c;  d[7] = brisk_img_linear(L, offs + 3 - s) - c;
+  d[8] = brisk_img_linear(L, offs + 3) - c;          d[9] = brisk_img_linear(L, offs + 3 + s) - c;
+  d[10] = brisk_img_linear(L, offs + 2 + 2 * s) - c; d[11] = brisk_img_linear(L, offs + 1 + 3 * s) - c;
+  d[12] = brisk_img_linear(L, offs + 3 * s) - c;     d[13] = brisk_img_linear(L, offs - 1 + 3 * s) - c;
+  d[14] = brisk_img_linear(L, offs - 2 + 2 * s) - c; d[15] = brisk_img_linear(L, offs - 3 + s) - c;
+  return brisk_oast9_16_M_from_d(d);
+}
+
+// thrmap_ value of pixel (x, y): disc contrast inside, 0 on the 3-pixel border (brisk-layer.cc:278-598)
+BRISK_HD int brisk_thrmap_at(const BriskLayerView& L, int x, int y) {
+  if (x < 3 || y < 3 || x >= L.w - 3 || y >= L.h - 3) return 0;
+  int mn, mx;
+  brisk_disc_minmax(L.img + (long)y * L.stride + x, L.stride, &mn, &mx);
+  return mx - mn;
+}
+
+struct BriskScaleList {  // agastPoints[i] of the ComputeScale walk
+  bool detected;         // the layer had no admitted provided point: its list are its own detections (det[start ...])
+  int count, start;
+};
+
+// the k-th ... iteration helper: coordinates of provided keypoint `idx` on layer l, and whether the layer admits it
+BRISK_HD bool brisk_provided_on_layer(const BriskGeom& G, int l, const BriskKeyPoint& kin, float* kx, float* ky) {
+  *kx = ((float)kin.x) / G.L[l].scale - G.L[l].offset;
+  *ky = ((float)kin.y) / G.L[l].scale - G.L[l].offset;
+  return !(*kx < 3 || *ky < 3 || *kx > G.L[l].w - 3 || *ky > G.L[l].h - 3);
+}
+
+BRISK_HD bool brisk_compute_scale_walk(const BriskGeom& G, uint8_t* pyr_frame, uint16_t* smap_frame, const BriskKeyPoint* in,
+                                       int n_in, bool suppress, uint32_t* det, int det_cap, BriskOrderedOut* out,
+                                       bool* cap_exceeded) {
+  BriskScaleList lists[BRISK_MAX_LAYERS];
+  int det_n = 0;
+  BriskTouch none;
+  none.on = false; none.mask = 0; none.x0 = 0; none.y0 = 0;
+  *cap_exceeded = false;
+  for (int i = 0; i < G.nlayers; ++i) {  // :99-126
+    const BriskLayerView L = brisk_view_of(G, pyr_frame, smap_frame, i);
+    lists[i].detected = false; lists[i].count = 0; lists[i].start = det_n;
+    for (int k = 0; k < n_in; ++k) {
+      float kx, ky;
+      if (!brisk_provided_on_layer(G, i, in[k], &kx, &ky)) continue;
+      // GetAgastScore(float, float, 0): the four integer accesses with threshold 0 (the blend itself is discarded)
+      const int x = (int)kx, y = (int)ky;
+      brisk_S_literal(L, x, y, 0); brisk_S_literal(L, x + 1, y, 0); brisk_S_literal(L, x, y + 1, 0); brisk_S_literal(L, x + 1, y + 1, 0);
+      lists[i].count++;
+    }
+    if (lists[i].count == 0) {  // GetAgastPoints on an empty list: detect (lower threshold G.lower_threshold = 0), raster order
+      lists[i].detected = true;
+      for (int y = 3; y <= L.h - 4; ++y)
+        for (int x = 3; x <= L.w - 4; ++x) {
+          const int D = brisk_detect_px(L.img + (long)y * L.stride + x, L.stride, G.threshold, G.lower_threshold);
+          if (!D) continue;
+          if (det_n >= det_cap) { *cap_exceeded = true; return false; }
+          det[det_n++] = (uint32_t)x | ((uint32_t)y << 16);
+          lists[i].count++;
+        }
+      for (int k = 0; k < lists[i].count; ++k) {  // scores_[offs] = cornerScore(b = thrmap_[offs]) == thrmap_[offs]
+        const int x = det[lists[i].start + k] & 0xFFFF, y = det[lists[i].start + k] >> 16;
+        L.smap[(long)y * L.stride + x] = (uint16_t)brisk_thrmap_at(L, x, y);
+      }
+    } else {  // brisk-layer.cc:106-116 with the float coordinates
+      const long total = (long)L.w * L.h;
+      for (int k = 0; k < n_in; ++k) {
+        float kx, ky;
+        if (!brisk_provided_on_layer(G, i, in[k], &kx, &ky)) continue;
+        const int offs = (int)(kx + ky * (float)L.w);
+        if ((long)offs - 3 * L.w - 1 < 0 || (long)offs + 3 * L.w + 1 >= total) return true;  // the ring leaves the image
+        const int ox = offs % L.w, oy = offs / L.w;
+        const int thr = brisk_thrmap_at(L, ox, oy);
+        const int M = brisk_M_linear(L, offs);
+        L.smap[(long)oy * L.stride + ox] = (uint16_t)(uint8_t)brisk_max(thr, brisk_min(M - 1, 254));
+      }
+    }
+  }
+  // entry k of agastPoints[l]: float coordinates + the keypoint whose remaining fields the output copies
+  // (sequential access only: `cursor` remembers where the previous entry of a provided-point list was found)
+  auto entry = [&](int l, int k, int* cursor, float* px, float* py, BriskKeyPoint* src) {
+    if (lists[l].detected) {
+      const uint32_t e = det[lists[l].start + k];
+      *px = (float)(e & 0xFFFF); *py = (float)(e >> 16);
+      src->x = *px; src->y = *py; src->size = 0.f; src->angle = -1.f; src->response = 0.f; src->octave = 0; src->class_id = -1;
+      return;
+    }
+    for (;; ++*cursor)
+      if (brisk_provided_on_layer(G, l, in[*cursor], px, py)) { *src = in[*cursor]; ++*cursor; return; }
+  };
+  if (!suppress && !G.single_layer) {  // :131-170, perform_2d_nonMax == false
+    for (int i = 0; i < G.nlayers; ++i) {
+      const BriskLayerView Li = brisk_view_of(G, pyr_frame, smap_frame, i);
+      if (lists[i].count > lists[0].count) return true;  // agastPoints.at(0)[n] throws std::out_of_range
+      int cur0 = 0;
+      for (int k = 0; k < lists[i].count; ++k) {
+        float px, py;
+        BriskKeyPoint kp;
+        entry(0, k, &cur0, &px, &py, &kp);
+        float dx, dy;
+        const float mx = brisk_patch_subpixel_f<2>(Li, px, py, dx, dy);
+        kp.x = px + dx; kp.y = py + dy;
+        kp.size = BRISK_BASIC_SIZE * G.L[i].scale;
+        kp.angle = -1.0f; kp.response = mx; kp.octave = 0;
+        brisk_ordered_emit(out, kp);
+      }
+    }
+    return false;
+  }
+  for (int i = 0; i < G.nlayers; ++i) {  // :172-209 (one layer) and :211-287
+    const bool has_above = !G.single_layer && (i + 1 < G.nlayers);
+    const bool has_below = !G.single_layer && (i > 0);
+    const BriskLayerView Lo = brisk_view_of(G, pyr_frame, smap_frame, i);
+    const BriskLayerView La = brisk_view_of(G, pyr_frame, smap_frame, has_above ? i + 1 : i);
+    const BriskLayerView Lb = brisk_view_of(G, pyr_frame, smap_frame, has_below ? i - 1 : i);
+    int cur = 0;
+    for (int k = 0; k < lists[i].count; ++k) {
+      float fxy[2];
+      BriskKeyPoint src, kp;
+      entry(i, k, &cur, &fxy[0], &fxy[1], &src);
+      BriskTouch touch;
+      touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
+      bool e5 = false;
+      kp = src;
+      if (!brisk_refine<2>(G, Lb, Lo, La, i, (int)fxy[0], (int)fxy[1], &kp, &e5, &touch, fxy)) continue;
+      kp.class_id = src.class_id;  // `agast::KeyPoint kp = keypoint;` keeps the provided class_id (:199, 244, 275)
+      brisk_ordered_emit(out, kp);
+    }
   }
   return false;
 }

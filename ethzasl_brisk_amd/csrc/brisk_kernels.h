@@ -78,6 +78,9 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                          const BriskOverlap* ov = nullptr);
 // zeroes what the previous batch (geometry Gprev, nframes frames) left in the score-state map
 void brisk_launch_smap_clear(const BriskGeom& Gprev, const BriskDetectBuffers& B, int nframes, hipStream_t s);
+// ComputeScale: pyramid + the provided-keypoint walk for one frame (d_in: n_in keypoints in device memory)
+void brisk_launch_compute_scale(const BriskGeom& G, const BriskDetectBuffers& B, const uint8_t* frame, int row_pitch,
+                                const BriskKeyPoint* d_in, int n_in, int suppress, hipStream_t s);
 // only stages layer 0 (descriptor-only calls)
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
                               long frame_pitch, int row_pitch, hipStream_t s);

@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * DT_R;
   const int lane = threadIdx.x & 63;
   {
-    const BriskPregate pg = brisk_pregate_make(thr);
+    const BriskPregate pg = brisk_pregate_make(thr, G.lower_threshold);
     unsigned R[DT_WR][3];
 #pragma unroll
     for (int r = 0; r < DT_WR; ++r) {
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
 
   // ---- phase B: exact contrast + closed-form segment test on the survivors (one lane each)
   const int nq = qcount;
-  const int cmp = (thr * BRISK_LOWER_THRESHOLD) / 100;
+  const int cmp = (thr * G.lower_threshold) / 100;
   const float kthr = brisk_b2_factor(thr);
   for (int i = threadIdx.x; i < nq; i += 256) {
     const int idx = queue[i];
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
         if (v[dy][dx] >= 0) { mx = max(mx, v[dy][dx]); mn = min(mn, v[dy][dx]); }
     const int tt = mx - mn;
     if (tt < cmp) continue;
-    const int tc = min(max(tt, BRISK_LOWER_THRESHOLD), BRISK_UPPER_THRESHOLD);
+    const int tc = min(max(tt, G.lower_threshold), BRISK_UPPER_THRESHOLD);
     const int b2 = brisk_b2_fast(tc, kthr);  // == (tc * thr) / 100 without quarter-rate integer multiplies
     const int c = v[3][3];
     if (mx - c <= b2 && c - mn <= b2) continue;  // no ring pixel can differ by more than b2
@@ -869,6 +869,22 @@ __global__ void __launch_bounds__(64) k_ordered_keypoints(BriskGeom G, uint8_t* 
   if (undefined) atomicOr(&counters[frame].overflow, 16);
   counters[frame].nkp = min(out.n, kp_cap);
   if (out.n > kp_cap) atomicOr(&counters[frame].overflow, 4);
+}
+
+// ComputeScale (brisk-feature-detector.cc:87-92): provided keypoints, one lane (brisk_compute_scale_walk); one frame.
+__global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr, uint16_t* smap, const BriskKeyPoint* in, int n_in,
+                                                       int suppress, BriskFrameCounters* counters, unsigned* det_scratch,
+                                                       int det_cap, BriskKeyPoint* kp_out, int kp_cap) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  counters[0].full_clear = 1;
+  BriskOrderedOut out;
+  out.kp = kp_out; out.cap = kp_cap; out.n = 0; out.mask = nullptr; out.mask_row_pitch = 0;
+  bool cap_exceeded = false;
+  const bool undefined = brisk_compute_scale_walk(G, pyr, smap, in, n_in, suppress != 0, det_scratch, det_cap, &out, &cap_exceeded);
+  if (undefined) atomicOr(&counters[0].overflow, 16);
+  if (cap_exceeded) atomicOr(&counters[0].overflow, 1);
+  counters[0].nkp = min(out.n, kp_cap);
+  if (out.n > kp_cap) atomicOr(&counters[0].overflow, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1835,12 +1851,8 @@ void brisk_launch_smap_clear(const BriskGeom& Gprev, const BriskDetectBuffers& B
   if (nframes > 0) hipLaunchKernelGGL(k_smap_clear, dim3(16, nframes), dim3(256), 0, s, Gprev, B.smap, B.cand, B.counters, B.cand_cap);
 }
 
-void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
-                         const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
-                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof,
-                         const BriskOverlap* ov) {
-  (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
-  brisk_prof_mark(prof, BRISK_STG_PYRAMID, s);
+static void launch_pyramid(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames, long frame_pitch,
+                           int row_pitch, hipStream_t s) {
   {
     // even chain: layer-0 copy + L2, L4, L6 from 64x64 blocks of the frame; odd chain: L1, L3, L5, L7 from 96x96 blocks
     const int even_levels = G.nlayers >= 7 ? 3 : G.nlayers >= 5 ? 2 : G.nlayers >= 3 ? 1 : 0;
@@ -1856,6 +1868,15 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
       hipLaunchKernelGGL(k_pyramid_level, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, B.pyr, l - 2, l, 0);
     }
   }
+}
+
+void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
+                         const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,
+                         long mask_frame_pitch, int mask_row_pitch, hipStream_t s, BriskProfiler* prof,
+                         const BriskOverlap* ov) {
+  (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
+  brisk_prof_mark(prof, BRISK_STG_PYRAMID, s);
+  launch_pyramid(G, B, nframes, frames, frame_pitch, row_pitch, s);
   // The integral image only needs layer 0 and the band sums (k_pyramid_even) and is HBM-bound; tie resolution
   // (one workgroup per frame, a chain of dependent decisions) and the final ordering are latency-bound and leave
   // most of the chip idle.  The integral kernel runs beside them on a second, low-priority stream (forked in front
@@ -1876,7 +1897,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                      B.cand_cap);
   if (ov && fork_at == 2) fork_integral();
   brisk_prof_mark(prof, BRISK_STG_CLASSIFY, s);
-  if (G.threshold < BRISK_FAST_PATH_MIN_THRESHOLD || G.no_scale_nms) {  // ordered path: the sequential algorithm on its literal cache
+  if (G.threshold < BRISK_FAST_PATH_MIN_THRESHOLD || G.no_scale_nms || G.lower_threshold != BRISK_LOWER_THRESHOLD) {  // ordered path: the sequential algorithm on its literal cache
     const long row_stride = (long)BRISK_MAX_LAYERS * B.tie_cap;
     hipLaunchKernelGGL(k_order_candidates, dim3(nframes), dim3(OC_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.tie_idx,
                        row_stride, B.cand_cap);
@@ -1911,6 +1932,14 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   hipLaunchKernelGGL(k_finalize_large, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys,
                      reinterpret_cast<unsigned*>(B.tie_idx), (long)BRISK_MAX_LAYERS * B.tie_cap, B.kp_out, B.cand_cap, B.kp_cap);
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
+}
+
+void brisk_launch_compute_scale(const BriskGeom& G, const BriskDetectBuffers& B, const uint8_t* frame, int row_pitch,
+                                const BriskKeyPoint* d_in, int n_in, int suppress, hipStream_t s) {
+  (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters), s);
+  launch_pyramid(G, B, 1, frame, 0, row_pitch, s);
+  hipLaunchKernelGGL(k_compute_scale, dim3(1), dim3(64), 0, s, G, B.pyr, B.smap, d_in, n_in, suppress, B.counters, B.keys,
+                     2 * B.cand_cap, B.kp_out, B.kp_cap);
 }
 
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,

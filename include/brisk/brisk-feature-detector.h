@@ -50,11 +50,33 @@ class BriskFeatureDetector {
     m_maxNumKpt = maxNumKpt > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)maxNumKpt;
   }
 
-  // Reference: brisk-feature-detector.cc:87-92 (scores for provided keypoints).  Not built: nothing in
-  // the reference calls it, and for ordinary inputs it reads score / image rows past the layer matrices
-  // (brisk-layer.cc:110-115 with float offsets), so there is no defined result to reproduce.
-  void ComputeScale(const agast::Mat& /*image*/, std::vector<agast::KeyPoint>& /*keypoints*/) const {
-    throw std::runtime_error("BriskFeatureDetector::ComputeScale is not implemented by the MI355X engine");
+  // brisk-feature-detector.cc:87-92: scores and scales for provided keypoints (`keypoints` is replaced by the result,
+  // up to one entry per layer that admits a point).  Runs the reference's sequential algorithm on the device; throws
+  // where the reference has no defined result (a point within a few rows of a layer's bottom border makes it read
+  // beyond the image, brisk-layer.cc:110-115; see brisk_hip_compute_scale).
+  void ComputeScale(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints) const {
+    if (image.empty() || image.type() != CV_8UC1) throw std::runtime_error("BriskFeatureDetector: image must be CV_8UC1");
+    brisk_hip_ctx* ctx = hip::DefaultContext();
+    const std::vector<agast::KeyPoint> in = keypoints;
+    brisk_hip_reserve(ctx, 65536, (int)in.size());
+    size_t cap = in.size() * (size_t)(octaves == 0 ? 1 : 2 * octaves) + 16384;
+    for (;;) {
+      keypoints.assign(cap, agast::KeyPoint());
+      int n = 0;
+      const int rc = brisk_hip_compute_scale(ctx, image.data, image.cols, image.rows, (int)image.step, threshold, octaves,
+                                             m_suppressScaleNonmaxima ? 1 : 0,
+                                             reinterpret_cast<const brisk_hip_keypoint*>(in.data()), (int)in.size(),
+                                             reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), (int)cap, &n);
+      if (rc == BRISK_HIP_ERR_CAPACITY && cap < (1u << 22)) {
+        cap *= 4;
+        brisk_hip_reserve(ctx, (int)(cap * 4), (int)cap);
+        continue;
+      }
+      if (rc != BRISK_HIP_OK) keypoints.clear();
+      hip::Check(ctx, rc, "brisk_hip_compute_scale");
+      keypoints.resize((size_t)n);
+      return;
+    }
   }
 
  protected:

@@ -85,6 +85,16 @@ int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int s
 int brisk_hip_detect_uniform(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
                              int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, double uniformity_radius,
                              int max_keypoints, brisk_hip_keypoint* out, int cap, int* n);
+/* BriskFeatureDetector::ComputeScale (brisk-feature-detector.cc:87-92; brisk-scale-space.cc:104-123 and the branches
+ * behind it): scores / scales for PROVIDED keypoints on a pyramid with lower threshold 0.  Every provided keypoint yields
+ * up to one output per layer that admits it (layer order, provided order inside a layer; class_id is kept).  Sequential
+ * on the device (ordered path), parity unpinned (nothing in the reference exercises this entry).
+ * BRISK_HIP_ERR_UNSUPPORTED where the reference has no defined result: a provided point in the last admitted rows of a
+ * layer (within about 5 rows x the layer's scale of the bottom border) makes the reference read beyond the image.
+ * in: n_in keypoints (only x, y and the copied-through fields matter); out: capacity cap; *n receives the count. */
+int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                            int suppress_scale_nonmaxima, const brisk_hip_keypoint* in, int n_in, brisk_hip_keypoint* out,
+                            int cap, int* n);
 /* BriskDescriptorExtractor::compute (brisk-descriptor-extractor.cc:612-778): filters `kps` in place
  * (border test), fills kps[i].angle, writes *n rows of descriptorSize() bytes at pitch desc_stride. */
 int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,

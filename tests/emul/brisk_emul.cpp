@@ -28,6 +28,7 @@ void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G) {  //
   G->nlayers = (octaves == 0) ? 1 : 2 * octaves;
   G->single_layer = (octaves == 0);
   G->w = w; G->h = h; G->threshold = threshold;
+  G->lower_threshold = BRISK_LOWER_THRESHOLD;
   int off = 0;
   for (int l = 0; l < G->nlayers; ++l) {
     BriskLayerGeom& L = G->L[l];
@@ -74,8 +75,9 @@ void touch_apply(Emul& E, int l_above, int x0, int y0, unsigned mask) {
 
 // mirrors k_copy_layer0 + k_pyramid_level + k_detect + k_classify_refine + k_tie_resolve + k_finalize
 void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int octaves, unsigned shuffle_seed, int jacobi,
-                bool use_cache, bool ordered = false, bool jacobi_no_scale_nms = false) {
+                bool use_cache, bool ordered = false, bool jacobi_no_scale_nms = false, int lower_threshold = BRISK_LOWER_THRESHOLD) {
   make_geometry(w, h, threshold, octaves, &E.G);
+  E.G.lower_threshold = lower_threshold;
   const BriskGeom& G = E.G;
   E.pyr.assign((size_t)G.pyr_elems + 256, 0);
   E.smap.assign((size_t)G.pyr_elems + 256, 0);
@@ -95,7 +97,7 @@ void run_detect(Emul& E, const uint8_t* img, int w, int h, int threshold, int oc
     BriskLayerView L = view(E, l);
     for (int y = 3; y <= L.h - 4; ++y)
       for (int x = 3; x <= L.w - 4; ++x) {
-        const int D = brisk_detect_px(L.img + (long)y * L.stride + x, L.stride, threshold);
+        const int D = brisk_detect_px(L.img + (long)y * L.stride + x, L.stride, threshold, E.G.lower_threshold);
         if (!D) continue;
         L.smap[(long)y * L.stride + x] = (uint16_t)D;
         BriskCand c;
@@ -297,6 +299,45 @@ int emul_detect(const uint8_t* img, int w, int h, int threshold, int octaves, un
     for (int l = 0; l < E.G.nlayers; ++l) nt += (int)E.ties[l].size();
     stats[1] = nt; stats[2] = E.relax_iters; stats[3] = E.max_chain; stats[4] = (int)brisk_cache_misses;
   }
+  return (int)E.kps.size();
+}
+
+// mirrors brisk_hip_compute_scale: pyramid with lower threshold 0, then the ComputeScale walk on one "lane";
+// returns -1 where the reference has no defined result
+int emul_compute_scale(const uint8_t* img, int w, int h, int threshold, int octaves, int suppress, const BriskKeyPoint* in,
+                       int n_in, BriskKeyPoint** out) {
+  Emul E;
+  if (n_in == 0) {  // empty list: plain detection on the lower-threshold-0 pyramid, ordered path
+    run_detect(E, img, w, h, threshold, octaves, 0, 0, false, true, !suppress, 0);
+    if (E.undefined) return -1;
+  } else {
+    make_geometry(w, h, threshold, octaves, &E.G);
+    E.G.lower_threshold = 0;
+    const BriskGeom& G = E.G;
+    E.pyr.assign((size_t)G.pyr_elems + 256, 0);
+    E.smap.assign((size_t)G.pyr_elems + 256, 0);
+    for (int y = 0; y < h; ++y) memcpy(E.pyr.data() + G.L[0].off + (size_t)y * G.L[0].stride, img + (size_t)y * w, w);
+    for (int l = 1; l < G.nlayers; ++l) {
+      const int sl = (l == 1) ? 0 : l - 2;
+      const uint8_t* src = E.pyr.data() + G.L[sl].off;
+      uint8_t* dst = E.pyr.data() + G.L[l].off;
+      for (int y = 0; y < G.L[l].h; ++y)
+        for (int x = 0; x < G.L[l].w; ++x)
+          dst[(size_t)y * G.L[l].stride + x] = (l == 1) ? brisk_twothird_px(src, G.L[sl].stride, G.L[sl].w, x, y)
+                                                        : brisk_half_px(src, G.L[sl].stride, G.L[sl].w, x, y);
+    }
+    std::vector<uint32_t> det(1 << 20);
+    E.kps.assign((size_t)n_in * G.nlayers + det.size() + 1, BriskKeyPoint());
+    BriskOrderedOut o;
+    o.kp = E.kps.data(); o.cap = (int)E.kps.size(); o.n = 0; o.mask = nullptr; o.mask_row_pitch = 0;
+    bool cap_exceeded = false;
+    if (brisk_compute_scale_walk(G, E.pyr.data(), E.smap.data(), in, n_in, suppress != 0, det.data(), (int)det.size(), &o,
+                                 &cap_exceeded) || cap_exceeded)
+      return -1;
+    E.kps.resize((size_t)o.n);
+  }
+  *out = (BriskKeyPoint*)malloc(sizeof(BriskKeyPoint) * (E.kps.size() + 1));
+  memcpy(*out, E.kps.data(), sizeof(BriskKeyPoint) * E.kps.size());
   return (int)E.kps.size();
 }
 

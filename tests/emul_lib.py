@@ -24,6 +24,7 @@ def lib():
         vp = C.c_void_p
         L.emul_detect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(vp), vp]
         L.emul_free.argtypes = [vp]
+        L.emul_compute_scale.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
         L.emul_oast_Kp.argtypes = [vp, C.c_int]
         L.emul_agast58_Kp.argtypes = [vp, C.c_int]
         L.emul_detect_px.argtypes = [vp, C.c_int, C.c_int]
@@ -57,6 +58,20 @@ def detect(img, threshold, octaves, shuffle_seed=0, jacobi=0):
     kps = np.frombuffer(C.string_at(out.value, n * KP.itemsize), dtype=KP).copy() if n else np.zeros(0, KP)
     lib().emul_free(out)
     return kps, stats
+
+
+def compute_scale(img, keypoints, threshold, octaves, suppress_scale_nonmaxima=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    k = np.ascontiguousarray(keypoints, KP)
+    out = C.c_void_p()
+    n = lib().emul_compute_scale(_p(img), w, h, threshold, octaves, int(bool(suppress_scale_nonmaxima)),
+                                 _p(k) if len(k) else None, len(k), C.byref(out))
+    if n < 0:
+        return None
+    kps = np.frombuffer(C.string_at(out.value, n * KP.itemsize), dtype=KP).copy() if n else np.zeros(0, KP)
+    lib().emul_free(out)
+    return kps
 
 
 class Pattern:

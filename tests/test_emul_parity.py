@@ -213,3 +213,47 @@ def test_ordered_path_no_scale_nms_branch_equals_oracle():
     img = synth.gen(320, 240, 3, 30)
     assert O.detect(img, 60, 2, suppress_scale_nonmaxima=False) is None
     assert E.detect(img, 60, 2, jacobi=16)[0] is None
+
+
+def provided_keypoints(img, thr, octaves, margin, seed=0, n_extra=40):
+    """a provided-keypoint list for ComputeScale: detected keypoints plus random ones (non-integral coordinates, other
+    class ids), all at least `margin` pixels above the bottom border so that the reference's linear map addressing
+    (brisk-layer.cc:110-115) stays inside every layer"""
+    rng = np.random.default_rng(seed)
+    h, w = img.shape
+    k = O.detect(img, thr, octaves)
+    extra = np.zeros(n_extra, O.KP)
+    extra["x"] = rng.uniform(0, w, n_extra).astype(np.float32)
+    extra["y"] = rng.uniform(0, h - margin, n_extra).astype(np.float32)
+    extra["size"] = 9
+    extra["angle"] = 33
+    extra["class_id"] = rng.integers(0, 1000, n_extra)
+    k = np.concatenate([k[k["y"] < h - margin], extra])
+    k["class_id"][::3] = 77
+    return k
+
+
+def test_compute_scale_walk_equals_oracle():
+    """BriskFeatureDetector::ComputeScale (provided keypoints): the sequential walk of the engine (same function as
+    the kernel's lane) against the oracle - all three branches (suppress / one layer / no scale NMS), the
+    detect-on-empty-layer case, the empty list, and an input the reference has no defined result for."""
+    img = synth.gen(320, 240, 9, 30)
+    for thr, octaves, suppress in ((60, 3, True), (60, 0, True), (60, 2, False), (25, 2, True), (8, 1, True)):
+        k = provided_keypoints(img, max(thr, 30), 3, 70, seed=thr)
+        ko = O.compute_scale(img, k, thr, octaves, suppress)
+        ke = E.compute_scale(img, k, thr, octaves, suppress)
+        assert ko is not None and len(ko) > 100, (thr, octaves, suppress)
+        assert same_kps(ke, ko), (thr, octaves, suppress, len(ke), len(ko))
+        assert set(ko["class_id"]) >= {77}
+    # only points near the top-left corner: the upper layers admit none of them and detect instead (lower threshold 0)
+    few = np.zeros(3, O.KP)
+    few["x"], few["y"], few["size"] = [4, 6.5, 5], [4, 5, 7.25], 12
+    ko = O.compute_scale(img, few, 60, 3)
+    assert ko is not None and len(ko) > 50 and same_kps(E.compute_scale(img, few, 60, 3), ko)
+    # empty list = detection with lower threshold 0
+    ko = O.compute_scale(img, few[:0], 60, 2)
+    assert len(ko) > 100 and same_kps(E.compute_scale(img, few[:0], 60, 2), ko)
+    # a point in the last admitted rows of a layer: the reference reads beyond the image
+    bad = np.zeros(1, O.KP)
+    bad["x"], bad["y"] = 100, 236.5
+    assert O.compute_scale(img, bad, 60, 3) is None and E.compute_scale(img, bad, 60, 3) is None

@@ -265,3 +265,30 @@ def test_custom_ptn_pattern_and_bilinear_branch(B, golden_harris):
             kg, dg = ext.compute(e["image"], k)
             assert len(ko) > 300 and same_kps(kg, ko), (ps, rot, sc, explain(kg, ko))
             assert np.array_equal(dg, do), (ps, rot, sc)
+
+
+def test_compute_scale_provided_keypoints(B):
+    """BriskFeatureDetector::ComputeScale (brisk-feature-detector.cc:87-92) through the C ABI: provided keypoints (detected
+    ones plus random non-integral ones with their own class ids) on the lower-threshold-0 pyramid; all three branches,
+    the detect-on-empty-layer case, the empty list, the undefined input (code 7), and a fast-path call afterwards."""
+    from test_emul_parity import provided_keypoints
+    ctx = B.Context(0)
+    img = synth.gen(320, 240, 9, 30)
+    for thr, octaves, suppress in ((60, 3, True), (60, 0, True), (60, 2, False), (25, 2, True), (8, 1, True)):
+        k = provided_keypoints(img, max(thr, 30), 3, 70, seed=thr)
+        ko = O.compute_scale(img, k, thr, octaves, suppress)
+        kg = B.BriskFeatureDetector(thr, octaves, suppress, context=ctx).ComputeScale(img, k)
+        assert ko is not None and len(ko) > 100 and same_kps(kg, ko), (thr, octaves, suppress, explain(kg, ko))
+    few = np.zeros(3, B.KEYPOINT)
+    few["x"], few["y"], few["size"] = [4, 6.5, 5], [4, 5, 7.25], 12
+    det = B.BriskFeatureDetector(60, 3, context=ctx)
+    assert same_kps(det.ComputeScale(img, few), O.compute_scale(img, few, 60, 3))
+    assert same_kps(B.BriskFeatureDetector(60, 2, context=ctx).ComputeScale(img, few[:0]), O.compute_scale(img, few[:0], 60, 2))
+    bad = np.zeros(1, B.KEYPOINT)
+    bad["x"], bad["y"] = 100, 236.5
+    with pytest.raises(B.BriskHipError) as ei:
+        det.ComputeScale(img, bad)
+    assert ei.value.code == 7
+    vga = synth.frame_vga(1)
+    assert same_kps(B.BriskFeatureDetector(70, 4, context=ctx).detect(vga), O.detect(vga, 70, 4))
+    ctx.close()

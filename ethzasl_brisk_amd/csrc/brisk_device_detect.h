@@ -409,79 +409,75 @@ BRISK_HD int brisk_Vf(const BriskLayerView& L, float xf, float yf, BriskTouch* t
 // ---------------------------------------------------------------------------------------------
 // Subpixel2D (brisk/src/brisk-scale-space.cc:1230-1364), including delta_y = delta_x1/2 (:1351,1355)
 // ---------------------------------------------------------------------------------------------
+// Least-squares quadric through the 3x3 patch, 18 q(x, y) = A x^2 + B y^2 + C x + D y + E x y + F with integer
+// coefficients, maximised over [-1, 1]^2.  The coefficients are exact integers, so they are written here from the
+// patch's row / column / diagonal sums; everything in floating point keeps the reference's order of operations (its
+// result is the oracle), including its fall-back rules: flat Hessian -> centre; not a maximum -> best corner; maximum
+// outside the square -> the better of the two edge-constrained maxima, with BOTH offsets set to that candidate's x
+// offset (:1351, 1355).
+struct BriskQuadric {
+  int A, B, C, D, E, F;
+};
+BRISK_HD float brisk_quadric_at(const BriskQuadric& q, float x, float y) {
+  return (float)((q.A * x * x + q.B * y * y + q.C * x + q.D * y + q.E * x * y + q.F) / 18.0);
+}
+BRISK_HD float brisk_clamp_unit(float v) { return v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v); }
+
 BRISK_HD_OUTLINE float brisk_subpixel2d(const int s_0_0, const int s_0_1, const int s_0_2, const int s_1_0,
                                 const int s_1_1, const int s_1_2, const int s_2_0, const int s_2_1,
                                 const int s_2_2, float& delta_x, float& delta_y) {
-  const int tmp1 = s_0_0 + s_0_2 - 2 * s_1_1 + s_2_0 + s_2_2;
-  const int coeff1 = 3 * (tmp1 + s_0_1 - ((s_1_0 + s_1_2) * 2) + s_2_1);
-  const int coeff2 = 3 * (tmp1 - ((s_0_1 + s_2_1) * 2) + s_1_0 + s_1_2);
-  const int tmp2 = s_0_2 - s_2_0;
-  const int tmp3 = (s_0_0 + tmp2 - s_2_2);
-  const int tmp4 = tmp3 - 2 * tmp2;
-  const int coeff3 = -3 * (tmp3 + s_0_1 - s_2_1);
-  const int coeff4 = -3 * (tmp4 + s_1_0 - s_1_2);
-  const int coeff5 = (s_0_0 - s_0_2 - s_2_0 + s_2_2) * 4;
-  const int coeff6 = -(s_0_0 + s_0_2 - ((s_1_0 + s_0_1 + s_1_2 + s_2_1) * 2) - 5 * s_1_1 + s_2_0 + s_2_2) * 2;
-  const int H_det = 4 * coeff1 * coeff2 - coeff5 * coeff5;
-  if (H_det == 0) {
+  // s_x_y: column x, row y of the patch
+  const int left = s_0_0 + s_0_1 + s_0_2, right = s_2_0 + s_2_1 + s_2_2, mid_col = s_1_0 + s_1_1 + s_1_2;
+  const int top = s_0_0 + s_1_0 + s_2_0, bottom = s_0_2 + s_1_2 + s_2_2, mid_row = s_0_1 + s_1_1 + s_2_1;
+  BriskQuadric q;
+  q.A = 3 * (left + right - 2 * mid_col);
+  q.B = 3 * (top + bottom - 2 * mid_row);
+  q.C = 3 * (right - left);
+  q.D = 3 * (bottom - top);
+  q.E = 4 * (s_0_0 - s_0_2 - s_2_0 + s_2_2);
+  q.F = 2 * (5 * s_1_1 + 2 * (s_1_0 + s_0_1 + s_1_2 + s_2_1) - (s_0_0 + s_0_2 + s_2_0 + s_2_2));
+  const int det = 4 * q.A * q.B - q.E * q.E;
+  if (det == 0) {
     delta_x = 0.0f;
     delta_y = 0.0f;
-    return (float)((float)coeff6 / 18.0);
+    return (float)((float)q.F / 18.0);
   }
-  if (!(H_det > 0 && coeff1 < 0)) {
-    int tmp_max = coeff3 + coeff4 + coeff5;
+  if (!(det > 0 && q.A < 0)) {  // no maximum inside: the best of the four corners, first one wins a draw
+    int best = q.C + q.D + q.E;
     delta_x = 1.0f;
     delta_y = 1.0f;
-    int tmp = -coeff3 + coeff4 - coeff5;
-    if (tmp > tmp_max) { tmp_max = tmp; delta_x = -1.0f; delta_y = 1.0f; }
-    tmp = coeff3 - coeff4 - coeff5;
-    if (tmp > tmp_max) { tmp_max = tmp; delta_x = 1.0f; delta_y = -1.0f; }
-    tmp = -coeff3 - coeff4 + coeff5;
-    if (tmp > tmp_max) { tmp_max = tmp; delta_x = -1.0f; delta_y = -1.0f; }
-    return (float)((float)(tmp_max + coeff1 + coeff2 + coeff6) / 18.0);
+    const int sx[3] = {-1, 1, -1}, sy[3] = {1, -1, -1};
+    for (int k = 0; k < 3; ++k) {
+      const int v = sx[k] * q.C + sy[k] * q.D + sx[k] * sy[k] * q.E;
+      if (v > best) { best = v; delta_x = (float)sx[k]; delta_y = (float)sy[k]; }
+    }
+    return (float)((float)(best + q.A + q.B + q.F) / 18.0);
   }
-  delta_x = (float)(2 * coeff2 * coeff3 - coeff4 * coeff5) / (float)(-H_det);
-  delta_y = (float)(2 * coeff1 * coeff4 - coeff3 * coeff5) / (float)(-H_det);
-  bool tx = false, tx_ = false, ty = false, ty_ = false;
-  if (delta_x > 1.0f) tx = true;
-  else if (delta_x < -1.0f) tx_ = true;
-  if (delta_y > 1.0f) ty = true;
-  if (delta_y < -1.0f) ty_ = true;
-  if (tx || tx_ || ty || ty_) {
-    float delta_x1 = 0.0f, delta_x2 = 0.0f, delta_y1 = 0.0f, delta_y2 = 0.0f;
-    if (tx) {
-      delta_x1 = 1.0f;
-      delta_y1 = -(float)(coeff4 + coeff5) / (float)(2 * coeff2);
-      if (delta_y1 > 1.0f) delta_y1 = 1.0f; else if (delta_y1 < -1.0f) delta_y1 = -1.0f;
-    } else if (tx_) {
-      delta_x1 = -1.0f;
-      delta_y1 = -(float)(coeff4 - coeff5) / (float)(2 * coeff2);
-      if (delta_y1 > 1.0f) delta_y1 = 1.0f; else if (delta_y1 < -1.0f) delta_y1 = -1.0f;
-    }
-    if (ty) {
-      delta_y2 = 1.0f;
-      delta_x2 = -(float)(coeff3 + coeff5) / (float)(2 * coeff1);
-      if (delta_x2 > 1.0f) delta_x2 = 1.0f; else if (delta_x2 < -1.0f) delta_x2 = -1.0f;
-    } else if (ty_) {
-      delta_y2 = -1.0f;
-      delta_x2 = -(float)(coeff3 - coeff5) / (float)(2 * coeff1);
-      if (delta_x2 > 1.0f) delta_x2 = 1.0f; else if (delta_x2 < -1.0f) delta_x2 = -1.0f;
-    }
-    const float max1 = (float)((coeff1 * delta_x1 * delta_x1 + coeff2 * delta_y1 * delta_y1 + coeff3 * delta_x1 +
-                                coeff4 * delta_y1 + coeff5 * delta_x1 * delta_y1 + coeff6) / 18.0);
-    const float max2 = (float)((coeff1 * delta_x2 * delta_x2 + coeff2 * delta_y2 * delta_y2 + coeff3 * delta_x2 +
-                                coeff4 * delta_y2 + coeff5 * delta_x2 * delta_y2 + coeff6) / 18.0);
-    if (max1 > max2) {
-      delta_x = delta_x1;
-      delta_y = delta_x1;  // sic (reference :1351)
-      return max1;
-    }
-    delta_x = delta_x2;
-    delta_y = delta_x2;  // sic (reference :1355)
-    return max2;
+  delta_x = (float)(2 * q.B * q.C - q.D * q.E) / (float)(-det);
+  delta_y = (float)(2 * q.A * q.D - q.C * q.E) / (float)(-det);
+  // which sides of the square the unconstrained maximum violates (x: only one side is ever noted, as in the reference)
+  const int out_x = delta_x > 1.0f ? 1 : (delta_x < -1.0f ? -1 : 0);
+  const int out_y = delta_y > 1.0f ? 1 : (delta_y < -1.0f ? -1 : 0);
+  if (out_x == 0 && out_y == 0) return brisk_quadric_at(q, delta_x, delta_y);
+  float ex = 0.0f, ey = 0.0f;  // maximum along the violated vertical edge x = out_x (or the centre if none)
+  if (out_x != 0) {
+    ex = (float)out_x;
+    ey = brisk_clamp_unit(-(float)(q.D + out_x * q.E) / (float)(2 * q.B));
   }
-  return (float)((coeff1 * delta_x * delta_x + coeff2 * delta_y * delta_y + coeff3 * delta_x + coeff4 * delta_y +
-                  coeff5 * delta_x * delta_y + coeff6) / 18.0);
+  float fx = 0.0f, fy = 0.0f;  // maximum along the violated horizontal edge y = out_y
+  if (out_y != 0) {
+    fy = (float)out_y;
+    fx = brisk_clamp_unit(-(float)(q.C + out_y * q.E) / (float)(2 * q.A));
+  }
+  const float m_e = brisk_quadric_at(q, ex, ey), m_f = brisk_quadric_at(q, fx, fy);
+  if (m_e > m_f) {
+    delta_x = ex;
+    delta_y = ex;  // sic (reference :1351)
+    return m_e;
+  }
+  delta_x = fx;
+  delta_y = fx;  // sic (reference :1355)
+  return m_f;
 }
 
 // 3x3 patch around (x, y) with integer score access + Subpixel2D
@@ -524,64 +520,51 @@ BRISK_HD float brisk_patch_subpixel_f(const BriskLayerView& L, float x, float y,
 // ---------------------------------------------------------------------------------------------
 // Refine1D family (brisk-scale-space.cc:1101-1228)
 // ---------------------------------------------------------------------------------------------
+// Parabola through the scores of the layer below, the layer itself and the layer above, at the relative scales
+// (lo, 1, hi) those layers have: octave (0.75, 1, 1.5), intra-octave (2/3, 1, 4/3), layer 0 against its virtual half-octave
+// (0.7, 1, 1.5).  The integer coefficient tables are the reference's (scores x 1024, rounded), the float steps keep its
+// order; the maximum's abscissa is clamped to [lo, hi].
+struct BriskScaleFit {
+  int a[3], b[3], c[3];      // 2nd, 1st, 0th order coefficient as combinations of (below, own, above)
+  float at_lo, at_hi;        // abscissae returned for a maximum at the outer samples
+  double lo, hi;             // clamp interval (compared in double, as written in the reference)
+  float clamp_lo, clamp_hi;
+  double denom;              // common factor of the tables x 1024
+  bool float_division;       // Refine1D_2 divides in float (:1226), the other two in double
+};
+BRISK_HD float brisk_scale_fit(const BriskScaleFit& f, const float s_below, const float s_own, const float s_above, float& max) {
+  const int v[3] = {(int)(1024.0 * s_below + 0.5), (int)(1024.0 * s_own + 0.5), (int)(1024.0 * s_above + 0.5)};
+  const int a = f.a[0] * v[0] + f.a[1] * v[1] + f.a[2] * v[2];
+  if (a >= 0) {  // no maximum: the largest sample (own layer first, then below, then above)
+    if (s_own >= s_below && s_own >= s_above) { max = s_own; return 1.0f; }
+    if (s_below >= s_own && s_below >= s_above) { max = s_below; return f.at_lo; }
+    if (s_above >= s_own && s_above >= s_below) { max = s_above; return f.at_hi; }
+  }
+  const int b = f.b[0] * v[0] + f.b[1] * v[1] + f.b[2] * v[2];
+  float r = -(float)b / (float)(2 * a);
+  if (r < f.lo) r = f.clamp_lo;
+  else if (r > f.hi) r = f.clamp_hi;
+  const int c = f.c[0] * v[0] + f.c[1] * v[1] + f.c[2] * v[2];
+  max = (float)c + (float)a * r * r + (float)b * r;
+  if (f.float_division) max = max / (float)(int)f.denom;
+  else max = (float)(max / f.denom);
+  return r;
+}
+// Refine1D (:1101-1143), Refine1D_1 (:1145-1186), Refine1D_2 (:1188-1228)
 BRISK_HD_OUTLINE float brisk_refine1d(const float s_05, const float s0, const float s05, float& max) {
-  const int i_05 = (int)(1024.0 * s_05 + 0.5);
-  const int i0 = (int)(1024.0 * s0 + 0.5);
-  const int i05 = (int)(1024.0 * s05 + 0.5);
-  const int three_a = 16 * i_05 - 24 * i0 + 8 * i05;
-  if (three_a >= 0) {
-    if (s0 >= s_05 && s0 >= s05) { max = s0; return 1.0f; }
-    if (s_05 >= s0 && s_05 >= s05) { max = s_05; return 0.75f; }
-    if (s05 >= s0 && s05 >= s_05) { max = s05; return 1.5f; }
-  }
-  const int three_b = -40 * i_05 + 54 * i0 - 14 * i05;
-  float ret_val = -(float)three_b / (float)(2 * three_a);
-  if (ret_val < 0.75) ret_val = 0.75f;
-  else if (ret_val > 1.5) ret_val = 1.5f;
-  const int three_c = +24 * i_05 - 27 * i0 + 6 * i05;
-  max = (float)three_c + (float)three_a * ret_val * ret_val + (float)three_b * ret_val;
-  max = (float)(max / 3072.0);
-  return ret_val;
+  const BriskScaleFit f = {{16, -24, 8}, {-40, 54, -14}, {24, -27, 6}, 0.75f, 1.5f, 0.75, 1.5, 0.75f, 1.5f, 3072.0, false};
+  return brisk_scale_fit(f, s_05, s0, s05, max);
 }
-
 BRISK_HD_OUTLINE float brisk_refine1d_1(const float s_05, const float s0, const float s05, float& max) {
-  const int i_05 = (int)(1024.0 * s_05 + 0.5);
-  const int i0 = (int)(1024.0 * s0 + 0.5);
-  const int i05 = (int)(1024.0 * s05 + 0.5);
-  const int two_a = 9 * i_05 - 18 * i0 + 9 * i05;
-  if (two_a >= 0) {
-    if (s0 >= s_05 && s0 >= s05) { max = s0; return 1.0f; }
-    if (s_05 >= s0 && s_05 >= s05) { max = s_05; return (float)0.6666666666666666666666666667; }
-    if (s05 >= s0 && s05 >= s_05) { max = s05; return (float)1.3333333333333333333333333333; }
-  }
-  const int two_b = -21 * i_05 + 36 * i0 - 15 * i05;
-  float ret_val = -(float)two_b / (float)(2 * two_a);
-  if (ret_val < 0.6666666666666666666666666667) ret_val = (float)0.666666666666666666666666667;
-  else if (ret_val > 1.33333333333333333333333333) ret_val = (float)1.333333333333333333333333333;
-  const int two_c = +12 * i_05 - 16 * i0 + 6 * i05;
-  max = (float)two_c + (float)two_a * ret_val * ret_val + (float)two_b * ret_val;
-  max = (float)(max / 2048.0);
-  return ret_val;
+  const BriskScaleFit f = {{9, -18, 9}, {-21, 36, -15}, {12, -16, 6},
+                           (float)0.6666666666666666666666666667, (float)1.3333333333333333333333333333,
+                           0.6666666666666666666666666667, 1.33333333333333333333333333,
+                           (float)0.666666666666666666666666667, (float)1.333333333333333333333333333, 2048.0, false};
+  return brisk_scale_fit(f, s_05, s0, s05, max);
 }
-
 BRISK_HD_OUTLINE float brisk_refine1d_2(const float s_05, const float s0, const float s05, float& max) {
-  const int i_05 = (int)(1024.0 * s_05 + 0.5);
-  const int i0 = (int)(1024.0 * s0 + 0.5);
-  const int i05 = (int)(1024.0 * s05 + 0.5);
-  const int a = 2 * i_05 - 4 * i0 + 2 * i05;
-  if (a >= 0) {
-    if (s0 >= s_05 && s0 >= s05) { max = s0; return 1.0f; }
-    if (s_05 >= s0 && s_05 >= s05) { max = s_05; return (float)0.7; }
-    if (s05 >= s0 && s05 >= s_05) { max = s05; return 1.5f; }
-  }
-  const int b = -5 * i_05 + 8 * i0 - 3 * i05;
-  float ret_val = -(float)b / (float)(2 * a);
-  if (ret_val < 0.7) ret_val = (float)0.7;
-  else if (ret_val > 1.5) ret_val = 1.5f;
-  const int c = +3 * i_05 - 3 * i0 + 1 * i05;
-  max = (float)c + (float)a * ret_val * ret_val + (float)b * ret_val;
-  max = max / 1024;
-  return ret_val;
+  const BriskScaleFit f = {{2, -4, 2}, {-5, 8, -3}, {3, -3, 1}, (float)0.7, 1.5f, 0.7, 1.5, (float)0.7, 1.5f, 1024.0, true};
+  return brisk_scale_fit(f, s_05, s0, s05, max);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -607,29 +607,29 @@ BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above,
     t->x0 = (int)x_1 - 1;
     t->y0 = (int)y_1 - 1;
   }
+  // The window [x_1, x1] x [y_1, y1] is sampled on a grid whose outer lines are the (fractional) window borders and
+  // whose inner lines are the integer positions in between: border samples are bilinear (and touch 2x2 blocks), inner
+  // samples are plain score reads.  Row-major scan; a sample above centre + drop threshold aborts - except on the
+  // last grid row, which the reference does not test (:843-863, :1027-1047); the maximum's position is recorded as
+  // the nearest inner line (xs / xe, ys / ye for the borders).
   const int xs = (int)(x_1 + 1), xe = (int)x1, ys = (int)(y_1 + 1), ye = (int)y1;
+  const int nix = brisk_max(xe - xs + 1, 0), niy = brisk_max(ye - ys + 1, 0);  // inner lines
   int max_x = xs;
   int max_y = ys;
-  float tmp_max;
-  float max = (float)brisk_Vf<DIRECT>(Lo, x_1, y_1, t);
-  if (max > threshold) return 0;
-  for (int x = xs; x <= xe; x++) {
-    tmp_max = (float)brisk_Vf<DIRECT>(Lo, (float)x, y_1, t);
-    if (tmp_max > threshold) return 0;
-    if (tmp_max > max) { max = tmp_max; max_x = x; }
-  }
-  tmp_max = (float)brisk_Vf<DIRECT>(Lo, x1, y_1, t);
-  if (tmp_max > threshold) return 0;
-  if (tmp_max > max) { max = tmp_max; max_x = xe; }
-
-  for (int y = ys; y <= ye; y++) {
-    tmp_max = (float)brisk_Vf<DIRECT>(Lo, x_1, (float)y, t);
-    if (tmp_max > threshold) return 0;
-    if (tmp_max > max) { max = tmp_max; max_x = xs; max_y = y; }
-    for (int x = xs; x <= xe; x++) {
-      tmp_max = (float)brisk_Vt<DIRECT>(Lo, x, y, t);
-      if (tmp_max > threshold) return 0;
-      if (!above && tmp_max == max) {  // tie rule exists only in GetScoreMaxBelow (:987-1010)
+  float max = 0.0f;
+  for (int r = 0; r < niy + 2; ++r) {
+    const bool border_y = (r == 0 || r == niy + 1);
+    const float yf = (r == 0) ? y_1 : (r == niy + 1) ? y1 : (float)(ys + r - 1);
+    const int ylab = (r == 0) ? ys : (r == niy + 1) ? ye : ys + r - 1;
+    for (int j = 0; j < nix + 2; ++j) {
+      const bool border_x = (j == 0 || j == nix + 1);
+      const float xf = (j == 0) ? x_1 : (j == nix + 1) ? x1 : (float)(xs + j - 1);
+      const int xlab = (j == 0) ? xs : (j == nix + 1) ? xe : xs + j - 1;
+      const float v = (border_x || border_y) ? (float)brisk_Vf<DIRECT>(Lo, xf, yf, t) : (float)brisk_Vt<DIRECT>(Lo, xlab, ylab, t);
+      if (r != niy + 1 && v > threshold) return 0;
+      if (r == 0 && j == 0) { max = v; continue; }
+      if (!above && !border_x && !border_y && v == max) {  // tie rule, GetScoreMaxBelow only (:987-1010)
+        const int x = xlab, y = ylab;
         const int t1 = 2 * (brisk_Vt<DIRECT>(Lo, x - 1, y, t) + brisk_Vt<DIRECT>(Lo, x + 1, y, t) + brisk_Vt<DIRECT>(Lo, x, y + 1, t) +
                             brisk_Vt<DIRECT>(Lo, x, y - 1, t)) +
                        (brisk_Vt<DIRECT>(Lo, x + 1, y + 1, t) + brisk_Vt<DIRECT>(Lo, x - 1, y + 1, t) + brisk_Vt<DIRECT>(Lo, x + 1, y - 1, t) +
@@ -640,22 +640,13 @@ BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above,
                         brisk_Vt<DIRECT>(Lo, max_x + 1, max_y - 1, t) + brisk_Vt<DIRECT>(Lo, max_x - 1, max_y - 1, t));
         if (t1 > t2) { max_x = x; max_y = y; }
       }
-      if (tmp_max > max) { max = tmp_max; max_x = x; max_y = y; }
+      if (v > max) {
+        max = v;
+        max_x = xlab;
+        if (r != 0) max_y = ylab;  // (the first grid row never moves the row label: it is ys already)
+      }
     }
-    tmp_max = (float)brisk_Vf<DIRECT>(Lo, x1, (float)y, t);
-    if (tmp_max > threshold) return 0;
-    if (tmp_max > max) { max = tmp_max; max_x = xe; max_y = y; }
   }
-
-  // bottom row: never tested against the drop threshold (:843-863, :1027-1047)
-  tmp_max = (float)brisk_Vf<DIRECT>(Lo, x_1, y1, t);
-  if (tmp_max > max) { max = tmp_max; max_x = xs; max_y = ye; }
-  for (int x = xs; x <= xe; x++) {
-    tmp_max = (float)brisk_Vf<DIRECT>(Lo, (float)x, y1, t);
-    if (tmp_max > max) { max = tmp_max; max_x = x; max_y = ye; }
-  }
-  tmp_max = (float)brisk_Vf<DIRECT>(Lo, x1, y1, t);
-  if (tmp_max > max) { max = tmp_max; max_x = xe; max_y = ye; }
 
   float dx_1, dy_1;
   const float refined_max = brisk_patch_subpixel<DIRECT>(Lo, max_x, max_y, t, dx_1, dy_1, nullptr);

@@ -60,7 +60,15 @@ BRISK_HD BriskSamplePoint brisk_pattern_point(const BriskPatternDev& P, int scal
 // pixels (x_right+1, y_bottom-1) and (x_left+1, y_bottom-1) instead of the bottom corners; the
 // golden vectors contain this behaviour, so it is reproduced.
 // integral: exclusive prefix sums, (rows+1) x (cols+1), row stride istride (u32, wrap-around).
-BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, const uint32_t* integral, int istride,
+// Pixel the reference reads at data[y * cols + x] for x that may reach cols (the displaced corner of :453 sits one
+// column right of the box: for a box that ends in the last column the linear address is the first pixel of the next
+// row).  The engine's rows are padded (stride >= cols), so the wrap is made explicit.
+BRISK_HD unsigned brisk_linear_px(const uint8_t* img, int stride, int cols, int x, int y) {
+  if (x >= cols) { x -= cols; y += 1; }
+  return img[(long)y * stride + x];
+}
+
+BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, int cols, const uint32_t* integral, int istride,
                                       float key_x, float key_y, const BriskSamplePoint& sp) {
   const float sigma_half = sp.sigma;
   const float xf = sp.x + key_x;
@@ -132,9 +140,8 @@ BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, const uint
   const unsigned tr = i13 - i03 - i12 + i02;  // pixel (x_right, y_top)
   unsigned br, bl;
   if (quirk) {
-    const uint8_t* pbot = img + (long)(y_bottom - 1) * stride;
-    br = pbot[x_right + 1];
-    bl = pbot[x_left + 1];
+    br = brisk_linear_px(img, stride, cols, x_right + 1, y_bottom - 1);
+    bl = brisk_linear_px(img, stride, cols, x_left + 1, y_bottom - 1);
   } else {
     br = i33 - i23 - i32 + i22;  // pixel (x_right, y_bottom)
     bl = i31 - i21 - i30 + i20;  // pixel (x_left, y_bottom)

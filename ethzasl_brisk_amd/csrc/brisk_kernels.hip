@@ -1605,7 +1605,7 @@ __device__ __forceinline__ DsPrep ds_prep(float key_x, float key_y, const BriskS
   p.quirk = (dx + dy > 2);
   return p;
 }
-__device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, const uint8_t* __restrict__ img, int stride,
+__device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, const uint8_t* __restrict__ img, int stride, int cols,
                                         const uint32_t* __restrict__ integral, int istride) {
   const uint32_t* r0 = integral + (long)p.y_top * istride;
   const uint32_t* r1 = r0 + istride;
@@ -1618,9 +1618,10 @@ __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, const uint8_t
   r.p30 = DS_GATHER(r3 + p.x_left); r.p32 = DS_GATHER(r3 + p.x_right);
   // displaced bottom corners of the reference quirk (brisk-descriptor-extractor.cc:453); unconditional loads on a
   // valid address, used only when the quirk applies
-  const uint8_t* pbot = img + (long)max(p.y_bottom - 1, 0) * stride;
-  r.br = pbot[p.x_right + 1];
-  r.bl = pbot[p.x_left + 1];
+  // (linear addressing of the reference: a box that ends in the last column reads the first pixel of the next row)
+  const int qy = max(p.y_bottom - 1, 0);
+  r.br = brisk_linear_px(img, stride, cols, p.x_right + 1, qy);
+  r.bl = brisk_linear_px(img, stride, cols, p.x_left + 1, qy);
 }
 __device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
   const uint32_t i00 = r.p00.x, i01 = r.p00.y, i02 = r.p02.x, i03 = r.p02.y;
@@ -1642,19 +1643,19 @@ __device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
 }
 
 // smoothed intensities of the lane's two pattern points (i0 = lane, i1 = lane + 64) into values[]
-__device__ __forceinline__ void ds_sample_pass(int* values, const uint8_t* __restrict__ img, int stride,
+__device__ __forceinline__ void ds_sample_pass(int* values, const uint8_t* __restrict__ img, int stride, int cols,
                                                const uint32_t* __restrict__ integ, int istride, float kx, float ky,
                                                const BriskSamplePoint& sa, const BriskSamplePoint& sb, bool va, bool vb,
                                                int i0, int i1) {
   if (__any((va && sa.sigma < 0.5f) || (vb && sb.sigma < 0.5f))) {  // bilinear branch of some point (:391-408): rare
-    if (va) values[i0] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, sa);
-    if (vb) values[i1] = brisk_smoothed_intensity(img, stride, integ, istride, kx, ky, sb);
+    if (va) values[i0] = brisk_smoothed_intensity(img, stride, cols, integ, istride, kx, ky, sa);
+    if (vb) values[i1] = brisk_smoothed_intensity(img, stride, cols, integ, istride, kx, ky, sb);
     return;
   }
   const DsPrep pa = ds_prep(kx, ky, sa, va), pb = ds_prep(kx, ky, sb, vb);
   DsRaw ra, rb;
-  ds_load(ra, pa, img, stride, integ, istride);
-  ds_load(rb, pb, img, stride, integ, istride);
+  ds_load(ra, pa, img, stride, cols, integ, istride);
+  ds_load(rb, pb, img, stride, cols, integ, istride);
   const int xa = ds_combine(pa, ra), xb = ds_combine(pb, rb);
   if (va) values[i0] = xa;
   if (vb) values[i1] = xb;
@@ -1719,7 +1720,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
     int theta = 0;
     if (P.rotation_invariant) {
       if (kangle == -1.0f) {
-        ds_sample_pass(values, img, stride, integ, istride, kx, ky, ds_point(ta, uv0a.x, uv0a.y), ds_point(tb, uv0b.x, uv0b.y),
+        ds_sample_pass(values, img, stride, G.L[0].w, integ, istride, kx, ky, ds_point(ta, uv0a.x, uv0a.y), ds_point(tb, uv0b.x, uv0b.y),
                        va, vb, i0, i1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1755,7 +1756,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
     {
       const double2* uvt = reinterpret_cast<const double2*>(P.uv) + (long)theta * np;
       const double2 ua = uvt[i0c], ub = uvt[i1c];
-      ds_sample_pass(values, img, stride, integ, istride, kx, ky, ds_point(ta, ua.x, ua.y), ds_point(tb, ub.x, ub.y), va, vb,
+      ds_sample_pass(values, img, stride, G.L[0].w, integ, istride, kx, ky, ds_point(ta, ua.x, ua.y), ds_point(tb, ub.x, ub.y), va, vb,
                      i0, i1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -456,6 +456,11 @@ int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kp
   P.rotation_invariant = rotation_invariant;
   P.scale_invariant = scale_invariant;
   const int istride = brisk_align_up(w + 1, 16);
+  // the image in the engine's layout: rows padded to a multiple of 64 bytes (a sampling function that assumed
+  // stride == cols would read the padding instead of the next row)
+  const int stride = brisk_align_up(w, BRISK_STRIDE_ALIGN);
+  std::vector<uint8_t> padded((size_t)stride * h + 256, 0xEE);
+  for (int y = 0; y < h; ++y) memcpy(padded.data() + (size_t)y * stride, img + (size_t)y * w, w);
   std::vector<uint32_t> integ((size_t)istride * (h + 1), 0);
   for (int y = 0; y < h; ++y) {
     uint32_t s = 0;
@@ -478,7 +483,7 @@ int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kp
     if (P.rotation_invariant) {
       if (kp->angle == -1.0f) {
         for (int i = 0; i < P.npoints; ++i) {
-          values[i] = brisk_smoothed_intensity(img, w, integ.data(), istride, kp->x, kp->y, brisk_pattern_point(P, scale, 0, i));
+          values[i] = brisk_smoothed_intensity(padded.data(), stride, w, integ.data(), istride, kp->x, kp->y, brisk_pattern_point(P, scale, 0, i));
         }
         int d0 = 0, d1 = 0;
         for (int p = 0; p < P.nlong; ++p) {
@@ -493,7 +498,7 @@ int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kp
       }
     }
     for (int i = 0; i < P.npoints; ++i) {
-      values[i] = brisk_smoothed_intensity(img, w, integ.data(), istride, kp->x, kp->y, brisk_pattern_point(P, scale, theta, i));
+      values[i] = brisk_smoothed_intensity(padded.data(), stride, w, integ.data(), istride, kp->x, kp->y, brisk_pattern_point(P, scale, theta, i));
     }
     uint8_t* drow = desc + (size_t)k * desc_pitch;
     memset(drow, 0, P.strings);

@@ -257,3 +257,25 @@ def test_compute_scale_walk_equals_oracle():
     bad = np.zeros(1, O.KP)
     bad["x"], bad["y"] = 100, 236.5
     assert O.compute_scale(img, bad, 60, 3) is None and E.compute_scale(img, bad, 60, 3) is None
+
+
+def test_describe_box_that_ends_in_the_last_column():
+    """SmoothedIntensity's displaced bottom corner (brisk-descriptor-extractor.cc:453) sits one column right of the box;
+    for a keypoint on the border limit that is column `cols`, which the reference's linear address turns into the first
+    pixel of the next row.  Widths whose rows the engine pads (426, 333): keypoints packed against the right border."""
+    oext = O.Extractor()
+    pat = E.Pattern()
+    _, size_list, _ = pat.tables()
+    for w, h in ((426, 320), (333, 201)):
+        img = synth.gen(w, h, 12, 50)
+        k = np.zeros(400, O.KP)
+        rng = np.random.default_rng(w)
+        k["size"] = rng.uniform(8.0, 14.0, len(k)).astype(np.float32)
+        k["y"] = rng.uniform(40, h - 40, len(k)).astype(np.float32)
+        k["angle"] = -1
+        for i in range(len(k)):
+            border = size_list[pat.scale_index(k["size"][i])]
+            k["x"][i] = np.float32(w - border) - np.float32(rng.uniform(0.0, 1.2))
+        ko, do = oext.compute(img, k)
+        ke, de = pat.describe(img, k)
+        assert len(ko) > 100 and same_kps(ke, ko) and np.array_equal(de, do)

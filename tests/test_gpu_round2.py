@@ -292,3 +292,24 @@ def test_compute_scale_provided_keypoints(B):
     vga = synth.frame_vga(1)
     assert same_kps(B.BriskFeatureDetector(70, 4, context=ctx).detect(vga), O.detect(vga, 70, 4))
     ctx.close()
+
+
+def test_describe_box_that_ends_in_the_last_column_gpu(B):
+    """the same as tests/test_emul_parity.py::test_describe_box_that_ends_in_the_last_column through the C ABI (found by
+    tools/soak.py: rows padded to 64 bytes made the displaced corner of :453 read padding instead of the next row)"""
+    ext = B.BriskDescriptorExtractor()
+    oext = O.Extractor()
+    _, size_list, size_thresh = ext.tables()
+    for w, h in ((426, 320), (333, 201), (1281, 723)):
+        img = synth.gen(w, h, 12, 50)
+        rng = np.random.default_rng(w)
+        k = np.zeros(400, B.KEYPOINT)
+        k["size"] = rng.uniform(8.0, 14.0, len(k)).astype(np.float32)
+        k["y"] = rng.uniform(40, h - 40, len(k)).astype(np.float32)
+        k["angle"] = -1
+        for i in range(len(k)):
+            sc = int(np.searchsorted(size_thresh, k["size"][i], side="right")) - 1
+            k["x"][i] = np.float32(w - size_list[max(sc, 0)]) - np.float32(rng.uniform(0.0, 1.2))
+        ko, do = oext.compute(img, k)
+        kg, dg = ext.compute(img, k)
+        assert len(ko) > 100 and same_kps(kg, ko) and np.array_equal(dg, do), (w, h)

@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       CB[r] = __builtin_amdgcn_perm(0u, R[r][1], 0x0c030c02u);   // (col 2, col 3)
     }
     // pass flags of the thread's 16 pixels: every pair's two sign bits (15 and 31) are shifted in from the top, so
-    // pair k = 2 * rr + (j >> 1) ends at bits 8 + k (column j even) and 24 + k (column j odd)
+    // pair k = 2 * rr + (j >> 1) ends at bits 16 - 2 DT_R + k (column j even) and 32 - 2 DT_R + k (column j odd)
     unsigned m = 0;
 #pragma unroll
     for (int rr = 0; rr < DT_R; ++rr) {
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       while (m) {
         const int bit = __ffs(m) - 1;
         m &= m - 1;
-        const int k = (bit & 15) - 8, half = bit >> 4;
+        const int k = (bit & 15) - (16 - 2 * DT_R), half = bit >> 4;
         queue[pos++] = (uint16_t)((ly + (k >> 1)) * DT_W + lx + ((k & 1) << 1) + half);
       }
     }

@@ -206,7 +206,7 @@ def launch_ranks(n, argv):
 def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per engine call (chunk) per GPU")
     ap.add_argument("--inner", type=int, default=32, help="chunks per step: a step is batch x inner frames per GPU")

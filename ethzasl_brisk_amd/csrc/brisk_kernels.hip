@@ -1690,6 +1690,9 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
     block_in_frame = blockIdx.x % bpf;
   }
   if (frame >= nframes) return;
+  // last frames first: the integral images are written in frame order just before, so the last ones are the ones
+  // still held by the Infinity Cache when this kernel starts (measured: 0.8 % of the kernel's time)
+  frame = nframes - 1 - frame;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int* values = values_s[wave];
   const int n = counters[frame].ndesc;

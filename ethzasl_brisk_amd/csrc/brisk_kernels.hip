@@ -896,7 +896,9 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 // Frames with more ties than the on-chip arrays hold run the same scheme per layer from global scratch, the
 // decisions then travel through the score-state map.
 // ------------------------------------------------------------------------------------------------
+#ifndef TR_WAVES
 #define TR_WAVES 16
+#endif
 #define TR_THREADS (TR_WAVES * 64)
 #define TR_WIN 9
 #define TR_MAXSORT 6144

@@ -119,7 +119,7 @@ def usable_cores():
 
 
 class CpuBaseline:
-    def __init__(self, max_workers=256, frames_per_worker=3):
+    def __init__(self, max_workers=128, frames_per_worker=3):
         import multiprocessing as mp
         self.visible = len(os.sched_getaffinity(0))
         self.cores = max(1, min(usable_cores(), max_workers))

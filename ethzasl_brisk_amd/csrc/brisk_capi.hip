@@ -571,12 +571,14 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
   const int slice = host_slice_frames() < nframes ? host_slice_frames() : nframes;
   const int dpitch = brisk_align_up(w, 64);           // device staging: rows at a 64-byte aligned pitch
   const size_t dframe = (size_t)dpitch * h;
+  bool fresh = false;
   if (!ctx->copy_stream) {
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->copied_ev[i], hipEventDisableTiming));
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->consumed_ev[i], hipEventDisableTiming));
     }
+    fresh = true;
   }
   if (ctx->hstage_bytes < dframe * slice) {
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -587,12 +589,17 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
     ctx->hstage_bytes = 0;
     for (int i = 0; i < 2; ++i) HIPCHK(ctx, hipMalloc(&ctx->d_hstage[i], dframe * slice + 256));
     ctx->hstage_bytes = dframe * slice;
+    fresh = true;
   }
   A.frame_pitch = (long)dframe;
   A.row_pitch = dpitch;
-  // the copy stream starts behind whatever this context's stream still has queued on the staging buffers
-  HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[0], s));
-  HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[1], s));
+  // Only host-fed calls touch the staging buffers, and every use records consumed_ev[b] behind the slice that read
+  // buffer b: the first copies of this call wait for exactly that, i.e. they overlap the tail of the previous call's
+  // compute.  (New buffers / events: nothing to wait for.)
+  if (fresh) {
+    HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[0], s));
+    HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[1], s));
+  }
   int k = 0;
   for (long f0 = 0; f0 < nframes; f0 += slice, ++k) {
     const int nf = (int)((nframes - f0 < slice) ? nframes - f0 : slice);

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "brisk_hip_pattern_destroy", "brisk_hip_pattern_descriptor_size", "brisk_hip_pattern_points",
     "brisk_hip_pattern_tables", "brisk_hip_detect", "brisk_hip_describe", "brisk_hip_detect_describe_batch",
     "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
-    "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
+    "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_debug_counters", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
     "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags",
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
     "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
@@ -86,6 +86,7 @@ def load_library():
     L.brisk_hip_batch_status.argtypes = [vp, C.c_int, ip]
     L.brisk_hip_debug_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, ip]
     L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
+    L.brisk_hip_debug_counters.argtypes = [vp, C.c_int, vp, ip]
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
     L.brisk_hip_set_streams.argtypes = [vp, C.c_int]
@@ -152,6 +153,14 @@ class Context:
         out = np.zeros((h.value, w.value), np.uint8)
         self.check(self._L.brisk_hip_debug_layer(self._h, frame, layer, which, _ptr(out), C.byref(w), C.byref(h)))
         return out
+
+    def debug_counters(self, frame):
+        """work counts of one frame of the last batch: candidates, keypoints, described, flags, ties per layer"""
+        out = np.zeros(28, np.int32)
+        nl = C.c_int()
+        self.check(self._L.brisk_hip_debug_counters(self._h, frame, _ptr(out), C.byref(nl)))
+        return {"candidates": int(out[0]), "keypoints": int(out[1]), "described": int(out[2]), "flags": int(out[3]),
+                "ties": [int(v) for v in out[4:4 + nl.value]], "experiment": [int(v) for v in out[20:28]]}
 
     def debug_integral(self, frame, w, h):
         out = np.zeros((h + 1, w + 1), np.uint32)

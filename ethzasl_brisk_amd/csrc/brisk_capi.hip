@@ -1169,4 +1169,21 @@ int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out) {
   return BRISK_HIP_OK;
 }
 
+// per-frame work counts of the last batch: out[0] = candidates, out[1] = keypoints, out[2] = described keypoints,
+// out[3] = overflow flags, out[4 ..] = tie candidates per layer (nlayers entries; returns nlayers in *nlayers), out[20 .. 27] = experiment words
+int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlayers) {
+  if (!ctx || !out || !nlayers) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (frame < 0 || frame >= ctx->slots || !ctx->B.counters) return fail(ctx, BRISK_HIP_ERR_ARG, "bad index");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  BriskFrameCounters c;
+  HIPCHK(ctx, hipMemcpy(&c, ctx->B.counters + frame, sizeof(c), hipMemcpyDeviceToHost));
+  out[0] = c.ncand; out[1] = c.nkp; out[2] = c.ndesc; out[3] = c.overflow;
+  *nlayers = ctx->G.nlayers;
+  for (int l = 0; l < ctx->G.nlayers; ++l) out[4 + l] = c.ntie[l];
+  for (int i = 0; i < 8; ++i) out[20 + i] = c.pad[i];
+  return BRISK_HIP_OK;
+}
+
 }  // extern "C"

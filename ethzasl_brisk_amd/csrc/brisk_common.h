@@ -98,7 +98,9 @@ struct BriskFrameCounters {
   int nredo;                        // candidates deferred to k_classify_refine_direct
   int nvalid_large;                 // > 0: k_finalize left the ordering of this many keypoints to k_finalize_large
   int full_clear;                   // the ordered path wrote the map outside the candidates' footprints: clear all of it
-  int pad[1];
+  int tie_ticket;                   // k_tie_resolve: work tickets (entry xcd of the batch, or entry 0 for fewer than 8 frames)
+  int tie_prog[BRISK_MAX_LAYERS];   // k_tie_resolve: rows of layer l whose ties are decided and whose touches are performed
+  int pad[8];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)

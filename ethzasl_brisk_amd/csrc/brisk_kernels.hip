@@ -888,129 +888,197 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tie_resolve: one workgroup per frame; layers in ascending order (layer i+1 needs the e3 touches of layer
-// i's resolved ties).  Inside a layer the tie candidates are rank-sorted into raster order and dealt to the
-// waves in contiguous segments; a wave spins until every raster-earlier tie candidate within Chebyshev distance 4 of its
-// candidate is decided (the earliest undecided candidate never waits, so the scheme cannot deadlock), then
-// replays the lazy score cache with one lane per pixel (8 probe values + the 5x5 raw block).
-// Frames with more ties than the on-chip arrays hold run the same scheme per layer from global scratch, the
-// decisions then travel through the score-state map.
+// k_tie_resolve: one workgroup per (frame, layer).  A layer's tie candidates are rank-sorted into raster order and
+// dealt round-robin to the waves; a wave spins until every raster-earlier tie candidate within Chebyshev distance 4 of
+// its candidate is decided (the earliest undecided candidate never waits, so the scheme cannot deadlock), then replays
+// the lazy score cache with one lane per pixel (8 probe values + the 5x5 raw block).
+//
+// Layers of one frame run concurrently as a pipeline: layer l + 1 needs the e3 touches (4x4 footprints on its map) of
+// the ties of layer l that pass.  The workgroup of layer l publishes its progress ("every tie above row Y is decided
+// and its touches are performed") in counters[frame].tie_prog[l]; a wave of layer l + 1 waits for the rows of layer l
+// whose footprints can reach its tie's 5x5 block.  Workgroups take their (frame, layer) from a ticket counter, so a
+// workgroup only ever waits for one that started before it (layer l draws its ticket before layer l + 1 of the same
+// frame): no assumption on the dispatch order of blockIdx, no deadlock.  All cross-workgroup data (map entries,
+// progress) move through agent-scope atomics; all workgroups of a frame share blockIdx.x % 8, i.e. an XCD and its L2.
+// Layers with more ties than the on-chip arrays hold are rank-sorted through global scratch and processed in chunks of
+// TR_CHUNK consecutive ranks with the same on-chip scheme.
 // ------------------------------------------------------------------------------------------------
 #ifndef TR_WAVES
 #define TR_WAVES 16
 #endif
 #define TR_THREADS (TR_WAVES * 64)
+#define TR_DWAVES (TR_WAVES - 1)  // deciding waves; the last wave writes the decisions to memory
 #define TR_WIN 9
-#define TR_MAXSORT 6144
+#ifndef TR_CHUNK
+#define TR_CHUNK 3072
+#endif
+#define TR_PROG_DONE 0x7FFFFFFF
+#define TR_DONE_BIT 4
+#define TR_BM_WORDS 512  // 16384 cells of 8x8 pixels (or 16x16, ... for larger layers)
+#ifdef TR_TIMING  // experiments: per-phase time of the decision loop (10 ns units) summed into counters[frame].pad[]
+#define TR_T(i) { const long long now_ = (long long)wall_clock64(); tacc[i] += (int)(now_ - tlast); tlast = now_; }
+#else
+#define TR_T(i)
+#endif
+
+// rows of the layer below that must be complete before a tie in row cy of this layer can be decided: a tie of the
+// layer below in row y touches rows y0 .. y0 + 3 with y0 = (int)((4y - 3) / 6) - 1 (below is an octave) or
+// (int)((6y - 4) / 8) - 1 (below is an intra-octave), brisk_score_max_other; the tie reads touches in rows cy - 2 .. cy + 2
+__device__ __forceinline__ int tr_rows_needed(int cy, bool below_is_octave) {
+  return below_is_octave ? ((cy + 5) * 3) / 2 + 2 : ((cy + 5) * 4) / 3 + 2;
+}
+
 __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                              BriskFrameCounters* counters, const int* tie_idx,
                                                              const uint8_t* blocks, unsigned* gscratch, int cand_cap,
-                                                             int tie_cap) {
+                                                             int tie_cap, int nframes, int lpw) {
   __shared__ uint8_t kp5s[TR_WAVES][32];
   __shared__ uint16_t win[TR_WAVES][TR_WIN * TR_WIN + 1];  // per-wave window of the tie being decided
-  __shared__ unsigned skey[TR_MAXSORT];
-  __shared__ int sorder[TR_MAXSORT];    // candidate index of the tie with raster rank r
-  __shared__ unsigned sxyd[TR_MAXSORT]; // its x | y << 13 | ... (the key) - D is taken from the window
+  __shared__ unsigned skey[TR_CHUNK > TR_THREADS ? TR_CHUNK : TR_THREADS];
+  __shared__ int sorder[TR_CHUNK];      // candidate index of the tie with raster rank r
+  __shared__ unsigned sxyd[TR_CHUNK];   // its key (layer, y, x)
   __shared__ int vals[TR_WAVES][40];
-  __shared__ int vals_ci[TR_MAXSORT];   // candidate index of the tie (unsorted order)
-  __shared__ uint16_t sfpm[TR_MAXSORT]; // e3 footprint mask of the tie with raster rank r
-  int* const tstat = reinterpret_cast<int*>(skey);          // after the sort: decision of rank r (0 = pending)
+  __shared__ int vals_ci[TR_CHUNK];     // candidate index of the tie (unsorted order)
+  __shared__ uint16_t sfpm[TR_CHUNK];   // e3 footprint mask of the tie with raster rank r
+  __shared__ unsigned below_bm[TR_BM_WORDS];  // cells of this layer that a tie of the layer below can touch
+  __shared__ int ticket_s, abort_s, seen_s;
+  int* const tstat = reinterpret_cast<int*>(skey);               // after the sort: decision of rank r (0 = pending)
   unsigned* const sfpxy = reinterpret_cast<unsigned*>(vals_ci);  // after the sort: footprint anchor of rank r
-  const int frame = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // ---- all layers' ties are gathered and rank-sorted once: the key is (layer, y, x), so every layer is a
-  // contiguous raster-ordered range [lstart[l], lstart[l+1]) of the sorted list
-  __shared__ int lstart[BRISK_MAX_LAYERS + 1];
+  const int nl = G.nlayers;
+  const int ngroups = (nl + lpw - 1) / lpw;  // workgroups per frame, `lpw` consecutive layers each
   if (tid == 0) {
-    int acc = 0;
-    for (int l = 0; l < G.nlayers; ++l) {
-      lstart[l] = acc;
-      acc += min(counters[frame].ntie[l], tie_cap);
+    abort_s = 0;
+    if (nframes >= 8) {  // one ticket counter per XCD residue: frames g * 8 + xcd, layer groups in ascending order
+      const int xcd = blockIdx.x & 7;
+      const int t = atomicAdd(&counters[xcd].tie_ticket, 1);
+      ticket_s = ((t / ngroups) * 8 + xcd) * ngroups + t % ngroups;
+    } else {
+      ticket_s = atomicAdd(&counters[0].tie_ticket, 1);
     }
-    for (int l = G.nlayers; l <= BRISK_MAX_LAYERS; ++l) lstart[l] = acc;
   }
   __syncthreads();
-  const int ntot = lstart[G.nlayers];
-  if (ntot == 0) return;
+  const int frame = ticket_s / ngroups, l0 = (ticket_s % ngroups) * lpw, l1 = min(l0 + lpw, nl);
+  if (frame >= nframes) return;
+  const BriskCand* C = cand + (long)frame * cand_cap;
   // a frame whose candidate or tie list overflowed is reported as an error and its result discarded; its map holds
   // tie candidates that are in no list, which nobody would ever decide: do not wait for them
-  if (counters[frame].overflow & 3) return;
-  __shared__ int abort_s;
-  if (tid == 0) abort_s = 0;
-  __syncthreads();
-  const bool sorted_path = ntot <= TR_MAXSORT;
-  if (sorted_path) {
-    for (int l = 0; l < G.nlayers; ++l) {
-      const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
-      const int n = lstart[l + 1] - lstart[l];
-      for (int j = tid; j < n; j += TR_THREADS) {
-        const int ci = list[j];
-        vals_ci[lstart[l] + j] = ci;
-        skey[lstart[l] + j] = cand[(long)frame * cand_cap + ci].key;
-      }
+  const bool skip_frame = (counters[frame].overflow & 3) != 0;
+  for (int l = l0; l < l1; ++l) {
+  int* const my_prog = &counters[frame].tie_prog[l];
+  const int n = min(counters[frame].ntie[l], tie_cap);
+  __syncthreads();  // (the previous layer's use of the on-chip arrays is over)
+  if (n == 0 || skip_frame) {
+    if (tid == 0) __hip_atomic_fetch_max(my_prog, TR_PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    continue;
+  }
+  if (tid == 0) seen_s = 0;
+  const BriskLayerView L = make_view(G, pyr, smap, frame, l);
+  const bool last = (l == nl - 1);
+  const bool float_patch = last || G.single_layer;
+  const bool touch2x2 = last && !G.single_layer;
+  const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
+  // the layer below is either this workgroup's previous layer (complete) or another workgroup's (in progress)
+  const bool below_elsewhere = (l == l0) && (l > 0);
+  const int* below_prog = below_elsewhere ? &counters[frame].tie_prog[l - 1] : nullptr;
+  const bool below_is_octave = ((l - 1) & 1) == 0;
+  int seen = below_elsewhere ? 0 : TR_PROG_DONE;  // last observed progress of the layer below (wave-uniform, monotone)
+  // Most ties do not depend on the layer below at all: only a tie of the layer below that passes touches this layer,
+  // and only inside its 4x4 footprint.  A coarse bitmap of this layer's cells within reach of such a footprint (the
+  // tie's 5x5 block is 2 pixels wide on each side) tells which ties have to wait for the layer below.
+  int bm_shift = 3;
+  while (((L.w >> bm_shift) + 1) * ((L.h >> bm_shift) + 1) > TR_BM_WORDS * 32) ++bm_shift;
+  const int bm_w = (L.w >> bm_shift) + 1;
+  if (below_elsewhere) {
+    for (int i = tid; i < TR_BM_WORDS; i += TR_THREADS) below_bm[i] = 0;
+    __syncthreads();
+    const int nb = min(counters[frame].ntie[l - 1], tie_cap);
+    const int* listb = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l - 1) * tie_cap;
+    for (int j = tid; j < nb; j += TR_THREADS) {
+      const BriskCand* c = &C[listb[j]];
+      if (!c->fp_mask) continue;
+      const int x0 = max((int)c->fp_x0 - 2, 0) >> bm_shift, x1 = min((int)c->fp_x0 + 5, L.w - 1) >> bm_shift;
+      const int y0 = max((int)c->fp_y0 - 2, 0) >> bm_shift, y1 = min((int)c->fp_y0 + 5, L.h - 1) >> bm_shift;
+      for (int y = y0; y <= y1; ++y)
+        for (int x = x0; x <= x1; ++x) atomicOr(&below_bm[(y * bm_w + x) >> 5], 1u << ((y * bm_w + x) & 31));
+    }
+    // (the barriers of the sort below order the bitmap before its first use)
+  }
+
+  // ---- raster order of the layer's ties
+  const bool on_chip = n <= TR_CHUNK;
+  unsigned* gkey = nullptr;
+  unsigned* gci = nullptr;
+  if (on_chip) {
+    for (int j = tid; j < n; j += TR_THREADS) {
+      const int ci = list[j];
+      vals_ci[j] = ci;
+      skey[j] = C[ci].key;
     }
     __syncthreads();
-    for (int j = tid; j < ntot; j += TR_THREADS) {
+    for (int j = tid; j < n; j += TR_THREADS) {
       const unsigned k = skey[j];
       int r = 0;
-      for (int q = 0; q < ntot; ++q) r += (skey[q] < k) ? 1 : 0;
+      for (int q = 0; q < n; ++q) r += (skey[q] < k) ? 1 : 0;
       sorder[r] = vals_ci[j];
       sxyd[r] = k;
     }
     __syncthreads();
+  } else {
+    // the sorted list goes to global scratch (this layer's share: the ties of all layers together are at most the
+    // candidates), ranked by counting smaller keys through LDS tiles
+    int off = 0;
+    for (int q = 0; q < l; ++q) off += min(counters[frame].ntie[q], tie_cap);
+    gkey = gscratch + (long)frame * cand_cap * 2 + off;
+    gci = gkey + cand_cap;
+    unsigned* tilek = skey;
+    for (int j0 = 0; j0 < n; j0 += TR_THREADS) {
+      const int j = j0 + tid;
+      const int ci = (j < n) ? list[j] : 0;
+      const unsigned myk = (j < n) ? C[ci].key : 0xFFFFFFFFu;
+      int rank = 0;
+      for (int t0 = 0; t0 < n; t0 += TR_THREADS) {
+        __syncthreads();
+        tilek[tid] = (t0 + tid < n) ? C[list[t0 + tid]].key : 0xFFFFFFFFu;
+        __syncthreads();
+        const int m = min(TR_THREADS, n - t0);
+        for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
+      }
+      if (j < n) { gkey[rank] = myk; gci[rank] = (unsigned)ci; }
+    }
+    __syncthreads();  // (same workgroup reads them back below: the barrier orders the plain stores)
+  }
+
+  uint16_t* wl = win[wave];
+  for (int c0 = 0; c0 < n; c0 += TR_CHUNK) {
+    const int nc = min(TR_CHUNK, n - c0);
+    if (!on_chip) {
+      __syncthreads();
+      for (int r = tid; r < nc; r += TR_THREADS) {
+        sxyd[r] = gkey[c0 + r];
+        sorder[r] = (int)gci[c0 + r];
+      }
+      __syncthreads();
+    }
     // everything the decision loop needs besides the smap window goes on chip: footprints by rank, decisions
-    for (int r = tid; r < ntot; r += TR_THREADS) {
-      const BriskCand* c = &cand[(long)frame * cand_cap + sorder[r]];
+    for (int r = tid; r < nc; r += TR_THREADS) {
+      const BriskCand* c = &C[sorder[r]];
       sfpxy[r] = (unsigned)(uint16_t)c->fp_x0 | ((unsigned)(uint16_t)c->fp_y0 << 16);
       sfpm[r] = c->fp_mask;
       tstat[r] = 0;
     }
     __syncthreads();
-  }
-  for (int l = 0; l < G.nlayers; ++l) {
-    const int n = lstart[l + 1] - lstart[l];
-    if (n == 0) continue;
-    const BriskLayerView L = make_view(G, pyr, smap, frame, l);
-    const bool last = (l == G.nlayers - 1);
-    const bool float_patch = last || G.single_layer;
-    const bool touch2x2 = last && !G.single_layer;
-    const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
-    // dense frame (the one-off sort of all layers does not fit on chip) but this layer alone does: sort just this
-    // layer into the on-chip arrays and run the on-chip scheme on it
-    const bool lds_layer = sorted_path || n <= TR_MAXSORT;
-    if (!sorted_path && lds_layer) {
-      __syncthreads();
-      for (int j = tid; j < n; j += TR_THREADS) {
-        const int ci = list[j];
-        vals_ci[j] = ci;
-        skey[j] = cand[(long)frame * cand_cap + ci].key;
-      }
-      __syncthreads();
-      for (int j = tid; j < n; j += TR_THREADS) {
-        const unsigned k = skey[j];
-        int r = 0;
-        for (int q = 0; q < n; ++q) r += (skey[q] < k) ? 1 : 0;
-        sorder[r] = vals_ci[j];
-        sxyd[r] = k;
-      }
-      __syncthreads();
-      for (int r = tid; r < n; r += TR_THREADS) {
-        const BriskCand* c = &cand[(long)frame * cand_cap + sorder[r]];
-        sfpxy[r] = (unsigned)(uint16_t)c->fp_x0 | ((unsigned)(uint16_t)c->fp_y0 << 16);
-        sfpm[r] = c->fp_mask;
-        tstat[r] = 0;
-      }
-      __syncthreads();
-    }
-    if (lds_layer) {
-      uint16_t* wl = win[wave];
-      const int lbeg = sorted_path ? lstart[l] : 0, lend = lbeg + n;
-      // Round-robin over the raster-sorted ties: neighbouring ties (which depend on each other) run on different
-      // waves back to back.  The only thing a tie needs from raster-earlier ties of its 9x9 window is their
-      // decision, which is exchanged through LDS (tstat); the window itself and the 5x5 score block of a wave's
-      // NEXT tie are prefetched into registers while the current one is decided.
-      int j = lbeg + wave;
-      unsigned pw0 = 0, pw1 = 0, pkb = 0;
+    // Round-robin over the raster-sorted ties: neighbouring ties (which depend on each other) run on different
+    // waves back to back.  The only thing a tie needs from raster-earlier ties of its 9x9 window is their
+    // decision, which is exchanged through LDS (tstat); the window itself and the 5x5 score block of a wave's
+    // NEXT tie are prefetched into registers while the current one is decided.
+    int j = (wave < TR_DWAVES) ? wave : nc;
+#ifdef TR_TIMING
+    int tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = (long long)wall_clock64();
+#endif
+    unsigned pw0 = 0, pw1 = 0, pkb = 0;
+    bool pvalid = false;
 #define TR_PREFETCH(jj)                                                                                          \
   {                                                                                                              \
     const unsigned k_ = sxyd[jj];                                                                                \
@@ -1020,168 +1088,195 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     const int qx1_ = cx_ + e1_ % TR_WIN - 4, qy1_ = cy_ + e1_ / TR_WIN - 4;                                      \
     pw0 = smap_load_fresh(L.smap, (long)min(max(qy0_, 0), L.h - 1) * L.stride + min(max(qx0_, 0), L.w - 1));     \
     pw1 = smap_load_fresh(L.smap, (long)min(max(qy1_, 0), L.h - 1) * L.stride + min(max(qx1_, 0), L.w - 1));     \
-    pkb = blocks[((long)frame * cand_cap + sorder[jj]) * 64 + min(lane, 24)];                                    \
     if (qx0_ < 0 || qy0_ < 0 || qx0_ >= L.w || qy0_ >= L.h) pw0 = 0;                                            \
     if (qx1_ < 0 || qy1_ < 0 || qx1_ >= L.w || qy1_ >= L.h) pw1 = 0;                                            \
   }
-      if (j < lend) TR_PREFETCH(j)
-      while (j < lend) {
-        unsigned v0 = pw0;
-        const unsigned v1 = pw1, kb = pkb;
-        const int ci = sorder[j];
-        const unsigned key = sxyd[j];
-        const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
-        {
-          const int jn = min(j + TR_WAVES, lend - 1);  // (the last prefetch of a wave is redundant, never out of range)
-          TR_PREFETCH(jn)
+#define TR_PREFETCH_BLOCK(jj) pkb = blocks[((long)frame * cand_cap + sorder[jj]) * 64 + min(lane, 24)];
+    // the window may only be read once the layer below is past the rows that can touch it
+#define TR_NEED(key_, need_)                                                                                     \
+  {                                                                                                              \
+    const int x_ = (int)((key_) & 0x1FFF), y_ = (int)(((key_) >> 13) & 0x1FFF);                                  \
+    const int cell_ = (y_ >> bm_shift) * bm_w + (x_ >> bm_shift);                                                \
+    need_ = (below_elsewhere && ((below_bm[cell_ >> 5] >> (cell_ & 31)) & 1u)) ? tr_rows_needed(y_, below_is_octave) : 0; \
+  }
+#define TR_POLL(need_)                                                                                           \
+  if (seen < need_) {                                                                                            \
+    seen = max(seen, __hip_atomic_load(&seen_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));                \
+    if (seen < need_) {                                                                                          \
+      seen = __hip_atomic_load(below_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                          \
+      if (lane == 0) __hip_atomic_fetch_max(&seen_s, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      \
+    }                                                                                                            \
+  }
+#define TR_TRY_PREFETCH(jj)                                                                                      \
+  {                                                                                                              \
+    int need_;                                                                                                   \
+    TR_NEED(sxyd[jj], need_)                                                                                     \
+    TR_POLL(need_)                                                                                               \
+    TR_T(1)                                                                                                      \
+    pvalid = seen >= need_;                                                                                      \
+    if (pvalid) TR_PREFETCH(jj)                                                                                  \
+    TR_PREFETCH_BLOCK(jj)                                                                                        \
+  }
+    if (j < nc) TR_TRY_PREFETCH(j)
+    while (j < nc) {
+      unsigned v0 = pw0;
+      unsigned v1 = pw1;
+      const unsigned kb = pkb;
+      const bool valid = pvalid;
+#ifdef TR_TIMING
+      asm volatile("" : "+v"(v0), "+v"(v1));
+      TR_T(0)
+#endif
+      const unsigned key = sxyd[j];
+      const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
+      {
+        const int jn = min(j + TR_DWAVES, nc - 1);  // (the last prefetch of a wave is redundant, never out of range)
+        TR_TRY_PREFETCH(jn)
+      }
+      TR_T(2)
+      if (!valid) {  // pipeline front: wait for the layer below, then read the window
+        int need;
+        TR_NEED(key, need)
+        for (int spin = 0; seen < need && spin < (1 << 20); ++spin) {
+          TR_POLL(need)
+          if (seen >= need || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+          __builtin_amdgcn_s_sleep(8);
         }
-        // decisions of the raster-earlier ties of the window (entries 0..39 of the 81)
-        {
-          const int dy = lane / TR_WIN - 4, dx = lane % TR_WIN - 4;
-          if (lane < 40 && BRISK_SM_D(v0) && BRISK_SM_STATUS(v0) == BRISK_ST_TIE) {
-            const unsigned k2 = ((unsigned)l << 26) | ((unsigned)(cy + dy) << 13) | (unsigned)(cx + dx);
-            int lo = lbeg, hi = j;
-            while (lo < hi) {
-              const int mid = (lo + hi) >> 1;
-              if (sxyd[mid] < k2) lo = mid + 1; else hi = mid;
-            }
-            if (lo < j && sxyd[lo] == k2) {
-              int st = 0;
-              for (int spin = 0; spin < (1 << 22); ++spin) {
-                st = __hip_atomic_load(&tstat[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (st || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                __builtin_amdgcn_s_sleep(1);
-              }
-              if (!st) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
-              if (st) v0 = (v0 & ~0x3000u) | ((unsigned)st << 12);
-            }
+        if (seen < need) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+        const unsigned s0 = pw0, s1 = pw1;  // keep the next tie's prefetch
+        TR_PREFETCH(j)
+        v0 = pw0; v1 = pw1;
+        pw0 = s0; pw1 = s1;
+      }
+      TR_T(7)
+      // decisions of the raster-earlier ties of the window (entries 0..39 of the 81)
+      {
+        const int dy = lane / TR_WIN - 4, dx = lane % TR_WIN - 4;
+        int lo = -1;
+        if (lane < 40 && BRISK_SM_D(v0) && BRISK_SM_STATUS(v0) == BRISK_ST_TIE) {
+          const unsigned k2 = ((unsigned)l << 26) | ((unsigned)(cy + dy) << 13) | (unsigned)(cx + dx);
+          int hi = j;
+          lo = 0;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sxyd[mid] < k2) lo = mid + 1; else hi = mid;
+          }
+          // (a pending raster-earlier tie of the window is always in this chunk: earlier chunks are complete and the
+          // window was read after they were)
+          if (!(lo < j && sxyd[lo] == k2)) {
+            __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+            lo = -1;
           }
         }
-        wl[lane] = (uint16_t)v0;
-        if (lane + 64 < TR_WIN * TR_WIN) wl[lane + 64] = (uint16_t)v1;
-        if (lane < 25) kp5s[wave][lane] = (uint8_t)kb;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
-        {  // lanes 0-7: the 8 probe values, lanes 32-56: the 5x5 raw block (vals[8..32])
-          const int slot = (lane < 8) ? lane : (lane >= 32 && lane < 57) ? lane - 24 : -1;
-          if (slot >= 0)
-            vals[wave][slot] = brisk_tie_slot_value<false>(L, float_patch, touch2x2, cx, cy, centre, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
+        TR_T(3)
+        if (lo >= 0) {
+          int st = 0;
+          for (int spin = 0; spin < (1 << 22); ++spin) {
+            st = __hip_atomic_load(&tstat[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 3;
+            if (st || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (!st) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+          if (st) v0 = (v0 & ~0x3000u) | ((unsigned)st << 12);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the eight neighbours of the tie list on eight lanes (a serial walk on one lane costs ~70 dependent LDS reads)
-        const bool nb_ok = (lane >= 8) || brisk_tie_neighbour_ok(centre, &vals[wave][0], &vals[wave][8], lane);
-        const bool pass_all = __all(nb_ok);
-        if (lane == 0) {
-          const bool pass = pass_all;
-          // publish the decision first (other waves spin on it), then the bookkeeping
-          __hip_atomic_store(&tstat[j], pass ? (int)BRISK_ST_PASS : (int)BRISK_ST_FAIL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        TR_T(4)
+      }
+      wl[lane] = (uint16_t)v0;
+      if (lane + 64 < TR_WIN * TR_WIN) wl[lane + 64] = (uint16_t)v1;
+      if (lane < 25) kp5s[wave][lane] = (uint8_t)kb;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
+      {  // lanes 0-7: the 8 probe values, lanes 32-56: the 5x5 raw block (vals[8..32])
+        const int slot = (lane < 8) ? lane : (lane >= 32 && lane < 57) ? lane - 24 : -1;
+        if (slot >= 0)
+          vals[wave][slot] = brisk_tie_slot_value<false>(L, float_patch, touch2x2, cx, cy, centre, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // the eight neighbours of the tie list on eight lanes (a serial walk on one lane costs ~70 dependent LDS reads)
+      const bool nb_ok = (lane >= 8) || brisk_tie_neighbour_ok(centre, &vals[wave][0], &vals[wave][8], lane);
+      const bool pass = __all(nb_ok);
+      const int dec = pass ? (int)BRISK_ST_PASS : (int)BRISK_ST_FAIL;
+      // the decision goes to LDS only (other waves spin on it); the writer wave takes it to memory
+      if (lane == 0) __hip_atomic_store(&tstat[j], dec, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __builtin_amdgcn_wave_barrier();
+      TR_T(5)
+#ifdef TR_TIMING
+      tacc[6] += 1;
+#endif
+      j += TR_DWAVES;
+    }
+    // ---- writer wave: decisions -> score-state map, candidate status, touches on the layer above; a tie counts as
+    // done for the layer above once these are performed; the progress is the row of the first tie that is not done.
+    // The deciding waves never wait for a memory write this way (an agent-scope atomic takes microseconds).
+    if (wave == TR_DWAVES) {
+      int w = 0, row_pub = -1;
+      for (int idle = 0; w < nc;) {
+        const int i = w + lane;
+        const int st = (i < nc) ? __hip_atomic_load(&tstat[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+        const bool todo = (st & 3) && !(st & TR_DONE_BIT);
+        if (todo) {
+          const unsigned key = sxyd[i];
+          const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
+          const bool pass = (st & 3) == (int)BRISK_ST_PASS;
           if (pass) smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
           else smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);       // TIE (10b) -> FAIL (11b)
-          cand[(long)frame * cand_cap + ci].status = pass ? BRISK_ST_PASS : BRISK_ST_FAIL;
-          const unsigned fpm = sfpm[j];
-          if (pass && fpm && l + 1 < G.nlayers) {
-            const int fx = (int16_t)(sfpxy[j] & 0xFFFFu), fy = (int16_t)(sfpxy[j] >> 16);
+          cand[(long)frame * cand_cap + sorder[i]].status = (uint8_t)(st & 3);
+          const unsigned fpm = (pass && !last) ? (unsigned)sfpm[i] : 0u;
+          if (fpm) {
+            const int fx = (int16_t)(sfpxy[i] & 0xFFFFu), fy = (int16_t)(sfpxy[i] >> 16);
             const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
             for (int b = 0; b < 16; ++b)
               if (fpm & (1u << b)) smap_or(La.smap, (long)(fy + (b >> 2)) * La.stride + fx + (b & 3), BRISK_SM_TOUCH);
           }
         }
-        __builtin_amdgcn_wave_barrier();
-        j += TR_WAVES;
-      }
-#undef TR_PREFETCH
-      // the touches are device-scope atomics performed at L2 and the next layer reads smap with L1-bypassing
-      // loads: completion of the atomics (vmcnt) + the workgroup barrier is all the ordering needed
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      continue;
-    }
-    // ---- more ties than the on-chip arrays hold (dense frames): the same in-order scheme with the sorted list of
-    // this layer in global scratch (gkey / gci, rank-sorted through LDS tiles) and the decisions exchanged through
-    // the score-state map itself: a wave re-reads its 9x9 window (L1-bypassing loads) until no raster-earlier tie
-    // in it is pending; decisions are published with device-scope atomics, as in the on-chip path.
-    {
-      unsigned* gkey = gscratch + (long)frame * cand_cap * 2;
-      unsigned* gci = gkey + cand_cap;
-      unsigned* tilek = skey;  // (free in this path)
-      for (int j0 = 0; j0 < n; j0 += TR_THREADS) {
-        const int j = j0 + tid;
-        const int ci = (j < n) ? list[j] : 0;
-        const unsigned myk = (j < n) ? cand[(long)frame * cand_cap + ci].key : 0xFFFFFFFFu;
-        int rank = 0;
-        for (int t0 = 0; t0 < n; t0 += TR_THREADS) {
-          __syncthreads();
-          tilek[tid] = (t0 + tid < n) ? cand[(long)frame * cand_cap + list[t0 + tid]].key : 0xFFFFFFFFu;
-          __syncthreads();
-          const int m = min(TR_THREADS, n - t0);
-          for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
+        if (__any(todo)) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (todo) __hip_atomic_fetch_or(&tstat[i], TR_DONE_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (j < n) { gkey[rank] = myk; gci[rank] = (unsigned)ci; }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      uint16_t* wl = win[wave];
-      for (int j = wave; j < n; j += TR_WAVES) {
-        const unsigned key = __hip_atomic_load(&gkey[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int ci = (int)__hip_atomic_load(&gci[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
-        if (lane < 25) kp5s[wave][lane] = blocks[((long)frame * cand_cap + ci) * 64 + lane];
-        for (int spin = 0; spin < (1 << 22); ++spin) {
-          bool pending = false;
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const int e = lane + 64 * t;
-            if (e < TR_WIN * TR_WIN) {
-              const int dy = e / TR_WIN - 4, dx = e % TR_WIN - 4;
-              const int qx = cx + dx, qy = cy + dy;
-              unsigned v = 0;
-              if (qx >= 0 && qy >= 0 && qx < L.w && qy < L.h) v = smap_load_fresh(L.smap, (long)qy * L.stride + qx);
-              wl[e] = (uint16_t)v;
-              if ((dy < 0 || (dy == 0 && dx < 0)) && BRISK_SM_D(v) && BRISK_SM_STATUS(v) == BRISK_ST_TIE) pending = true;
-            }
+        const unsigned long long decided = __ballot((i < nc) && (st & 3));
+        const int lead = (~decided == 0ull) ? 64 : __builtin_ctzll(~decided);
+        if (lead) {
+          w += lead;
+          idle = 0;
+          if (lane == 0 && !last && w < nc) {
+            const int row = (int)((sxyd[w] >> 13) & 0x1FFF);
+            if (row > row_pub) __hip_atomic_fetch_max(my_prog, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          if (!__any(pending) || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-          if (spin == (1 << 20)) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+          if (w < nc) row_pub = max(row_pub, (int)((sxyd[w] >> 13) & 0x1FFF));
+        } else {
+          if (++idle > (1 << 22)) {  // (never observed)
+            __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+          }
           __builtin_amdgcn_s_sleep(2);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
-        {
-          const int slot = (lane < 8) ? lane : (lane >= 32 && lane < 57) ? lane - 24 : -1;
-          if (slot >= 0)
-            vals[wave][slot] = brisk_tie_slot_value<false>(L, float_patch, touch2x2, cx, cy, centre, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bool nb_ok = (lane >= 8) || brisk_tie_neighbour_ok(centre, &vals[wave][0], &vals[wave][8], lane);
-        const bool pass = __all(nb_ok);
-        if (lane == 0) {
-          BriskCand* c = &cand[(long)frame * cand_cap + ci];
-          // bookkeeping first, the decision last: whoever sees the new status may rely on the touches
-          if (pass && c->fp_mask && l + 1 < G.nlayers) {
-            const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
-            for (int b = 0; b < 16; ++b)
-              if (c->fp_mask & (1u << b))
-                smap_or(La.smap, (long)(c->fp_y0 + (b >> 2)) * La.stride + c->fp_x0 + (b & 3), BRISK_SM_TOUCH);
-          }
-          c->status = pass ? BRISK_ST_PASS : BRISK_ST_FAIL;
-          if (pass) smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
-          else smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);       // TIE (10b) -> FAIL (11b)
-        }
-        __builtin_amdgcn_wave_barrier();
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+    }
+#ifdef TR_TIMING
+    if (lane == 0 && wave < TR_DWAVES)
+      for (int i = 0; i < 8; ++i) atomicAdd(&counters[frame].pad[i], tacc[i]);
+#endif
+#undef TR_TRY_PREFETCH
+#undef TR_POLL
+#undef TR_NEED
+#undef TR_PREFETCH_BLOCK
+#undef TR_PREFETCH
+    // the touches are agent-scope atomics and the readers use L1-bypassing loads: completion of the atomics (vmcnt) +
+    // the workgroup barrier is all the ordering the next chunk and the progress word need
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && !last) {
+      const int c1 = c0 + nc;
+      const int row = (c1 < n) ? (int)((gkey[c1] >> 13) & 0x1FFF) : TR_PROG_DONE;
+      __hip_atomic_fetch_max(my_prog, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  }  // layers of this workgroup
+  __syncthreads();
   if (tid == 0 && abort_s) atomicOr(&counters[frame].overflow, 8);  // a wait ran into its bound: reported as an error
 }
 
@@ -1930,8 +2025,17 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                      B.tie_idx, B.cand_cap, B.tie_cap);
   brisk_prof_mark(prof, BRISK_STG_TIES, s);
   if (ov && fork_at == 0) fork_integral();
-  hipLaunchKernelGGL(k_tie_resolve, dim3(nframes), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                     B.blocks, B.keys, B.cand_cap, B.tie_cap);
+  {
+    // Small batches: one workgroup per (frame, layer), the layers of a frame run as a pipeline (a frame is ready in the
+    // time of its largest layer instead of the sum).  Large batches fill the chip with one workgroup per frame; the
+    // pipeline would only add workgroups that wait for each other.  With 8 or more frames every XCD residue of
+    // blockIdx gets whole frames.
+    static const int lpw_knob = env_knob("BRISK_TR_LPW", 0);
+    const int lpw = lpw_knob ? min(lpw_knob, G.nlayers) : (nframes * G.nlayers <= 1024 ? 1 : G.nlayers);
+    const int tr_grid = (nframes >= 8 ? (nframes + 7) / 8 * 8 : nframes) * ((G.nlayers + lpw - 1) / lpw);
+    hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
+                       B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw);
+  }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,
                      B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);

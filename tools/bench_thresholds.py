@@ -29,5 +29,6 @@ for thr in [int(a) for a in sys.argv[1:]] or (80, 50, 30):
     torch.cuda.synchronize()
     ms, _ = ctx.profile_read()
     nd, nk = len(ctx.batch_download(0, False)[0]), len(ctx.batch_download(0, True)[0])
+    print("thr %d" % thr, ctx.debug_counters(0))
     print("thr %d flags %d detected %d described %d total %.2f ms / 64 frames %s"
           % (thr, flags, nd, nk, sum(ms.values()), {k: round(v, 2) for k, v in ms.items()}))

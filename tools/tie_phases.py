@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-phase time of k_tie_resolve's decision loop (needs the TR_TIMING build variant:
+python -c "from ethzasl_brisk_amd import build; build.build_variant('libbrisk_trtiming', ['TR_TIMING'])";
+BRISK_HIP_LIB=ethzasl_brisk_amd/libbrisk_trtiming.so python3 tools/tie_phases.py [threshold] [frames])."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import ethzasl_brisk_amd as B
+import synth
+
+thr = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+frames = np.stack([synth.frame_1080p(i) for i in range(4)])
+d = torch.from_numpy(frames).cuda()
+batch = d[torch.arange(n, device="cuda") % 4].contiguous()
+_, h, w = batch.shape
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(2):
+    ctx.detect_batch(batch.data_ptr(), n, w, h, w * h, w, thr, 4, st)
+torch.cuda.synchronize()
+ctx.batch_status(n)
+ctx.profile_enable(True)
+for _ in range(3):
+    ctx.detect_batch(batch.data_ptr(), n, w, h, w * h, w, thr, 4, st)
+torch.cuda.synchronize()
+ms, _ = ctx.profile_read()
+c = ctx.debug_counters(0)
+e = c["experiment"]
+names = ["prefetched window arrives", "layer-below need + poll", "next prefetch issue",
+         "search", "spin on earlier ties", "replay -> decision", None, "wait for the layer below + window read"]
+print("thr %d, %d frames: k_tie_resolve %.3f ms; frame 0 ties %s" % (thr, n, ms.get("k_tie_resolve", 0), c["ties"]))
+if e[6]:
+    for i, nm in enumerate(names):
+        if nm:
+            print("  %-52s %7.2f us per tie iteration" % (nm, e[i] * 0.01 / e[6]))
+    print("  total %.2f us per iteration, %d iterations" % ((sum(e) - e[6]) * 0.01 / e[6], e[6]))

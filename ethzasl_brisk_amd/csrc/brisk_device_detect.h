@@ -1242,6 +1242,121 @@ BRISK_HD int brisk_state_at(const BriskLayerView& L, const bool float_patch, con
   return (Kp >= t_last) ? Kp : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// brisk_state_at in two steps for the tie kernel.  The only inputs of the replay that can still change while a tie
+// waits are the decisions of raster-earlier tie candidates that were pending (status TIE) when its window was read;
+// they enter through the `tc` events alone.  brisk_state_static does everything else before the wait and lists the
+// neighbours whose tc event is still open; brisk_state_resolve finishes with the decided statuses:
+//   cached / any: OR over the events; t_last: the value of the LAST event in raster order (a neighbour's probe event
+//   precedes its own touch event), so an open touch event that fires overrides t_last iff no static event follows it.
+// packed: bits 0-7 Kp (or the final value), 8-15 t_last, 16-21 index of the last static event + 1, 22 cached, 23 any,
+// 31 final (value needs no resolve).
+// ---------------------------------------------------------------------------------------------
+#define BRISK_SS_FINAL 0x80000000u
+BRISK_HD int brisk_clz(unsigned v) { return __builtin_clz(v); }  // v != 0
+BRISK_HD unsigned brisk_state_static(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int px,
+                                     int py, int cx, int cy, bool own, const uint16_t* sm_local, int lx0, int ly0, int lw,
+                                     const uint8_t* kp5, unsigned* dynmask) {
+  *dynmask = 0;
+  if (brisk_border3(L, px, py)) return BRISK_SS_FINAL;
+  const uint16_t* wp = sm_local + (py - ly0) * lw + (px - lx0);
+  const unsigned smp = wp[0];
+  const int D = BRISK_SM_D(smp);
+  if (D > 2) return BRISK_SS_FINAL | (unsigned)D;
+  const int Kp = (int)kp5[(py - cy + 2) * 5 + (px - cx + 2)];
+  if (Kp == 0) return BRISK_SS_FINAL;
+  bool cached = (smp & BRISK_SM_TOUCH) != 0, any = cached;
+  int t_last = cached ? 1 : 0;
+  int last_static = 0;  // index + 1 of the last static event
+  unsigned dyn = 0;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    const int oy = i / 5 - 2, ox = i % 5 - 2;
+    if (ox == 0 && oy == 0) continue;
+    const int ddx = -ox, ddy = -oy;  // p - q
+    const int qx = px + ox, qy = py + oy;
+    const unsigned smq = wp[oy * lw + ox];
+    const int Dq = BRISK_SM_D(smq);
+    const bool self = (qx == cx) && (qy == cy);
+    const bool earlier = (qy < cy) || (qy == cy && qx <= cx);
+    const bool act = earlier && (Dq != 0) && !(self && !own);
+    const bool near = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1;
+    if (near) {
+      const bool pr = act && (brisk_probe_index(ddx, ddy) < (int)BRISK_SM_NPROBED(smq));
+      any = any || pr;
+      t_last = pr ? Dq : t_last;
+      last_static = pr ? i + 1 : last_static;
+      cached = cached || (pr && Dq <= Kp);
+    }
+    bool touched = false;
+    if (!float_patch) {
+      touched = near && (smq & BRISK_SM_E5);
+    } else {
+      if (pass_touch2x2 && ddx >= 0 && ddx <= 1 && ddy >= 0 && ddy <= 1) touched = true;
+      if ((smq & BRISK_SM_E5) && ddx >= -1 && ddx <= 2 && ddy >= -1 && ddy <= 2) touched = true;
+    }
+    const bool open = act && !self && touched;
+    const unsigned stq = BRISK_SM_STATUS(smq);
+    const bool tc = open && (stq == BRISK_ST_PASS);
+    any = any || tc;
+    t_last = tc ? 1 : t_last;
+    last_static = tc ? i + 1 : last_static;
+    cached = cached || tc;
+    dyn |= (open && stq == BRISK_ST_TIE) ? (1u << i) : 0u;
+  }
+  *dynmask = dyn;
+  return (unsigned)Kp | ((unsigned)t_last << 8) | ((unsigned)last_static << 16) | (cached ? 1u << 22 : 0u) | (any ? 1u << 23 : 0u);
+}
+
+// sm_local now carries the decided statuses of the neighbours listed in dynmask
+BRISK_HD int brisk_state_resolve(unsigned packed, unsigned dynmask, int px, int py, const uint16_t* sm_local, int lx0,
+                                 int ly0, int lw) {
+  if (packed & BRISK_SS_FINAL) return (int)(packed & 0xFFu);
+  const int Kp = (int)(packed & 0xFFu);
+  int t_last = (int)((packed >> 8) & 0xFFu);
+  const int last_static = (int)((packed >> 16) & 0x3Fu);
+  bool cached = (packed >> 22) & 1u, any = (packed >> 23) & 1u;
+  const uint16_t* wp = sm_local + (py - ly0) * lw + (px - lx0);
+  int hi_fired = 0;  // index + 1 of the last open event that fires
+  for (unsigned m = dynmask; m;) {
+    const int i = 31 - brisk_clz(m);
+    m &= ~(1u << i);
+    const int oy = i / 5 - 2, ox = i % 5 - 2;
+    if (BRISK_SM_STATUS((unsigned)wp[oy * lw + ox]) == BRISK_ST_PASS) { hi_fired = i + 1; break; }  // highest index first
+  }
+  if (hi_fired) {
+    cached = true; any = true;
+    if (hi_fired >= last_static) t_last = 1;
+  }
+  if (Kp >= 3 && cached) return Kp;
+  if (!any) return 0;
+  return (Kp >= t_last) ? Kp : 0;
+}
+
+// slot 0..7 = probe values, slot 8..32 = raw values (the tie kernel's lanes): static step / resolve step
+BRISK_HD unsigned brisk_tie_slot_static(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx,
+                                        int cy, int slot, const uint16_t* sm_local, int lx0, int ly0, int lw,
+                                        const uint8_t* kp5, unsigned* dynmask) {
+  const bool probe = slot < 8;
+  const int q = probe ? 0 : slot - 8;
+  const int px = cx + (probe ? brisk_probe_dx(slot) : (q % 5) - 2), py = cy + (probe ? brisk_probe_dy(slot) : (q / 5) - 2);
+  *dynmask = 0;
+  if (!probe && px == cx && py == cy) return BRISK_SS_FINAL;  // (the centre: the caller substitutes it)
+  return brisk_state_static(L, float_patch, pass_touch2x2, px, py, cx, cy, !probe, sm_local, lx0, ly0, lw, kp5, dynmask);
+}
+BRISK_HD int brisk_tie_slot_resolve(const BriskLayerView& L, unsigned packed, unsigned dynmask, int cx, int cy, int centre,
+                                    int slot, const uint16_t* sm_local, int lx0, int ly0, int lw, const uint8_t* kp5) {
+  const bool probe = slot < 8;
+  const int q = probe ? 0 : slot - 8;
+  const int px = cx + (probe ? brisk_probe_dx(slot) : (q % 5) - 2), py = cy + (probe ? brisk_probe_dy(slot) : (q / 5) - 2);
+  if (!probe && px == cx && py == cy) return centre;
+  const int m = brisk_state_resolve(packed, dynmask, px, py, sm_local, lx0, ly0, lw);
+  if (!probe || m > 2) return m;
+  if (brisk_border3(L, px, py)) return 0;
+  const int K = (int)kp5[(py - cy + 2) * 5 + (px - cx + 2)];
+  return (K >= centre) ? K : 0;
+}
+
 // IsMax2D steps 3-4 (brisk-scale-space.cc:499-530) for a tie candidate, split so that the per-pixel
 // cache replays can run one lane per pixel:
 //   ret[k]   (k = 0..7, probe order)  value the candidate's k-th probe returns

@@ -1123,10 +1123,6 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       unsigned v1 = pw1;
       const unsigned kb = pkb;
       const bool valid = pvalid;
-#ifdef TR_TIMING
-      asm volatile("" : "+v"(v0), "+v"(v1));
-      TR_T(0)
-#endif
       const unsigned key = sxyd[j];
       const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
       {
@@ -1149,10 +1145,20 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
         pw0 = s0; pw1 = s1;
       }
       TR_T(7)
-      // decisions of the raster-earlier ties of the window (entries 0..39 of the 81)
+      // the window as it was read (ties that were pending then show status TIE) and the score block go to LDS
+      wl[lane] = (uint16_t)v0;
+      if (lane + 64 < TR_WIN * TR_WIN) wl[lane + 64] = (uint16_t)v1;
+      if (lane < 25) kp5s[wave][lane] = (uint8_t)kb;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
+      // lanes 0-7: the 8 probe values, lanes 32-56: the 5x5 raw block (vals[8..32])
+      const int slot = (lane < 8) ? lane : (lane >= 32 && lane < 57) ? lane - 24 : -1;
+      // raster-earlier ties of the window (entries 0..39 of the 81) that were pending: where their decisions will appear
+      int lo = -1;
       {
         const int dy = lane / TR_WIN - 4, dx = lane % TR_WIN - 4;
-        int lo = -1;
         if (lane < 40 && BRISK_SM_D(v0) && BRISK_SM_STATUS(v0) == BRISK_ST_TIE) {
           const unsigned k2 = ((unsigned)l << 26) | ((unsigned)(cy + dy) << 13) | (unsigned)(cx + dx);
           int hi = j;
@@ -1168,31 +1174,29 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
             lo = -1;
           }
         }
-        TR_T(3)
-        if (lo >= 0) {
-          int st = 0;
-          for (int spin = 0; spin < (1 << 22); ++spin) {
-            st = __hip_atomic_load(&tstat[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 3;
-            if (st || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (!st) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
-          if (st) v0 = (v0 & ~0x3000u) | ((unsigned)st << 12);
-        }
-        TR_T(4)
       }
-      wl[lane] = (uint16_t)v0;
-      if (lane + 64 < TR_WIN * TR_WIN) wl[lane + 64] = (uint16_t)v1;
-      if (lane < 25) kp5s[wave][lane] = (uint8_t)kb;
+      TR_T(3)
+      // everything of the cache replay that does not depend on those decisions, before waiting for them
+      unsigned spk = BRISK_SS_FINAL, sdyn = 0;
+      if (slot >= 0) spk = brisk_tie_slot_static(L, float_patch, touch2x2, cx, cy, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave], &sdyn);
+      TR_T(5)
+      if (lo >= 0) {
+        int st = 0;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+          st = __hip_atomic_load(&tstat[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 3;
+          if (st || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!st) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+        if (st) wl[lane] = (uint16_t)((v0 & ~0x3000u) | ((unsigned)st << 12));
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
-      {  // lanes 0-7: the 8 probe values, lanes 32-56: the 5x5 raw block (vals[8..32])
-        const int slot = (lane < 8) ? lane : (lane >= 32 && lane < 57) ? lane - 24 : -1;
-        if (slot >= 0)
-          vals[wave][slot] = brisk_tie_slot_value<false>(L, float_patch, touch2x2, cx, cy, centre, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
-      }
+      TR_T(4)
+      // the open events with the decisions in
+      if (slot >= 0)
+        vals[wave][slot] = brisk_tie_slot_resolve(L, spk, sdyn, cx, cy, centre, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1203,7 +1207,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       // the decision goes to LDS only (other waves spin on it); the writer wave takes it to memory
       if (lane == 0) __hip_atomic_store(&tstat[j], dec, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       __builtin_amdgcn_wave_barrier();
-      TR_T(5)
+      TR_T(0)
 #ifdef TR_TIMING
       tacc[6] += 1;
 #endif

@@ -370,6 +370,58 @@ int emul_b2_fast_mismatches(void) {
   return bad;
 }
 
+// The tie kernel's two-step replay (brisk_state_static before the wait for pending ties, brisk_state_resolve after it)
+// against the one-step brisk_state_at, on random 9x9 windows: `n` random candidates, all 33 slots, the three touch
+// geometries; raster-earlier decided ties are shown as pending (status TIE) to the static step.  Returns mismatches.
+int emul_state_split_mismatches(unsigned seed, int n) {
+  auto rnd = [&seed]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+  int bad = 0;
+  for (int it = 0; it < n; ++it) {
+    BriskLayerView L;
+    memset(&L, 0, sizeof(L));
+    L.w = 12 + (int)(rnd() % 30);
+    L.h = 12 + (int)(rnd() % 30);
+    L.stride = L.w;
+    const int cx = 3 + (int)(rnd() % (unsigned)(L.w - 6)), cy = 3 + (int)(rnd() % (unsigned)(L.h - 6));
+    uint16_t wfin[81], wpre[81];
+    const unsigned density = 2 + rnd() % 6;
+    for (int e = 0; e < 81; ++e) {
+      const int dy = e / 9 - 4, dx = e % 9 - 4;
+      const int qx = cx + dx, qy = cy + dy;
+      unsigned v = 0;
+      const bool inside = qx >= 0 && qy >= 0 && qx < L.w && qy < L.h;
+      const bool centre = (dx == 0 && dy == 0);
+      const bool earlier = dy < 0 || (dy == 0 && dx < 0);
+      if (inside && (centre || rnd() % 8 < density)) {
+        const unsigned dsel = rnd() % 4;
+        const unsigned D = dsel == 0 ? 1 + rnd() % 2 : dsel == 1 ? 3 + rnd() % 3 : 1 + rnd() % 255;
+        const unsigned st = centre ? BRISK_ST_TIE : earlier ? (unsigned[]){BRISK_ST_REJ, BRISK_ST_PASS, BRISK_ST_FAIL, BRISK_ST_PASS}[rnd() % 4] : rnd() % 4;
+        v = D | ((rnd() % 9) << 8) | (st << 12) | ((rnd() % 2) ? BRISK_SM_E5 : 0u);
+      }
+      if (inside && rnd() % 4 == 0) v |= BRISK_SM_TOUCH;
+      wfin[e] = (uint16_t)v;
+      unsigned vp = v;
+      const unsigned st = BRISK_SM_STATUS(v);
+      if (earlier && BRISK_SM_D(v) && (st == BRISK_ST_PASS || st == BRISK_ST_FAIL) && rnd() % 2) vp = (v & ~0x3000u) | (BRISK_ST_TIE << 12);
+      wpre[e] = (uint16_t)vp;
+    }
+    uint8_t kp5[25];
+    for (int q = 0; q < 25; ++q) kp5[q] = (uint8_t)((rnd() % 3 == 0) ? rnd() % 6 : rnd() % 256);
+    const int centre = BRISK_SM_D(wfin[40]);
+    for (int geo = 0; geo < 3; ++geo) {
+      const bool float_patch = geo > 0, touch2x2 = geo == 2;
+      for (int slot = 0; slot < 33; ++slot) {
+        const int ref = brisk_tie_slot_value<false>(L, float_patch, touch2x2, cx, cy, centre, slot, wfin, cx - 4, cy - 4, 9, kp5);
+        unsigned dyn = 0;
+        const unsigned pk = brisk_tie_slot_static(L, float_patch, touch2x2, cx, cy, slot, wpre, cx - 4, cy - 4, 9, kp5, &dyn);
+        const int got = brisk_tie_slot_resolve(L, pk, dyn, cx, cy, centre, slot, wfin, cx - 4, cy - 4, 9, kp5);
+        if (ref != got) ++bad;
+      }
+    }
+  }
+  return bad;
+}
+
 // k_detect phase A: the packed pre-gate must be a NECESSARY condition of brisk_detect_px.  Walks an image exactly as
 // the kernel pairs the pixels (two horizontally adjacent centres per call) and returns the number of detections the
 // pre-gate would have dropped (must be 0); *survivors receives the number of pixels that pass it.

@@ -152,6 +152,15 @@ def test_tie_decision_on_eight_lanes_equals_serial():
     assert L.emul_tie_decide_mismatches(7, 200000) == 0
 
 
+def test_two_step_tie_replay_equals_one_step():
+    """the tie kernel replays the cache in two steps (everything static before it waits for pending ties, the open
+    touch events after): identical to brisk_state_at on random windows, every slot, every touch geometry"""
+    import ctypes as C
+    L = E.lib()
+    L.emul_state_split_mismatches.argtypes = [C.c_uint, C.c_int]
+    assert L.emul_state_split_mismatches(11, 60000) == 0
+
+
 def test_pregate_is_a_necessary_condition():
     """k_detect phase A (packed 16-bit pre-gate on the compass pixels) must never drop a pixel that
     brisk_detect_px (the exact per-pixel detection) accepts: synthetic frames, pure noise, saturated blocks, all

@@ -31,8 +31,8 @@ torch.cuda.synchronize()
 ms, _ = ctx.profile_read()
 c = ctx.debug_counters(0)
 e = c["experiment"]
-names = ["prefetched window arrives", "layer-below need + poll", "next prefetch issue",
-         "search", "spin on earlier ties", "replay -> decision", None, "wait for the layer below + window read"]
+names = ["resolve -> decision", "layer-below need + poll", "next prefetch issue", "window -> LDS + search",
+         "spin on earlier ties", "static replay", None, "wait for the layer below + window read"]
 print("thr %d, %d frames: k_tie_resolve %.3f ms; frame 0 ties %s" % (thr, n, ms.get("k_tie_resolve", 0), c["ties"]))
 if e[6]:
     for i, nm in enumerate(names):

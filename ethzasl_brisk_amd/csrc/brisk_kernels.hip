@@ -1288,19 +1288,22 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
 // k_finalize: keypoints of a frame in (layer, y, x) order.  One workgroup per frame; ranks by
 // counting smaller keys among the valid candidates (a few thousand at most).
 // ------------------------------------------------------------------------------------------------
+#ifndef FN_THREADS
 #define FN_THREADS 512
+#endif
 #define FN_BUCKETS 2048
-#define FN_SMALL 3072   // up to this many keypoints: rank by counting smaller keys (tiled through LDS)
+#define FN_SMALL 3072   // up to this many keypoints: rank by counting smaller keys (keys on chip)
 __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
                                                           unsigned* keys_scratch, BriskKeyPoint* kp_out, int cand_cap,
                                                           int kp_cap, const uint8_t* mask, long mask_pitch_frame,
                                                           int mask_row_pitch) {
   __shared__ int nvalid;
-  __shared__ unsigned tilek[FN_THREADS];
+  __shared__ __attribute__((aligned(16))) unsigned skey[FN_SMALL + 4];
+  __shared__ unsigned sidx[FN_SMALL];
   const int frame = blockIdx.x, tid = threadIdx.x;
   const int n = min(counters[frame].ncand, cand_cap);
   const BriskCand* C = cand + (long)frame * cand_cap;
-  unsigned* keys = keys_scratch + (long)frame * cand_cap * 2;  // [key][cand index]
+  unsigned* keys = keys_scratch + (long)frame * cand_cap * 2;  // [key][cand index] (k_finalize_large reads them)
   if (tid == 0) nvalid = 0;
   __syncthreads();
   for (int i = tid; i < n; i += FN_THREADS) {
@@ -1314,6 +1317,7 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
       const int j = atomicAdd(&nvalid, 1);
       keys[2 * j] = c.key;
       keys[2 * j + 1] = (unsigned)i;
+      if (j < FN_SMALL) { skey[j] = c.key; sidx[j] = (unsigned)i; }
     }
   }
   __threadfence_block();
@@ -1323,19 +1327,17 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
     if (tid == 0) counters[frame].nvalid_large = nv;
     return;
   }
-  for (int j0 = 0; j0 < nv; j0 += FN_THREADS) {
-    const int j = j0 + tid;
-    const unsigned myk = (j < nv) ? keys[2 * j] : 0xFFFFFFFFu;
+  if (tid < 4) skey[nv + tid] = 0xFFFFFFFFu;  // the count below reads four keys at a time
+  __syncthreads();
+  for (int j = tid; j < nv; j += FN_THREADS) {
+    const unsigned myk = skey[j];
     int rank = 0;
-    for (int t0 = 0; t0 < nv; t0 += FN_THREADS) {
-      __syncthreads();
-      tilek[tid] = (t0 + tid < nv) ? keys[2 * (t0 + tid)] : 0xFFFFFFFFu;
-      __syncthreads();
-      const int m = min(FN_THREADS, nv - t0);
-      for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
+    for (int q = 0; q < nv; q += 4) {
+      const uint4 kk = *reinterpret_cast<const uint4*>(&skey[q]);
+      rank += (kk.x < myk ? 1 : 0) + (kk.y < myk ? 1 : 0) + (kk.z < myk ? 1 : 0) + (kk.w < myk ? 1 : 0);
     }
-    if (j < nv && rank < kp_cap) {
-      const BriskCand& c = C[keys[2 * j + 1]];
+    if (rank < kp_cap) {
+      const BriskCand& c = C[sidx[j]];
       BriskKeyPoint kp;
       kp.x = c.kx; kp.y = c.ky; kp.size = c.ksize; kp.angle = -1.0f; kp.response = c.kresp;
       kp.octave = G.single_layer ? 0 : c.layer; kp.class_id = -1;
@@ -1562,63 +1564,75 @@ static void launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32
 
 // ------------------------------------------------------------------------------------------------
 #define DP_MAXSORT 4096
-#define DP_THREADS 512
+#ifndef DP_THREADS
+#define DP_THREADS 1024
+#endif
 // k_desc_prepare: per frame, scale index + border filter (brisk-descriptor-extractor.cc:636-662),
 // stable compaction into dkp (keypoints) / dscale.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
                                                        const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
                                                        BriskKeyPoint* dkp, int* dscale, int* dperm, uint4* drec, int kp_cap) {
-  __shared__ int scan[DP_THREADS];
+  __shared__ int wtot[DP_THREADS / 64];
   __shared__ int base;
-  __shared__ unsigned pkey[DP_MAXSORT];
-  const int frame = blockIdx.x, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) unsigned pkey[DP_MAXSORT + 4];
+  const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
   const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;
   if (tid == 0) base = 0;
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
     const int i = i0 + tid;
-    int keep = 0, sc = 0;
+    bool keep = false;
+    int sc = 0;
     BriskKeyPoint kp;
     if (i < n) {
       kp = K[i];
       sc = brisk_scale_index(P, kp.size);
-      keep = brisk_inside_border(P, sc, kp.x, kp.y, G.L[0].w, G.L[0].h) ? 1 : 0;
+      keep = brisk_inside_border(P, sc, kp.x, kp.y, G.L[0].w, G.L[0].h);
     }
-    scan[tid] = keep;
+    // stable compaction: position = kept keypoints before this one (ballots inside the wave, wave totals through LDS)
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wave] = __popcll(bal);
     __syncthreads();
-    for (int off = 1; off < DP_THREADS; off <<= 1) {
-      int add = (tid >= off) ? scan[tid - off] : 0;
-      __syncthreads();
-      scan[tid] += add;
-      __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < DP_THREADS / 64; ++k) {
+      const int t = wtot[k];
+      wbase += (k < wave) ? t : 0;
+      total += t;
     }
     if (keep) {
-      const int j = base + scan[tid] - 1;
+      const int j = base + wbase + before;
       dkp[(long)frame * kp_cap + j] = kp;
       dscale[(long)frame * kp_cap + j] = sc;
+      if (j < DP_MAXSORT)
+        pkey[j] = ((unsigned)((int)kp.y >> 6) << 24) | ((unsigned)((int)kp.x & 0x1FFF) << 11) | (unsigned)(j & 0x7FF);
     }
     __syncthreads();
-    if (tid == 0) base += scan[DP_THREADS - 1];
+    if (tid == 0) base += total;
     __syncthreads();
   }
   if (tid == 0) counters[frame].ndesc = base;
   // Processing order for k_describe: keypoints sorted by 64-row band, then x, so that keypoints sampled at the
   // same time touch the same part of the integral image (the output order stays (layer, y, x)).
-  __syncthreads();
   const int m = base;
   int* perm = dperm + (long)frame * kp_cap;
   if (m <= DP_MAXSORT) {
-    for (int j = tid; j < m; j += DP_THREADS) {
-      const BriskKeyPoint& q = dkp[(long)frame * kp_cap + j];
-      pkey[j] = ((unsigned)((int)q.y >> 6) << 24) | ((unsigned)((int)q.x & 0x1FFF) << 11) | (unsigned)(j & 0x7FF);
-    }
+    if (tid < 4) pkey[m + tid] = 0xFFFFFFFFu;  // the count below reads four keys at a time
     __syncthreads();
     for (int j = tid; j < m; j += DP_THREADS) {
       const unsigned kj = pkey[j];
       int r = 0;
-      for (int q = 0; q < m; ++q) r += (pkey[q] < kj || (pkey[q] == kj && q < j)) ? 1 : 0;
+      if (m <= 2048) {  // the keys carry j: all different
+        for (int q = 0; q < m; q += 4) {
+          const uint4 kk = *reinterpret_cast<const uint4*>(&pkey[q]);
+          r += (kk.x < kj ? 1 : 0) + (kk.y < kj ? 1 : 0) + (kk.z < kj ? 1 : 0) + (kk.w < kj ? 1 : 0);
+        }
+      } else {
+        for (int q = 0; q < m; ++q) r += (pkey[q] < kj || (pkey[q] == kj && q < j)) ? 1 : 0;
+      }
       perm[r] = j;
     }
   } else {

@@ -907,7 +907,6 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 #define TR_WAVES 16
 #endif
 #define TR_THREADS (TR_WAVES * 64)
-#define TR_DWAVES (TR_WAVES - 1)  // deciding waves; the last wave writes the decisions to memory
 #define TR_WIN 9
 #ifndef TR_CHUNK
 #define TR_CHUNK 3072
@@ -945,6 +944,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   int* const tstat = reinterpret_cast<int*>(skey);               // after the sort: decision of rank r (0 = pending)
   unsigned* const sfpxy = reinterpret_cast<unsigned*>(vals_ci);  // after the sort: footprint anchor of rank r
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nthreads = blockDim.x, dwaves = (nthreads >> 6) - 1;  // deciding waves; the last wave writes the decisions to memory
   const int nl = G.nlayers;
   const int ngroups = (nl + lpw - 1) / lpw;  // workgroups per frame, `lpw` consecutive layers each
   if (tid == 0) {
@@ -990,11 +990,11 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   while (((L.w >> bm_shift) + 1) * ((L.h >> bm_shift) + 1) > TR_BM_WORDS * 32) ++bm_shift;
   const int bm_w = (L.w >> bm_shift) + 1;
   if (below_elsewhere) {
-    for (int i = tid; i < TR_BM_WORDS; i += TR_THREADS) below_bm[i] = 0;
+    for (int i = tid; i < TR_BM_WORDS; i += nthreads) below_bm[i] = 0;
     __syncthreads();
     const int nb = min(counters[frame].ntie[l - 1], tie_cap);
     const int* listb = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l - 1) * tie_cap;
-    for (int j = tid; j < nb; j += TR_THREADS) {
+    for (int j = tid; j < nb; j += nthreads) {
       const BriskCand* c = &C[listb[j]];
       if (!c->fp_mask) continue;
       const int x0 = max((int)c->fp_x0 - 2, 0) >> bm_shift, x1 = min((int)c->fp_x0 + 5, L.w - 1) >> bm_shift;
@@ -1010,13 +1010,13 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   unsigned* gkey = nullptr;
   unsigned* gci = nullptr;
   if (on_chip) {
-    for (int j = tid; j < n; j += TR_THREADS) {
+    for (int j = tid; j < n; j += nthreads) {
       const int ci = list[j];
       vals_ci[j] = ci;
       skey[j] = C[ci].key;
     }
     __syncthreads();
-    for (int j = tid; j < n; j += TR_THREADS) {
+    for (int j = tid; j < n; j += nthreads) {
       const unsigned k = skey[j];
       int r = 0;
       for (int q = 0; q < n; ++q) r += (skey[q] < k) ? 1 : 0;
@@ -1032,16 +1032,16 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     gkey = gscratch + (long)frame * cand_cap * 2 + off;
     gci = gkey + cand_cap;
     unsigned* tilek = skey;
-    for (int j0 = 0; j0 < n; j0 += TR_THREADS) {
+    for (int j0 = 0; j0 < n; j0 += nthreads) {
       const int j = j0 + tid;
       const int ci = (j < n) ? list[j] : 0;
       const unsigned myk = (j < n) ? C[ci].key : 0xFFFFFFFFu;
       int rank = 0;
-      for (int t0 = 0; t0 < n; t0 += TR_THREADS) {
+      for (int t0 = 0; t0 < n; t0 += nthreads) {
         __syncthreads();
         tilek[tid] = (t0 + tid < n) ? C[list[t0 + tid]].key : 0xFFFFFFFFu;
         __syncthreads();
-        const int m = min(TR_THREADS, n - t0);
+        const int m = min(nthreads, n - t0);
         for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
       }
       if (j < n) { gkey[rank] = myk; gci[rank] = (unsigned)ci; }
@@ -1054,14 +1054,14 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     const int nc = min(TR_CHUNK, n - c0);
     if (!on_chip) {
       __syncthreads();
-      for (int r = tid; r < nc; r += TR_THREADS) {
+      for (int r = tid; r < nc; r += nthreads) {
         sxyd[r] = gkey[c0 + r];
         sorder[r] = (int)gci[c0 + r];
       }
       __syncthreads();
     }
     // everything the decision loop needs besides the smap window goes on chip: footprints by rank, decisions
-    for (int r = tid; r < nc; r += TR_THREADS) {
+    for (int r = tid; r < nc; r += nthreads) {
       const BriskCand* c = &C[sorder[r]];
       sfpxy[r] = (unsigned)(uint16_t)c->fp_x0 | ((unsigned)(uint16_t)c->fp_y0 << 16);
       sfpm[r] = c->fp_mask;
@@ -1072,7 +1072,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     // waves back to back.  The only thing a tie needs from raster-earlier ties of its 9x9 window is their
     // decision, which is exchanged through LDS (tstat); the window itself and the 5x5 score block of a wave's
     // NEXT tie are prefetched into registers while the current one is decided.
-    int j = (wave < TR_DWAVES) ? wave : nc;
+    int j = (wave < dwaves) ? wave : nc;
 #ifdef TR_TIMING
     int tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = (long long)wall_clock64();
@@ -1126,7 +1126,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       const unsigned key = sxyd[j];
       const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
       {
-        const int jn = min(j + TR_DWAVES, nc - 1);  // (the last prefetch of a wave is redundant, never out of range)
+        const int jn = min(j + dwaves, nc - 1);  // (the last prefetch of a wave is redundant, never out of range)
         TR_TRY_PREFETCH(jn)
       }
       TR_T(2)
@@ -1211,12 +1211,12 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
 #ifdef TR_TIMING
       tacc[6] += 1;
 #endif
-      j += TR_DWAVES;
+      j += dwaves;
     }
     // ---- writer wave: decisions -> score-state map, candidate status, touches on the layer above; a tie counts as
     // done for the layer above once these are performed; the progress is the row of the first tie that is not done.
     // The deciding waves never wait for a memory write this way (an agent-scope atomic takes microseconds).
-    if (wave == TR_DWAVES) {
+    if (wave == dwaves) {
       int w = 0, row_pub = -1;
       for (int idle = 0; w < nc;) {
         const int i = w + lane;
@@ -1261,7 +1261,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       }
     }
 #ifdef TR_TIMING
-    if (lane == 0 && wave < TR_DWAVES)
+    if (lane == 0 && wave < dwaves)
       for (int i = 0; i < 8; ++i) atomicAdd(&counters[frame].pad[i], tacc[i]);
 #endif
 #undef TR_TRY_PREFETCH
@@ -2051,7 +2051,11 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     static const int lpw_knob = env_knob("BRISK_TR_LPW", 0);
     const int lpw = lpw_knob ? min(lpw_knob, G.nlayers) : (nframes * G.nlayers <= 1024 ? 1 : G.nlayers);
     const int tr_grid = (nframes >= 8 ? (nframes + 7) / 8 * 8 : nframes) * ((G.nlayers + lpw - 1) / lpw);
-    hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(TR_THREADS), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
+    // waves per workgroup: 16 (15 deciding) where the frame's latency counts; 12 for the large batches, whose integral
+    // kernel on the side stream then finds room for three of its workgroups per CU instead of two (measured: 1 %)
+    static const int waves_knob = env_knob("BRISK_TR_WAVES", 0);
+    const int tr_waves = waves_knob ? min(max(waves_knob, 2), TR_WAVES) : (lpw == G.nlayers && G.nlayers > 1 ? 12 : TR_WAVES);
+    hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
                        B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw);
   }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);

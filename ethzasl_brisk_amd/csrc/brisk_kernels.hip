@@ -4,14 +4,14 @@
 //   k_smap_clear        zeroes what the previous batch left in the score-state map (sparse)
 //   k_pyramid_even/odd  fused half / two-third sampling chains from 64x64 / 96x96 blocks  (HBM-bound)
 //   k_pyramid_level     one level at a time (layers beyond the fused depth)
-//   k_detect            threshold map + adaptive OAST 9_16 test, LDS-tiled                (dominant kernel, VALU-bound)
+//   k_detect            threshold map + adaptive OAST 9_16 test, LDS-tiled                (VALU-bound)
 //   k_score_blocks      lane-parallel scores around every candidate (own 5x5, 4x4 above / below)
 //   k_classify_refine   IsMax2D steps 1-2 + 3-D refinement, one lane per candidate (+ _direct safety net)
-//   k_tie_resolve       order-faithful replay of the lazy score cache for ties            (1 WG/frame, latency-bound)
+//   k_tie_resolve       order-faithful replay of the lazy score cache for ties            (1 WG per frame and layer, latency-bound)
 //   k_finalize          (layer, y, x) ordering + keypoint output
 //   k_integral_final    exclusive 2-D prefix sum (u32) from the band column sums          (HBM-bound, side stream)
 //   k_desc_prepare      scale index + border filter + stable compaction + processing order
-//   k_describe          pattern sampling, orientation, 384/512 bit tests                  (gather / L2-bound)
+//   k_describe          pattern sampling, orientation, 384/512 bit tests                  (dominant kernel; gather / L2-bound)
 // (the Hamming matcher kernels live in brisk_match.hip)
 // No MFMA: the path is byte/integer stencil + gather work.
 #include <hip/hip_runtime.h>
@@ -2051,10 +2051,10 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     static const int lpw_knob = env_knob("BRISK_TR_LPW", 0);
     const int lpw = lpw_knob ? min(lpw_knob, G.nlayers) : (nframes * G.nlayers <= 1024 ? 1 : G.nlayers);
     const int tr_grid = (nframes >= 8 ? (nframes + 7) / 8 * 8 : nframes) * ((G.nlayers + lpw - 1) / lpw);
-    // waves per workgroup: 16 (15 deciding) where the frame's latency counts; 12 for the large batches, whose integral
-    // kernel on the side stream then finds room for three of its workgroups per CU instead of two (measured: 1 %)
+    // waves per workgroup: 16 (15 deciding).  (12 leave room for a third integral workgroup per CU on the side stream
+    // of a large batch: the batch gets 1 % faster, the tie kernel itself 40 % slower - not taken.)
     static const int waves_knob = env_knob("BRISK_TR_WAVES", 0);
-    const int tr_waves = waves_knob ? min(max(waves_knob, 2), TR_WAVES) : (lpw == G.nlayers && G.nlayers > 1 ? 12 : TR_WAVES);
+    const int tr_waves = waves_knob ? min(max(waves_knob, 2), TR_WAVES) : TR_WAVES;
     hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
                        B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw);
   }

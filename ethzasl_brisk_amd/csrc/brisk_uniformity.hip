@@ -4,8 +4,13 @@
 // of ScaleSpaceLayer (brisk/include/brisk/internal/scale-space-layer-inl.h:88-97).  In the reference the filter is
 // only wired into the Harris ScaleSpaceFeatureDetector (scale-space-layer-inl.h:372-375); the engine offers it behind
 // BriskFeatureDetector for BASELINE config 4 ("uniformity-enforced").  The algorithm is a greedy pass over the
-// keypoints in descending score order against an occupancy image, i.e. sequential by construction: one workgroup per
-// frame walks the sorted list, the 31 x 31 occupancy update of an accepted point is spread over the workgroup.
+// keypoints in descending score order against an occupancy image.  What a point reads from that image is
+//   min(255, sum of the mask values that the ACCEPTED earlier points within 15 cells added at its cell)
+// (saturating adds of non-negative values commute), so no image is needed: k_uniformity decides the points in score
+// order with one wave per point, a wave waits (in LDS) only for the decisions of the earlier points within 15 cells of
+// its own and sums their contributions directly.  Frames with more points than the on-chip arrays hold take the
+// literal walk over an occupancy image in global memory (k_uniformity_seq: one workgroup per frame, the 31 x 31 update
+// of an accepted point spread over the workgroup).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,7 +29,7 @@ __device__ __forceinline__ unsigned uf_load_fresh(const uint8_t* p) {
 
 // kp: [frame][kp_cap] keypoints of the detector (rewritten: kept keypoints in descending score order);
 // order: [frame][kp_cap] scratch; tmp: [frame][kp_cap] scratch; occ: [frame][oh * ow] zeroed occupancy images
-__global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
+__global__ void __launch_bounds__(UF_THREADS) k_uniformity_seq(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
                                                            int* __restrict__ order, BriskKeyPoint* __restrict__ tmp,
                                                            uint8_t* __restrict__ occ, long occ_frame, int ow, int kp_cap,
                                                            float scaling, int max_keypoints) {
@@ -38,7 +43,10 @@ __global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __rest
   BriskKeyPoint* T = tmp + (long)frame * kp_cap;
   int* ord = order + (long)frame * kp_cap;
   uint8_t* O = occ + (long)frame * occ_frame;
-  if (n == 0) return;
+  if (n <= UF_LDS_POINTS) return;  // k_uniformity has done this frame
+  for (long i = tid; i < occ_frame / 16; i += UF_THREADS) reinterpret_cast<uint4*>(O)[i] = make_uint4(0, 0, 0, 0);
+  __threadfence();
+  __syncthreads();
   // rank by (score descending, input index ascending)
   for (int j0 = 0; j0 < n; j0 += UF_THREADS) {
     const int j = j0 + tid;
@@ -124,10 +132,119 @@ __global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __rest
   if (tid == 0) counters[frame].nkp = kept;
 }
 
+// mask value a point adds at offset (dx, dy) = (cell - its own cell) (scale-space-layer-inl.h:89-97,
+// uniformity-enforcement-inl.h:150-170): ceil(lut * 0.99 * nsc) as u8
+__device__ __forceinline__ int uf_contribution(int dx, int dy, float nsc) {
+  const double v = 1 - (double)(dx * dx + dy * dy) / (double)(15 * 15);
+  const float lut = (float)(v > 0.0 ? v : 0.0);
+  const float nsc99 = 0.99f * nsc;
+  return (int)(uint8_t)(int)ceilf(lut * nsc99);
+}
+
+__global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
+                                                           int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap,
+                                                           float scaling, int max_keypoints) {
+  __shared__ float tile[UF_THREADS];
+  __shared__ int pcell[UF_LDS_POINTS];     // cy << 16 | cx of the point with score rank r
+  __shared__ float pnsc[UF_LDS_POINTS];    // its normalised score
+  __shared__ int dec[UF_LDS_POINTS];       // 0 pending, 1 accepted, 2 rejected
+  __shared__ int wsum[UF_THREADS / 64];
+  const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = min(counters[frame].nkp, kp_cap);
+  BriskKeyPoint* K = kp + (long)frame * kp_cap;
+  BriskKeyPoint* T = tmp + (long)frame * kp_cap;
+  int* ord = order + (long)frame * kp_cap;
+  if (n == 0 || n > UF_LDS_POINTS) return;  // (the larger frames: k_uniformity_seq)
+  // rank by (score descending, input index ascending)
+  for (int j0 = 0; j0 < n; j0 += UF_THREADS) {
+    const int j = j0 + tid;
+    const float mine = (j < n) ? K[j].response : 0.f;
+    int rank = 0;
+    for (int t0 = 0; t0 < n; t0 += UF_THREADS) {
+      __syncthreads();
+      tile[tid] = (t0 + tid < n) ? K[t0 + tid].response : 0.f;
+      __syncthreads();
+      const int m = min(UF_THREADS, n - t0);
+      if (j < n)
+        for (int q = 0; q < m; ++q) {
+          const float s = tile[q];
+          rank += (s > mine || (s == mine && t0 + q < j)) ? 1 : 0;
+        }
+    }
+    if (j < n) ord[rank] = j;
+  }
+  __threadfence();
+  __syncthreads();
+  const float maxScore = K[__hip_atomic_load(&ord[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)].response;
+  for (int r = tid; r < n; r += UF_THREADS) {
+    const BriskKeyPoint p = K[__hip_atomic_load(&ord[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    pcell[r] = ((int)(p.y * scaling + 16) << 16) | (int)(p.x * scaling + 16);
+    pnsc[r] = sqrtf(sqrtf(p.response / maxScore)) * 255.0f;
+    dec[r] = 0;
+  }
+  __syncthreads();
+  // decisions in score order, one wave per point: the wave's lanes scan the earlier points, a lane that finds one
+  // within reach waits for its decision (the earliest undecided point never waits) and adds what it contributed
+  for (int r = wave; r < n; r += UF_THREADS / 64) {
+    const int cyr = pcell[r] >> 16, cxr = pcell[r] & 0xFFFF;
+    int sum = 0;
+    for (int j0 = 0; j0 < r; j0 += 64) {
+      const int j = j0 + lane;
+      if (j < r) {
+        const int c = pcell[j];
+        const int dy = cyr - (c >> 16), dx = cxr - (c & 0xFFFF);
+        if (dx >= -15 && dx <= 15 && dy >= -15 && dy <= 15) {
+          int d = 0;
+          for (int spin = 0; spin < (1 << 24); ++spin) {
+            d = __hip_atomic_load(&dec[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (d) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (d == 0) atomicOr(&counters[frame].overflow, 8);  // (never observed) reported as an internal error
+          if (d == 1) sum += uf_contribution(dx, dy, pnsc[j]);
+        }
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const double s0 = (double)(sum > 255 ? 255 : sum);
+    const bool acc = !(pnsc[r] < s0);
+    if (lane == 0) __hip_atomic_store(&dec[r], acc ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  // the accepted points in score order, at most max_keypoints of them
+  int run = 0;
+  __shared__ int kept_s;
+  for (int r0 = 0; r0 < n; r0 += UF_THREADS) {
+    const int r = r0 + tid;
+    const bool a = (r < n) && dec[r] == 1;
+    const unsigned long long bal = __ballot(a);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int before = run, total = 0;
+    for (int q = 0; q < UF_THREADS / 64; ++q) {
+      const int t = wsum[q];
+      before += (q < wave) ? t : 0;
+      total += t;
+    }
+    const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (a && pos < max_keypoints) T[pos] = K[__hip_atomic_load(&ord[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    run += total;
+    __syncthreads();
+  }
+  if (tid == 0) kept_s = min(run, max_keypoints);
+  __threadfence();
+  __syncthreads();
+  const int kept = kept_s;
+  for (int i = tid; i < kept; i += UF_THREADS) K[i] = T[i];
+  if (tid == 0) counters[frame].nkp = kept;
+}
+
 void brisk_launch_uniformity(BriskKeyPoint* kp, BriskFrameCounters* counters, int* order, BriskKeyPoint* tmp, uint8_t* occ,
                              long occ_frame, int ow, int kp_cap, float scaling, int max_keypoints, int nframes, hipStream_t s) {
   if (nframes <= 0) return;
-  (void)hipMemsetAsync(occ, 0, (size_t)occ_frame * nframes, s);
-  hipLaunchKernelGGL(k_uniformity, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, occ, occ_frame, ow, kp_cap,
-                     scaling, max_keypoints);
+  hipLaunchKernelGGL(k_uniformity, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, kp_cap, scaling,
+                     max_keypoints);
+  // frames with more points than k_uniformity's on-chip arrays hold (it left them untouched; clears its own image)
+  hipLaunchKernelGGL(k_uniformity_seq, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, occ, occ_frame, ow,
+                     kp_cap, scaling, max_keypoints);
 }

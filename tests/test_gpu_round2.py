@@ -313,3 +313,26 @@ def test_describe_box_that_ends_in_the_last_column_gpu(B):
         ko, do = oext.compute(img, k)
         kg, dg = ext.compute(img, k)
         assert len(ko) > 100 and same_kps(kg, ko) and np.array_equal(dg, do), (w, h)
+
+
+def test_uniformity_dense_clusters_and_beyond_on_chip_capacity(B):
+    """k_uniformity decides the points in score order with waits only between points within 15 cells: a dense frame
+    whose points form long dependency chains (radius 20 px: every point has earlier neighbours), and a frame with more
+    points than the on-chip arrays hold (> 8192: the literal walk over an occupancy image, k_uniformity_seq); with and
+    without a keypoint budget."""
+    img = synth.frame_1080p(3)
+    h, w = img.shape
+    ko = O.detect(img, 50, 4)
+    assert 5000 < len(ko) <= 8192
+    ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+    for radius, budget in ((20.0, 0x7FFFFFFF), (3.0, 0x7FFFFFFF), (6.0, 700)):
+        want = O.enforce_uniformity(ko, h, w, radius, budget)
+        got = B.BriskFeatureDetector(50, 4, context=ctx, uniformityRadius=radius, maxNumKpt=budget).detect(img, capacity=65536)
+        assert same_kps(got, want), (radius, budget, len(got), len(want), explain(got, want))
+    ko = O.detect(img, 38, 4)
+    assert len(ko) > 8192
+    for radius, budget in ((5.0, 0x7FFFFFFF), (5.0, 3000)):
+        want = O.enforce_uniformity(ko, h, w, radius, budget)
+        got = B.BriskFeatureDetector(38, 4, context=ctx, uniformityRadius=radius, maxNumKpt=budget).detect(img, capacity=65536)
+        assert same_kps(got, want), (radius, budget, len(got), len(want), explain(got, want))
+    ctx.close()

@@ -2044,12 +2044,15 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   brisk_prof_mark(prof, BRISK_STG_TIES, s);
   if (ov && fork_at == 0) fork_integral();
   {
-    // Small batches: one workgroup per (frame, layer), the layers of a frame run as a pipeline (a frame is ready in the
-    // time of its largest layer instead of the sum).  Large batches fill the chip with one workgroup per frame; the
-    // pipeline would only add workgroups that wait for each other.  With 8 or more frames every XCD residue of
-    // blockIdx gets whole frames.
+    // Small batches (up to 64 frames x 8 layers): one workgroup per (frame, layer), the layers of a frame run as a
+    // pipeline (a frame is ready in the time of its largest layer instead of the sum; dense frames gain most).  Larger
+    // batches: groups of consecutive layers so that about one workgroup per CU is at work, i.e. one workgroup per frame
+    // from 256 frames on - the chip is full anyway and a workgroup that waits for the layer below only takes a slot
+    // (128 frames: 0.69 ms with one layer per workgroup, 0.35 with four, 0.45 with eight).  With 8 or more frames
+    // every XCD residue of blockIdx gets whole frames.
     static const int lpw_knob = env_knob("BRISK_TR_LPW", 0);
-    const int lpw = lpw_knob ? min(lpw_knob, G.nlayers) : (nframes * G.nlayers <= 1024 ? 1 : G.nlayers);
+    const int lpw = lpw_knob ? min(lpw_knob, G.nlayers)
+                             : (nframes * G.nlayers <= 512 ? 1 : min((nframes * G.nlayers + 255) / 256, G.nlayers));
     const int tr_grid = (nframes >= 8 ? (nframes + 7) / 8 * 8 : nframes) * ((G.nlayers + lpw - 1) / lpw);
     // waves per workgroup: 16 (15 deciding).  (12 leave room for a third integral workgroup per CU on the side stream
     // of a large batch: the batch gets 1 % faster, the tie kernel itself 40 % slower - not taken.)

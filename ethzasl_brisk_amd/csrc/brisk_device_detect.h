@@ -1357,6 +1357,14 @@ BRISK_HD int brisk_tie_slot_resolve(const BriskLayerView& L, unsigned packed, un
   return (K >= centre) ? K : 0;
 }
 
+// k_tie_resolve runs the layers of a frame as a pipeline: rows of the layer below that must be complete before a tie in
+// row cy of this layer can be decided.  A tie of the layer below in row y touches rows y0 .. y0 + 3 of this layer with
+// y0 = (int)((4y - 3) / 6) - 1 (below is an octave) or (int)((6y - 4) / 8) - 1 (below is an intra-octave)
+// (brisk_score_max_other); the tie reads touches in rows cy - 2 .. cy + 2.  All rows < the returned value must be done.
+BRISK_HD int brisk_tie_rows_needed(int cy, bool below_is_octave) {
+  return below_is_octave ? ((cy + 5) * 3) / 2 + 2 : ((cy + 5) * 4) / 3 + 2;
+}
+
 // IsMax2D steps 3-4 (brisk-scale-space.cc:499-530) for a tie candidate, split so that the per-pixel
 // cache replays can run one lane per pixel:
 //   ret[k]   (k = 0..7, probe order)  value the candidate's k-th probe returns

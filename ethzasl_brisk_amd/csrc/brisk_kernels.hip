@@ -920,13 +920,6 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 #define TR_T(i)
 #endif
 
-// rows of the layer below that must be complete before a tie in row cy of this layer can be decided: a tie of the
-// layer below in row y touches rows y0 .. y0 + 3 with y0 = (int)((4y - 3) / 6) - 1 (below is an octave) or
-// (int)((6y - 4) / 8) - 1 (below is an intra-octave), brisk_score_max_other; the tie reads touches in rows cy - 2 .. cy + 2
-__device__ __forceinline__ int tr_rows_needed(int cy, bool below_is_octave) {
-  return below_is_octave ? ((cy + 5) * 3) / 2 + 2 : ((cy + 5) * 4) / 3 + 2;
-}
-
 __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                              BriskFrameCounters* counters, const int* tie_idx,
                                                              const uint8_t* blocks, unsigned* gscratch, int cand_cap,
@@ -1097,7 +1090,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   {                                                                                                              \
     const int x_ = (int)((key_) & 0x1FFF), y_ = (int)(((key_) >> 13) & 0x1FFF);                                  \
     const int cell_ = (y_ >> bm_shift) * bm_w + (x_ >> bm_shift);                                                \
-    need_ = (below_elsewhere && ((below_bm[cell_ >> 5] >> (cell_ & 31)) & 1u)) ? tr_rows_needed(y_, below_is_octave) : 0; \
+    need_ = (below_elsewhere && ((below_bm[cell_ >> 5] >> (cell_ & 31)) & 1u)) ? brisk_tie_rows_needed(y_, below_is_octave) : 0; \
   }
 #define TR_POLL(need_)                                                                                           \
   if (seen < need_) {                                                                                            \

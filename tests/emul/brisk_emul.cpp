@@ -302,6 +302,37 @@ int emul_detect(const uint8_t* img, int w, int h, int threshold, int octaves, un
   return (int)E.kps.size();
 }
 
+// k_tie_resolve lets a tie of layer l + 1 in row cy start as soon as the layer below has finished its rows
+// < brisk_tie_rows_needed(cy): every candidate of layer l whose touch footprint (4x4 block on layer l + 1, recorded by
+// the refinement code itself) has a pixel within 2 rows of cy must lie in such a row.  Returns the violations found
+// (a) on the candidates of an image, (b) on the footprint formula for every row up to the engine's size limit.
+int emul_tie_rows_needed_violations(const uint8_t* img, int w, int h, int threshold, int octaves) {
+  Emul E;
+  brisk_cache_misses = 0;
+  run_detect(E, img, w, h, threshold, octaves, 0, 2, true, false, false);
+  int bad = 0;
+  for (const BriskCand& c : E.cand) {
+    if (!c.fp_mask || c.layer + 1 >= E.G.nlayers) continue;
+    const int ha = E.G.L[c.layer + 1].h;
+    for (int b = 0; b < 16; ++b) {
+      if (!(c.fp_mask & (1u << b))) continue;
+      const int row = c.fp_y0 + (b >> 2);
+      for (int cy = row - 2; cy <= row + 2; ++cy)
+        if (cy >= 0 && cy < ha && !((int)c.y < brisk_tie_rows_needed(cy, (c.layer & 1) == 0))) ++bad;
+    }
+  }
+  for (int y = 0; y < 8192; ++y)
+    for (int oct = 0; oct < 2; ++oct) {
+      // first row of the footprint (brisk_score_max_other, `above` branch)
+      const float y_1 = oct ? (float)((float)(4 * y - 1 - 2) / 6.0) : (float)(6 * y - 1 - 3) / 8.0f;
+      const int y0 = (int)y_1 - 1;
+      for (int row = y0; row <= y0 + 3; ++row)
+        for (int cy = row - 2; cy <= row + 2; ++cy)
+          if (cy >= 0 && !(y < brisk_tie_rows_needed(cy, oct != 0))) ++bad;
+    }
+  return bad;
+}
+
 // mirrors brisk_hip_compute_scale: pyramid with lower threshold 0, then the ComputeScale walk on one "lane";
 // returns -1 where the reference has no defined result
 int emul_compute_scale(const uint8_t* img, int w, int h, int threshold, int octaves, int suppress, const BriskKeyPoint* in,

@@ -161,6 +161,18 @@ def test_two_step_tie_replay_equals_one_step():
     assert L.emul_state_split_mismatches(11, 60000) == 0
 
 
+def test_tie_pipeline_row_bound_covers_every_touch_footprint():
+    """k_tie_resolve's layer pipeline: a tie may start once the layer below is past brisk_tie_rows_needed(row); every
+    footprint the refinement code records (and the footprint formula for every row) must respect that bound"""
+    import ctypes as C
+    L = E.lib()
+    L.emul_tie_rows_needed_violations.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    for img, thr, octv in ((synth.frame_vga(1), 40, 4), (synth.gen(333, 201, 3, 40), 30, 3)):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape
+        assert L.emul_tie_rows_needed_violations(img.ctypes.data, w, h, thr, octv) == 0
+
+
 def test_pregate_is_a_necessary_condition():
     """k_detect phase A (packed 16-bit pre-gate on the compass pixels) must never drop a pixel that
     brisk_detect_px (the exact per-pixel detection) accepts: synthetic frames, pure noise, saturated blocks, all

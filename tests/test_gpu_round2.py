@@ -336,3 +336,43 @@ def test_uniformity_dense_clusters_and_beyond_on_chip_capacity(B):
         got = B.BriskFeatureDetector(38, 4, context=ctx, uniformityRadius=radius, maxNumKpt=budget).detect(img, capacity=65536)
         assert same_kps(got, want), (radius, budget, len(got), len(want), explain(got, want))
     ctx.close()
+
+
+def test_tie_kernel_chunked_path_on_a_small_chunk_build(B):
+    """k_tie_resolve processes layers with more ties than its on-chip arrays hold in chunks of consecutive raster
+    ranks.  A build of the same sources with 64-tie chunks (every layer of these images then takes many chunks, sorted
+    through global scratch) in a fresh process: tie-heavy blocks, pure noise, a batch of 12 frames with one workgroup
+    per (frame, layer) - all bit-equal to the oracle."""
+    import subprocess
+    import sys
+    from ethzasl_brisk_amd import build
+    lib = build.build_variant("libbrisk_test_chunk64", ["TR_CHUNK=64"])
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, oracle_lib as O, synth, ethzasl_brisk_amd as B
+from test_gpu_parity import same_kps, explain
+ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+rng = np.random.default_rng(5)
+blocks = np.kron((rng.integers(0, 2, (30, 40)) * 200 + 20).astype(np.uint8), np.ones((8, 8), np.uint8))
+noise = np.random.default_rng(1).integers(0, 256, (240, 320), dtype=np.uint8)
+for img, thr, octv in ((blocks, 60, 3), (noise, 25, 4), (synth.frame_vga(3), 30, 4)):
+    img = np.ascontiguousarray(img)
+    ko = O.detect(img, thr, octv)
+    kg = B.BriskFeatureDetector(thr, octv, context=ctx).detect(img, capacity=65536)
+    assert same_kps(kg, ko), explain(kg, ko)
+frames = np.stack([synth.gen(426, 320, 70 + i, 60) for i in range(12)])
+d = torch.from_numpy(frames).cuda()
+n, h, w = frames.shape
+ctx.detect_batch(d.data_ptr(), n, w, h, w * h, w, 35, 4, torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+for f in range(n):
+    kd, _ = ctx.batch_download(f, described=False)
+    ko = O.detect(frames[f], 35, 4)
+    assert same_kps(kd, ko), (f, explain(kd, ko))
+print("chunked path ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BRISK_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "chunked path ok" in r.stdout

@@ -174,6 +174,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   const long ifr = iframe > c->iframe_elems_alloc ? iframe : c->iframe_elems_alloc;
   free_buffers(c);
   c->B.cand_cap = c->cand_cap; c->B.kp_cap = c->kp_cap; c->B.tie_cap = c->tie_cap;
+  c->B.band_h = 96;  // band height of the detector's pyramid kernel (the descriptor-only call uses its own)
   HIPCHK(c, hipMalloc(&c->B.pyr, (size_t)slots * pyr + 256));
   HIPCHK(c, hipMalloc(&c->B.smap, ((size_t)slots * pyr + 256) * sizeof(uint16_t)));
   HIPCHK(c, hipMalloc(&c->B.cand, (size_t)slots * c->cand_cap * sizeof(BriskCand)));
@@ -196,6 +197,10 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   // the score-state map is kept all-zero between batches: k_detect writes detections only, the next detect batch
   // first clears what the previous one left (k_smap_clear)
   HIPCHK(c, hipMemset(c->B.smap, 0, ((size_t)slots * pyr + 256) * sizeof(uint16_t)));
+  // hipMemset on device memory runs on the null stream and may return before it is done; the engine's streams are
+  // non-blocking (not ordered against the null stream): without this wait the first batch on fresh buffers could start
+  // writing detections into a map that is still being zeroed (seen once the pyramid kernel got fast enough)
+  HIPCHK(c, hipDeviceSynchronize());
   c->dirty_frames = 0;
   c->slots = slots; c->pyr_elems_alloc = pyr; c->iframe_elems_alloc = ifr;
   c->D.istride = istride;
@@ -239,6 +244,7 @@ int brisk_hip_create(int device, brisk_hip_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return BRISK_HIP_ERR_NO_DEVICE;
   brisk_hip_ctx* c = new brisk_hip_ctx();
   c->device = device;
+  c->B.band_h = 96;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return BRISK_HIP_ERR_HIP;
@@ -443,7 +449,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
 // frames [f0, f0 + nf) of the batch: d_frames points at frame f0's image, results go to frame slots f0...
 static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_frames, long f0, int nf, hipStream_t si,
                        BriskProfiler* prof, bool overlap_integral) {
-  const int nbands = (A.h + 63) / 64;
+  const int nbands = (A.h + ctx->B.band_h - 1) / ctx->B.band_h;
   BriskDetectBuffers Bi = ctx->B;
   Bi.pyr += f0 * ctx->G.pyr_elems;
   Bi.smap += f0 * ctx->G.pyr_elems;
@@ -842,7 +848,9 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   BriskPatternDev P = pat->dev;
   P.rotation_invariant = rotation_invariant ? 1 : 0;
   P.scale_invariant = scale_invariant ? 1 : 0;
-  brisk_launch_describe(ctx->G, P, ctx->B, ctx->D, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, nullptr);
+  BriskDetectBuffers Bd = ctx->B;
+  Bd.band_h = 64;  // brisk_launch_layer0_only: k_pyramid_even's 64-row band sums
+  brisk_launch_describe(ctx->G, P, Bd, ctx->D, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, nullptr);
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;
   ctx->last_has_desc = true;

@@ -26,7 +26,8 @@ struct BriskDetectBuffers {
   unsigned* keys;                // [slots][2 * cand_cap]
   BriskFrameCounters* counters;  // [slots]
   BriskKeyPoint* kp_out;         // [slots][kp_cap]
-  uint32_t* bandsum;             // [slots][nbands][istride] column sums of 64-row bands of layer 0 (for the integral)
+  uint32_t* bandsum;             // [slots][nbands][istride] column sums of band_h-row bands of layer 0 (for the integral)
+  int band_h;                    // 96 after the detector's pyramid (k_pyramid_fused), 64 after the descriptor-only layer-0 kernel
   int istride;                   // integral / bandsum row stride (elements)
   int cand_cap, tie_cap, kp_cap;
 };

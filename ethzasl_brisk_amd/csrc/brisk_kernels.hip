@@ -2,7 +2,8 @@
 //
 // Kernel inventory (one launch handles a whole batch of frames; blockIdx.y or a decoded index = frame):
 //   k_smap_clear        zeroes what the previous batch left in the score-state map (sparse)
-//   k_pyramid_even/odd  fused half / two-third sampling chains from 64x64 / 96x96 blocks  (HBM-bound)
+//   k_pyramid_fused     layer-0 copy, band sums, half and two-third sampling chains from 96x96 blocks (HBM-bound)
+//   k_pyramid_even      layer-0 copy + half sampling chain from 64x64 blocks (descriptor-only call: layer 0 alone)
 //   k_pyramid_level     one level at a time (layers beyond the fused depth)
 //   k_detect            threshold map + adaptive OAST 9_16 test, LDS-tiled                (VALU-bound)
 //   k_score_blocks      lane-parallel scores around every candidate (own 5x5, 4x4 above / below)
@@ -110,9 +111,9 @@ __global__ void __launch_bounds__(256) k_pyramid_level(BriskGeom G, uint8_t* __r
 // Fused pyramid kernels.  Halfsample8 output (c, r) depends only on the source block (2c..2c+1, 2r..2r+1) and
 // Twothirdsample8 output pairs only on a 3x3 source block, so whole chains of levels can be produced from one
 // aligned source block without any halo:
-//   k_pyramid_even: 64x64 block of the input frame -> layer 0 copy (aligned pyramid layout), L2 32x32, L4 16x16,
-//                   L6 8x8; the intermediate levels stay in LDS.
-//   k_pyramid_odd : 96x96 block of layer 0 -> L1 64x64 (two-third), L3 32x32, L5 16x16, L7 8x8.
+//   k_pyramid_even : 64x64 block of the input frame -> layer 0 copy (aligned pyramid layout), L2 32x32, L4 16x16,
+//                    L6 8x8; the intermediate levels stay in LDS.
+//   k_pyramid_fused: 96x96 block of the input frame -> layer 0 copy, L2 / L4 / L6 and L1 64x64 (two-third), L3, L5, L7.
 // Layers beyond the fused depth (more than 4 octaves) are produced by k_pyramid_level.
 // The exact column classes of the reference depend on absolute output columns and source widths, which
 // brisk_half_px / brisk_twothird_px receive unchanged (LDS tiles are addressed with absolute coordinates).
@@ -234,68 +235,124 @@ __global__ void __launch_bounds__(256) k_pyramid_even(BriskGeom G, const uint8_t
   }
 }
 
-__global__ void __launch_bounds__(256) k_pyramid_odd(BriskGeom G, uint8_t* __restrict__ pyr, int nlevels, int tiles_x,
-                                                      int tiles_y) {
-  __shared__ __attribute__((aligned(16))) uint8_t t0[96 * 96], t1[64 * 64], t3[32 * 32], t5[16 * 16];
+// ------------------------------------------------------------------------------------------------
+// k_pyramid_fused: both chains from ONE read of the frame.  96x96 block of the input frame -> layer-0 copy (aligned
+// pyramid layout), the column sums of the block's 96-row band (carry rows of the integral image kernel), L2 48x48,
+// L4 24x24, L6 12x12 (half sampling) and L1 64x64 (two-third), L3 32x32, L5 16x16, L7 8x8.  Separate kernels
+// for the two chains read layer 0 a second time for the odd chain (2.07 MB of the 8.3 MB per 1080p frame); they remain for the
+// descriptor-only call (k_pyramid_even: layer 0 + 64-row band sums).
+// ------------------------------------------------------------------------------------------------
+#define PF_BAND 96
+__global__ void __launch_bounds__(256) k_pyramid_fused(BriskGeom G, const uint8_t* __restrict__ frames, long frame_pitch,
+                                                        int row_pitch, uint8_t* __restrict__ pyr, int even_levels,
+                                                        int odd_levels, int tiles_x, int tiles_y,
+                                                        uint32_t* __restrict__ bandsum, int istride) {
+  __shared__ __attribute__((aligned(16))) uint8_t t0[96 * 96], t1[64 * 64], t2[48 * 48], t3[32 * 32], t4[24 * 24], t5[16 * 16];
+  __shared__ unsigned psum[2][96];
   const int frame = blockIdx.y;
+  // XCD-aware tile order (see k_detect): x-adjacent tile rows share 128-byte lines, keep them in one L2
   const int nt = tiles_x * tiles_y;
   const int res = blockIdx.x & 7;
   const int tsw = res * (nt >> 3) + min(res, nt & 7) + (blockIdx.x >> 3);
   const int bx = (tsw % tiles_x) * 96, by = (tsw / tiles_x) * 96;
-  uint8_t* P = pyr + (long)frame * G.pyr_elems;
   const int w = G.L[0].w, h = G.L[0].h, s0 = G.L[0].stride;
-  const uint8_t* src = P + G.L[0].off;
-  if (by + 96 <= h && bx + 96 <= s0) {  // interior block: 16-byte loads (a block row = 6 lanes), issued back to back
+  const uint8_t* src = frames + (long)frame * frame_pitch;
+  uint8_t* P = pyr + (long)frame * G.pyr_elems;
+  uint8_t* L0 = P + G.L[0].off;
+  // stage the 96x96 source block (zero outside the image) and write the layer-0 copy.  Interior blocks of 16-byte
+  // aligned frames: 16-byte loads and stores (a block row = 6 lanes), issued back to back.  Otherwise nine dword
+  // loads per thread (unconditional, on a safe address when the dword is not fully inside the row).
+  const bool wide = (((unsigned)row_pitch | (uintptr_t)src) & 15) == 0 && by + 96 <= h && bx + 96 <= w;
+  if (wide) {
     uint4 stg[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int i = min((int)threadIdx.x + k * 256, 96 * 6 - 1);
-      stg[k] = *reinterpret_cast<const uint4*>(src + (long)(by + i / 6) * s0 + bx + (i % 6) * 16);
+      stg[k] = *reinterpret_cast<const uint4*>(src + (long)(by + i / 6) * row_pitch + bx + (i % 6) * 16);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int i = threadIdx.x + k * 256;
-      if (i < 96 * 6) *reinterpret_cast<uint4*>(&t0[i * 16]) = stg[k];
+      if (i < 96 * 6) {
+        *reinterpret_cast<uint4*>(L0 + (long)(by + i / 6) * s0 + bx + (i % 6) * 16) = stg[k];
+        *reinterpret_cast<uint4*>(&t0[i * 16]) = stg[k];
+      }
     }
-  } else {  // stage the 96x96 source block: nine dword loads per thread, issued back to back on clamped addresses
+  } else {
+    const bool aligned = ((row_pitch | (uintptr_t)src) & 3) == 0;
+    const long safe_off = -(long)((uintptr_t)src & 3);
     unsigned stg[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int i = threadIdx.x + k * 256;
       const int r = i / 24, c4 = (i % 24) * 4;
-      const int cy = min(by + r, h - 1), cx = min(bx + c4, s0 - 4);
-      stg[k] = *reinterpret_cast<const unsigned*>(src + (long)cy * s0 + cx);
+      const int gy = by + r, gx = bx + c4;
+      const bool full = aligned && gy < h && gx + 3 < w;
+      stg[k] = *reinterpret_cast<const unsigned*>(src + (full ? (long)gy * row_pitch + gx : safe_off));
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int i = threadIdx.x + k * 256;
       const int r = i / 24, c4 = (i % 24) * 4;
-      *reinterpret_cast<unsigned*>(&t0[i * 4]) = (by + r < h && bx + c4 < s0) ? stg[k] : 0u;
+      const int gy = by + r, gx = bx + c4;
+      const bool full = aligned && gy < h && gx + 3 < w;
+      unsigned v = full ? stg[k] : 0u;
+      if (gy < h) {
+        if (!full)
+          for (int q = 0; q < 4; ++q)
+            if (gx + q < w) v |= (unsigned)src[(long)gy * row_pitch + gx + q] << (8 * q);
+        if (gx < s0) *reinterpret_cast<unsigned*>(L0 + (long)gy * s0 + gx) = v;
+      }
+      *reinterpret_cast<unsigned*>(&t0[i * 4]) = v;
     }
   }
   __syncthreads();
-  {  // L1 = two-third sample: 64x64 outputs at origin (bx/3*2, by/3*2)
-    const int ox = bx / 3 * 2, oy = by / 3 * 2;
-    const int dw = G.L[1].w, dh = G.L[1].h, dstride = G.L[1].stride;
+  // column sums of this 96-row band (the integral image kernel's carry rows): integral column = pixel column + 1
+  {
+    const int c = threadIdx.x % 96, half = threadIdx.x / 96;
+    if (half < 2) {
+      unsigned sum = 0;
+#pragma unroll 8
+      for (int r = 0; r < 48; ++r) sum += t0[(half * 48 + r) * 96 + c];
+      psum[half][c] = sum;
+    }
+  }
+  // first level of both chains (both read the frame block): L2 48x48 and L1 64x64
+  {
     const TileRef st = {t0, bx, by, 96};
-    pyramid_tile_level<true>(tile_origin(st), 96, w, P + G.L[1].off, dstride, dw, dh, ox, oy, 64, t1);
+    if (even_levels >= 1)
+      pyramid_tile_level<false>(tile_origin(st), 96, w, P + G.L[2].off, G.L[2].stride, G.L[2].w, G.L[2].h, bx >> 1, by >> 1, 48, t2);
+    if (odd_levels >= 0)
+      pyramid_tile_level<true>(tile_origin(st), 96, w, P + G.L[1].off, G.L[1].stride, G.L[1].w, G.L[1].h, bx / 3 * 2, by / 3 * 2, 64, t1);
   }
   __syncthreads();
-  TileRef srct = {t1, bx / 3 * 2, by / 3 * 2, 64};
-  uint8_t* dst_lds[3] = {t3, t5, nullptr};
-  int sw = G.L[1].w;
-#pragma unroll
-  for (int k = 1; k <= 3; ++k) {
-    if (k > nlevels) break;
-    const int l = 2 * k + 1;
-    const int tw = 64 >> k;
-    const int ox = srct.x0 >> 1, oy = srct.y0 >> 1;
-    const int dw = G.L[l].w, dh = G.L[l].h, dstride = G.L[l].stride;
-    uint8_t* dl = dst_lds[k - 1];
-    pyramid_tile_level<false>(tile_origin(srct), srct.tw, sw, P + G.L[l].off, dstride, dw, dh, ox, oy, tw, dl);
-    __syncthreads();
-    srct.p = dl; srct.x0 = ox; srct.y0 = oy; srct.tw = tw;
-    sw = dw;
+  if (threadIdx.x < 96) {
+    const int c = threadIdx.x;
+    uint32_t* row = bandsum + ((long)frame * tiles_y + by / PF_BAND) * istride;
+    if (bx + c + 1 < istride) row[bx + c + 1] = psum[0][c] + psum[1][c];
+    if (bx == 0 && c == 0) row[0] = 0;
+  }
+  // second level: L4 24x24 from L2, L3 32x32 from L1
+  {
+    const TileRef s2 = {t2, bx >> 1, by >> 1, 48}, s1 = {t1, bx / 3 * 2, by / 3 * 2, 64};
+    if (even_levels >= 2)
+      pyramid_tile_level<false>(tile_origin(s2), 48, G.L[2].w, P + G.L[4].off, G.L[4].stride, G.L[4].w, G.L[4].h, bx >> 2, by >> 2, 24, t4);
+    if (odd_levels >= 1)
+      pyramid_tile_level<false>(tile_origin(s1), 64, G.L[1].w, P + G.L[3].off, G.L[3].stride, G.L[3].w, G.L[3].h, bx / 3, by / 3, 32, t3);
+  }
+  __syncthreads();
+  // third level: L6 12x12 from L4, L5 16x16 from L3
+  {
+    const TileRef s4 = {t4, bx >> 2, by >> 2, 24}, s3 = {t3, bx / 3, by / 3, 32};
+    if (even_levels >= 3)
+      pyramid_tile_level<false>(tile_origin(s4), 24, G.L[4].w, P + G.L[6].off, G.L[6].stride, G.L[6].w, G.L[6].h, bx >> 3, by >> 3, 12, nullptr);
+    if (odd_levels >= 2)
+      pyramid_tile_level<false>(tile_origin(s3), 32, G.L[3].w, P + G.L[5].off, G.L[5].stride, G.L[5].w, G.L[5].h, bx / 6, by / 6, 16, t5);
+  }
+  __syncthreads();
+  if (odd_levels >= 3) {  // L7 8x8 from L5
+    const TileRef s5 = {t5, bx / 6, by / 6, 16};
+    pyramid_tile_level<false>(tile_origin(s5), 16, G.L[5].w, P + G.L[7].off, G.L[7].stride, G.L[7].w, G.L[7].h, bx / 12, by / 12, 8, nullptr);
   }
 }
 
@@ -1429,7 +1486,7 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize_large(BriskGeom G, cons
 // ------------------------------------------------------------------------------------------------
 // Integral image (brisk/include/brisk/internal/integral-image.h:56-161): exclusive 2-D prefix sums, u32,
 // (h+1) x (w+1) with row stride istride.  The image is read once more and the integral written once:
-//   (k_pyramid_even)     column sums of every 64-row band, produced while the frame block is in LDS anyway
+//   (k_pyramid_fused / k_pyramid_even)  column sums of every 96- / 64-row band, produced while the frame block is in LDS anyway
 //   k_integral_final     per band: carry row = prefix over the bands above, then row after row the
 //                        workgroup scans the row (wave shuffles + one barrier) and adds it to the running
 //                        column accumulators it keeps in registers; 16-byte aligned stores.
@@ -1481,13 +1538,13 @@ template <int NCH>
 __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, const uint8_t* __restrict__ pyr,
                                                                const uint32_t* __restrict__ bandsum,
                                                                uint32_t* __restrict__ integral, int istride, long iframe_elems,
-                                                               int nbands) {
+                                                               int nbands, int band_h) {
   __shared__ unsigned wave_tot[2][II_THREADS / 64];
   const int frame = blockIdx.y, band = blockIdx.x;
   const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
   const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
   uint32_t* out = integral + (long)frame * iframe_elems;
-  const int y0 = band * II_BAND, y1 = min(h, y0 + II_BAND);
+  const int y0 = band * band_h, y1 = min(h, y0 + band_h);
   int buf = 0;
   unsigned acc[NCH][4];  // running integral values of this thread's columns (row above the current one)
   // first pixel row of the band: in flight while the carry row is computed
@@ -1546,13 +1603,14 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
 }
 
 static void launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
-                            long iframe_elems, int nbands, int nframes, hipStream_t s) {
+                            long iframe_elems, int band_h, int nframes, hipStream_t s) {
+  const int nbands = (G.L[0].h + band_h - 1) / band_h;
   const int nchunks = (G.L[0].w + 1 + II_CHUNK - 1) / II_CHUNK;
   const dim3 grid(nbands, nframes), block(II_THREADS);
   static const int pad_lds = env_knob("BRISK_II_LDS", 0);  // tuning experiments: dynamic LDS bytes = fewer workgroups per CU
-  if (nchunks <= 1) hipLaunchKernelGGL(k_integral_final<1>, grid, block, pad_lds, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
-  else if (nchunks == 2) hipLaunchKernelGGL(k_integral_final<2>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
-  else hipLaunchKernelGGL(k_integral_final<II_MAXCHUNKS>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands);
+  if (nchunks <= 1) hipLaunchKernelGGL(k_integral_final<1>, grid, block, pad_lds, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
+  else if (nchunks == 2) hipLaunchKernelGGL(k_integral_final<2>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
+  else hipLaunchKernelGGL(k_integral_final<II_MAXCHUNKS>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1966,15 +2024,12 @@ void brisk_launch_smap_clear(const BriskGeom& Gprev, const BriskDetectBuffers& B
 static void launch_pyramid(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames, long frame_pitch,
                            int row_pitch, hipStream_t s) {
   {
-    // even chain: layer-0 copy + L2, L4, L6 from 64x64 blocks of the frame; odd chain: L1, L3, L5, L7 from 96x96 blocks
+    // layer-0 copy, band sums and both chains (L2, L4, L6 / L1, L3, L5, L7) from 96x96 blocks of the frame
     const int even_levels = G.nlayers >= 7 ? 3 : G.nlayers >= 5 ? 2 : G.nlayers >= 3 ? 1 : 0;
-    const int odd_levels = G.nlayers >= 8 ? 3 : G.nlayers >= 6 ? 2 : G.nlayers >= 4 ? 1 : 0;
-    const int etx = (G.L[0].stride + 63) / 64, ety = (G.L[0].h + 63) / 64;
-    hipLaunchKernelGGL(k_pyramid_even, dim3(etx * ety, nframes), dim3(256), 0, s, G, frames, frame_pitch, row_pitch, B.pyr,
-                       even_levels, etx, ety, B.bandsum, B.istride);
-    const int otx = (G.L[0].w + 95) / 96, oty = (G.L[0].h + 95) / 96;
-    if (G.nlayers >= 2)
-      hipLaunchKernelGGL(k_pyramid_odd, dim3(otx * oty, nframes), dim3(256), 0, s, G, B.pyr, odd_levels, otx, oty);
+    const int odd_levels = G.nlayers >= 8 ? 3 : G.nlayers >= 6 ? 2 : G.nlayers >= 4 ? 1 : G.nlayers >= 2 ? 0 : -1;
+    const int ftx = (G.L[0].stride + 95) / 96, fty = (G.L[0].h + PF_BAND - 1) / PF_BAND;
+    hipLaunchKernelGGL(k_pyramid_fused, dim3(ftx * fty, nframes), dim3(256), 0, s, G, frames, frame_pitch, row_pitch, B.pyr,
+                       even_levels, odd_levels, ftx, fty, B.bandsum, B.istride);
     for (int l = 8; l < G.nlayers; ++l) {  // more than 4 octaves: remaining levels one by one
       const long items = (long)(G.L[l].stride / 4) * G.L[l].h;
       hipLaunchKernelGGL(k_pyramid_level, dim3(grid_for(items, 256, 2048), nframes), dim3(256), 0, s, G, B.pyr, l - 2, l, 0);
@@ -1989,17 +2044,16 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
   brisk_prof_mark(prof, BRISK_STG_PYRAMID, s);
   launch_pyramid(G, B, nframes, frames, frame_pitch, row_pitch, s);
-  // The integral image only needs layer 0 and the band sums (k_pyramid_even) and is HBM-bound; tie resolution
+  // The integral image only needs layer 0 and the band sums (pyramid kernel) and is HBM-bound; tie resolution
   // (one workgroup per frame, a chain of dependent decisions) and the final ordering are latency-bound and leave
   // most of the chip idle.  The integral kernel runs beside them on a second, low-priority stream (forked in front
   // of the tie kernel) and is joined before the descriptor kernels.
   static const int fork_at = env_knob("BRISK_INTEGRAL_FORK", 0);  // experiments: 1 = beside k_detect, 2 = beside the score blocks
   auto fork_integral = [&]() {
-    const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
     (void)hipEventRecord(ov->fork, s);
     (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
     brisk_prof_mark_side(prof, 0, ov->side);
-    launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, nbands, nframes, ov->side);
+    launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, B.band_h, nframes, ov->side);
     brisk_prof_mark_side(prof, 1, ov->side);
     (void)hipEventRecord(ov->join, ov->side);
   };
@@ -2080,10 +2134,9 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
                            long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov) {
-  const int nbands = (G.L[0].h + II_BAND - 1) / II_BAND;
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
   if (!ov)
-    launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, nbands, nframes, s);
+    launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap);

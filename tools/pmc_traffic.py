@@ -44,7 +44,7 @@ def main():
             continue
         f, wr = fetch.get(k, 0.0), write.get(k, 0.0)
         out["kernels"][k] = {"fetch_raw": f, "fetch_corrected": f * corr, "write": wr, "hbm_bytes_per_launch": f * corr + wr}
-    group_of = {"k_pyramid_even": "pyramid", "k_pyramid_odd": "pyramid", "k_pyramid_level": "pyramid", "k_detect": "detect",
+    group_of = {"k_pyramid_fused": "pyramid", "k_pyramid_even": "pyramid", "k_pyramid_odd": "pyramid", "k_pyramid_level": "pyramid", "k_detect": "detect",
                 "k_score_blocks": "nms", "k_classify_refine": "nms", "k_classify_refine_direct": "nms", "k_tie_resolve": "nms",
                 "k_finalize": "nms", "k_finalize_large": "nms", "k_smap_clear": "nms", "k_order_candidates": "nms",
                 "k_ordered_keypoints": "nms", "k_nms": "nms", "k_integral_final": "integral", "k_desc_prepare": "describe",

@@ -1109,6 +1109,7 @@ int brisk_hip_stream_ceiling(brisk_hip_ctx* ctx, size_t bytes, double* copy_GBps
   if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(ctx, BRISK_HIP_ERR_HIP, "hipMalloc failed"); }
   (void)hipMemset(a, 1, bytes);
   (void)hipMemset(b, 2, bytes);
+  (void)hipDeviceSynchronize();  // (null-stream memsets are not ordered against the context's non-blocking stream)
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);

@@ -45,6 +45,8 @@ struct brisk_hip_ctx {
   BriskTileTable T{};
   int last_nframes = 0;
   bool last_has_desc = false;
+  const uint8_t* last_l0_ext = nullptr;  // layer 0 of the last batch was read in place from the caller's frames (debug_layer)
+  long last_l0_pitch = 0;
   BriskProfiler prof;
   int debug_flags = 0;
   // sub-batch streams: a batch is split into nsub slices that run on their own streams, so that the latency-bound
@@ -483,8 +485,23 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
     ov.side = ctx->side; ov.fork = ctx->side_fork; ov.join = ctx->side_join; ov.Dd = &Di;
     ovp = &ov;
   }
+  // Layer 0 in place: frames that already have the pyramid's layer-0 layout are read where they are (fast path only;
+  // the ordered path and ComputeScale keep their private copy)
+  BriskGeom Gs = ctx->G;
+  {
+    static const bool inplace_on = !(getenv("BRISK_L0_INPLACE") && atoi(getenv("BRISK_L0_INPLACE")) == 0);
+    const bool ordered = Gs.threshold < BRISK_FAST_PATH_MIN_THRESHOLD || Gs.no_scale_nms || Gs.lower_threshold != BRISK_LOWER_THRESHOLD;
+    if (A.do_detect && inplace_on && !ordered && A.row_pitch == Gs.L[0].stride &&
+        ((((uintptr_t)d_frames) | (uintptr_t)A.frame_pitch) & 15) == 0) {
+      Gs.l0_ext = d_frames;
+      Gs.l0_pitch = A.frame_pitch;
+      if (f0 == 0) { ctx->last_l0_ext = d_frames; ctx->last_l0_pitch = A.frame_pitch; }
+    } else if (f0 == 0) {
+      ctx->last_l0_ext = nullptr;
+    }
+  }
   if (A.do_detect) {
-    brisk_launch_detect(ctx->G, ctx->T, Bi, nf, d_frames, A.frame_pitch, A.row_pitch,
+    brisk_launch_detect(Gs, ctx->T, Bi, nf, d_frames, A.frame_pitch, A.row_pitch,
                         A.d_mask ? A.d_mask + f0 * A.mask_frame_pitch : nullptr, A.mask_frame_pitch, A.mask_row_pitch, si, prof, ovp);
   }
   if (A.do_detect && A.uni_radius > 0.0) {
@@ -497,7 +514,7 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
   }
   if (A.do_describe) {
     BriskPatternDev P = A.pat->dev;
-    brisk_launch_describe(ctx->G, P, Bi, Di, nf, Bi.kp_out, &Bi.counters[0].nkp, sizeof(BriskFrameCounters), si, prof, ovp);
+    brisk_launch_describe(Gs, P, Bi, Di, nf, Bi.kp_out, &Bi.counters[0].nkp, sizeof(BriskFrameCounters), si, prof, ovp);
   }
   return BRISK_HIP_OK;
 }
@@ -809,6 +826,7 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
   ctx->dirtyG = ctx->G;
   ctx->dirty_frames = 1;  // (the kernel marks the frame for a complete clear: the walk writes the cache anywhere)
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in, in, sizeof(BriskKeyPoint) * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
+  ctx->last_l0_ext = nullptr;
   brisk_launch_compute_scale(ctx->G, ctx->B, ctx->d_stage, pitch, ctx->d_kp_in, n_in, suppress_scale_nonmaxima ? 1 : 0,
                              ctx->stream);
   HIPCHK(ctx, hipGetLastError());
@@ -844,6 +862,7 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
     ctx->dirty_frames = 0;
   }
   HIPCHK(ctx, hipMemsetAsync(ctx->B.counters, 0, sizeof(BriskFrameCounters), ctx->stream));
+  ctx->last_l0_ext = nullptr;
   brisk_launch_layer0_only(ctx->G, ctx->B, 1, ctx->d_stage, (long)img_bytes, pitch, ctx->stream);
   BriskPatternDev P = pat->dev;
   P.rotation_invariant = rotation_invariant ? 1 : 0;
@@ -1154,7 +1173,9 @@ int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, u
   HIPCHK(ctx, hipDeviceSynchronize());
   const size_t base = (size_t)frame * ctx->G.pyr_elems + L.off;
   if (which == 0) {
-    HIPCHK(ctx, hipMemcpy2D(out, L.w, ctx->B.pyr + base, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+    // (layer 0 of a batch that read the caller's frames in place: the caller's buffer must still be alive)
+    const uint8_t* src = (layer == 0 && ctx->last_l0_ext) ? ctx->last_l0_ext + (size_t)frame * ctx->last_l0_pitch : ctx->B.pyr + base;
+    HIPCHK(ctx, hipMemcpy2D(out, L.w, src, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
   } else {
     std::vector<uint16_t> tmp((size_t)L.stride * L.h);
     HIPCHK(ctx, hipMemcpy(tmp.data(), ctx->B.smap + base, tmp.size() * 2, hipMemcpyDeviceToHost));

@@ -70,6 +70,11 @@ struct BriskGeom {
                        // bits 8-15 k_describe blocks per frame / 8; bit16 integral image not overlapped; bit17 matcher
                        // always through the distance matrix
   BriskLayerGeom L[BRISK_MAX_LAYERS];
+  // Layer 0 read in place: when the caller's frames already have the pyramid's layer-0 layout (row pitch = L[0].stride,
+  // 16-byte aligned) the detector's kernels read them directly and no layer-0 copy is written (2 MB per 1080p frame).
+  // l0_ext = first frame of the launch (null: layer 0 lives in the pyramid buffer), l0_pitch = bytes between frames.
+  const uint8_t* l0_ext;
+  long l0_pitch;
 };
 
 // binary-identical to cv::KeyPoint
@@ -118,3 +123,8 @@ struct BriskPatternDev {
 };
 
 BRISK_HD int brisk_align_up(int v, int a) { return (v + a - 1) / a * a; }
+// image of layer l of frame `frame` (frame index inside the launch)
+BRISK_HD const uint8_t* brisk_layer_img(const BriskGeom& G, const uint8_t* pyr, int frame, int l) {
+  if (l == 0 && G.l0_ext) return G.l0_ext + (long)frame * G.l0_pitch;
+  return pyr + (long)frame * G.pyr_elems + G.L[l].off;
+}

@@ -37,7 +37,7 @@ __device__ __forceinline__ BriskLayerView make_view(const BriskGeom& G, uint8_t*
                                                     int l) {
   BriskLayerView v;
   const long base = (long)frame * G.pyr_elems + G.L[l].off;
-  v.img = pyr + base;
+  v.img = brisk_layer_img(G, pyr, frame, l);
   v.smap = smap + base;
   v.w = G.L[l].w;
   v.h = G.L[l].h;
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_pyramid_fused(BriskGeom G, const uint8_
     for (int k = 0; k < 3; ++k) {
       const int i = threadIdx.x + k * 256;
       if (i < 96 * 6) {
-        *reinterpret_cast<uint4*>(L0 + (long)(by + i / 6) * s0 + bx + (i % 6) * 16) = stg[k];
+        if (!G.l0_ext) *reinterpret_cast<uint4*>(L0 + (long)(by + i / 6) * s0 + bx + (i % 6) * 16) = stg[k];
         *reinterpret_cast<uint4*>(&t0[i * 16]) = stg[k];
       }
     }
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) k_pyramid_fused(BriskGeom G, const uint8_
         if (!full)
           for (int q = 0; q < 4; ++q)
             if (gx + q < w) v |= (unsigned)src[(long)gy * row_pitch + gx + q] << (8 * q);
-        if (gx < s0) *reinterpret_cast<unsigned*>(L0 + (long)gy * s0 + gx) = v;
+        if (gx < s0 && !G.l0_ext) *reinterpret_cast<unsigned*>(L0 + (long)gy * s0 + gx) = v;
       }
       *reinterpret_cast<unsigned*>(&t0[i * 4]) = v;
     }
@@ -413,8 +413,8 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   const int t = tid_sw - T.first_tile[l];
   const int tx = t % T.tiles_x[l], ty = t / T.tiles_x[l];
   const int w = G.L[l].w, h = G.L[l].h, stride = G.L[l].stride;
-  const long base = (long)frame * G.pyr_elems + G.L[l].off;
-  const uint8_t* img = pyr + base;
+  const long base = (long)frame * G.pyr_elems + G.L[l].off;  // (score-state map)
+  const uint8_t* img = brisk_layer_img(G, pyr, frame, l);
   const int x0 = tx * DT_W, y0 = ty * DT_H;
   const int thr = G.threshold;
 
@@ -615,6 +615,7 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = min(counters[frame].ncand, cand_cap);
   const uint8_t* fimg = pyr + (long)frame * G.pyr_elems;
+  const uint8_t* img0 = G.l0_ext ? G.l0_ext + (long)frame * G.l0_pitch : nullptr;  // layer 0 read in place
   const uint16_t* fsm = smap + (long)frame * G.pyr_elems;
   // lane role: 0 own 5x5 (lanes 0-24), 1 4x4 above (32-47), 2 4x4 below or the 5_8 3x3 on layer 0 (48-63), 3 unused
   const int role = (lane < 25) ? 0 : (lane >= 32 && lane < 48) ? 1 : (lane >= 48) ? 2 : 3;
@@ -658,7 +659,8 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
         const int poy = (which == 0) ? oy0 : (which == 1) ? oy1 : oy2;
         const int gx = min(max((pox & ~3) + 4 * d, 0), pg.z - 4);
         const int gy = min(max(poy + r, 0), pg.y - 1);
-        pv[k][t] = *reinterpret_cast<const unsigned*>(fimg + pg.w + (long)gy * pg.z + gx);
+        const uint8_t* limg = (pl == 0 && img0) ? img0 : fimg + pg.w;  // (layer geometry from LDS: pl differs between lanes)
+        pv[k][t] = *reinterpret_cast<const unsigned*>(limg + (long)gy * pg.z + gx);
       }
       // (b) the lane's pixel
       int ll = l, px = 0, py = 0, which = 0;
@@ -1542,7 +1544,7 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
   __shared__ unsigned wave_tot[2][II_THREADS / 64];
   const int frame = blockIdx.y, band = blockIdx.x;
   const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
-  const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
+  const uint8_t* img = brisk_layer_img(G, pyr, frame, 0);
   uint32_t* out = integral + (long)frame * iframe_elems;
   const int y0 = band * band_h, y1 = min(h, y0 + band_h);
   int buf = 0;
@@ -1862,7 +1864,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int* values = values_s[wave];
   const int n = counters[frame].ndesc;
-  const uint8_t* img = pyr + (long)frame * G.pyr_elems + G.L[0].off;
+  const uint8_t* img = brisk_layer_img(G, pyr, frame, 0);
   const int stride = G.L[0].stride;
   const uint32_t* integ = integral + (long)frame * iframe_elems;
   const uint4* rec = drec + (long)frame * kp_cap;

@@ -106,7 +106,9 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
  * detect (threshold, octaves) then describe (pat) for every frame on `stream` (hipStream_t, may be
  * NULL = the context's stream, a non-blocking stream that is NOT ordered with the legacy default stream: pass
  * your own stream if other work has to be ordered with the batch).  Asynchronous: synchronise the stream before
- * reading results. */
+ * reading results.  The frames must stay unchanged until then: when they already have the pyramid's layer-0 layout
+ * (row_pitch = width, a multiple of 64; 16-byte aligned base and frame pitch) every kernel reads them in place
+ * instead of from a private copy (the reference clones the image, brisk-scale-space.cc:74; the result is the same). */
 int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames,
                                     int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
                                     int octaves, void* stream);

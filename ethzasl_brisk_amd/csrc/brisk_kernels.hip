@@ -129,19 +129,49 @@ __device__ __forceinline__ const uint8_t* tile_origin(const TileRef& t) { return
 // `so` (addressed with absolute source coordinates, row pitch stw) of a source layer of width sw.  Four horizontally
 // adjacent outputs per thread: one dword store to the pyramid (and to the next LDS tile) instead of four byte stores;
 // tile origins are multiples of 8, layer offsets / strides multiples of 64.
+// rounded-up average of four byte pairs at once: (a + b + 1) >> 1 per byte = (a | b) - ((a ^ b) >> 1)
+__device__ __forceinline__ unsigned swar_avg(unsigned a, unsigned b) { return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu); }
+
 template <bool TWOTHIRD>
 __device__ __forceinline__ void pyramid_tile_level(const uint8_t* so, int stw, int sw, uint8_t* __restrict__ dst, int dstride,
                                                    int dw, int dh, int ox, int oy, int tw, uint8_t* dl) {
   const int qw = tw >> 2;
+  // output columns below `fast_cols` belong to the reference's SIMD class of nested rounded averages (Halfsample8:
+  // the 32-column double blocks, image-down-sampling.cc:308-330; Twothirdsample8: the 15 -> 10 column blocks,
+  // :714-751): four outputs at a time on packed bytes.  The other column classes take the per-pixel functions.
+  const int fast_cols = TWOTHIRD ? (sw / 15) * 10 : 16 * ((sw / 16) / 2);
   for (int i = threadIdx.x; i < tw * qw; i += 256) {
     const int r = i / qw, c = (i % qw) * 4;
     const int gx = ox + c, gy = oy + r;
     unsigned v = 0;
     if (gy < dh) {
+      if (gx + 3 < fast_cols) {
+        if (TWOTHIRD) {
+          // source columns 3 (gx / 2) .. + 5 (2-byte aligned) of the outer row (A or C) and the middle row B
+          const uint8_t* pa = so + (long)(3 * (gy >> 1) + ((gy & 1) ? 2 : 0)) * stw + 3 * (gx >> 1);
+          const uint8_t* pb = so + (long)(3 * (gy >> 1) + 1) * stw + 3 * (gx >> 1);
+          const uint16_t* ha = reinterpret_cast<const uint16_t*>(pa);
+          const uint16_t* hb = reinterpret_cast<const uint16_t*>(pb);
+          const unsigned a_lo = (unsigned)ha[0] | ((unsigned)ha[1] << 16), a_hi = ha[2];
+          const unsigned b_lo = (unsigned)hb[0] | ((unsigned)hb[1] << 16), b_hi = hb[2];
+          const unsigned u_lo = swar_avg(swar_avg(a_lo, b_lo), a_lo), u_hi = swar_avg(swar_avg(a_hi, b_hi), a_hi);  // u0..u3, u4 u5
+          const unsigned X = __builtin_amdgcn_perm(u_hi, u_lo, 0x05030200u);  // u0 u2 u3 u5: the outer columns
+          const unsigned M = __builtin_amdgcn_perm(u_hi, u_lo, 0x04040101u);  // u1 u1 u4 u4: the middle columns
+          v = swar_avg(swar_avg(X, M), X);
+        } else {
+          const uint2 T = *reinterpret_cast<const uint2*>(so + (long)(2 * gy) * stw + 2 * gx);
+          const uint2 B = *reinterpret_cast<const uint2*>(so + (long)(2 * gy + 1) * stw + 2 * gx);
+          const unsigned V0 = swar_avg(T.x, B.x), V1 = swar_avg(T.y, B.y);         // vertical: v0..v3, v4..v7
+          const unsigned E = __builtin_amdgcn_perm(V1, V0, 0x06040200u);           // v0 v2 v4 v6
+          const unsigned O = __builtin_amdgcn_perm(V1, V0, 0x07050301u);           // v1 v3 v5 v7
+          v = swar_avg(E, O);
+        }
+      } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (gx + q < dw)
-          v |= (unsigned)(TWOTHIRD ? brisk_twothird_px(so, stw, sw, gx + q, gy) : brisk_half_px(so, stw, sw, gx + q, gy)) << (8 * q);
+        for (int q = 0; q < 4; ++q)
+          if (gx + q < dw)
+            v |= (unsigned)(TWOTHIRD ? brisk_twothird_px(so, stw, sw, gx + q, gy) : brisk_half_px(so, stw, sw, gx + q, gy)) << (8 * q);
+      }
       if (gx < dstride) *reinterpret_cast<unsigned*>(dst + (long)gy * dstride + gx) = v;
     }
     if (dl) *reinterpret_cast<unsigned*>(&dl[r * tw + c]) = v;

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) k_pyramid_fused(BriskGeom G, const uint8_
                                                         int odd_levels, int tiles_x, int tiles_y,
                                                         uint32_t* __restrict__ bandsum, int istride) {
   __shared__ __attribute__((aligned(16))) uint8_t t0[96 * 96], t1[64 * 64], t2[48 * 48], t3[32 * 32], t4[24 * 24], t5[16 * 16];
-  __shared__ unsigned psum[2][96];
+  __shared__ uint2 psum[8][24];
   const int frame = blockIdx.y;
   // XCD-aware tile order (see k_detect): x-adjacent tile rows share 128-byte lines, keep them in one L2
   const int nt = tiles_x * tiles_y;
@@ -338,14 +338,17 @@ __global__ void __launch_bounds__(256) k_pyramid_fused(BriskGeom G, const uint8_
   }
   __syncthreads();
   // column sums of this 96-row band (the integral image kernel's carry rows): integral column = pixel column + 1
-  {
-    const int c = threadIdx.x % 96, half = threadIdx.x / 96;
-    if (half < 2) {
-      unsigned sum = 0;
-#pragma unroll 8
-      for (int r = 0; r < 48; ++r) sum += t0[(half * 48 + r) * 96 + c];
-      psum[half][c] = sum;
+  // (four columns per dword read, even / odd bytes summed in 16-bit halves: 96 rows x 255 < 65536)
+  if (threadIdx.x < 192) {
+    const int cq = threadIdx.x % 24, rg = threadIdx.x / 24;  // dword column, group of 12 rows
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+      const unsigned v = *reinterpret_cast<const unsigned*>(&t0[(rg * 12 + r) * 96 + cq * 4]);
+      lo += v & 0x00FF00FFu;
+      hi += (v >> 8) & 0x00FF00FFu;
     }
+    psum[rg][cq] = make_uint2(lo, hi);
   }
   // first level of both chains (both read the frame block): L2 48x48 and L1 64x64
   {
@@ -357,9 +360,16 @@ __global__ void __launch_bounds__(256) k_pyramid_fused(BriskGeom G, const uint8_
   }
   __syncthreads();
   if (threadIdx.x < 96) {
-    const int c = threadIdx.x;
+    const int c = threadIdx.x, cq = c >> 2, k = c & 3;
+    unsigned tot = 0;
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+      const uint2 p = psum[rg][cq];
+      const unsigned w = (k & 1) ? p.y : p.x;     // columns 1, 3 in the odd-byte sums
+      tot += (k & 2) ? (w >> 16) : (w & 0xFFFFu);
+    }
     uint32_t* row = bandsum + ((long)frame * tiles_y + by / PF_BAND) * istride;
-    if (bx + c + 1 < istride) row[bx + c + 1] = psum[0][c] + psum[1][c];
+    if (bx + c + 1 < istride) row[bx + c + 1] = tot;
     if (bx == 0 && c == 0) row[0] = 0;
   }
   // second level: L4 24x24 from L2, L3 32x32 from L1

@@ -1541,12 +1541,7 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize_large(BriskGeom G, cons
 // exclusive offset of `total` among the workgroup's threads (thread order) + the workgroup total
 __device__ __forceinline__ unsigned ii_wg_scan(unsigned total, unsigned (*wave_tot)[II_THREADS / 64], int buf, unsigned* wg_total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned incl = total;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
+  const unsigned incl = (unsigned)wave_inclusive_scan((int)total);  // DPP row shifts / broadcasts: no LDS traffic
   if (lane == 63) wave_tot[buf][wave] = incl;
   __syncthreads();
   unsigned woff = 0, tot = 0;

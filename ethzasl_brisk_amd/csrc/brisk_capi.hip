@@ -407,6 +407,7 @@ struct BatchArgs {
   int uni_max;
   bool no_scale_nms = false;  // suppressScaleNonmaxima == false with octaves > 0
   int lower_threshold = BRISK_LOWER_THRESHOLD;  // 0: ComputeScale's pyramid (brisk-feature-detector.cc:90)
+  bool inplace_ok = true;  // layer 0 may be read from the frame buffer (not for the host-fed path's recycled staging buffers)
 };
 
 // geometry, workspace, restoring the all-zero score-state map, profiler bookkeeping: once per batch, on stream s
@@ -491,7 +492,7 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
   {
     static const bool inplace_on = !(getenv("BRISK_L0_INPLACE") && atoi(getenv("BRISK_L0_INPLACE")) == 0);
     const bool ordered = Gs.threshold < BRISK_FAST_PATH_MIN_THRESHOLD || Gs.no_scale_nms || Gs.lower_threshold != BRISK_LOWER_THRESHOLD;
-    if (A.do_detect && inplace_on && !ordered && A.row_pitch == Gs.L[0].stride &&
+    if (A.do_detect && A.inplace_ok && inplace_on && !ordered && A.row_pitch == Gs.L[0].stride &&
         ((((uintptr_t)d_frames) | (uintptr_t)A.frame_pitch) & 15) == 0) {
       Gs.l0_ext = d_frames;
       Gs.l0_pitch = A.frame_pitch;
@@ -588,6 +589,7 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
   if (!h_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   BatchArgs A{pat, w, h, threshold, octaves, 0, 0, nullptr, 0, 0, true, true, ctx->uni_radius, ctx->uni_max};
+  A.inplace_ok = false;  // the staging buffers are recycled slice after slice: the engine keeps its own layer-0 copy (the link, not the engine, bounds this path)
   hipStream_t s = ctx->stream;
   int rc = batch_begin(ctx, A, nframes, s);
   if (rc) return rc;

@@ -345,28 +345,27 @@ BRISK_HD int brisk_V58(const BriskLayerView& L, int x, int y) {
 // Anchors of the score blocks a candidate at (x, y) on `layer` can read on the neighbouring layers
 // (GetScoreMaxAbove / GetScoreMaxBelow windows incl. the 3x3 patch around their maximum and the tie rule):
 // 4x4 blocks, above anchored at (int(x_1) - 1, ...), below at (int(x_1), ...).
+// The window starts of brisk_score_max_other are float quotients ((float)((float)(4x - 3) / 6.0), (6x - 4) / 8.0f,
+// (8x - 3) / 6.0, (6x - 2) / 4.0); only their truncations are needed here.  The exact quotients are multiples of 1/6, 1/8
+// or 1/4 - never within a float rounding of the next integer - so the truncated float quotient equals the truncated
+// integer quotient (checked against the float expressions for every coordinate, tests/test_emul_parity.py).
 BRISK_HD void brisk_block_anchor(bool above, bool odd, int x_layer, int y_layer, int* ax, int* ay) {
-  float x_1, y_1;
   if (above) {
     if (!odd) {
-      x_1 = (float)((float)(4 * (x_layer)-1 - 2) / 6.0);
-      y_1 = (float)((float)(4 * (y_layer)-1 - 2) / 6.0);
+      *ax = (4 * x_layer - 3) / 6 - 1;
+      *ay = (4 * y_layer - 3) / 6 - 1;
     } else {
-      x_1 = (float)(6 * (x_layer)-1 - 3) / 8.0f;
-      y_1 = (float)(6 * (y_layer)-1 - 3) / 8.0f;
+      *ax = (6 * x_layer - 4) / 8 - 1;
+      *ay = (6 * y_layer - 4) / 8 - 1;
     }
-    *ax = (int)x_1 - 1;
-    *ay = (int)y_1 - 1;
   } else {
     if (!odd) {
-      x_1 = (float)((float)(8 * (x_layer) + 1 - 4) / 6.0);
-      y_1 = (float)((float)(8 * (y_layer) + 1 - 4) / 6.0);
+      *ax = (8 * x_layer - 3) / 6;
+      *ay = (8 * y_layer - 3) / 6;
     } else {
-      x_1 = (float)((float)(6 * (x_layer) + 1 - 3) / 4.0);
-      y_1 = (float)((float)(6 * (y_layer) + 1 - 3) / 4.0);
+      *ax = (6 * x_layer - 2) / 4;
+      *ay = (6 * y_layer - 2) / 4;
     }
-    *ax = (int)x_1;
-    *ay = (int)y_1;
   }
 }
 

@@ -453,6 +453,24 @@ int emul_state_split_mismatches(unsigned seed, int n) {
   return bad;
 }
 
+// brisk_block_anchor uses integer quotients where brisk_score_max_other (and the reference, brisk-scale-space.cc:786-801,
+// 946-962) truncates float quotients: identical for every coordinate the engine admits
+int emul_block_anchor_mismatches(void) {
+  int bad = 0;
+  for (int v = 0; v < 8192; ++v) {
+    int ax, ay;
+    brisk_block_anchor(true, false, v, v, &ax, &ay);
+    if (ax != (int)(float)((float)(4 * v - 1 - 2) / 6.0) - 1 || ay != ax) ++bad;
+    brisk_block_anchor(true, true, v, v, &ax, &ay);
+    if (ax != (int)((float)(6 * v - 1 - 3) / 8.0f) - 1 || ay != ax) ++bad;
+    brisk_block_anchor(false, false, v, v, &ax, &ay);
+    if (ax != (int)(float)((float)(8 * v + 1 - 4) / 6.0) || ay != ax) ++bad;
+    brisk_block_anchor(false, true, v, v, &ax, &ay);
+    if (ax != (int)(float)((float)(6 * v + 1 - 3) / 4.0) || ay != ax) ++bad;
+  }
+  return bad;
+}
+
 // k_detect phase A: the packed pre-gate must be a NECESSARY condition of brisk_detect_px.  Walks an image exactly as
 // the kernel pairs the pixels (two horizontally adjacent centres per call) and returns the number of detections the
 // pre-gate would have dropped (must be 0); *survivors receives the number of pixels that pass it.

@@ -173,6 +173,10 @@ def test_tie_pipeline_row_bound_covers_every_touch_footprint():
         assert L.emul_tie_rows_needed_violations(img.ctypes.data, w, h, thr, octv) == 0
 
 
+def test_block_anchor_integer_quotients_equal_the_float_ones():
+    assert E.lib().emul_block_anchor_mismatches() == 0
+
+
 def test_pregate_is_a_necessary_condition():
     """k_detect phase A (packed 16-bit pre-gate on the compass pixels) must never drop a pixel that
     brisk_detect_px (the exact per-pixel detection) accepts: synthetic frames, pure noise, saturated blocks, all

@@ -321,6 +321,11 @@ class BriskDescriptorExtractor:
     def descriptorSize(self):
         return self._ctx._L.brisk_hip_pattern_descriptor_size(self._h)
 
+    @property
+    def points(self):
+        """number of pattern points (60 for briskV1, 66 for briskV2)"""
+        return self._ctx._L.brisk_hip_pattern_points(self._h)
+
     def descriptorType(self):
         return 0  # CV_8U
 

@@ -1,0 +1,90 @@
+"""GPU tests added in round 3 (run with -m gpu): launch configurations of the batch path that the earlier suites never
+reached at 1080p - tie workgroups that own 2..7 layers (batches of 65..255 frames), the 32-blocks-per-frame branch of
+the score-block / classification kernels - and the re-built descriptor kernel (tail points of the pattern batched per
+wave) on every pattern size."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+from test_gpu_parity import same_kps, explain  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import ethzasl_brisk_amd as B
+    from ethzasl_brisk_amd import build
+    build.build()
+    B.load_library()
+    return B
+
+
+def _run_batch_and_compare(B, frames_distinct, n, thr, octaves, w, h, every_slot=True):
+    """n slots filled round-robin from the distinct frames; every slot (or the first, middle and last ones of each
+    distinct frame) is compared with the oracle: keypoints as detected, keypoints as described, descriptors."""
+    import torch
+    nd = len(frames_distinct)
+    X = O.Extractor()
+    want = []
+    for img in frames_distinct:
+        ko = O.detect(img, thr, octaves)
+        want.append((ko,) + X.compute(img, ko))
+    stack = np.stack([frames_distinct[f % nd] for f in range(n)])
+    d = torch.from_numpy(stack).cuda()
+    cap = max(len(k[0]) for k in want)
+    ctx = B.Context(0, 4 * cap, 2 * cap) if cap > 12000 else B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    for rep in range(2):  # the second batch runs on the dirty workspace of the first
+        ctx.detect_describe_batch(ext, d.data_ptr(), n, w, h, w * h, w, thr, octaves, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ctx.batch_status(n) == 0
+        slots = range(n) if every_slot else sorted(set(list(range(nd)) + list(range(n // 2, n // 2 + nd)) + list(range(n - nd, n))))
+        for f in slots:
+            ko, ko2, do = want[f % nd]
+            kd, _ = ctx.batch_download(f, described=False)
+            kg, dg = ctx.batch_download(f, described=True)
+            assert same_kps(kd, ko), (n, rep, f, explain(kd, ko))
+            assert same_kps(kg, ko2), (n, rep, f, explain(kg, ko2))
+            assert np.array_equal(dg, do), (n, rep, f)
+    ctx.close()
+    return sum(len(k[1]) for k in want)
+
+
+@pytest.mark.parametrize("n", [96, 128, 200, 255, 65])
+def test_1080p_batches_between_65_and_255_frames(B, n):
+    """lpw (layers per tie workgroup) = 3, 4, 7, 8 and 2 at BASELINE config-2 content; eight distinct frames, every
+    slot of the batch - the last one included - bit-equal to the oracle."""
+    distinct = [synth.frame_1080p(300 + s) for s in range(8)]
+    total = _run_batch_and_compare(B, distinct, n, 80, 4, 1920, 1080)
+    assert total > 6000
+
+
+def test_1080p_dense_threshold_30_at_128_frames(B):
+    """A dense regime (threshold 30: ~30 k detections and as many ties per frame) at 128 frames: the tie workgroups own
+    four layers each and take the chunked sort."""
+    distinct = [synth.frame_1080p(400 + s) for s in range(3)]
+    total = _run_batch_and_compare(B, distinct, 128, 30, 4, 1920, 1080, every_slot=False)
+    assert total > 30000
+
+
+@pytest.mark.parametrize("version,points", [(2, 66), (1, 60)])
+def test_describe_many_keypoints_per_wave_patterns(B, version, points):
+    """k_describe on runs of keypoints per wave: V2 (66 points: the two tail points go through the batched tail pass)
+    and V1 (60 points: no tail); provided keypoints without and with orientation, all flags."""
+    img = synth.frame_1080p(77)
+    ko = O.detect(img, 60, 4)
+    assert len(ko) > 1500
+    for rot, scl in ((True, True), (False, True), (True, False)):
+        ext = B.BriskDescriptorExtractor(rot, scl, version)
+        assert ext.points == points
+        X = O.Extractor(rot, scl, version)
+        k2, d2 = ext.compute(img, ko)
+        ko2, do = X.compute(img, ko)
+        assert same_kps(k2, ko2), explain(k2, ko2)
+        assert np.array_equal(d2, do)
+        # again with the estimated angles provided (angle != -1 skips the orientation pass)
+        k3, d3 = ext.compute(img, ko2)
+        ko3, do3 = X.compute(img, ko2)
+        assert same_kps(k3, ko3) and np.array_equal(d3, do3)

@@ -14,6 +14,7 @@
 #include "brisk_common.h"
 #include "brisk_kernels.h"
 #include "brisk_pattern.h"
+#include "brisk_device_describe.h"
 
 static_assert(sizeof(brisk_hip_keypoint) == 28 && sizeof(BriskKeyPoint) == 28, "cv::KeyPoint layout");
 
@@ -312,7 +313,7 @@ static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_mult = take(64 * n * 4), o_sigma = take(64 * n * 4), o_uv = take((size_t)BRISK_NROT * n * 16);
-  const size_t o_scl = take(64 * n * 8);
+  const size_t o_scl = take(64 * n * 8), o_tab = take(64 * n * 16);
   const size_t o_thr = take(64 * 4), o_size = take(64 * 4), o_sp = take((size_t)H.nshort * 4), o_lp = take((size_t)H.nlong * 16);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMalloc(&p->blob, off));
@@ -320,6 +321,25 @@ static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
   HIPCHK(ctx, hipMemcpy(b + o_mult, H.mult.data(), 64 * n * 4, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(b + o_sigma, H.sigma.data(), 64 * n * 4, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(b + o_scl, H.scaling.data(), 64 * n * 8, hipMemcpyHostToDevice));
+  {
+    // {mult, sigma, scaling | shift << 24 | plain << 30, magic multiplier of scaling2 (plain: scaling2 itself)}
+    std::vector<int> tab(64 * n * 4);
+    for (size_t i = 0; i < 64 * n; ++i) {
+      memcpy(&tab[4 * i], &H.mult[i], 4);
+      memcpy(&tab[4 * i + 1], &H.sigma[i], 4);
+      const int scaling = H.scaling[2 * i], scaling2 = H.scaling[2 * i + 1];
+      if (scaling2 >= 2 && scaling >= 0 && scaling < (1 << 24)) {
+        int M, sh;
+        brisk_div_magic(scaling2, &M, &sh);
+        tab[4 * i + 2] = scaling | (sh << 24);
+        tab[4 * i + 3] = M;
+      } else {  // degenerate boxes (never sampled through the box branch in practice): plain division on the device
+        tab[4 * i + 2] = (scaling & 0xFFFFFF) | (1 << 30);
+        tab[4 * i + 3] = scaling2;
+      }
+    }
+    HIPCHK(ctx, hipMemcpy(b + o_tab, tab.data(), 64 * n * 16, hipMemcpyHostToDevice));
+  }
   HIPCHK(ctx, hipMemcpy(b + o_uv, H.uv.data(), (size_t)BRISK_NROT * n * 16, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(b + o_thr, H.size_thresh.data(), 64 * 4, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(b + o_size, H.size_list.data(), 64 * 4, hipMemcpyHostToDevice));
@@ -328,8 +348,11 @@ static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
   BriskPatternDev& d = p->dev;
   d.npoints = H.npoints; d.nshort = H.nshort; d.nlong = H.nlong; d.strings = H.strings;
   d.rotation_invariant = 1; d.scale_invariant = 1; d.basicscale = H.basicscale;
+  d.has_bilinear = 0;
+  for (float sg : H.sigma) d.has_bilinear |= (sg < 0.5f) ? 1 : 0;
   d.mult = (const float*)(b + o_mult); d.sigma = (const float*)(b + o_sigma); d.uv = (const double*)(b + o_uv);
   d.scaling = (const int*)(b + o_scl);
+  d.tab = (const int*)(b + o_tab);
   d.size_thresh = (const float*)(b + o_thr); d.size_list = (const int*)(b + o_size);
   d.short_pairs = (const uint16_t*)(b + o_sp); d.long_pairs = (const int*)(b + o_lp);
   return BRISK_HIP_OK;
@@ -1214,7 +1237,8 @@ int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlaye
   out[0] = c.ncand; out[1] = c.nkp; out[2] = c.ndesc; out[3] = c.overflow;
   *nlayers = ctx->G.nlayers;
   for (int l = 0; l < ctx->G.nlayers; ++l) out[4 + l] = c.ntie[l];
-  for (int i = 0; i < 8; ++i) out[20 + i] = c.pad[i];
+  for (int i = 0; i < 6; ++i) out[20 + i] = c.pad[i];
+  out[26] = c.orient_ticket; out[27] = c.desc_ticket;
   return BRISK_HIP_OK;
 }
 

@@ -105,16 +105,20 @@ struct BriskFrameCounters {
   int full_clear;                   // the ordered path wrote the map outside the candidates' footprints: clear all of it
   int tie_ticket;                   // k_tie_resolve: work tickets (entry xcd of the batch, or entry 0 for fewer than 8 frames)
   int tie_prog[BRISK_MAX_LAYERS];   // k_tie_resolve: rows of layer l whose ties are decided and whose touches are performed
-  int pad[8];
+  int orient_ticket, desc_ticket;   // k_describe (stage 0 / 1): next run of keypoints (in processing order) to be handed out
+  int pad[6];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)
 struct BriskPatternDev {
   int npoints, nshort, nlong, strings;   // strings = descriptor bytes (48 / 64)
   int rotation_invariant, scale_invariant, basicscale;
+  int has_bilinear;       // some (scale, point) has sigma < 0.5: SmoothedIntensity's bilinear branch (:391-408) is reachable
   const float* mult;      // [64][npoints]  multiplier m so that x = (float)((double)m * U)
   const float* sigma;     // [64][npoints]  box half side
   const int* scaling;     // [64][npoints][2] {scaling, scaling2} of the box (functions of sigma only, :412-413)
+  const int* tab;         // [64][npoints][4] {mult, sigma (float bits), scaling, scaling2}: the three tables above in one
+                          // 16-byte record per (scale, point) - what k_describe loads (device copy only, may be null on the host)
   const double* uv;       // [1024][npoints][2] unit-scale rotated offsets (x, y)
   const float* size_thresh;  // [64] size_thresh[s] = smallest keypoint size with scale index >= s
   const int* size_list;   // [64] border per scale index

@@ -1,0 +1,513 @@
+// brisk_describe.hip - descriptor kernels of the MI355X BRISK engine (gfx950): k_desc_prepare (scale index, border
+// filter, processing order) and k_describe (pattern sampling, orientation, bits).  The integral image kernel lives in
+// brisk_kernels.hip (it shares the pyramid kernel's band sums).
+// brisk/src/brisk-descriptor-extractor.cc:612-778 is the reference of everything here.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "brisk_common.h"
+#include "brisk_device_describe.h"
+#include "brisk_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+#define DP_MAXSORT 4096
+#ifndef DP_THREADS
+#define DP_THREADS 1024
+#endif
+// k_desc_prepare: per frame, scale index + border filter (brisk-descriptor-extractor.cc:636-662),
+// stable compaction into dkp (keypoints) / dscale.  One workgroup per frame.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
+                                                       const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
+                                                       BriskKeyPoint* dkp, int* dscale, int* dperm, uint4* drec, int kp_cap) {
+  __shared__ int wtot[DP_THREADS / 64];
+  __shared__ int base;
+  __shared__ __attribute__((aligned(16))) unsigned pkey[DP_MAXSORT + 4];
+  const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
+  const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
+    const int i = i0 + tid;
+    bool keep = false;
+    int sc = 0;
+    BriskKeyPoint kp;
+    if (i < n) {
+      kp = K[i];
+      sc = brisk_scale_index(P, kp.size);
+      keep = brisk_inside_border(P, sc, kp.x, kp.y, G.L[0].w, G.L[0].h);
+    }
+    // stable compaction: position = kept keypoints before this one (ballots inside the wave, wave totals through LDS)
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < DP_THREADS / 64; ++k) {
+      const int t = wtot[k];
+      wbase += (k < wave) ? t : 0;
+      total += t;
+    }
+    if (keep) {
+      const int j = base + wbase + before;
+      dkp[(long)frame * kp_cap + j] = kp;
+      dscale[(long)frame * kp_cap + j] = sc;
+      if (j < DP_MAXSORT)
+        pkey[j] = ((unsigned)((int)kp.y >> 6) << 24) | ((unsigned)((int)kp.x & 0x1FFF) << 11) | (unsigned)(j & 0x7FF);
+    }
+    __syncthreads();
+    if (tid == 0) base += total;
+    __syncthreads();
+  }
+  if (tid == 0) { counters[frame].ndesc = base; counters[frame].desc_ticket = 0; counters[frame].orient_ticket = 0; }
+  // Processing order for k_describe: keypoints sorted by 64-row band, then x, so that keypoints sampled at the
+  // same time touch the same part of the integral image (the output order stays (layer, y, x)).
+  const int m = base;
+  int* perm = dperm + (long)frame * kp_cap;
+  if (m <= DP_MAXSORT) {
+    if (tid < 4) pkey[m + tid] = 0xFFFFFFFFu;  // the count below reads four keys at a time
+    __syncthreads();
+    for (int j = tid; j < m; j += DP_THREADS) {
+      const unsigned kj = pkey[j];
+      int r = 0;
+      if (m <= 2048) {  // the keys carry j: all different
+        for (int q = 0; q < m; q += 4) {
+          const uint4 kk = *reinterpret_cast<const uint4*>(&pkey[q]);
+          r += (kk.x < kj ? 1 : 0) + (kk.y < kj ? 1 : 0) + (kk.z < kj ? 1 : 0) + (kk.w < kj ? 1 : 0);
+        }
+      } else {
+        for (int q = 0; q < m; ++q) r += (pkey[q] < kj || (pkey[q] == kj && q < j)) ? 1 : 0;
+      }
+      perm[r] = j;
+    }
+  } else {
+    for (int j = tid; j < m; j += DP_THREADS) perm[j] = j;
+  }
+  // the keypoints again, in processing order, as one 16-byte record each: k_describe reads them with a single
+  // (prefetchable) load instead of the dependent chain order -> keypoint -> scale
+  __syncthreads();
+  for (int r = tid; r < m; r += DP_THREADS) {
+    const int j = perm[r];
+    const BriskKeyPoint& q = dkp[(long)frame * kp_cap + j];
+    drec[(long)frame * kp_cap + r] = make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.angle),
+                                                 (unsigned)dscale[(long)frame * kp_cap + j] | ((unsigned)j << 8));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_describe: persistent waves, one RUN of consecutive keypoints (in processing order) per ticket.
+//
+// What bounds this kernel is the vector L1 / L2 path of the gathers (tools/microbench_gather.hip, profiles/r03_*): a
+// describe-shaped pass costs the same at 1 and at 8 waves per SIMD, but 2.3 x less when the keypoints that are in
+// flight on an XCD at the same time are neighbours (their lines are then L2 hits).  So:
+//  * keypoints are dealt in their spatial processing order through one ticket counter per frame, and every wave first
+//    serves the frames of its own XCD (frame % 8 == XCC id; speed only: afterwards it serves whatever is left, so the
+//    result does not depend on where the hardware places a workgroup);
+//  * the samples of a run are laid out flat, lane = (keypoint, pattern point): RUN x npoints samples in
+//    ceil(RUN x npoints / 64) rounds of one sample per lane - a 66-point pattern no longer pays a second, 97 % idle
+//    round per keypoint - and the orientations of a run are computed together (one fp64 atan2 per run, not per
+//    keypoint);
+//  * the number of resident waves is a launch parameter (persistent grid, dynamic LDS as the occupancy limiter).
+// Per round the lane's parameters for the NEXT round (table entry of (scale, point), rotated unit offset) are already
+// in flight.  Long pairs: integer wave reductions (order independent); bits: 64-wide ballots.
+// ------------------------------------------------------------------------------------------------
+#ifndef DS_WAVES
+#define DS_WAVES 4
+#endif
+#define DS_MAXRUN 8
+#define DS_MAXQ 256        // frames per work queue (more frames per launch: more queues)
+#ifndef DS_RUN_BATCH
+#define DS_RUN_BATCH 4   // keypoints per ticket in batches of >= 8 frames
+#endif
+#ifndef DS_BLOCKS_PER_CU
+#define DS_BLOCKS_PER_CU 3
+#endif
+#define DS_LP_LDS 1024
+#define DS_GETREG_XCC_ID (20 | (3 << 11))  // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
+
+typedef uint32_t __attribute__((ext_vector_type(2))) ds_u32x2;
+
+struct DsLane {  // a lane's sample of one round
+  float kx, ky;
+  int4 tab;      // {mult, sigma (float bits), scaling | shift << 24, magic} of (scale, point): BriskPatternDev::tab
+  int ti;        // scale * npoints + point
+  double2 uv;    // unit offset of the point at the keypoint's rotation
+  int slot;      // keypoint-in-run * npoints + point
+};
+struct DsPrep {
+  int x_left, y_top, x_right, y_bottom;
+  unsigned A, B, C, D, r_x_1_i, r_y_1_i, r_x1_i, r_y1_i;
+  int scaling, magic, shift;  // acc / scaling2 as a multiplication (brisk_div_by_magic); shift < 0: plain division by `magic`
+  bool quirk;
+};
+struct DsRaw {
+  ds_u32x2 p00, p02, p10, p12, p20, p22, p30, p32;
+  unsigned br, bl;
+};
+// SmoothedIntensity split into address / load / combine stages (device only; the arithmetic is that of
+// brisk_smoothed_intensity in brisk_device_describe.h, box branch)
+__device__ __forceinline__ DsPrep ds_prep(float xf, float yf, float sigma_half, int tab_z, int tab_w) {
+  DsPrep p;
+  const int scaling = tab_z & 0xFFFFFF;
+  p.scaling = scaling; p.magic = tab_w; p.shift = (tab_z & (1 << 30)) ? -1 : ((tab_z >> 24) & 31);
+  const float x_1 = xf - sigma_half, x1 = xf + sigma_half, y_1 = yf - sigma_half, y1 = yf + sigma_half;
+  p.x_left = (int)(x_1 + 0.5); p.y_top = (int)(y_1 + 0.5); p.x_right = (int)(x1 + 0.5); p.y_bottom = (int)(y1 + 0.5);
+  const float r_x_1 = (float)((float)p.x_left - x_1 + 0.5);
+  const float r_y_1 = (float)((float)p.y_top - y_1 + 0.5);
+  const float r_x1 = (float)(x1 - (float)p.x_right + 0.5);
+  const float r_y1 = (float)(y1 - (float)p.y_bottom + 0.5);
+  const int dx = p.x_right - p.x_left - 1, dy = p.y_bottom - p.y_top - 1;
+  p.A = (unsigned)(int)((r_x_1 * r_y_1) * scaling);
+  p.B = (unsigned)(int)((r_x1 * r_y_1) * scaling);
+  p.C = (unsigned)(int)((r_x1 * r_y1) * scaling);
+  p.D = (unsigned)(int)((r_x_1 * r_y1) * scaling);
+  p.r_x_1_i = (unsigned)(int)(r_x_1 * scaling);
+  p.r_y_1_i = (unsigned)(int)(r_y_1 * scaling);
+  p.r_x1_i = (unsigned)(int)(r_x1 * scaling);
+  p.r_y1_i = (unsigned)(int)(r_y1 * scaling);
+  p.quirk = (dx + dy > 2);
+  return p;
+}
+// The 4 x 4 integral samples as eight 8-byte gathers through a buffer descriptor of the frame's integral image: four
+// 32-bit offsets per lane (the corners), the second row of each pair through the scalar offset; plus the two displaced
+// bottom corners of the reference quirk (brisk-descriptor-extractor.cc:453) from the image (linear addressing of the
+// reference: a box that ends in the last column reads the first pixel of the next row).
+__device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, __amdgpu_buffer_rsrc_t rs_img, int stride, int cols,
+                                        __amdgpu_buffer_rsrc_t rs_int, int istride) {
+  const int rowb = istride * 4;
+  const int o_t = p.y_top * rowb, o_b = p.y_bottom * rowb;
+  const int o_tl = o_t + p.x_left * 4, o_tr = o_t + p.x_right * 4, o_bl = o_b + p.x_left * 4, o_br = o_b + p.x_right * 4;
+  r.p00 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, 0, 0);
+  r.p02 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, 0, 0);
+  r.p10 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, rowb, 0);
+  r.p12 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, rowb, 0);
+  r.p20 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl, 0, 0);
+  r.p22 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, 0, 0);
+  r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl, rowb, 0);
+  r.p32 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, rowb, 0);
+  int qy = max(p.y_bottom - 1, 0);
+  int xr = p.x_right + 1, xl = p.x_left + 1;
+  const int o_q = qy * stride;
+  const int wrap = stride - cols;  // x >= cols: first pixels of the next row
+  r.br = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xr + (xr >= cols ? wrap : 0), 0, 0);
+  r.bl = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xl + (xl >= cols ? wrap : 0), 0, 0);
+}
+__device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
+  const uint32_t i00 = r.p00.x, i01 = r.p00.y, i02 = r.p02.x, i03 = r.p02.y;
+  const uint32_t i10 = r.p10.x, i11 = r.p10.y, i12 = r.p12.x, i13 = r.p12.y;
+  const uint32_t i20 = r.p20.x, i21 = r.p20.y, i22 = r.p22.x, i23 = r.p22.y;
+  const uint32_t i30 = r.p30.x, i31 = r.p30.y, i32 = r.p32.x, i33 = r.p32.y;
+  const unsigned tl = i11 - i01 - i10 + i00;  // pixel (x_left, y_top)
+  const unsigned tr = i13 - i03 - i12 + i02;  // pixel (x_right, y_top)
+  const unsigned br = p.quirk ? r.br : (i33 - i23 - i32 + i22);
+  const unsigned bl = p.quirk ? r.bl : (i31 - i21 - i30 + i20);
+  const uint32_t top = i12 - i11 - i02 + i01;
+  const uint32_t bottom = i32 - i31 - i22 + i21;
+  const uint32_t left = i21 - i20 - i11 + i10;
+  const uint32_t right = i23 - i22 - i13 + i12;
+  const uint32_t middle = i22 - i21 - i12 + i11;
+  const uint32_t acc = p.A * tl + p.B * tr + p.C * br + p.D * bl + p.r_y_1_i * top + p.r_y1_i * bottom + p.r_x_1_i * left +
+                       p.r_x1_i * right + (unsigned)p.scaling * middle;
+  if (__any(p.shift < 0)) return p.shift < 0 ? (int)acc / p.magic : brisk_div_by_magic((int)acc, p.magic, p.shift);
+  return brisk_div_by_magic((int)acc, p.magic, p.shift);
+}
+struct DsWaveCtx {
+  const BriskPatternDev* P;
+  const uint4* krec;   // LDS: the run's keypoint records {x, y, angle (float bits), scale | index << 8}
+  const int* kth;      // LDS: rotation index of each keypoint of the run
+  int* vals;           // LDS: [RUN][npoints] smoothed intensities
+  int np, total;       // pattern points, samples of this run
+  unsigned inv20;      // (1 << 20) / np + 1: s / np == (s * inv20) >> 20 for s < 2048
+  int lane;
+};
+// parameters of sample s (clamped to the run's last sample: surplus lanes repeat it and are masked at the loads)
+__device__ __forceinline__ DsLane ds_fetch(const DsWaveCtx& c, int s, bool rotated) {
+  DsLane L;
+  const int sc = min(s, c.total - 1);
+  const int kq = (int)(((unsigned)sc * c.inv20) >> 20);
+  const int pt = sc - kq * c.np;
+  const uint4 rec = c.krec[kq];
+  const int theta = rotated ? c.kth[kq] : 0;
+  L.kx = __uint_as_float(rec.x); L.ky = __uint_as_float(rec.y);
+  L.ti = (int)(rec.w & 0xFF) * c.np + pt;
+  L.tab = reinterpret_cast<const int4*>(c.P->tab)[L.ti];
+  L.uv = reinterpret_cast<const double2*>(c.P->uv)[theta * c.np + pt];
+  L.slot = sc;
+  return L;
+}
+// one sampling pass over the run: every sample's smoothed intensity into vals[]
+// GENERIC: the pattern has points on the bilinear branch of SmoothedIntensity (sigma < 0.5, :391-408; only with a small
+// patternScale): every sample through the generic function of brisk_device_describe.h
+template <bool GENERIC>
+__device__ __forceinline__ void ds_pass(const DsWaveCtx& c, bool rotated, const uint8_t* __restrict__ img, __amdgpu_buffer_rsrc_t rs_img,
+                                        int stride, int cols, const uint32_t* __restrict__ integ, __amdgpu_buffer_rsrc_t rs_int,
+                                        int istride) {
+  DsLane cur = ds_fetch(c, c.lane, rotated);
+  for (int s0 = 0; s0 < c.total; s0 += 64) {
+    DsLane nxt = cur;
+    if (s0 + 64 < c.total) nxt = ds_fetch(c, s0 + 64 + c.lane, rotated);
+    const bool valid = s0 + c.lane < c.total;
+    const double m = (double)__int_as_float(cur.tab.x);
+    const float sigma = __int_as_float(cur.tab.y);
+    const float xf = (float)(m * cur.uv.x) + cur.kx, yf = (float)(m * cur.uv.y) + cur.ky;
+    int value;
+    if (GENERIC) {
+      BriskSamplePoint sp;
+      sp.x = (float)(m * cur.uv.x); sp.y = (float)(m * cur.uv.y); sp.sigma = sigma;
+      sp.scaling = c.P->scaling[2 * cur.ti]; sp.scaling2 = c.P->scaling[2 * cur.ti + 1];
+      value = valid ? brisk_smoothed_intensity(img, stride, cols, integ, istride, cur.kx, cur.ky, sp) : 0;
+    } else {
+      const DsPrep p = ds_prep(xf, yf, sigma, cur.tab.z, cur.tab.w);
+      DsRaw r;
+      if (valid) ds_load(r, p, rs_img, stride, cols, rs_int, istride);
+      value = ds_combine(p, r);
+    }
+    if (valid) c.vals[cur.slot] = value;
+    cur = nxt;
+  }
+}
+
+// rec.z of a keypoint whose orientation was estimated by the first stage: a negative quiet NaN that carries the rotation
+// index (the keypoint's angle itself goes to dkp[].angle); any other value is the angle the caller provided
+#define DS_THETA_TAG 0xFFC00000u
+
+// STAGE 0: orientation of the keypoints that have none (angle == -1): unrotated pattern, long pairs, atan2.
+// STAGE 1: rotated pattern, short-pair bits.
+// Two launches of the same persistent structure: each stage's ticket is a short chain (records -> parameters -> gathers
+// -> LDS -> result), the fp64 atan2 (38 VGPRs on top of everything live around it) stays out of the stage that does most
+// of the sampling, and the keypoints in flight on an XCD at any time are one contiguous stretch of the processing order.
+template <int RUN, int STAGE, bool GENERIC>
+__global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
+                                                            const uint32_t* __restrict__ integral, int istride,
+                                                            long iframe_elems, BriskFrameCounters* counters,
+                                                            BriskKeyPoint* dkp, uint4* __restrict__ drec,
+                                                            uint8_t* desc, int kp_cap, int desc_pitch, int nframes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ds_lds[];
+  // LDS: long pairs {i, j, wdx, wdy} (stage 0) or short pairs i | j << 16 (stage 1) | per wave: records, rotations, values
+  const int np = P.npoints;
+  const bool lp_in_lds = P.nlong <= DS_LP_LDS;
+  int4* lp_s = reinterpret_cast<int4*>(ds_lds);
+  unsigned* sp_s = reinterpret_cast<unsigned*>(ds_lds);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int table_bytes = STAGE == 0 ? (lp_in_lds ? P.nlong * 16 : 0) : ((P.nshort * 4 + 15) & ~15);
+  const int per_wave = RUN * 16 + ((RUN * 4 + 15) & ~15) + ((RUN * np * 4 + 15) & ~15) + DS_MAXQ * 4;
+  unsigned char* wbase = ds_lds + table_bytes + wave * per_wave;
+  uint4* krec = reinterpret_cast<uint4*>(wbase);
+  int* kth = reinterpret_cast<int*>(wbase + RUN * 16);
+  int* vals = reinterpret_cast<int*>(wbase + RUN * 16 + ((RUN * 4 + 15) & ~15));
+  int* cum = reinterpret_cast<int*>(wbase + RUN * 16 + ((RUN * 4 + 15) & ~15) + ((RUN * np * 4 + 15) & ~15));
+  if (STAGE == 0) {
+    if (lp_in_lds)
+      for (int p = threadIdx.x; p < P.nlong; p += DS_WAVES * 64) lp_s[p] = reinterpret_cast<const int4*>(P.long_pairs)[p];
+  } else {
+    for (int p = threadIdx.x; p < P.nshort; p += DS_WAVES * 64) sp_s[p] = (unsigned)P.short_pairs[2 * p] | ((unsigned)P.short_pairs[2 * p + 1] << 16);
+  }
+  __syncthreads();  // the only workgroup barrier: from here on the waves are independent
+
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(DS_GETREG_XCC_ID) & 7);
+  const int stride = G.L[0].stride, cols = G.L[0].w;
+  const int img_bytes = (G.L[0].h - 1) * stride + cols;
+  DsWaveCtx c;
+  c.P = &P; c.krec = krec; c.kth = kth; c.vals = vals; c.np = np; c.lane = lane;
+  c.inv20 = (1u << 20) / (unsigned)np + 1u;
+  const int nwords = P.strings / 8;  // 64-bit words of a descriptor
+
+  // Work queue: the frames are dealt to `ngroups` groups (frame % ngroups; 8 = one group per XCD), each group is ONE
+  // queue of runs - its frames from the last to the first (the integral images are written in frame order just before
+  // this kernel: the last ones are what the Infinity Cache still holds), each frame's keypoints in processing order -
+  // behind one ticket counter (in the counters of the group's first frame).  A wave serves the group of its own XCD
+  // first (speed only), then the others (so that the result never depends on where the hardware places a workgroup).
+  const int ngroups = nframes < 8 ? 1 : (nframes <= 8 * DS_MAXQ ? 8 : (nframes + DS_MAXQ - 1) / DS_MAXQ);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int g = (xcc + gi) % ngroups;
+    if (g >= nframes) continue;
+    const int m = (nframes - 1 - g) / ngroups + 1;  // frames of the group
+    // cum[j] = runs of the group's first j + 1 frames in queue order (frame of entry j: g + (m - 1 - j) * ngroups)
+    int carry = 0;
+    for (int j0 = 0; j0 < m; j0 += 64) {
+      const int j = j0 + lane;
+      int r = j < m ? (counters[g + (m - 1 - j) * ngroups].ndesc + RUN - 1) / RUN : 0;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(r, off, 64);
+        if (lane >= off) r += t;
+      }
+      if (j < m) cum[j] = carry + r;
+      carry += __shfl(r, 63, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int total = __builtin_amdgcn_readfirstlane(carry);
+    int* ticket = STAGE == 0 ? &counters[g].orient_ticket : &counters[g].desc_ticket;
+    // tickets are taken one run ahead (an agent-scope atomic takes microseconds); groups of other XCDs - normally
+    // finished by their own waves - get a plain look first
+    int next = total;
+    if (lane == 0 && (gi == 0 || __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total))
+      next = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int qj = 0;  // queue entry (frame) of the current ticket: tickets only grow
+    for (;;) {
+      const int tk = __builtin_amdgcn_readfirstlane(next);
+      if (tk >= total) break;
+      if (lane == 0) next = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (tk >= cum[qj]) ++qj;
+      qj = __builtin_amdgcn_readfirstlane(qj);
+      const int frame = g + (m - 1 - qj) * ngroups;
+      const int run = __builtin_amdgcn_readfirstlane(tk - (qj ? cum[qj - 1] : 0));
+      const int n = __builtin_amdgcn_readfirstlane(counters[frame].ndesc);
+      const uint8_t* img = brisk_layer_img(G, pyr, frame, 0);
+      const uint32_t* integ = integral + (long)frame * iframe_elems;
+      const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, img_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_int =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(integ), 0, (int)(iframe_elems * 4), 0x00020000);
+      uint4* rec = drec + (long)frame * kp_cap;
+      {
+        const int k0 = run * RUN;
+        const int cnt = min(RUN, n - k0);
+        c.total = cnt * np;
+        uint4 myrec = make_uint4(0, 0, 0, 0);
+        if (lane < cnt) myrec = rec[k0 + lane];
+        if (STAGE == 0) {
+          // orientation (:714-739): unrotated pattern, 856 long pairs per keypoint; runs without a keypoint that needs it
+          // are skipped (provided angles)
+          const bool estimate = lane < cnt && __uint_as_float(myrec.z) == -1.0f;
+          if (!__any(estimate)) continue;
+          if (lane < cnt) krec[lane] = myrec;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          ds_pass<GENERIC>(c, false, img, rs_img, stride, cols, integ, rs_int, istride);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          int md0 = 0, md1 = 0;
+          for (int kq = 0; kq < cnt; ++kq) {
+            const int* v = vals + kq * np;
+            int d0 = 0, d1 = 0;
+            if (lp_in_lds) {
+              for (int p = lane; p < P.nlong; p += 64) {
+                const int4 q = lp_s[p];
+                const int delta_t = v[q.x] - v[q.y];
+                d0 += delta_t * q.z / 1024;
+                d1 += delta_t * q.w / 1024;
+              }
+            } else {
+              for (int p = lane; p < P.nlong; p += 64) {
+                int a, b;
+                brisk_long_pair(v, P.long_pairs + 4 * p, &a, &b);
+                d0 += a;
+                d1 += b;
+              }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+              d0 += __shfl_xor(d0, off, 64);
+              d1 += __shfl_xor(d1, off, 64);
+            }
+            if (lane == kq) { md0 = d0; md1 = d1; }
+          }
+          if (estimate) {  // one fp64 atan2 for the whole run
+            const float ang = brisk_angle_from_direction(md0, md1);
+            dkp[(long)frame * kp_cap + (int)(myrec.w >> 8)].angle = ang;
+            rec[k0 + lane].z = DS_THETA_TAG | (unsigned)brisk_theta_from_angle(ang, true);
+          }
+          __builtin_amdgcn_wave_barrier();  // krec / vals are reused by the wave's next run
+        } else {
+          int theta = 0;
+          if (P.rotation_invariant)
+            theta = (myrec.z & DS_THETA_TAG) == DS_THETA_TAG ? (int)(myrec.z & 0x3FFu) : brisk_theta_from_angle(__uint_as_float(myrec.z), false);
+          if (lane < cnt) { krec[lane] = myrec; kth[lane] = theta; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          ds_pass<GENERIC>(c, true, img, rs_img, stride, cols, integ, rs_int, istride);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // bit p = values[i] > values[j], LSB first in little-endian u32 words (:538-564)
+          for (int kq = 0; kq < cnt; ++kq) {
+            const int* v = vals + kq * np;
+            const int k = (int)(__builtin_amdgcn_readfirstlane((int)krec[kq].w) >> 8);
+            unsigned long long mine = 0;
+            for (int w = 0; w < nwords; ++w) {
+              const int p = w * 64 + lane;
+              bool bit = false;
+              if (p < P.nshort) { const unsigned q = sp_s[p]; bit = v[q & 0xFFFF] > v[q >> 16]; }
+              const unsigned long long m = __ballot(bit);
+              if (lane == w) mine = m;
+            }
+            if (lane < nwords)
+              *reinterpret_cast<unsigned long long*>(desc + ((long)frame * kp_cap + k) * desc_pitch + lane * 8) = mine;
+          }
+          __builtin_amdgcn_wave_barrier();  // krec / kth / vals are reused by the wave's next run
+        }
+      }
+    }
+  }
+}
+
+static size_t describe_lds_bytes(const BriskPatternDev& P, int run, int stage) {
+  const size_t table = stage == 0 ? (P.nlong <= DS_LP_LDS ? (size_t)P.nlong * 16 : 0) : (((size_t)P.nshort * 4 + 15) & ~(size_t)15);
+  const size_t per_wave = (size_t)run * 16 + (((size_t)run * 4 + 15) & ~(size_t)15) + (((size_t)run * P.npoints * 4 + 15) & ~(size_t)15) + DS_MAXQ * 4;
+  return table + DS_WAVES * per_wave;
+}
+
+typedef void (*ds_kernel_t)(BriskGeom, BriskPatternDev, const uint8_t*, const uint32_t*, int, long, BriskFrameCounters*, BriskKeyPoint*, uint4*,
+                            uint8_t*, int, int, int);
+template <int STAGE>
+static ds_kernel_t describe_kernel(int run) {
+  return run == 8 ? k_describe<8, STAGE, false> : run == 4 ? k_describe<4, STAGE, false> : run == 2 ? k_describe<2, STAGE, false> : k_describe<1, STAGE, false>;
+}
+
+void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
+                           const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
+                           long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov) {
+  brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
+  if (!ov)
+    brisk_launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s);
+  brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
+  hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
+                     Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap);
+  // with `ov` the integral image is already running beside the detector's tail (brisk_launch_detect) and
+  // k_desc_prepare (one workgroup per frame, does not read it): join only in front of the sampling kernel
+  if (ov) (void)hipStreamWaitEvent(s, ov->join, 0);
+  brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
+  {
+    // Persistent grid: `wpc` waves per CU (the dynamic LDS request keeps the hardware from placing more workgroups on a
+    // CU than that), runs of `run` keypoints per ticket.  Test / tuning knobs: debug bits 8-11 = run, 12-15 = workgroups
+    // per CU.  Few frames: single keypoints per ticket (latency), many: runs of 4 (fewer, fuller sampling rounds).
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      (void)hipGetDevice(&dev);
+      ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    int run = (G.debug_flags >> 8) & 0xF;
+    if (!run) run = nframes >= 8 ? DS_RUN_BATCH : 1;
+    if (P.has_bilinear) run = 1;
+    const int run1 = run;
+    run = run >= 8 ? 8 : run >= 4 ? 4 : run >= 2 ? 2 : 1;
+    int bpc = (G.debug_flags >> 12) & 0xF;
+    if (!bpc) bpc = DS_BLOCKS_PER_CU;
+    for (int stage = P.rotation_invariant ? 0 : 1; stage < 2; ++stage) {
+      if (stage == 0) {  // tuning knobs of the orientation stage alone: debug bits 20-23 workgroups per CU, 24-27 run
+        if ((G.debug_flags >> 20) & 0xF) bpc = (G.debug_flags >> 20) & 0xF;
+        const int r0 = (G.debug_flags >> 24) & 0xF;
+        if (r0 && !P.has_bilinear) run = r0 >= 8 ? 8 : r0 >= 4 ? 4 : r0 >= 2 ? 2 : 1;
+      } else if (P.rotation_invariant) {
+        bpc = ((G.debug_flags >> 12) & 0xF) ? ((G.debug_flags >> 12) & 0xF) : DS_BLOCKS_PER_CU;
+        run = run1;
+      }
+      size_t lds = describe_lds_bytes(P, run, stage);
+      const size_t lds_limit = 160 * 1024 / (size_t)(bpc + 1) + 512;  // bpc + 1 workgroups of this size do not fit a CU
+      if (lds < lds_limit && bpc < 8 && !(G.debug_flags & (1 << 28))) lds = lds_limit;  // bit 28: no padding (other kernels share the CUs)
+      ds_kernel_t fn = stage == 0 ? describe_kernel<0>(run) : describe_kernel<1>(run);
+      if (P.has_bilinear) fn = stage == 0 ? k_describe<1, 0, true> : k_describe<1, 1, true>;
+      (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(fn, dim3(ncu * bpc), dim3(DS_WAVES * 64), lds, s, G, P, B.pyr, Dd.integral, Dd.istride, Dd.iframe_elems,
+                         B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, nframes);
+    }
+  }
+  brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);
+}

@@ -156,6 +156,34 @@ BRISK_HD int brisk_smoothed_intensity(const uint8_t* img, int stride, int cols, 
   return (int)acc / scaling2;
 }
 
+// Exact signed division by an invariant divisor d >= 2 (Granlund / Montgomery, "Hacker's Delight" 10-1): multiplier and
+// shift on the host, three or four integer operations per division on the device.  n / d == brisk_div_by_magic(n, M, sh)
+// for EVERY 32-bit n (C semantics: truncation toward zero), checked in tests/test_emul_parity.py.
+BRISK_HD void brisk_div_magic(int d, int* M, int* sh) {
+  const unsigned two31 = 0x80000000u;
+  const unsigned ad = (unsigned)d;
+  const unsigned t = two31;
+  const unsigned anc = t - 1 - t % ad;
+  int p = 31;
+  unsigned q1 = two31 / anc, r1 = two31 - q1 * anc, q2 = two31 / ad, r2 = two31 - q2 * ad, delta;
+  do {
+    p = p + 1;
+    q1 = 2 * q1; r1 = 2 * r1;
+    if (r1 >= anc) { q1 = q1 + 1; r1 = r1 - anc; }
+    q2 = 2 * q2; r2 = 2 * r2;
+    if (r2 >= ad) { q2 = q2 + 1; r2 = r2 - ad; }
+    delta = ad - r2;
+  } while (q1 < delta || (q1 == delta && r1 == 0));
+  *M = (int)(q2 + 1);
+  *sh = p - 32;
+}
+BRISK_HD int brisk_div_by_magic(int n, int M, int sh) {
+  int q = (int)(((long long)M * (long long)n) >> 32);
+  if (M < 0) q += n;
+  q >>= sh;
+  return q + (int)((unsigned)q >> 31);
+}
+
 // long-pair contribution (:721-730): C integer division truncates toward zero
 BRISK_HD void brisk_long_pair(const int* values, const int* lp /* i, j, wdx, wdy */, int* d0, int* d1) {
   const int delta_t = values[lp[0]] - values[lp[1]];

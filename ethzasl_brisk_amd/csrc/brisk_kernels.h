@@ -85,6 +85,9 @@ void brisk_launch_compute_scale(const BriskGeom& G, const BriskDetectBuffers& B,
 // only stages layer 0 (descriptor-only calls)
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,
                               long frame_pitch, int row_pitch, hipStream_t s);
+// integral image of layer 0 from the band sums the pyramid kernel left (brisk_kernels.hip)
+void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
+                           long iframe_elems, int band_h, int nframes, hipStream_t s);
 // kp_in: [slots][kp_cap]; n_in: per-frame counts at byte stride n_in_stride
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,

@@ -19,7 +19,6 @@
 #include <stdlib.h>
 
 #include "brisk_common.h"
-#include "brisk_device_describe.h"
 #include "brisk_device_detect.h"
 #include "brisk_kernels.h"
 
@@ -1673,7 +1672,7 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
   }
 }
 
-static void launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
+void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
                             long iframe_elems, int band_h, int nframes, hipStream_t s) {
   const int nbands = (G.L[0].h + band_h - 1) / band_h;
   const int nchunks = (G.L[0].w + 1 + II_CHUNK - 1) / II_CHUNK;
@@ -1682,339 +1681,6 @@ static void launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32
   if (nchunks <= 1) hipLaunchKernelGGL(k_integral_final<1>, grid, block, pad_lds, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
   else if (nchunks == 2) hipLaunchKernelGGL(k_integral_final<2>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
   else hipLaunchKernelGGL(k_integral_final<II_MAXCHUNKS>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
-}
-
-// ------------------------------------------------------------------------------------------------
-#define DP_MAXSORT 4096
-#ifndef DP_THREADS
-#define DP_THREADS 1024
-#endif
-// k_desc_prepare: per frame, scale index + border filter (brisk-descriptor-extractor.cc:636-662),
-// stable compaction into dkp (keypoints) / dscale.  One workgroup per frame.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
-                                                       const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
-                                                       BriskKeyPoint* dkp, int* dscale, int* dperm, uint4* drec, int kp_cap) {
-  __shared__ int wtot[DP_THREADS / 64];
-  __shared__ int base;
-  __shared__ __attribute__((aligned(16))) unsigned pkey[DP_MAXSORT + 4];
-  const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
-  const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;
-  if (tid == 0) base = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
-    const int i = i0 + tid;
-    bool keep = false;
-    int sc = 0;
-    BriskKeyPoint kp;
-    if (i < n) {
-      kp = K[i];
-      sc = brisk_scale_index(P, kp.size);
-      keep = brisk_inside_border(P, sc, kp.x, kp.y, G.L[0].w, G.L[0].h);
-    }
-    // stable compaction: position = kept keypoints before this one (ballots inside the wave, wave totals through LDS)
-    const unsigned long long bal = __ballot(keep);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wtot[wave] = __popcll(bal);
-    __syncthreads();
-    int wbase = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < DP_THREADS / 64; ++k) {
-      const int t = wtot[k];
-      wbase += (k < wave) ? t : 0;
-      total += t;
-    }
-    if (keep) {
-      const int j = base + wbase + before;
-      dkp[(long)frame * kp_cap + j] = kp;
-      dscale[(long)frame * kp_cap + j] = sc;
-      if (j < DP_MAXSORT)
-        pkey[j] = ((unsigned)((int)kp.y >> 6) << 24) | ((unsigned)((int)kp.x & 0x1FFF) << 11) | (unsigned)(j & 0x7FF);
-    }
-    __syncthreads();
-    if (tid == 0) base += total;
-    __syncthreads();
-  }
-  if (tid == 0) counters[frame].ndesc = base;
-  // Processing order for k_describe: keypoints sorted by 64-row band, then x, so that keypoints sampled at the
-  // same time touch the same part of the integral image (the output order stays (layer, y, x)).
-  const int m = base;
-  int* perm = dperm + (long)frame * kp_cap;
-  if (m <= DP_MAXSORT) {
-    if (tid < 4) pkey[m + tid] = 0xFFFFFFFFu;  // the count below reads four keys at a time
-    __syncthreads();
-    for (int j = tid; j < m; j += DP_THREADS) {
-      const unsigned kj = pkey[j];
-      int r = 0;
-      if (m <= 2048) {  // the keys carry j: all different
-        for (int q = 0; q < m; q += 4) {
-          const uint4 kk = *reinterpret_cast<const uint4*>(&pkey[q]);
-          r += (kk.x < kj ? 1 : 0) + (kk.y < kj ? 1 : 0) + (kk.z < kj ? 1 : 0) + (kk.w < kj ? 1 : 0);
-        }
-      } else {
-        for (int q = 0; q < m; ++q) r += (pkey[q] < kj || (pkey[q] == kj && q < j)) ? 1 : 0;
-      }
-      perm[r] = j;
-    }
-  } else {
-    for (int j = tid; j < m; j += DP_THREADS) perm[j] = j;
-  }
-  // the keypoints again, in processing order, as one 16-byte record each: k_describe reads them with a single
-  // (prefetchable) load instead of the dependent chain order -> keypoint -> scale
-  __syncthreads();
-  for (int r = tid; r < m; r += DP_THREADS) {
-    const int j = perm[r];
-    const BriskKeyPoint& q = dkp[(long)frame * kp_cap + j];
-    drec[(long)frame * kp_cap + r] = make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.angle),
-                                                 (unsigned)dscale[(long)frame * kp_cap + j] | ((unsigned)j << 8));
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_describe: one WAVE per keypoint (4 waves per workgroup, wave-strided over the frame's keypoints), no
-// workgroup barriers.  Lane i samples pattern point i (points 64.. take a second round), the long pairs are
-// reduced with integer wave reductions (order independent), the short-pair bits are packed with 64-wide ballots.
-// ------------------------------------------------------------------------------------------------
-#ifndef DS_WAVES
-#define DS_WAVES 4
-#endif
-#define DS_LP_LDS 1024
-
-// ---- SmoothedIntensity split into address / load / combine stages (device only; the arithmetic is that of
-// brisk_smoothed_intensity in brisk_device_describe.h, box branch), so that the gathers of a lane's two pattern
-// points are in flight together and nothing but the gathers sits between a keypoint and its bits.
-struct DsTab {  // scale-dependent part of a pattern point (prefetched one keypoint ahead)
-  float mult, sigma;
-  int scaling, scaling2;
-};
-__device__ __forceinline__ DsTab ds_tab(const BriskPatternDev& P, int scale, int i) {
-  const int si = scale * P.npoints + i;
-  DsTab t;
-  t.mult = P.mult[si];
-  t.sigma = P.sigma[si];
-  const int2 sc = *reinterpret_cast<const int2*>(P.scaling + 2 * si);
-  t.scaling = sc.x; t.scaling2 = sc.y;
-  return t;
-}
-__device__ __forceinline__ BriskSamplePoint ds_point(const DsTab& t, double ux, double uy) {
-  BriskSamplePoint sp;
-  const double m = (double)t.mult;
-  sp.x = (float)(m * ux);
-  sp.y = (float)(m * uy);
-  sp.sigma = t.sigma; sp.scaling = t.scaling; sp.scaling2 = t.scaling2;
-  return sp;
-}
-struct DsPrep {
-  int x_left, y_top, x_right, y_bottom;
-  unsigned A, B, C, D, r_x_1_i, r_y_1_i, r_x1_i, r_y1_i;
-  int scaling, scaling2;
-  bool quirk;
-};
-typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) ds_u32x2;
-struct DsRaw {
-  ds_u32x2 p00, p02, p10, p12, p20, p22, p30, p32;
-  unsigned br, bl;
-};
-// valid == false: a harmless sample at the image origin (the value is discarded)
-__device__ __forceinline__ DsPrep ds_prep(float key_x, float key_y, const BriskSamplePoint& sp, bool valid) {
-  DsPrep p;
-  const float sigma_half = valid ? sp.sigma : 1.0f;
-  const float xf = valid ? sp.x + key_x : 2.0f;
-  const float yf = valid ? sp.y + key_y : 2.0f;
-  p.scaling = sp.scaling; p.scaling2 = valid ? sp.scaling2 : 1;
-  const float x_1 = xf - sigma_half, x1 = xf + sigma_half, y_1 = yf - sigma_half, y1 = yf + sigma_half;
-  p.x_left = (int)(x_1 + 0.5); p.y_top = (int)(y_1 + 0.5); p.x_right = (int)(x1 + 0.5); p.y_bottom = (int)(y1 + 0.5);
-  const float r_x_1 = (float)((float)p.x_left - x_1 + 0.5);
-  const float r_y_1 = (float)((float)p.y_top - y_1 + 0.5);
-  const float r_x1 = (float)(x1 - (float)p.x_right + 0.5);
-  const float r_y1 = (float)(y1 - (float)p.y_bottom + 0.5);
-  const int dx = p.x_right - p.x_left - 1, dy = p.y_bottom - p.y_top - 1;
-  const int scaling = sp.scaling;
-  p.A = (unsigned)(int)((r_x_1 * r_y_1) * scaling);
-  p.B = (unsigned)(int)((r_x1 * r_y_1) * scaling);
-  p.C = (unsigned)(int)((r_x1 * r_y1) * scaling);
-  p.D = (unsigned)(int)((r_x_1 * r_y1) * scaling);
-  p.r_x_1_i = (unsigned)(int)(r_x_1 * scaling);
-  p.r_y_1_i = (unsigned)(int)(r_y_1 * scaling);
-  p.r_x1_i = (unsigned)(int)(r_x1 * scaling);
-  p.r_y1_i = (unsigned)(int)(r_y1 * scaling);
-  p.quirk = (dx + dy > 2);
-  return p;
-}
-__device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, const uint8_t* __restrict__ img, int stride, int cols,
-                                        const uint32_t* __restrict__ integral, int istride) {
-  const uint32_t* r0 = integral + (long)p.y_top * istride;
-  const uint32_t* r1 = r0 + istride;
-  const uint32_t* r2 = integral + (long)p.y_bottom * istride;
-  const uint32_t* r3 = r2 + istride;
-#define DS_GATHER(ptr) (*reinterpret_cast<const ds_u32x2*>(ptr))
-  r.p00 = DS_GATHER(r0 + p.x_left); r.p02 = DS_GATHER(r0 + p.x_right);
-  r.p10 = DS_GATHER(r1 + p.x_left); r.p12 = DS_GATHER(r1 + p.x_right);
-  r.p20 = DS_GATHER(r2 + p.x_left); r.p22 = DS_GATHER(r2 + p.x_right);
-  r.p30 = DS_GATHER(r3 + p.x_left); r.p32 = DS_GATHER(r3 + p.x_right);
-  // displaced bottom corners of the reference quirk (brisk-descriptor-extractor.cc:453); unconditional loads on a
-  // valid address, used only when the quirk applies
-  // (linear addressing of the reference: a box that ends in the last column reads the first pixel of the next row)
-  const int qy = max(p.y_bottom - 1, 0);
-  r.br = brisk_linear_px(img, stride, cols, p.x_right + 1, qy);
-  r.bl = brisk_linear_px(img, stride, cols, p.x_left + 1, qy);
-}
-__device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
-  const uint32_t i00 = r.p00.x, i01 = r.p00.y, i02 = r.p02.x, i03 = r.p02.y;
-  const uint32_t i10 = r.p10.x, i11 = r.p10.y, i12 = r.p12.x, i13 = r.p12.y;
-  const uint32_t i20 = r.p20.x, i21 = r.p20.y, i22 = r.p22.x, i23 = r.p22.y;
-  const uint32_t i30 = r.p30.x, i31 = r.p30.y, i32 = r.p32.x, i33 = r.p32.y;
-  const unsigned tl = i11 - i01 - i10 + i00;  // pixel (x_left, y_top)
-  const unsigned tr = i13 - i03 - i12 + i02;  // pixel (x_right, y_top)
-  const unsigned br = p.quirk ? r.br : (i33 - i23 - i32 + i22);
-  const unsigned bl = p.quirk ? r.bl : (i31 - i21 - i30 + i20);
-  const uint32_t top = i12 - i11 - i02 + i01;
-  const uint32_t bottom = i32 - i31 - i22 + i21;
-  const uint32_t left = i21 - i20 - i11 + i10;
-  const uint32_t right = i23 - i22 - i13 + i12;
-  const uint32_t middle = i22 - i21 - i12 + i11;
-  const uint32_t acc = p.A * tl + p.B * tr + p.C * br + p.D * bl + p.r_y_1_i * top + p.r_y1_i * bottom + p.r_x_1_i * left +
-                       p.r_x1_i * right + (unsigned)p.scaling * middle;
-  return (int)acc / p.scaling2;
-}
-
-// smoothed intensities of the lane's two pattern points (i0 = lane, i1 = lane + 64) into values[]
-__device__ __forceinline__ void ds_sample_pass(int* values, const uint8_t* __restrict__ img, int stride, int cols,
-                                               const uint32_t* __restrict__ integ, int istride, float kx, float ky,
-                                               const BriskSamplePoint& sa, const BriskSamplePoint& sb, bool va, bool vb,
-                                               int i0, int i1) {
-  if (__any((va && sa.sigma < 0.5f) || (vb && sb.sigma < 0.5f))) {  // bilinear branch of some point (:391-408): rare
-    if (va) values[i0] = brisk_smoothed_intensity(img, stride, cols, integ, istride, kx, ky, sa);
-    if (vb) values[i1] = brisk_smoothed_intensity(img, stride, cols, integ, istride, kx, ky, sb);
-    return;
-  }
-  const DsPrep pa = ds_prep(kx, ky, sa, va), pb = ds_prep(kx, ky, sb, vb);
-  DsRaw ra, rb;
-  ds_load(ra, pa, img, stride, cols, integ, istride);
-  ds_load(rb, pb, img, stride, cols, integ, istride);
-  const int xa = ds_combine(pa, ra), xb = ds_combine(pb, rb);
-  if (va) values[i0] = xa;
-  if (vb) values[i1] = xb;
-}
-
-__global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
-                                                            const uint32_t* __restrict__ integral, int istride,
-                                                            long iframe_elems, const BriskFrameCounters* counters,
-                                                            BriskKeyPoint* dkp, const uint4* __restrict__ drec,
-                                                            uint8_t* desc, int kp_cap, int desc_pitch, int bpf, int nframes) {
-  __shared__ int values_s[DS_WAVES][BRISK_MAX_POINTS];
-  __shared__ int4 lp_s[DS_LP_LDS];                 // long pairs {i, j, wdx, wdy}
-  __shared__ unsigned sp_s[BRISK_MAX_SHORT];       // short pairs i | j << 16
-  // the pair tables are read once per keypoint by every wave: keep them in LDS for the block's lifetime
-  const bool lp_in_lds = P.nlong <= DS_LP_LDS;
-  if (lp_in_lds)
-    for (int p = threadIdx.x; p < P.nlong; p += DS_WAVES * 64) lp_s[p] = reinterpret_cast<const int4*>(P.long_pairs)[p];
-  for (int p = threadIdx.x; p < P.nshort; p += DS_WAVES * 64) sp_s[p] = (unsigned)P.short_pairs[2 * p] | ((unsigned)P.short_pairs[2 * p + 1] << 16);
-  __syncthreads();
-  // 1-D grid of bpf blocks per frame.  All blocks of a frame get the same blockIdx.x % 8, i.e. the same XCD: a
-  // frame's integral image (8.3 MB @1080p, gathered ~16 times per 128-B line) then lives in ONE L2 while the frame
-  // is being described instead of being pulled through all eight.
-  // (with fewer than 8 frames the affinity would leave XCDs idle: blocks of a frame are then spread over all of them)
-  int frame, block_in_frame;
-  if (nframes >= 8) {
-    const int xcd = blockIdx.x & 7;
-    const int jj = blockIdx.x >> 3;
-    frame = (jj / bpf) * 8 + xcd;
-    block_in_frame = jj % bpf;
-  } else {
-    frame = blockIdx.x / bpf;
-    block_in_frame = blockIdx.x % bpf;
-  }
-  if (frame >= nframes) return;
-  // last frames first: the integral images are written in frame order just before, so the last ones are the ones
-  // still held by the Infinity Cache when this kernel starts (measured: 0.8 % of the kernel's time)
-  frame = nframes - 1 - frame;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int* values = values_s[wave];
-  const int n = counters[frame].ndesc;
-  const uint8_t* img = brisk_layer_img(G, pyr, frame, 0);
-  const int stride = G.L[0].stride;
-  const uint32_t* integ = integral + (long)frame * iframe_elems;
-  const uint4* rec = drec + (long)frame * kp_cap;
-  const int np = P.npoints;
-  const int i0 = lane, i1 = lane + 64;
-  const bool va = i0 < np, vb = i1 < np;
-  const int i0c = min(i0, np - 1), i1c = min(i1, np - 1);
-  // unrotated pattern offsets of this lane's points: the same for every keypoint's orientation pass
-  const double2 uv0a = reinterpret_cast<const double2*>(P.uv)[i0c], uv0b = reinterpret_cast<const double2*>(P.uv)[i1c];
-  // Software pipeline over the wave's keypoints: the record of keypoint j+2 and the scale-dependent pattern columns of
-  // keypoint j+1 are loaded while keypoint j is sampled, so a keypoint's critical path is
-  //   gathers (orientation) -> rotated offsets uv[theta] -> gathers (descriptor)      : three memory round trips.
-  const int step = bpf * DS_WAVES;
-  int jp = block_in_frame * DS_WAVES + wave;
-  if (jp >= n) return;
-  uint4 rc = rec[jp];
-  uint4 rn = rec[min(jp + step, n - 1)];
-  DsTab ta = ds_tab(P, (int)(rc.w & 0xFF), i0c), tb = ds_tab(P, (int)(rc.w & 0xFF), i1c);
-  for (; jp < n; jp += step) {
-    const uint4 rn2 = rec[min(jp + 2 * step, n - 1)];
-    const DsTab tna = ds_tab(P, (int)(rn.w & 0xFF), i0c), tnb = ds_tab(P, (int)(rn.w & 0xFF), i1c);
-    const int k = (int)(rc.w >> 8);
-    const float kx = __uint_as_float(rc.x), ky = __uint_as_float(rc.y), kangle = __uint_as_float(rc.z);
-    int theta = 0;
-    if (P.rotation_invariant) {
-      if (kangle == -1.0f) {
-        ds_sample_pass(values, img, stride, G.L[0].w, integ, istride, kx, ky, ds_point(ta, uv0a.x, uv0a.y), ds_point(tb, uv0b.x, uv0b.y),
-                       va, vb, i0, i1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int d0 = 0, d1 = 0;
-        if (lp_in_lds) {
-          for (int p = lane; p < P.nlong; p += 64) {
-            const int4 q = lp_s[p];
-            const int delta_t = values[q.x] - values[q.y];
-            d0 += delta_t * q.z / 1024;
-            d1 += delta_t * q.w / 1024;
-          }
-        } else {
-          for (int p = lane; p < P.nlong; p += 64) {
-            int a, b;
-            brisk_long_pair(values, P.long_pairs + 4 * p, &a, &b);
-            d0 += a;
-            d1 += b;
-          }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-          d0 += __shfl_xor(d0, off, 64);
-          d1 += __shfl_xor(d1, off, 64);
-        }
-        const float ang = brisk_angle_from_direction(d0, d1);  // every lane, same value
-        if (lane == 0) dkp[(long)frame * kp_cap + k].angle = ang;
-        theta = brisk_theta_from_angle(ang, true);
-        __builtin_amdgcn_wave_barrier();
-      } else {
-        theta = brisk_theta_from_angle(kangle, false);
-      }
-    }
-    {
-      const double2* uvt = reinterpret_cast<const double2*>(P.uv) + (long)theta * np;
-      const double2 ua = uvt[i0c], ub = uvt[i1c];
-      ds_sample_pass(values, img, stride, G.L[0].w, integ, istride, kx, ky, ds_point(ta, ua.x, ua.y), ds_point(tb, ub.x, ub.y), va, vb,
-                     i0, i1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // bit p = values[i] > values[j], LSB first in little-endian u32 words (:538-564)
-    uint8_t* drow = desc + ((long)frame * kp_cap + k) * desc_pitch;
-    const int nbits = P.strings * 8;
-    for (int p0 = 0; p0 < nbits; p0 += 64) {
-      const int p = p0 + lane;
-      bool bit = false;
-      if (p < P.nshort) { const unsigned q = sp_s[p]; bit = values[q & 0xFFFF] > values[q >> 16]; }
-      const unsigned long long m = __ballot(bit);
-      if (lane == 0) *reinterpret_cast<unsigned long long*>(drow + p0 / 8) = m;
-    }
-    __builtin_amdgcn_wave_barrier();  // values[] is reused by the wave's next keypoint
-    rc = rn; rn = rn2; ta = tna; tb = tnb;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2124,7 +1790,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     (void)hipEventRecord(ov->fork, s);
     (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
     brisk_prof_mark_side(prof, 0, ov->side);
-    launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, B.band_h, nframes, ov->side);
+    brisk_launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, B.band_h, nframes, ov->side);
     brisk_prof_mark_side(prof, 1, ov->side);
     (void)hipEventRecord(ov->join, ov->side);
   };
@@ -2202,26 +1868,3 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
                      etx, ety, B.bandsum, B.istride);
 }
 
-void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
-                           const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
-                           long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov) {
-  brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
-  if (!ov)
-    launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s);
-  brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
-  hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
-                     Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap);
-  // with `ov` the integral image is already running beside the detector's tail (brisk_launch_detect) and
-  // k_desc_prepare (one workgroup per frame, does not read it): join only in front of the sampling kernel
-  if (ov) (void)hipStreamWaitEvent(s, ov->join, 0);
-  brisk_prof_mark(prof, BRISK_STG_DESCRIBE, s);
-  {
-    // blocks per frame (test knob: debug bits 8-15, x8); small batches get enough blocks to cover all CUs
-    const int bpf = ((G.debug_flags >> 8) & 0xFF) ? (((G.debug_flags >> 8) & 0xFF) * 8) : (nframes >= 8 ? 128 : 1024 / nframes);
-    const int groups = (nframes + 7) / 8;
-    const int nblocks = nframes >= 8 ? groups * 8 * bpf : nframes * bpf;
-    hipLaunchKernelGGL(k_describe, dim3(nblocks), dim3(DS_WAVES * 64), 0, s, G, P, B.pyr, Dd.integral, Dd.istride,
-                       Dd.iframe_elems, B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, bpf, nframes);
-  }
-  brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);
-}

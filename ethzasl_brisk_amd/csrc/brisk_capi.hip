@@ -349,6 +349,9 @@ static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
   d.npoints = H.npoints; d.nshort = H.nshort; d.nlong = H.nlong; d.strings = H.strings;
   d.rotation_invariant = 1; d.scale_invariant = 1; d.basicscale = H.basicscale;
   d.has_bilinear = 0;
+  d.reg_tables = (H.nlong <= 896 && H.nshort <= 512 && H.npoints <= 128) ? 1 : 0;
+  for (int i = 0; i < H.nlong; ++i)
+    if (H.long_pairs[4 * i + 2] < -32768 || H.long_pairs[4 * i + 2] > 32767 || H.long_pairs[4 * i + 3] < -32768 || H.long_pairs[4 * i + 3] > 32767) d.reg_tables = 0;
   for (float sg : H.sigma) d.has_bilinear |= (sg < 0.5f) ? 1 : 0;
   d.mult = (const float*)(b + o_mult); d.sigma = (const float*)(b + o_sigma); d.uv = (const double*)(b + o_uv);
   d.scaling = (const int*)(b + o_scl);
@@ -1237,7 +1240,8 @@ int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlaye
   out[0] = c.ncand; out[1] = c.nkp; out[2] = c.ndesc; out[3] = c.overflow;
   *nlayers = ctx->G.nlayers;
   for (int l = 0; l < ctx->G.nlayers; ++l) out[4 + l] = c.ntie[l];
-  for (int i = 0; i < 6; ++i) out[20 + i] = c.pad[i];
+  for (int i = 0; i < 5; ++i) out[20 + i] = c.pad[i];
+  out[25] = c.nestimate;
   out[26] = c.orient_ticket; out[27] = c.desc_ticket;
   return BRISK_HIP_OK;
 }

@@ -106,13 +106,15 @@ struct BriskFrameCounters {
   int tie_ticket;                   // k_tie_resolve: work tickets (entry xcd of the batch, or entry 0 for fewer than 8 frames)
   int tie_prog[BRISK_MAX_LAYERS];   // k_tie_resolve: rows of layer l whose ties are decided and whose touches are performed
   int orient_ticket, desc_ticket;   // k_describe (stage 0 / 1): next run of keypoints (in processing order) to be handed out
-  int pad[6];
+  int nestimate;                    // kept keypoints that came without an angle (k_describe stage 0 skips frames that have none)
+  int pad[5];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)
 struct BriskPatternDev {
   int npoints, nshort, nlong, strings;   // strings = descriptor bytes (48 / 64)
   int rotation_invariant, scale_invariant, basicscale;
+  int reg_tables;         // at most 896 long pairs with 16-bit weights, at most 512 short pairs, at most 128 points: k_describe keeps the pair tables in registers
   int has_bilinear;       // some (scale, point) has sigma < 0.5: SmoothedIntensity's bilinear branch (:391-408) is reachable
   const float* mult;      // [64][npoints]  multiplier m so that x = (float)((double)m * U)
   const float* sigma;     // [64][npoints]  box half side

@@ -17,16 +17,40 @@
 // k_desc_prepare: per frame, scale index + border filter (brisk-descriptor-extractor.cc:636-662),
 // stable compaction into dkp (keypoints) / dscale.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------------
+// Sort key of the processing order (spatial locality of the keypoints that k_describe has in flight together); the
+// low 11 bits carry the keypoint's index so that up to 2048 keys are all different.  mode (experiments, debug bits 4-7):
+// 0 = 64-row bands, x inside a band; 1 = Hilbert curve over 64 x 64 pixel tiles; 2 / 3 = bands of 128 / 32 rows;
+// 4 = scale class (index >> 4) first, then 64-row bands
+__device__ __forceinline__ unsigned dp_order_key(int x, int y, int sc, int j, int mode) {
+  const unsigned low = (unsigned)(j & 0x7FF);
+  if (mode == 1) {
+    unsigned tx = (unsigned)x >> 6, ty = (unsigned)y >> 6, d = 0;
+    for (unsigned s = 64; s > 0; s >>= 1) {  // 128 x 128 tiles cover the engine's 8191-pixel limit
+      const unsigned rx = (tx & s) ? 1u : 0u, ry = (ty & s) ? 1u : 0u;
+      d += s * s * ((3u * rx) ^ ry);
+      if (ry == 0) {
+        if (rx == 1) { tx = 127u - tx; ty = 127u - ty; }
+        const unsigned t = tx; tx = ty; ty = t;
+      }
+    }
+    return (d << 18) | (((unsigned)x & 63u) << 12) | low;
+  }
+  if (mode == 2) return ((unsigned)(y >> 7) << 24) | (((unsigned)x & 0x1FFFu) << 11) | low;
+  if (mode == 3) return ((unsigned)(y >> 5) << 24) | (((unsigned)x & 0x1FFFu) << 11) | low;
+  if (mode == 4) return ((unsigned)(sc >> 4) << 30) | (((unsigned)(y >> 6) & 0x7Fu) << 23) | ((((unsigned)x >> 1) & 0xFFFu) << 11) | low;
+  return ((unsigned)(y >> 6) << 24) | (((unsigned)x & 0x1FFFu) << 11) | low;
+}
+
 __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
                                                        const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
                                                        BriskKeyPoint* dkp, int* dscale, int* dperm, uint4* drec, int kp_cap) {
   __shared__ int wtot[DP_THREADS / 64];
-  __shared__ int base;
+  __shared__ int base, nest;
   __shared__ __attribute__((aligned(16))) unsigned pkey[DP_MAXSORT + 4];
   const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
   const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;
-  if (tid == 0) base = 0;
+  if (tid == 0) { base = 0; nest = 0; }
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
     const int i = i0 + tid;
@@ -42,6 +66,8 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
     const unsigned long long bal = __ballot(keep);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) wtot[wave] = __popcll(bal);
+    const unsigned long long bal_e = __ballot(keep && kp.angle == -1.0f);  // keypoints whose orientation has to be estimated
+    if (lane == 0 && bal_e) atomicAdd(&nest, __popcll(bal_e));
     __syncthreads();
     int wbase = 0, total = 0;
 #pragma unroll
@@ -54,14 +80,13 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
       const int j = base + wbase + before;
       dkp[(long)frame * kp_cap + j] = kp;
       dscale[(long)frame * kp_cap + j] = sc;
-      if (j < DP_MAXSORT)
-        pkey[j] = ((unsigned)((int)kp.y >> 6) << 24) | ((unsigned)((int)kp.x & 0x1FFF) << 11) | (unsigned)(j & 0x7FF);
+      if (j < DP_MAXSORT) pkey[j] = dp_order_key((int)kp.x, (int)kp.y, sc, j, (G.debug_flags >> 4) & 0xF);
     }
     __syncthreads();
     if (tid == 0) base += total;
     __syncthreads();
   }
-  if (tid == 0) { counters[frame].ndesc = base; counters[frame].desc_ticket = 0; counters[frame].orient_ticket = 0; }
+  if (tid == 0) { counters[frame].ndesc = base; counters[frame].nestimate = nest; counters[frame].desc_ticket = 0; counters[frame].orient_ticket = 0; }
   // Processing order for k_describe: keypoints sorted by 64-row band, then x, so that keypoints sampled at the
   // same time touch the same part of the integral image (the output order stays (layer, y, x)).
   const int m = base;
@@ -114,17 +139,19 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
 // in flight.  Long pairs: integer wave reductions (order independent); bits: 64-wide ballots.
 // ------------------------------------------------------------------------------------------------
 #ifndef DS_WAVES
-#define DS_WAVES 4
+#define DS_WAVES 2
 #endif
 #define DS_MAXRUN 8
 #define DS_MAXQ 256        // frames per work queue (more frames per launch: more queues)
 #ifndef DS_RUN_BATCH
-#define DS_RUN_BATCH 4   // keypoints per ticket in batches of >= 8 frames
+#define DS_RUN_BATCH 2   // keypoints per ticket in batches of >= 8 frames
 #endif
 #ifndef DS_BLOCKS_PER_CU
 #define DS_BLOCKS_PER_CU 3
 #endif
 #define DS_LP_LDS 1024
+#define DS_REG_LONG 14   // long pairs per lane held in registers (REGTAB): 896 pairs
+#define DS_REG_SHORT 8   // short pairs per lane: 512 bits
 #define DS_GETREG_XCC_ID (20 | (3 << 11))  // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
 
 typedef uint32_t __attribute__((ext_vector_type(2))) ds_u32x2;
@@ -213,106 +240,144 @@ __device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
   if (__any(p.shift < 0)) return p.shift < 0 ? (int)acc / p.magic : brisk_div_by_magic((int)acc, p.magic, p.shift);
   return brisk_div_by_magic((int)acc, p.magic, p.shift);
 }
-struct DsWaveCtx {
-  const BriskPatternDev* P;
-  const uint4* krec;   // LDS: the run's keypoint records {x, y, angle (float bits), scale | index << 8}
-  const int* kth;      // LDS: rotation index of each keypoint of the run
-  int* vals;           // LDS: [RUN][npoints] smoothed intensities
-  int np, total;       // pattern points, samples of this run
-  unsigned inv20;      // (1 << 20) / np + 1: s / np == (s * inv20) >> 20 for s < 2048
-  int lane;
-};
-// parameters of sample s (clamped to the run's last sample: surplus lanes repeat it and are masked at the loads)
-__device__ __forceinline__ DsLane ds_fetch(const DsWaveCtx& c, int s, bool rotated) {
-  DsLane L;
-  const int sc = min(s, c.total - 1);
-  const int kq = (int)(((unsigned)sc * c.inv20) >> 20);
-  const int pt = sc - kq * c.np;
-  const uint4 rec = c.krec[kq];
-  const int theta = rotated ? c.kth[kq] : 0;
-  L.kx = __uint_as_float(rec.x); L.ky = __uint_as_float(rec.y);
-  L.ti = (int)(rec.w & 0xFF) * c.np + pt;
-  L.tab = reinterpret_cast<const int4*>(c.P->tab)[L.ti];
-  L.uv = reinterpret_cast<const double2*>(c.P->uv)[theta * c.np + pt];
-  L.slot = sc;
-  return L;
-}
-// one sampling pass over the run: every sample's smoothed intensity into vals[]
+// one sample: address stage + gathers (issue), and its combine stage
 // GENERIC: the pattern has points on the bilinear branch of SmoothedIntensity (sigma < 0.5, :391-408; only with a small
 // patternScale): every sample through the generic function of brisk_device_describe.h
-template <bool GENERIC>
-__device__ __forceinline__ void ds_pass(const DsWaveCtx& c, bool rotated, const uint8_t* __restrict__ img, __amdgpu_buffer_rsrc_t rs_img,
-                                        int stride, int cols, const uint32_t* __restrict__ integ, __amdgpu_buffer_rsrc_t rs_int,
-                                        int istride) {
-  DsLane cur = ds_fetch(c, c.lane, rotated);
-  for (int s0 = 0; s0 < c.total; s0 += 64) {
-    DsLane nxt = cur;
-    if (s0 + 64 < c.total) nxt = ds_fetch(c, s0 + 64 + c.lane, rotated);
-    const bool valid = s0 + c.lane < c.total;
-    const double m = (double)__int_as_float(cur.tab.x);
-    const float sigma = __int_as_float(cur.tab.y);
-    const float xf = (float)(m * cur.uv.x) + cur.kx, yf = (float)(m * cur.uv.y) + cur.ky;
-    int value;
-    if (GENERIC) {
-      BriskSamplePoint sp;
-      sp.x = (float)(m * cur.uv.x); sp.y = (float)(m * cur.uv.y); sp.sigma = sigma;
-      sp.scaling = c.P->scaling[2 * cur.ti]; sp.scaling2 = c.P->scaling[2 * cur.ti + 1];
-      value = valid ? brisk_smoothed_intensity(img, stride, cols, integ, istride, cur.kx, cur.ky, sp) : 0;
-    } else {
-      const DsPrep p = ds_prep(xf, yf, sigma, cur.tab.z, cur.tab.w);
-      DsRaw r;
-      if (valid) ds_load(r, p, rs_img, stride, cols, rs_int, istride);
-      value = ds_combine(p, r);
-    }
-    if (valid) c.vals[cur.slot] = value;
-    cur = nxt;
-  }
-}
+struct DsFrame {  // wave-uniform: the frame a ticket belongs to
+  const uint8_t* img;
+  const uint32_t* integ;
+  __amdgpu_buffer_rsrc_t rs_img, rs_int;
+};
+struct DsTicket {  // wave-uniform
+  int frame, k0, cnt, total;
+  bool ok;
+};
 
-// rec.z of a keypoint whose orientation was estimated by the first stage: a negative quiet NaN that carries the rotation
-// index (the keypoint's angle itself goes to dkp[].angle); any other value is the angle the caller provided
-#define DS_THETA_TAG 0xFFC00000u
-
-// STAGE 0: orientation of the keypoints that have none (angle == -1): unrotated pattern, long pairs, atan2.
-// STAGE 1: rotated pattern, short-pair bits.
-// Two launches of the same persistent structure: each stage's ticket is a short chain (records -> parameters -> gathers
-// -> LDS -> result), the fp64 atan2 (38 VGPRs on top of everything live around it) stays out of the stage that does most
-// of the sampling, and the keypoints in flight on an XCD at any time are one contiguous stretch of the processing order.
-template <int RUN, int STAGE, bool GENERIC>
+// One persistent launch.  What the vector memory path delivers depends on how many of the gathered lines are L2 hits
+// (profiles/r03_microbench_describe_shape*: 53 samples/ns chip-wide at 99 % hits, 23 at 52 %, HBM misses cost twice
+// what Infinity Cache misses cost): a keypoint's two passes run back to back in one wave (they sample the same patch: a
+// two-launch split doubles the compulsory misses - measured, and in tools/cache_sim.py), the keypoints an XCD has in
+// flight are one contiguous stretch of the spatial processing order, tickets are taken two runs ahead and the next
+// run's records are requested before the current run's gathers.
+template <int RUN, bool GENERIC, bool REGTAB>
 __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
                                                             const uint32_t* __restrict__ integral, int istride,
                                                             long iframe_elems, BriskFrameCounters* counters,
                                                             BriskKeyPoint* dkp, uint4* __restrict__ drec,
                                                             uint8_t* desc, int kp_cap, int desc_pitch, int nframes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ds_lds[];
-  // LDS: long pairs {i, j, wdx, wdy} (stage 0) or short pairs i | j << 16 (stage 1) | per wave: records, rotations, values
+  // LDS: long pairs {i, j, wdx, wdy} | short pairs i | j << 16 | per wave: records and rotations of a run, values, the
+  // work queue's cumulative run / keypoint counts
   const int np = P.npoints;
-  const bool lp_in_lds = P.nlong <= DS_LP_LDS;
+  // REGTAB (at most 896 long pairs with 16-bit weights, at most 512 short pairs - the built-in patterns): every lane
+  // keeps ITS pairs in registers for the kernel's lifetime (pair p belongs to lane p % 64), so a keypoint's long-pair sum
+  // is 28 independent LDS reads + arithmetic instead of 14 dependent table -> values round trips.  Otherwise the tables
+  // live in LDS (long pairs beyond DS_LP_LDS: in global memory).
+  const bool lp_in_lds = !REGTAB && P.nlong <= DS_LP_LDS;
   int4* lp_s = reinterpret_cast<int4*>(ds_lds);
-  unsigned* sp_s = reinterpret_cast<unsigned*>(ds_lds);
+  unsigned* sp_s = reinterpret_cast<unsigned*>(lp_s + (lp_in_lds ? P.nlong : 0));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int table_bytes = STAGE == 0 ? (lp_in_lds ? P.nlong * 16 : 0) : ((P.nshort * 4 + 15) & ~15);
-  const int per_wave = RUN * 16 + ((RUN * 4 + 15) & ~15) + ((RUN * np * 4 + 15) & ~15) + DS_MAXQ * 4;
+  const int table_bytes = REGTAB ? 0 : ((lp_in_lds ? P.nlong * 16 : 0) + ((P.nshort * 4 + 15) & ~15));
+  const int vals_bytes = (RUN * np * 4 + 15) & ~15;
+  const int per_wave = RUN * 16 + ((RUN * 4 + 15) & ~15) + vals_bytes + 2 * DS_MAXQ * 4;
   unsigned char* wbase = ds_lds + table_bytes + wave * per_wave;
-  uint4* krec = reinterpret_cast<uint4*>(wbase);
-  int* kth = reinterpret_cast<int*>(wbase + RUN * 16);
+  uint4* krec = reinterpret_cast<uint4*>(wbase);            // [RUN]
+  int* kth = reinterpret_cast<int*>(wbase + RUN * 16);     // [RUN]
   int* vals = reinterpret_cast<int*>(wbase + RUN * 16 + ((RUN * 4 + 15) & ~15));
-  int* cum = reinterpret_cast<int*>(wbase + RUN * 16 + ((RUN * 4 + 15) & ~15) + ((RUN * np * 4 + 15) & ~15));
-  if (STAGE == 0) {
+  int* cum = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(vals) + vals_bytes);  // [DS_MAXQ] runs up to and including entry j
+  int* cnt_q = cum + DS_MAXQ;                                                              // [DS_MAXQ] keypoints of entry j
+  unsigned lp_ij[DS_REG_LONG], lp_w[DS_REG_LONG], sp_ij[DS_REG_SHORT];  // i | j << 8, wdx (low half) | wdy << 16; i | j << 16
+  if (REGTAB) {
+#pragma unroll
+    for (int t = 0; t < DS_REG_LONG; ++t) {
+      const int p = t * 64 + lane;
+      lp_ij[t] = 0; lp_w[t] = 0;  // beyond the table: weight 0 contributes nothing
+      if (p < P.nlong) {
+        const int4 q = reinterpret_cast<const int4*>(P.long_pairs)[p];
+        lp_ij[t] = (unsigned)q.x | ((unsigned)q.y << 8);
+        lp_w[t] = ((unsigned)q.z & 0xFFFFu) | ((unsigned)q.w << 16);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < DS_REG_SHORT; ++t) {
+      const int p = t * 64 + lane;
+      sp_ij[t] = 0xFFFFFFFFu;  // beyond the table: bit 0
+      if (p < P.nshort) sp_ij[t] = (unsigned)P.short_pairs[2 * p] | ((unsigned)P.short_pairs[2 * p + 1] << 16);
+    }
+  } else {
     if (lp_in_lds)
       for (int p = threadIdx.x; p < P.nlong; p += DS_WAVES * 64) lp_s[p] = reinterpret_cast<const int4*>(P.long_pairs)[p];
-  } else {
     for (int p = threadIdx.x; p < P.nshort; p += DS_WAVES * 64) sp_s[p] = (unsigned)P.short_pairs[2 * p] | ((unsigned)P.short_pairs[2 * p + 1] << 16);
+    __syncthreads();  // the only workgroup barrier: from here on the waves are independent
   }
-  __syncthreads();  // the only workgroup barrier: from here on the waves are independent
 
   const int xcc = (int)(__builtin_amdgcn_s_getreg(DS_GETREG_XCC_ID) & 7);
   const int stride = G.L[0].stride, cols = G.L[0].w;
   const int img_bytes = (G.L[0].h - 1) * stride + cols;
-  DsWaveCtx c;
-  c.P = &P; c.krec = krec; c.kth = kth; c.vals = vals; c.np = np; c.lane = lane;
-  c.inv20 = (1u << 20) / (unsigned)np + 1u;
-  const int nwords = P.strings / 8;  // 64-bit words of a descriptor
+  const unsigned inv20 = (1u << 20) / (unsigned)np + 1u;  // s / np == (s * inv20) >> 20 for s < 2048
+  const int nwords = P.strings / 8;                        // 64-bit words of a descriptor
+  const int4* tab4 = reinterpret_cast<const int4*>(P.tab);
+  const double2* uv2 = reinterpret_cast<const double2*>(P.uv);
+
+  auto wave_sync = [&]() {  // LDS written by some lanes, read by others of the same wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // parameters of sample s of the run (clamped to the run's last sample: surplus lanes repeat it and are masked at the
+  // loads)
+  auto fetch = [&](int total, int s, bool rotated) {
+    DsLane L;
+    const int sc = min(s, total - 1);
+    const int kq = (int)(((unsigned)sc * inv20) >> 20);
+    const int pt = sc - kq * np;
+    const uint4 rec = krec[kq];
+    const int theta = rotated ? kth[kq] : 0;
+    L.kx = __uint_as_float(rec.x); L.ky = __uint_as_float(rec.y);
+    L.ti = (int)(rec.w & 0xFF) * np + pt;
+    L.tab = tab4[L.ti];
+    L.uv = uv2[theta * np + pt];
+    L.slot = sc;
+    return L;
+  };
+  // one sampling pass over the run: one sample per lane and round, lane = (keypoint, pattern point); the parameters of
+  // the next round are requested before the current round's gathers.  (Measured and dropped: all rounds of a pass in
+  // flight together - parameters of every round, then every round's gathers, then the combines: 234 VGPRs, no faster.)
+  auto pass = [&](const DsFrame& F, int total, bool rotated) {
+    DsLane Lc = fetch(total, lane, rotated);
+    for (int s0 = 0; s0 < total; s0 += 64) {
+      const bool valid = s0 + lane < total;
+      DsLane Ln = Lc;
+      if (s0 + 64 < total) Ln = fetch(total, s0 + 64 + lane, rotated);
+      const double mm = (double)__int_as_float(Lc.tab.x);
+      const float sigma = __int_as_float(Lc.tab.y);
+      const float xf = (float)(mm * Lc.uv.x) + Lc.kx, yf = (float)(mm * Lc.uv.y) + Lc.ky;
+      int value;
+      if (GENERIC) {
+        BriskSamplePoint sp;
+        sp.x = (float)(mm * Lc.uv.x); sp.y = (float)(mm * Lc.uv.y); sp.sigma = sigma;
+        sp.scaling = P.scaling[2 * Lc.ti]; sp.scaling2 = P.scaling[2 * Lc.ti + 1];
+        value = valid ? brisk_smoothed_intensity(F.img, stride, cols, F.integ, istride, Lc.kx, Lc.ky, sp) : 0;
+      } else {
+        const DsPrep pr = ds_prep(xf, yf, sigma, Lc.tab.z, Lc.tab.w);
+        DsRaw raw;
+        if (valid) ds_load(raw, pr, F.rs_img, stride, cols, F.rs_int, istride);
+        value = ds_combine(pr, raw);
+      }
+      if (valid) vals[Lc.slot] = value;
+      Lc = Ln;
+    }
+    wave_sync();
+  };
+  auto frame_of = [&](int frame) {
+    DsFrame F;
+    F.img = brisk_layer_img(G, pyr, frame, 0);
+    F.integ = integral + (long)frame * iframe_elems;
+    // timing experiments (debug bits 29 / 30): a descriptor without records drops every gather through it
+    F.rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(F.img), 0, (G.debug_flags & (1 << 30)) ? 0 : img_bytes, 0x00020000);
+    F.rs_int = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(F.integ), 0, (G.debug_flags & (1 << 29)) ? 0 : (int)(iframe_elems * 4), 0x00020000);
+    return F;
+  };
 
   // Work queue: the frames are dealt to `ngroups` groups (frame % ngroups; 8 = one group per XCD), each group is ONE
   // queue of runs - its frames from the last to the first (the integral images are written in frame order just before
@@ -323,141 +388,161 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   for (int gi = 0; gi < ngroups; ++gi) {
     const int g = (xcc + gi) % ngroups;
     if (g >= nframes) continue;
-    const int m = (nframes - 1 - g) / ngroups + 1;  // frames of the group
-    // cum[j] = runs of the group's first j + 1 frames in queue order (frame of entry j: g + (m - 1 - j) * ngroups)
+    const int m = (nframes - 1 - g) / ngroups + 1;  // frames of the group; queue entry j is frame g + (m - 1 - j) * ngroups
+    __builtin_amdgcn_wave_barrier();
     int carry = 0;
     for (int j0 = 0; j0 < m; j0 += 64) {
       const int j = j0 + lane;
-      int r = j < m ? (counters[g + (m - 1 - j) * ngroups].ndesc + RUN - 1) / RUN : 0;
+      const int nkp = j < m ? counters[g + (m - 1 - j) * ngroups].ndesc : 0;
+      int r = (nkp + RUN - 1) / RUN;
       for (int off = 1; off < 64; off <<= 1) {
         const int t = __shfl_up(r, off, 64);
         if (lane >= off) r += t;
       }
-      if (j < m) cum[j] = carry + r;
+      if (j < m) { cum[j] = carry + r; cnt_q[j] = nkp; }
       carry += __shfl(r, 63, 64);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int total = __builtin_amdgcn_readfirstlane(carry);
-    int* ticket = STAGE == 0 ? &counters[g].orient_ticket : &counters[g].desc_ticket;
-    // tickets are taken one run ahead (an agent-scope atomic takes microseconds); groups of other XCDs - normally
-    // finished by their own waves - get a plain look first
-    int next = total;
-    if (lane == 0 && (gi == 0 || __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total))
-      next = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int qj = 0;  // queue entry (frame) of the current ticket: tickets only grow
-    for (;;) {
-      const int tk = __builtin_amdgcn_readfirstlane(next);
-      if (tk >= total) break;
-      if (lane == 0) next = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (tk >= cum[qj]) ++qj;
-      qj = __builtin_amdgcn_readfirstlane(qj);
-      const int frame = g + (m - 1 - qj) * ngroups;
-      const int run = __builtin_amdgcn_readfirstlane(tk - (qj ? cum[qj - 1] : 0));
-      const int n = __builtin_amdgcn_readfirstlane(counters[frame].ndesc);
-      const uint8_t* img = brisk_layer_img(G, pyr, frame, 0);
-      const uint32_t* integ = integral + (long)frame * iframe_elems;
-      const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, img_bytes, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_int =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(integ), 0, (int)(iframe_elems * 4), 0x00020000);
-      uint4* rec = drec + (long)frame * kp_cap;
-      {
-        const int k0 = run * RUN;
-        const int cnt = min(RUN, n - k0);
-        c.total = cnt * np;
-        uint4 myrec = make_uint4(0, 0, 0, 0);
-        if (lane < cnt) myrec = rec[k0 + lane];
-        if (STAGE == 0) {
-          // orientation (:714-739): unrotated pattern, 856 long pairs per keypoint; runs without a keypoint that needs it
-          // are skipped (provided angles)
-          const bool estimate = lane < cnt && __uint_as_float(myrec.z) == -1.0f;
-          if (!__any(estimate)) continue;
-          if (lane < cnt) krec[lane] = myrec;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          ds_pass<GENERIC>(c, false, img, rs_img, stride, cols, integ, rs_int, istride);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          int md0 = 0, md1 = 0;
-          for (int kq = 0; kq < cnt; ++kq) {
-            const int* v = vals + kq * np;
-            int d0 = 0, d1 = 0;
-            if (lp_in_lds) {
-              for (int p = lane; p < P.nlong; p += 64) {
-                const int4 q = lp_s[p];
-                const int delta_t = v[q.x] - v[q.y];
-                d0 += delta_t * q.z / 1024;
-                d1 += delta_t * q.w / 1024;
-              }
-            } else {
-              for (int p = lane; p < P.nlong; p += 64) {
-                int a, b;
-                brisk_long_pair(v, P.long_pairs + 4 * p, &a, &b);
-                d0 += a;
-                d1 += b;
-              }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-              d0 += __shfl_xor(d0, off, 64);
-              d1 += __shfl_xor(d1, off, 64);
-            }
-            if (lane == kq) { md0 = d0; md1 = d1; }
-          }
-          if (estimate) {  // one fp64 atan2 for the whole run
-            const float ang = brisk_angle_from_direction(md0, md1);
-            dkp[(long)frame * kp_cap + (int)(myrec.w >> 8)].angle = ang;
-            rec[k0 + lane].z = DS_THETA_TAG | (unsigned)brisk_theta_from_angle(ang, true);
-          }
-          __builtin_amdgcn_wave_barrier();  // krec / vals are reused by the wave's next run
-        } else {
-          int theta = 0;
-          if (P.rotation_invariant)
-            theta = (myrec.z & DS_THETA_TAG) == DS_THETA_TAG ? (int)(myrec.z & 0x3FFu) : brisk_theta_from_angle(__uint_as_float(myrec.z), false);
-          if (lane < cnt) { krec[lane] = myrec; kth[lane] = theta; }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          ds_pass<GENERIC>(c, true, img, rs_img, stride, cols, integ, rs_int, istride);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          // bit p = values[i] > values[j], LSB first in little-endian u32 words (:538-564)
-          for (int kq = 0; kq < cnt; ++kq) {
-            const int* v = vals + kq * np;
-            const int k = (int)(__builtin_amdgcn_readfirstlane((int)krec[kq].w) >> 8);
-            unsigned long long mine = 0;
-            for (int w = 0; w < nwords; ++w) {
-              const int p = w * 64 + lane;
-              bool bit = false;
-              if (p < P.nshort) { const unsigned q = sp_s[p]; bit = v[q & 0xFFFF] > v[q >> 16]; }
-              const unsigned long long m = __ballot(bit);
-              if (lane == w) mine = m;
-            }
-            if (lane < nwords)
-              *reinterpret_cast<unsigned long long*>(desc + ((long)frame * kp_cap + k) * desc_pitch + lane * 8) = mine;
-          }
-          __builtin_amdgcn_wave_barrier();  // krec / kth / vals are reused by the wave's next run
-        }
+    wave_sync();
+    const int total_runs = __builtin_amdgcn_readfirstlane(carry);
+    int* ticket = &counters[g].desc_ticket;
+    int qj = 0;  // queue entry of the last decoded ticket: a wave's tickets only grow
+    auto decode = [&](int tk) {
+      DsTicket T;
+      T.ok = tk < total_runs;
+      T.frame = 0; T.k0 = 0; T.cnt = 0; T.total = 0;
+      if (T.ok) {
+        while (tk >= cum[qj]) ++qj;
+        qj = __builtin_amdgcn_readfirstlane(qj);
+        T.frame = g + (m - 1 - qj) * ngroups;
+        const int run = __builtin_amdgcn_readfirstlane(tk - (qj ? cum[qj - 1] : 0));
+        T.k0 = run * RUN;
+        T.cnt = min(RUN, __builtin_amdgcn_readfirstlane(cnt_q[qj]) - T.k0);
+        T.total = T.cnt * np;
       }
+      return T;
+    };
+    // Fewer than 8 frames (one queue for the whole chip; typically one frame per call, where latency matters): the runs
+    // are dealt statically, wave w takes runs w, w + waves, ... - no atomics.  Otherwise lane 0 takes tickets from the
+    // group's counter (an agent-scope atomic takes microseconds: taken two runs ahead).
+    const bool static_deal = ngroups == 1;
+    int static_next = (int)(blockIdx.x * DS_WAVES + wave);
+    auto take = [&]() {
+      int t = total_runs;
+      if (static_deal) {
+        t = min(static_next, total_runs);
+        static_next += (int)(gridDim.x * DS_WAVES);
+      } else if (lane == 0) {
+        t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return t;
+    };
+    // groups of other XCDs - normally finished by their own waves - get a plain look first
+    if (gi > 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= total_runs) continue;
+    int t1 = take();
+    int t2 = take();
+    DsTicket cur = decode(__builtin_amdgcn_readfirstlane(t1));
+    uint4 myrec = make_uint4(0, 0, 0, 0);
+    if (lane < cur.cnt) myrec = (drec + (long)cur.frame * kp_cap)[cur.k0 + lane];
+    while (cur.ok) {
+      const DsTicket nxt = decode(__builtin_amdgcn_readfirstlane(t2));
+      t2 = take();
+      uint4 nrec = make_uint4(0, 0, 0, 0);
+      if (lane < nxt.cnt) nrec = (drec + (long)nxt.frame * kp_cap)[nxt.k0 + lane];  // in flight under this run's gathers
+      const DsFrame F = frame_of(cur.frame);
+      if (lane < cur.cnt) krec[lane] = myrec;
+      const bool estimate = P.rotation_invariant && lane < cur.cnt && __uint_as_float(myrec.z) == -1.0f;
+      int theta = 0;
+      if (__any(estimate)) {
+        // orientation (:714-739): unrotated pattern, long pairs
+        wave_sync();
+        pass(F, cur.total, false);
+        int md0 = 0, md1 = 0;
+        for (int kq = 0; kq < cur.cnt; ++kq) {
+          const int* v = vals + kq * np;
+          int d0 = 0, d1 = 0;
+          if (REGTAB) {
+            int va[DS_REG_LONG], vb[DS_REG_LONG];
+#pragma unroll
+            for (int t = 0; t < DS_REG_LONG; ++t) { va[t] = v[lp_ij[t] & 0xFF]; vb[t] = v[(lp_ij[t] >> 8) & 0xFF]; }
+#pragma unroll
+            for (int t = 0; t < DS_REG_LONG; ++t) {
+              const int delta_t = va[t] - vb[t];
+              d0 += delta_t * (int)(short)(lp_w[t] & 0xFFFFu) / 1024;
+              d1 += delta_t * ((int)lp_w[t] >> 16) / 1024;
+            }
+          } else if (lp_in_lds) {
+            for (int p = lane; p < P.nlong; p += 64) {
+              const int4 q = lp_s[p];
+              const int delta_t = v[q.x] - v[q.y];
+              d0 += delta_t * q.z / 1024;
+              d1 += delta_t * q.w / 1024;
+            }
+          } else {
+            for (int p = lane; p < P.nlong; p += 64) {
+              int a, b;
+              brisk_long_pair(v, P.long_pairs + 4 * p, &a, &b);
+              d0 += a;
+              d1 += b;
+            }
+          }
+          for (int off = 32; off > 0; off >>= 1) {
+            d0 += __shfl_xor(d0, off, 64);
+            d1 += __shfl_xor(d1, off, 64);
+          }
+          if (lane == kq) { md0 = d0; md1 = d1; }
+        }
+        if (estimate) {  // one fp64 atan2 for the whole run
+          const float ang = brisk_angle_from_direction(md0, md1);
+          dkp[(long)cur.frame * kp_cap + (int)(myrec.w >> 8)].angle = ang;
+          theta = brisk_theta_from_angle(ang, true);
+        }
+        __builtin_amdgcn_wave_barrier();  // every lane is done with vals[] of the orientation pass
+      }
+      if (P.rotation_invariant && !estimate) theta = brisk_theta_from_angle(__uint_as_float(myrec.z), false);
+      if (lane < cur.cnt) kth[lane] = theta;
+      wave_sync();
+      pass(F, cur.total, true);
+      // bit p = values[i] > values[j], LSB first in little-endian u32 words (:538-564)
+      for (int kq = 0; kq < cur.cnt; ++kq) {
+        const int* v = vals + kq * np;
+        const int k = (int)(__builtin_amdgcn_readfirstlane((int)krec[kq].w) >> 8);
+        unsigned long long mine = 0;
+        if (REGTAB) {
+          int va[DS_REG_SHORT], vb[DS_REG_SHORT];
+#pragma unroll
+          for (int w = 0; w < DS_REG_SHORT; ++w) { va[w] = v[sp_ij[w] & 0xFF]; vb[w] = v[(sp_ij[w] >> 16) & 0xFF]; }
+#pragma unroll
+          for (int w = 0; w < DS_REG_SHORT; ++w) {
+            const unsigned long long mk = __ballot(sp_ij[w] != 0xFFFFFFFFu && va[w] > vb[w]);
+            if (lane == w) mine = mk;
+          }
+        } else {
+          for (int w = 0; w < nwords; ++w) {
+            const int p = w * 64 + lane;
+            bool bit = false;
+            if (p < P.nshort) { const unsigned q = sp_s[p]; bit = v[q & 0xFFFF] > v[q >> 16]; }
+            const unsigned long long mk = __ballot(bit);
+            if (lane == w) mine = mk;
+          }
+        }
+        if (lane < nwords)
+          *reinterpret_cast<unsigned long long*>(desc + ((long)cur.frame * kp_cap + k) * desc_pitch + lane * 8) = mine;
+      }
+      __builtin_amdgcn_wave_barrier();  // vals[], krec[], kth[] are reused
+      cur = nxt;
+      myrec = nrec;
     }
   }
 }
 
-static size_t describe_lds_bytes(const BriskPatternDev& P, int run, int stage) {
-  const size_t table = stage == 0 ? (P.nlong <= DS_LP_LDS ? (size_t)P.nlong * 16 : 0) : (((size_t)P.nshort * 4 + 15) & ~(size_t)15);
-  const size_t per_wave = (size_t)run * 16 + (((size_t)run * 4 + 15) & ~(size_t)15) + (((size_t)run * P.npoints * 4 + 15) & ~(size_t)15) + DS_MAXQ * 4;
+static size_t describe_lds_bytes(const BriskPatternDev& P, int run, bool regtab) {
+  const size_t table = regtab ? 0 : (P.nlong <= DS_LP_LDS ? (size_t)P.nlong * 16 : 0) + (((size_t)P.nshort * 4 + 15) & ~(size_t)15);
+  const size_t per_wave = (size_t)run * 16 + (((size_t)run * 4 + 15) & ~(size_t)15) + (((size_t)run * P.npoints * 4 + 15) & ~(size_t)15) + 2 * DS_MAXQ * 4;
   return table + DS_WAVES * per_wave;
 }
 
 typedef void (*ds_kernel_t)(BriskGeom, BriskPatternDev, const uint8_t*, const uint32_t*, int, long, BriskFrameCounters*, BriskKeyPoint*, uint4*,
                             uint8_t*, int, int, int);
-template <int STAGE>
-static ds_kernel_t describe_kernel(int run) {
-  return run == 8 ? k_describe<8, STAGE, false> : run == 4 ? k_describe<4, STAGE, false> : run == 2 ? k_describe<2, STAGE, false> : k_describe<1, STAGE, false>;
-}
 
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
@@ -486,28 +571,19 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
     int run = (G.debug_flags >> 8) & 0xF;
     if (!run) run = nframes >= 8 ? DS_RUN_BATCH : 1;
     if (P.has_bilinear) run = 1;
-    const int run1 = run;
     run = run >= 8 ? 8 : run >= 4 ? 4 : run >= 2 ? 2 : 1;
     int bpc = (G.debug_flags >> 12) & 0xF;
     if (!bpc) bpc = DS_BLOCKS_PER_CU;
-    for (int stage = P.rotation_invariant ? 0 : 1; stage < 2; ++stage) {
-      if (stage == 0) {  // tuning knobs of the orientation stage alone: debug bits 20-23 workgroups per CU, 24-27 run
-        if ((G.debug_flags >> 20) & 0xF) bpc = (G.debug_flags >> 20) & 0xF;
-        const int r0 = (G.debug_flags >> 24) & 0xF;
-        if (r0 && !P.has_bilinear) run = r0 >= 8 ? 8 : r0 >= 4 ? 4 : r0 >= 2 ? 2 : 1;
-      } else if (P.rotation_invariant) {
-        bpc = ((G.debug_flags >> 12) & 0xF) ? ((G.debug_flags >> 12) & 0xF) : DS_BLOCKS_PER_CU;
-        run = run1;
-      }
-      size_t lds = describe_lds_bytes(P, run, stage);
-      const size_t lds_limit = 160 * 1024 / (size_t)(bpc + 1) + 512;  // bpc + 1 workgroups of this size do not fit a CU
-      if (lds < lds_limit && bpc < 8 && !(G.debug_flags & (1 << 28))) lds = lds_limit;  // bit 28: no padding (other kernels share the CUs)
-      ds_kernel_t fn = stage == 0 ? describe_kernel<0>(run) : describe_kernel<1>(run);
-      if (P.has_bilinear) fn = stage == 0 ? k_describe<1, 0, true> : k_describe<1, 1, true>;
-      (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(fn, dim3(ncu * bpc), dim3(DS_WAVES * 64), lds, s, G, P, B.pyr, Dd.integral, Dd.istride, Dd.iframe_elems,
-                         B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, nframes);
-    }
+    const bool regtab = P.reg_tables && !P.has_bilinear;
+    size_t lds = describe_lds_bytes(P, run, regtab);
+    const size_t lds_limit = 160 * 1024 / (size_t)(bpc + 1) + 512;  // bpc + 1 workgroups of this size do not fit a CU
+    if (lds < lds_limit && !(G.debug_flags & (1 << 28))) lds = lds_limit;  // bit 28: no padding (other kernels share the CUs)
+    ds_kernel_t fn = run == 8 ? k_describe<8, false, true> : run == 4 ? k_describe<4, false, true> : run == 2 ? k_describe<2, false, true> : k_describe<1, false, true>;
+    if (!regtab) fn = run == 8 ? k_describe<8, false, false> : run == 4 ? k_describe<4, false, false> : run == 2 ? k_describe<2, false, false> : k_describe<1, false, false>;
+    if (P.has_bilinear) fn = k_describe<1, true, false>;
+    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fn, dim3(ncu * bpc), dim3(DS_WAVES * 64), lds, s, G, P, B.pyr, Dd.integral, Dd.istride, Dd.iframe_elems,
+                       B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, nframes);
   }
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);
 }

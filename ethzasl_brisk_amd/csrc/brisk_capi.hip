@@ -563,6 +563,8 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
                      int lower_threshold = BRISK_LOWER_THRESHOLD) {
   if (!d_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
+  // timing experiments only (debug bit 27): the descriptor half of a batch alone, on the keypoints the previous batch left
+  if (do_detect && do_describe && (ctx->debug_flags & (1 << 27)) && ctx->last_nframes >= nframes) do_detect = false;
   BatchArgs A{pat, w, h, threshold, octaves, frame_pitch, row_pitch, d_mask, mask_frame_pitch, mask_row_pitch, do_detect,
               do_describe, uni_radius < 0.0 ? ctx->uni_radius : uni_radius, uni_radius < 0.0 ? ctx->uni_max : uni_max};
   A.no_scale_nms = no_scale_nms;

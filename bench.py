@@ -180,8 +180,13 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, deadline_s=None):
+    """N fresh children, one per GPU.  All of them are watched: the first rank that exits non-zero (bad GPU, import
+    error, RCCL initialisation ...) ends the run - the others would otherwise sit in a rendezvous or a collective until
+    some timeout - and an overall deadline bounds the whole launch.  Only child processes are ever killed."""
+    import threading
     port = os.environ.get("MASTER_PORT") or str(_free_port())
+    deadline_s = deadline_s or float(os.environ.get("BRISK_BENCH_DEADLINE_S", "1800"))
     children = []
     for r in range(n):
         env = dict(os.environ)
@@ -190,11 +195,38 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                          stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = children[0].communicate()
-    rcs = [children[0].returncode] + [c.wait() for c in children[1:]]
-    if any(rcs):
-        sys.stderr.write("bench.py: rank exit codes %r\n" % (rcs,))
+    chunks = []
+    drain = threading.Thread(target=lambda: chunks.append(children[0].stdout.read()), daemon=True)
+    drain.start()
+    t_end = time.monotonic() + deadline_s
+    failed = None
+    while True:
+        rcs = [c.poll() for c in children]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % bad[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > t_end:
+            failed = "deadline of %.0f s exceeded" % deadline_s
+            break
+        time.sleep(0.05)
+    if failed:
+        for c in children:
+            if c.poll() is None:
+                c.terminate()
+        t_kill = time.monotonic() + 5.0
+        for c in children:
+            try:
+                c.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                c.kill()
+                c.wait()
+        sys.stderr.write("bench.py: %s; rank exit codes %r\n" % (failed, [c.returncode for c in children]))
         sys.exit(1)
+    drain.join(timeout=10)
+    out0 = b"".join(chunks)
     lines = [ln for ln in out0.decode().splitlines() if ln.strip().startswith("{")]
     if len(lines) != 1:
         sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
@@ -222,6 +254,9 @@ def parse_args(argv):
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL result gather even with one rank (self-test)")
     ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results become wrong)")
     ap.add_argument("--pattern-version", type=int, default=2)
+    ap.add_argument("--min-region-s", type=float, default=2.0,
+                    help="--frames mode: the step is repeated until the timed region is at least this long")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="launcher self-test: this rank exits with code 7 at start-up")
     return ap.parse_args(argv)
 
 
@@ -242,6 +277,9 @@ def main():
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
+    if args.fail_rank == rank:
+        sys.stderr.write("bench.py: rank %d fails on request (--fail-rank)\n" % rank)
+        sys.exit(7)
 
     # the CPU baseline workers are forked before torch / HIP exist in this process (rank 0, N=1 only)
     cpu = None
@@ -287,6 +325,9 @@ def main():
 
     import synth
     import ethzasl_brisk_amd as B
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d wants cuda:%d but only %d device(s) are visible\n" % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(4)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -357,29 +398,67 @@ def main():
         torch.cuda.synchronize()
     mean_kp = float(np.mean([len(ctx.batch_download(f, True, strings)[0]) for f in range(min(chunk, 8))]))
 
-    ctx.profile_enable(True)
-    if ctl is not None:
-        dist.barrier(group=ctl)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    # --frames (config 3, strong scaling): one step is a few milliseconds per rank; it is repeated until the timed region
+    # is at least --min-region-s long (every rank uses the same count: the slowest rank's probe decides)
+    reps = 1
+    if args.frames:
+        if ctl is not None:
+            dist.barrier(group=ctl)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
         step()
-    if gather:
-        gather.finish()                      # the last transfers are part of the timed region
-    torch.cuda.synchronize()
-    if ctl is not None:
-        dist.barrier(group=ctl)
-    dt = time.perf_counter() - t0
+        if gather:
+            gather.finish()
+        torch.cuda.synchronize()
+        tp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64)
+        if ctl is not None:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX, group=ctl)
+        reps = max(1, int(np.ceil(args.min_region_s / max(float(tp.item()) * args.steps, 1e-9))))
+    for attempt in range(4):
+        ctx.profile_enable(True)             # (resets the accumulated stage times)
+        if ctl is not None:
+            dist.barrier(group=ctl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps * reps):
+            step()
+        if gather:
+            gather.finish()                      # the last transfers are part of the timed region
+        torch.cuda.synchronize()
+        dt_rank = time.perf_counter() - t0       # this rank's own time (before the barrier)
+        if ctl is not None:
+            dist.barrier(group=ctl)
+        dt = time.perf_counter() - t0
+        if ctl is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+            dt = float(t.item())
+        if not args.frames or dt >= 0.9 * args.min_region_s or attempt == 3:
+            break
+        reps = int(np.ceil(reps * args.min_region_s / dt * 1.15))  # the probe was not representative: a longer region
     stage_ms, ncalls = ctx.profile_read()
     fpl = ctx.profile_frames_per_launch() or chunk   # frames per timed kernel launch (one stream slice)
     ctx.profile_enable(False)
 
+    # per-rank throughput (own frames / own time) and what the result gather costs when nothing hides it
+    nsteps = args.steps * reps
+    rank_fps = torch.zeros(world, dtype=torch.float64)
+    rank_fps[rank] = chunk * inner * nsteps / dt_rank
     if ctl is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
-        dt = float(t.item())
+        dist.all_reduce(rank_fps, op=dist.ReduceOp.SUM, group=ctl)
+    gather_ms = None
+    if gather:
+        torch.cuda.synchronize()
+        if ctl is not None:
+            dist.barrier(group=ctl)
+        tg = time.perf_counter()
+        for _ in range(4):
+            gather.run()
+        gather.finish()
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) / 4 * 1e3 * inner
 
-    total_frames = frames_per_step_total * args.steps
+    total_frames = frames_per_step_total * nsteps
     fps = total_frames / dt
     groups = algorithmic_bytes(W, H, OCTAVES, int(round(mean_kp)))
     per_frame_bytes = sum(groups.values())
@@ -400,14 +479,17 @@ def main():
     out = {
         "metric": METRIC,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
+        "ms_per_step": round(dt / nsteps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "1080p synthetic textured stream (SURVEY App. C recipe, 300 rects), 4 octaves, "
                                "AGAST threshold 80, default 66-point pattern (48-byte descriptors)",
                    "frames_per_step_per_gpu": chunk * inner, "frames_per_step_total": frames_per_step_total,
                    "chunk_frames": chunk, "chunks_per_step": inner,
-                   "ms_per_chunk": round(dt / args.steps / inner * 1e3, 4),
-                   "timed_region_s": round(dt, 3),
+                   "ms_per_chunk": round(dt / nsteps / inner * 1e3, 4),
+                   "timed_region_s": round(dt, 3), "steps_effective": nsteps,
+                   "per_rank_frames_per_s": [round(float(v), 1) for v in rank_fps],
+                   "gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4),
+                   "gather_note": None if gather_ms is None else "result gather of one step run alone after the timed region (inside it the transfers overlap the next chunk's kernels)",
                    "stream_slices": args.streams, "frames_per_kernel_launch": fpl, "distinct_frames_per_gpu": nd,
                    "mean_keypoints_per_frame": round(mean_kp, 1),
                    "parallelism": "frames sharded over %d rank(s)%s" % (world, (", asynchronous RCCL gather of keypoints+descriptors to rank 0 after every chunk (overlaps the next chunk)" if (world > 1 and gather) else "") + gather_note),
@@ -533,31 +615,53 @@ def dry_run(args, rank, world, chunk, chunk_max, inner, scaling, frames_per_step
     kps = torch.randn((chunk, cap, 7), generator=g)
     desc = torch.randint(0, 256, (chunk, cap, pitch), generator=g, dtype=torch.uint8)
     pg = sharding.PaddedGather(counts, kps, desc, strings, cap, dst=0, frames_max=chunk_max) if world > 1 else None
-    if ctl is not None:
-        dist.barrier(group=ctl)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    def step():
         for _ in range(inner):
             if pg:
                 pg.start()
-    last = pg.finish() if pg else None
-    if ctl is not None:
-        dist.barrier(group=ctl)
-    dt = time.perf_counter() - t0
-    if ctl is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
-        dt = float(t.item())
+            else:
+                time.sleep(0.001)
+
+    reps = 1
+    if args.frames:  # same rule as the real run: repeat the step until the timed region is long enough
+        if ctl is not None:
+            dist.barrier(group=ctl)
+        tp = time.perf_counter()
+        step()
+        if pg:
+            pg.finish()
+        tp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64)
+        if ctl is not None:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX, group=ctl)
+        reps = max(1, int(-(-args.min_region_s // max(float(tp.item()) * args.steps, 1e-9))))
+    for attempt in range(4):
+        if ctl is not None:
+            dist.barrier(group=ctl)
+        t0 = time.perf_counter()
+        for _ in range(args.steps * reps):
+            step()
+        last = pg.finish() if pg else None
+        if ctl is not None:
+            dist.barrier(group=ctl)
+        dt = time.perf_counter() - t0
+        if ctl is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+            dt = float(t.item())
+        if not args.frames or dt >= 0.9 * args.min_region_s or attempt == 3:
+            break
+        reps = int(-(-(reps * args.min_region_s * 1.15) // dt))
     if rank == 0:
         if last is not None:
             ac, gk, gd = last
             assert ac.shape == (world, chunk_max) and len(gk) == world and torch.equal(ac[0][:chunk], counts)
         out = {"metric": METRIC, "value": 0.0, "unit": "frames/s", "n_gpus": dist.get_world_size() if world > 1 else 1,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps * reps, 1) * 1e3, 4),
                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "dry": True,
                "config": {"workload": "DRY RUN: launcher / sharding / gather plumbing on CPU tensors, no engine",
                           "frames_per_step_total": frames_per_step_total, "chunk_frames": chunk, "chunks_per_step": inner,
+                          "timed_region_s": round(dt, 3), "steps_effective": args.steps * reps,
                           "shard_sizes": [len(sharding.shard_frames(args.frames, r, world)) for r in range(world)] if args.frames else None,
                           "backend": args.backend}}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

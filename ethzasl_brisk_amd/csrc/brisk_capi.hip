@@ -98,6 +98,22 @@ static int workspace_release(brisk_hip_ctx* c, hipStream_t s) {
   return BRISK_HIP_OK;
 }
 
+// Every exit after the workspace was acquired must leave done_ev behind the work already queued (kernels of earlier
+// slices, the side-stream integral, the score-state map clear): the next call, possibly on another stream, orders itself
+// behind that event.  The guard records it on the error paths too.
+struct WorkspaceGuard {
+  brisk_hip_ctx* c;
+  hipStream_t s;
+  bool armed;
+  WorkspaceGuard(brisk_hip_ctx* c_, hipStream_t s_) : c(c_), s(s_), armed(true) {}
+  ~WorkspaceGuard() { if (armed) (void)workspace_release(c, s); }
+  int release() { armed = false; return workspace_release(c, s); }
+};
+// waits for THIS context's queued work only (other contexts - one per host thread in the C++ classes - keep running)
+static hipError_t wait_own_work(brisk_hip_ctx* c) {
+  return c->done_valid ? hipEventSynchronize(c->done_ev) : hipSuccess;
+}
+
 #define HIPCHK(ctx, call)                                                                       \
   do {                                                                                          \
     hipError_t e_ = (call);                                                                     \
@@ -518,7 +534,10 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
   {
     static const bool inplace_on = !(getenv("BRISK_L0_INPLACE") && atoi(getenv("BRISK_L0_INPLACE")) == 0);
     const bool ordered = Gs.threshold < BRISK_FAST_PATH_MIN_THRESHOLD || Gs.no_scale_nms || Gs.lower_threshold != BRISK_LOWER_THRESHOLD;
-    if (A.do_detect && A.inplace_ok && inplace_on && !ordered && A.row_pitch == Gs.L[0].stride &&
+    // (width == stride: the caller's rows have no pad columns, so nothing is read that the argument check did not
+    // cover - a pitch of align_up(width, 64) with width % 64 != 0 would make the clamped 16-byte loads read the caller's
+    // pad bytes, up to 63 of them beyond the last frame's last row)
+    if (A.do_detect && A.inplace_ok && inplace_on && !ordered && A.row_pitch == Gs.L[0].stride && A.w == Gs.L[0].stride &&
         ((((uintptr_t)d_frames) | (uintptr_t)A.frame_pitch) & 15) == 0) {
       Gs.l0_ext = d_frames;
       Gs.l0_pitch = A.frame_pitch;
@@ -571,6 +590,7 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
   A.lower_threshold = lower_threshold;
   int rc = batch_begin(ctx, A, nframes, s);
   if (rc) return rc;
+  WorkspaceGuard guard(ctx, s);
   int nsub = ctx->nsub;
   if (nsub > 8) nsub = 8;
   if (nframes < 16 * nsub) nsub = nframes >= 32 ? 2 : 1;
@@ -600,6 +620,7 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
       HIPCHK(ctx, hipStreamWaitEvent(s, ctx->join_ev[i], 0));
     }
   }
+  guard.armed = false;  // batch_end records the event itself
   return batch_end(ctx, A, nframes, s);
 }
 
@@ -621,6 +642,7 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
   hipStream_t s = ctx->stream;
   int rc = batch_begin(ctx, A, nframes, s);
   if (rc) return rc;
+  WorkspaceGuard guard(ctx, s);
   const int slice = host_slice_frames() < nframes ? host_slice_frames() : nframes;
   const int dpitch = brisk_align_up(w, 64);           // device staging: rows at a 64-byte aligned pitch
   const size_t dframe = (size_t)dpitch * h;
@@ -674,6 +696,7 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
     if (rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[b], s));
   }
+  guard.armed = false;  // batch_end records the event itself
   return batch_end(ctx, A, nframes, s);
 }
 
@@ -731,7 +754,7 @@ int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags)
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (nframes <= 0 || nframes > ctx->slots) return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame count");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, wait_own_work(ctx));
   std::vector<BriskFrameCounters> c(nframes);
   HIPCHK(ctx, hipMemcpy(c.data(), ctx->B.counters, sizeof(BriskFrameCounters) * nframes, hipMemcpyDeviceToHost));
   int f = 0;
@@ -743,7 +766,7 @@ int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags)
 static int download_locked(brisk_hip_ctx* ctx, int frame, int which, brisk_hip_keypoint* kps, int cap, int* n,
                            uint8_t* desc, int desc_stride, int strings) {
   if (frame < 0 || frame >= ctx->slots) return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame index");
-  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, wait_own_work(ctx));
   BriskFrameCounters c;
   HIPCHK(ctx, hipMemcpy(&c, ctx->B.counters + frame, sizeof(c), hipMemcpyDeviceToHost));
   int rc = overflow_to_rc(ctx, c.overflow);
@@ -794,6 +817,7 @@ static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int
   if (rc) return rc;
   const int pitch = brisk_align_up(w, 64);
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
+  WorkspaceGuard guard(ctx, ctx->stream);  // (run_batch records the event again at its own end: harmless)
   HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
   const uint8_t* d_mask = nullptr;
   if (mask) {
@@ -838,6 +862,7 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
   rc = ensure_stage(ctx, img_bytes * 2);
   if (rc) return rc;
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
+  WorkspaceGuard guard(ctx, ctx->stream);
   HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
   if (n_in == 0) {
     // an empty list makes GetKeypoints detect (brisk-scale-space.cc:104): plain detection on the pyramid ComputeScale
@@ -862,7 +887,7 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;
   ctx->last_has_desc = false;
-  if (workspace_release(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
+  if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
   return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
 }
 
@@ -883,6 +908,7 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   rc = ensure_buffers(ctx, 1, ctx->G);
   if (rc) return rc;
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
+  WorkspaceGuard guard(ctx, ctx->stream);
   HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
   const int n_in = *n;
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, &n_in, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -903,7 +929,7 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;
   ctx->last_has_desc = true;
-  if (workspace_release(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
+  if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
   return download_locked(ctx, 0, 1, kps, n_in, n, desc, desc_stride, pat->host.strings);
 }
 
@@ -1115,7 +1141,7 @@ int brisk_hip_profile_read(brisk_hip_ctx* ctx, float* avg_ms, int* calls) {
   if (!ctx || !avg_ms) return BRISK_HIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, wait_own_work(ctx));
   BriskProfiler& P = ctx->prof;
   const int n = P.calls < BRISK_PROF_MAX_CALLS ? P.calls : BRISK_PROF_MAX_CALLS;
   for (int k = 0; k < BRISK_PROF_STAGES; ++k) {
@@ -1200,7 +1226,7 @@ int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, u
   *w = L.w; *h = L.h;
   if (!out) return BRISK_HIP_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, wait_own_work(ctx));
   const size_t base = (size_t)frame * ctx->G.pyr_elems + L.off;
   if (which == 0) {
     // (layer 0 of a batch that read the caller's frames in place: the caller's buffer must still be alive)
@@ -1223,7 +1249,7 @@ int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (frame < 0 || frame >= ctx->slots) return fail(ctx, BRISK_HIP_ERR_ARG, "bad index");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, wait_own_work(ctx));
   HIPCHK(ctx, hipMemcpy2D(out, (size_t)(ctx->G.w + 1) * 4, ctx->D.integral + (size_t)frame * ctx->D.iframe_elems,
                           (size_t)ctx->D.istride * 4, (size_t)(ctx->G.w + 1) * 4, ctx->G.h + 1, hipMemcpyDeviceToHost));
   return BRISK_HIP_OK;
@@ -1236,7 +1262,7 @@ int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlaye
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (frame < 0 || frame >= ctx->slots || !ctx->B.counters) return fail(ctx, BRISK_HIP_ERR_ARG, "bad index");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, wait_own_work(ctx));
   BriskFrameCounters c;
   HIPCHK(ctx, hipMemcpy(&c, ctx->B.counters + frame, sizeof(c), hipMemcpyDeviceToHost));
   out[0] = c.ncand; out[1] = c.nkp; out[2] = c.ndesc; out[3] = c.overflow;

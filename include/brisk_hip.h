@@ -116,7 +116,11 @@ int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern*
  * hipHostRegister for full speed; pageable memory works but copies synchronously).  The frames are moved in slices of 64
  * into two device staging buffers on a copy stream while the previous slice is computed on the context's stream; the
  * results stay in HBM exactly as after brisk_hip_detect_describe_batch (brisk_hip_batch_results / _download /
- * _status).  Returns when everything is queued; brisk_hip_batch_status synchronises. */
+ * _status).  Returns when everything is queued; brisk_hip_batch_status synchronises.
+ * LIFETIME: the copy stream keeps reading h_frames after the call has returned.  The host frames must stay valid AND
+ * unchanged until brisk_hip_batch_status / brisk_hip_batch_download has returned for this batch (or the next call on the
+ * context has been synchronised): a caller that refills a pinned ring right after the call gets results from mixed
+ * frames, silently. */
 int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames,
                                          int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
                                          int octaves);

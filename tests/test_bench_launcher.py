@@ -48,3 +48,27 @@ def test_under_an_external_launcher_no_second_spawn():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_a_rank_that_dies_early_ends_the_run_quickly():
+    """Rank 1 exits at start-up while rank 0 waits in the rendezvous: the launcher notices, ends rank 0 and fails within
+    seconds instead of sitting in init_process_group until torch's timeout."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--backend", "gloo", "--dry", "--steps", "1", "--warmup", "0", "--batch", "2", "--inner", "1",
+              "--fail-rank", "1"], timeout=120)
+    assert r.returncode == 1 and time.time() - t0 < 60, (r.returncode, time.time() - t0)
+    assert b"rank 1 exited with code 7" in r.stderr and b"rank exit codes" in r.stderr
+
+
+def test_launcher_deadline():
+    r = _run(["--gpus", "2", "--backend", "gloo", "--dry", "--steps", "1", "--warmup", "0", "--frames", "64", "--min-region-s", "30"],
+             {"BRISK_BENCH_DEADLINE_S": "4"}, timeout=120)
+    assert r.returncode == 1 and b"deadline" in r.stderr
+
+
+def test_frames_mode_repeats_the_step_until_the_region_is_long_enough():
+    r = _run(["--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2", "--warmup", "0", "--frames", "16", "--min-region-s", "0.5"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["config"]["timed_region_s"] >= 0.45 and d["config"]["steps_effective"] >= 2 and d["config"]["steps_effective"] % 2 == 0

@@ -88,3 +88,34 @@ def test_describe_many_keypoints_per_wave_patterns(B, version, points):
         k3, d3 = ext.compute(img, ko2)
         ko3, do3 = X.compute(img, ko2)
         assert same_kps(k3, ko3) and np.array_equal(d3, do3)
+
+
+def test_padded_pitch_with_odd_width_is_not_read_in_place(B):
+    """Width 1000 at a caller pitch of 1024 with garbage in the pad columns, in a buffer that ends with the last pixel of
+    the last frame: the engine must take its private layer-0 copy (reading in place would use the pad bytes and read up to
+    63 bytes past the buffer) and match the oracle."""
+    import torch
+    w, h, pitch, n = 1000, 600, 1024, 3
+    imgs = [synth.gen(w, h, 900 + i, 120) for i in range(n)]
+    nbytes = (n - 1) * pitch * h + (h - 1) * pitch + w
+    buf = np.random.default_rng(5).integers(0, 256, nbytes, dtype=np.uint8)
+    for f, img in enumerate(imgs):
+        for y in range(h):
+            o = f * pitch * h + y * pitch
+            buf[o:o + w] = img[y]
+    d = torch.from_numpy(buf).cuda()
+    assert d.data_ptr() % 16 == 0
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    ctx.detect_describe_batch(ext, d.data_ptr(), n, w, h, pitch * h, pitch, 70, 4, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.batch_status(n) == 0
+    X = O.Extractor()
+    for f, img in enumerate(imgs):
+        ko = O.detect(img, 70, 4)
+        ko2, do = X.compute(img, ko)
+        kd, _ = ctx.batch_download(f, described=False)
+        kg, dg = ctx.batch_download(f, described=True)
+        assert same_kps(kd, ko), (f, explain(kd, ko))
+        assert same_kps(kg, ko2) and np.array_equal(dg, do), f
+    ctx.close()

@@ -9,8 +9,6 @@ def kernel_name(n):
     n = n.strip()
     if n.startswith("void "):
         n = n[5:]
-    if n.startswith("k_describe<"):  # k_describe<RUN, STAGE, GENERIC>: the two stages are different kernels
-        return "k_describe_stage" + n.split("<")[1].split(",")[1].strip()
     return n.split("(")[0].split("<")[0]
 import sys
 from collections import defaultdict

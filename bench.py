@@ -413,7 +413,7 @@ def main():
         tp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64)
         if ctl is not None:
             dist.all_reduce(tp, op=dist.ReduceOp.MAX, group=ctl)
-        reps = max(1, int(np.ceil(args.min_region_s / max(float(tp.item()) * args.steps, 1e-9))))
+        reps = max(1, int(np.ceil(1.1 * args.min_region_s / max(float(tp.item()) * args.steps, 1e-9))))
     for attempt in range(4):
         ctx.profile_enable(True)             # (resets the accumulated stage times)
         if ctl is not None:
@@ -433,7 +433,7 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
             dt = float(t.item())
-        if not args.frames or dt >= 0.9 * args.min_region_s or attempt == 3:
+        if not args.frames or dt >= args.min_region_s or attempt == 3:
             break
         reps = int(np.ceil(reps * args.min_region_s / dt * 1.15))  # the probe was not representative: a longer region
     stage_ms, ncalls = ctx.profile_read()
@@ -648,7 +648,7 @@ def dry_run(args, rank, world, chunk, chunk_max, inner, scaling, frames_per_step
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
             dt = float(t.item())
-        if not args.frames or dt >= 0.9 * args.min_region_s or attempt == 3:
+        if not args.frames or dt >= args.min_region_s or attempt == 3:
             break
         reps = int(-(-(reps * args.min_region_s * 1.15) // dt))
     if rank == 0:

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "brisk_hip_pattern_tables", "brisk_hip_detect", "brisk_hip_describe", "brisk_hip_detect_describe_batch",
     "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
     "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_debug_counters", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
-    "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags",
+    "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags", "brisk_hip_debug_image_reuse",
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
     "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
     "brisk_hip_reserve", "brisk_hip_detect_uniform", "brisk_hip_detect_describe_batch_host", "brisk_hip_stream_ceiling",
@@ -89,6 +89,7 @@ def load_library():
     L.brisk_hip_debug_counters.argtypes = [vp, C.c_int, vp, ip]
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
+    L.brisk_hip_debug_image_reuse.argtypes = [vp]
     L.brisk_hip_set_streams.argtypes = [vp, C.c_int]
     L.brisk_hip_profile_frames_per_launch.argtypes = [vp]
     L.brisk_hip_profile_stage_name.argtypes = [C.c_int]
@@ -176,6 +177,10 @@ class Context:
 
     def profile_frames_per_launch(self):
         return self._L.brisk_hip_profile_frames_per_launch(self._h)
+
+    def debug_image_reuse(self):
+        """describe calls that reused the device copy of the image a detect call had uploaded"""
+        return self._L.brisk_hip_debug_image_reuse(self._h)
 
     def debug_set_flags(self, flags):
         self.check(self._L.brisk_hip_debug_set_flags(self._h, flags))

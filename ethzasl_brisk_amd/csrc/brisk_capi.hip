@@ -84,7 +84,41 @@ struct brisk_hip_ctx {
   size_t hstage_bytes = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t copied_ev[2] = {nullptr, nullptr}, consumed_ev[2] = {nullptr, nullptr};
+  // The image of the last host-buffer detect call is still on the device (staging buffer, layer 0 and the pyramid
+  // kernel's 96-row band sums of slot 0).  The reference API forces detect() and compute() to be two calls on the same
+  // cv::Mat (test-binary-equal.cc:215,237), not two uploads: a describe call that names the same host buffer - same
+  // pointer, size, stride and the same 64-bit hash over a 1/16 sample of its pixels - reuses the device copy.
+  struct {
+    bool valid = false;
+    const uint8_t* ptr = nullptr;
+    int w = 0, h = 0, stride = 0;
+    uint64_t hash = 0;
+    const uint8_t* l0_ext = nullptr;  // layer 0 was read in place from the staging buffer (width a multiple of 64)
+    int hits = 0;                     // describe calls that reused the device copy (brisk_hip_debug_image_reuse)
+  } img_cache;
 };
+
+// 64-bit hash over one 8-byte word of every 128 bytes of every row (row-dependent phase): ~130 KB of a 1080p frame, a few
+// microseconds.  A caller that changes the image between detect() and compute() is noticed unless the change avoids all
+// sampled words (BRISK_HIP_IMAGE_CACHE=0 turns the reuse off).
+static uint64_t image_sample_hash(const uint8_t* img, int w, int h, int stride) {
+  uint64_t hsh = 0x9E3779B97F4A7C15ull ^ ((uint64_t)w << 32) ^ (uint64_t)h;
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* row = img + (size_t)y * stride;
+    for (int x = (y * 24) & 127; x + 8 <= w; x += 128) {
+      uint64_t v;
+      memcpy(&v, row + x, 8);
+      hsh = (hsh ^ v) * 0xFF51AFD7ED558CCDull;
+      hsh ^= hsh >> 32;
+    }
+    if (w < 8) for (int x = 0; x < w; ++x) hsh = (hsh ^ row[x]) * 0x100000001B3ull;
+  }
+  return hsh;
+}
+static bool image_cache_enabled() {
+  static const bool on = !(getenv("BRISK_HIP_IMAGE_CACHE") && atoi(getenv("BRISK_HIP_IMAGE_CACHE")) == 0);
+  return on;
+}
 
 // the workspace is reused by every call: order this call's stream behind the previous call's work
 static int workspace_acquire(brisk_hip_ctx* c, hipStream_t s) {
@@ -188,6 +222,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
     return BRISK_HIP_OK;
   }
   HIPCHK(c, hipDeviceSynchronize());
+  c->img_cache.valid = false;
   const int slots = nframes > c->slots ? nframes : c->slots;
   const long pyr = G.pyr_elems > c->pyr_elems_alloc ? G.pyr_elems : c->pyr_elems_alloc;
   const long ifr = iframe > c->iframe_elems_alloc ? iframe : c->iframe_elems_alloc;
@@ -231,6 +266,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
 static int ensure_stage(brisk_hip_ctx* c, size_t bytes) {
   if (bytes <= c->stage_bytes) return BRISK_HIP_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->img_cache.valid = false;
   hipFree(c->d_stage);
   c->d_stage = nullptr;
   c->stage_bytes = 0;
@@ -482,6 +518,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   }
   rc = workspace_acquire(ctx, s);
   if (rc) return fail(ctx, rc, "hipStreamWaitEvent failed");
+  ctx->img_cache.valid = false;  // slot 0 is rewritten (detect_host sets it again for its own image)
   brisk_prof_begin_call(&ctx->prof);
   if (A.do_detect) {
     if (ctx->dirty_frames > 0) brisk_launch_smap_clear(ctx->dirtyG, ctx->B, ctx->dirty_frames, s);
@@ -828,6 +865,12 @@ static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int
   rc = run_batch(ctx, nullptr, ctx->d_stage, 1, w, h, (long)img_bytes, pitch, threshold, octaves, d_mask, (long)img_bytes,
                  pitch, ctx->stream, true, false, uni_radius, uni_max, !suppress_scale_nonmaxima);
   if (rc) return rc;
+  if (image_cache_enabled()) {
+    ctx->img_cache.valid = true;
+    ctx->img_cache.ptr = img; ctx->img_cache.w = w; ctx->img_cache.h = h; ctx->img_cache.stride = stride;
+    ctx->img_cache.hash = image_sample_hash(img, w, h, stride);  // (while the GPU works)
+    ctx->img_cache.l0_ext = ctx->last_l0_ext;
+  }
   return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
 }
 
@@ -863,6 +906,7 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
   if (rc) return rc;
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   WorkspaceGuard guard(ctx, ctx->stream);
+  ctx->img_cache.valid = false;
   HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
   if (n_in == 0) {
     // an empty list makes GetKeypoints detect (brisk-scale-space.cc:104): plain detection on the pyramid ComputeScale
@@ -909,7 +953,12 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   if (rc) return rc;
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   WorkspaceGuard guard(ctx, ctx->stream);
-  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  // the image of the last detect call, still on the device?  (same host buffer, same sampled hash)
+  const bool reuse = ctx->img_cache.valid && ctx->img_cache.ptr == img && ctx->img_cache.w == w && ctx->img_cache.h == h &&
+                     ctx->img_cache.stride == stride && ctx->img_cache.hash == image_sample_hash(img, w, h, stride);
+  ctx->img_cache.valid = reuse;  // an uploaded image overwrites the staging buffer (and is not remembered itself)
+  if (reuse) ctx->img_cache.hits++;
+  if (!reuse) HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
   const int n_in = *n;
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, &n_in, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   if (n_in) HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in, kps, sizeof(BriskKeyPoint) * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
@@ -918,13 +967,22 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
     ctx->dirty_frames = 0;
   }
   HIPCHK(ctx, hipMemsetAsync(ctx->B.counters, 0, sizeof(BriskFrameCounters), ctx->stream));
-  ctx->last_l0_ext = nullptr;
-  brisk_launch_layer0_only(ctx->G, ctx->B, 1, ctx->d_stage, (long)img_bytes, pitch, ctx->stream);
+  BriskDetectBuffers Bd = ctx->B;
+  if (reuse) {
+    // layer 0 (in the pyramid buffer, or read in place from the staging buffer) and the pyramid kernel's 96-row band
+    // sums are what the detect call left
+    ctx->G.l0_ext = ctx->img_cache.l0_ext;
+    ctx->G.l0_pitch = (long)img_bytes;
+    ctx->last_l0_ext = ctx->img_cache.l0_ext;
+    ctx->last_l0_pitch = (long)img_bytes;
+  } else {
+    ctx->last_l0_ext = nullptr;
+    brisk_launch_layer0_only(ctx->G, ctx->B, 1, ctx->d_stage, (long)img_bytes, pitch, ctx->stream);
+    Bd.band_h = 64;  // brisk_launch_layer0_only: k_pyramid_even's 64-row band sums
+  }
   BriskPatternDev P = pat->dev;
   P.rotation_invariant = rotation_invariant ? 1 : 0;
   P.scale_invariant = scale_invariant ? 1 : 0;
-  BriskDetectBuffers Bd = ctx->B;
-  Bd.band_h = 64;  // brisk_launch_layer0_only: k_pyramid_even's 64-row band sums
   brisk_launch_describe(ctx->G, P, Bd, ctx->D, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, nullptr);
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;
@@ -1243,6 +1301,8 @@ int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, u
   }
   return BRISK_HIP_OK;
 }
+
+int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx) { return ctx ? ctx->img_cache.hits : 0; }
 
 int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out) {
   if (!ctx || !out) return BRISK_HIP_ERR_ARG;

@@ -209,6 +209,9 @@ int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, u
 int brisk_hip_debug_set_flags(brisk_hip_ctx* ctx, int flags);
 /* integral image of frame slot `frame` after the last describe: (h+1) x (w+1) u32, tightly packed */
 int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out);
+/* number of brisk_hip_describe calls that found their image still on the device (left there by brisk_hip_detect on the
+ * same host buffer: same pointer, size, stride and sampled hash) and skipped the upload and the layer-0 pass */
+int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx);
 /* per-frame work counts of the last batch (tools only): out[0] candidates, out[1] keypoints, out[2] described
  * keypoints, out[3] overflow flags, out[4 + l] tie candidates of layer l, out[20 .. 27] experiment words; out holds 28 ints. */
 int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlayers);

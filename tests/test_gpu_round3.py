@@ -119,3 +119,38 @@ def test_padded_pitch_with_odd_width_is_not_read_in_place(B):
         assert same_kps(kd, ko), (f, explain(kd, ko))
         assert same_kps(kg, ko2) and np.array_equal(dg, do), f
     ctx.close()
+
+
+def test_detect_then_compute_on_the_same_buffer_uploads_once_and_notices_changes(B):
+    """The drop-in classes call detect() and compute() on the same image: the second call reuses the device copy (same
+    host pointer, size, stride, sampled hash).  Results equal the oracle's; an image changed in place between the two
+    calls is noticed (new upload, results of the CHANGED image); another buffer with the same content is uploaded."""
+    ctx = B.Context(0)
+    det = B.BriskFeatureDetector(70, 4, context=ctx)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    X = O.Extractor()
+    for name, img in (("vga", synth.frame_vga(3)), ("odd_width", synth.gen(1001, 587, 12, 150)), ("1080p", synth.frame_1080p(9))):
+        img = np.ascontiguousarray(img)
+        h0 = ctx.debug_image_reuse()
+        k = det.detect(img)
+        k2, d2 = ext.compute(img, k)
+        assert ctx.debug_image_reuse() == h0 + 1, name
+        ko = O.detect(img, 70, 4)
+        ko2, do = X.compute(img, ko)
+        assert same_kps(k, ko) and same_kps(k2, ko2) and np.array_equal(d2, do), name
+        k3, d3 = ext.compute(img, k)                      # again: still on the device
+        assert ctx.debug_image_reuse() == h0 + 2 and same_kps(k3, ko2) and np.array_equal(d3, do), name
+        # the image changes in place between detect and compute
+        k = det.detect(img)
+        img[40:140, 60:200] = 255 - img[40:140, 60:200]
+        k4, d4 = ext.compute(img, k)
+        assert ctx.debug_image_reuse() == h0 + 2, name      # noticed: uploaded again
+        ko4, do4 = X.compute(img, k)
+        assert same_kps(k4, ko4) and np.array_equal(d4, do4), name
+        # same content in another buffer: not the detect call's image
+        k = det.detect(img)
+        other = img.copy()
+        k5, d5 = ext.compute(other, k)
+        ko5, do5 = X.compute(other, k)
+        assert ctx.debug_image_reuse() == h0 + 2 and same_kps(k5, ko5) and np.array_equal(d5, do5), name
+    ctx.close()

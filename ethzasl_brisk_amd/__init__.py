@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
     "brisk_hip_pattern_tables", "brisk_hip_detect", "brisk_hip_describe", "brisk_hip_detect_describe_batch",
     "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
     "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_debug_counters", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
-    "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags", "brisk_hip_debug_image_reuse",
+    "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags", "brisk_hip_debug_image_reuse", "brisk_hip_set_bucketing", "brisk_hip_halfsample16", "brisk_hip_twothirdsample16",
+    "brisk_hip_integral_image16",
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
     "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
     "brisk_hip_reserve", "brisk_hip_detect_uniform", "brisk_hip_detect_describe_batch_host", "brisk_hip_stream_ceiling",
@@ -90,6 +91,9 @@ def load_library():
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_image_reuse.argtypes = [vp]
+    L.brisk_hip_set_bucketing.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    for f in (L.brisk_hip_halfsample16, L.brisk_hip_twothirdsample16, L.brisk_hip_integral_image16):
+        f.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.brisk_hip_set_streams.argtypes = [vp, C.c_int]
     L.brisk_hip_profile_frames_per_launch.argtypes = [vp]
     L.brisk_hip_profile_stage_name.argtypes = [C.c_int]
@@ -172,6 +176,31 @@ class Context:
         """Optional uniformity enforcement after the detector (0 = off); see brisk_hip_set_uniformity."""
         self.check(self._L.brisk_hip_set_uniformity(self._h, float(radius), int(max_keypoints)))
 
+    def set_bucketing(self, num_buckets_u, num_buckets_v, max_keypoints):
+        """Optional KeyPointBucketing after the detector while uniformity is off ((0, 0, *) = off); see brisk_hip_set_bucketing."""
+        self.check(self._L.brisk_hip_set_bucketing(self._h, int(num_buckets_u), int(num_buckets_v), int(max_keypoints)))
+
+    def _image16(self, fn, image, out):
+        img = np.ascontiguousarray(image, np.uint16)
+        h, w = img.shape
+        self.check(fn(self._h, _ptr(img), w, h, w, _ptr(out), out.shape[1]))
+        return out
+
+    def halfsample16(self, image):
+        """brisk::Halfsample16 (image-down-sampling.cc:56-139)"""
+        h, w = np.shape(image)
+        return self._image16(self._L.brisk_hip_halfsample16, image, np.zeros((h // 2, w // 2), np.uint16))
+
+    def twothirdsample16(self, image):
+        """brisk::Twothirdsample16 (image-down-sampling.cc:394-548)"""
+        h, w = np.shape(image)
+        return self._image16(self._L.brisk_hip_twothirdsample16, image, np.zeros((h // 3 * 2, w // 3 * 2), np.uint16))
+
+    def integral_image16(self, image):
+        """brisk::IntegralImage16 (internal/integral-image.h:163-218): (h + 1) x (w + 1) float32"""
+        h, w = np.shape(image)
+        return self._image16(self._L.brisk_hip_integral_image16, image, np.zeros((h + 1, w + 1), np.float32))
+
     def set_streams(self, n):
         self.check(self._L.brisk_hip_set_streams(self._h, n))
 
@@ -253,12 +282,14 @@ class BriskFeatureDetector:
     """Mirror of brisk::BriskFeatureDetector (brisk/include/brisk/brisk-feature-detector.h:51-83)."""
 
     def __init__(self, thresh, octaves=3, suppressScaleNonmaxima=True, context=None, uniformityRadius=0.0,
-                 maxNumKpt=0x7FFFFFFF):
+                 maxNumKpt=0x7FFFFFFF, numBucketsU=0, numBucketsV=0):
         self.threshold = int(thresh)
         self.octaves = int(octaves)
         self.m_suppressScaleNonmaxima = bool(suppressScaleNonmaxima)
         # engine option (not reference behaviour of this class): EnforceKeyPointUniformity as a post-filter
         self.uniformityRadius, self.maxNumKpt = float(uniformityRadius), int(maxNumKpt)
+        # engine option as well: KeyPointBucketing (what the reference's ScaleSpaceLayer uses while uniformity is off)
+        self.numBucketsU, self.numBucketsV = int(numBucketsU), int(numBucketsV)
         self._ctx = context or default_context()
 
     def detect(self, image, mask=None, capacity=16384):
@@ -275,6 +306,7 @@ class BriskFeatureDetector:
         out = np.zeros(capacity, KEYPOINT)
         n = C.c_int()
         c = self._ctx
+        c.set_bucketing(self.numBucketsU, self.numBucketsV, self.maxNumKpt)  # (context state: set per call; (0, 0) = off)
         c.check(c._L.brisk_hip_detect_uniform(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
                                               int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0,
                                               self.uniformityRadius, self.maxNumKpt, _ptr(out), capacity, C.byref(n)))

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbrisk_hip.so")
-SOURCES = ["brisk_kernels.hip", "brisk_describe.hip", "brisk_match.hip", "brisk_uniformity.hip", "brisk_capi.hip", "brisk_pattern.cpp"]
+SOURCES = ["brisk_kernels.hip", "brisk_describe.hip", "brisk_image16.hip", "brisk_match.hip", "brisk_uniformity.hip", "brisk_capi.hip", "brisk_pattern.cpp"]
 # -ffp-contract=off: the reference binary has no FMA contraction (built with -mssse3 only); the
 # sub-pixel / sub-scale float expressions must round after every operation to stay bit-exact.
 # -simplifycfg-sink-common=false: sinking the common tails of the per-layer-class branches of the refinement code

@@ -68,6 +68,8 @@ struct brisk_hip_ctx {
   // optional uniformity enforcement after the detector (brisk_hip_set_uniformity / brisk_hip_detect_uniform)
   double uni_radius = 0.0;
   int uni_max = 0x7FFFFFFF;
+  // the other post-filter of the reference (KeyPointBucketing; used when uniformity enforcement is off): 0 buckets = off
+  int bk_u = 0, bk_v = 0, bk_max = 0;
   uint8_t* d_occ = nullptr;
   size_t occ_bytes = 0;
   BriskKeyPoint* d_uni_tmp = nullptr;
@@ -499,23 +501,35 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   ctx->G.lower_threshold = A.lower_threshold;
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
-  if (A.do_detect && A.uni_radius > 0.0) {
-    const float scaling = (float)(15.0 / (float)A.uni_radius);
-    const int oh = (int)(A.h * ceil(scaling) + 32), ow = (int)(A.w * ceil(scaling) + 32);
-    const size_t need = (size_t)(((long)oh * ow + 255) / 256 * 256) * nframes + 64;
+  const bool bucketing = A.do_detect && !(A.uni_radius > 0.0) && ctx->bk_u > 0;
+  if ((A.do_detect && A.uni_radius > 0.0) || bucketing) {
+    size_t need = 0;
+    if (!bucketing) {
+      const float scaling = (float)(15.0 / (float)A.uni_radius);
+      const int oh = (int)(A.h * ceil(scaling) + 32), ow = (int)(A.w * ceil(scaling) + 32);
+      need = (size_t)(((long)oh * ow + 255) / 256 * 256) * nframes + 64;
+    }
     const size_t items = (size_t)ctx->slots * ctx->kp_cap;
     if (need > ctx->occ_bytes || items > ctx->uni_items) {
       HIPCHK(ctx, hipDeviceSynchronize());
-      if (ctx->d_occ) (void)hipFree(ctx->d_occ);
-      if (ctx->d_uni_tmp) (void)hipFree(ctx->d_uni_tmp);
-      if (ctx->d_uni_order) (void)hipFree(ctx->d_uni_order);
-      ctx->d_occ = nullptr; ctx->d_uni_tmp = nullptr; ctx->d_uni_order = nullptr; ctx->occ_bytes = 0; ctx->uni_items = 0;
-      HIPCHK(ctx, hipMalloc(&ctx->d_occ, need));
-      HIPCHK(ctx, hipMalloc(&ctx->d_uni_tmp, items * sizeof(BriskKeyPoint)));
-      HIPCHK(ctx, hipMalloc(&ctx->d_uni_order, items * sizeof(int)));
-      ctx->occ_bytes = need; ctx->uni_items = items;
+      if (need > ctx->occ_bytes) {
+        if (ctx->d_occ) (void)hipFree(ctx->d_occ);
+        ctx->d_occ = nullptr; ctx->occ_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_occ, need));
+        ctx->occ_bytes = need;
+      }
+      if (items > ctx->uni_items) {
+        if (ctx->d_uni_tmp) (void)hipFree(ctx->d_uni_tmp);
+        if (ctx->d_uni_order) (void)hipFree(ctx->d_uni_order);
+        ctx->d_uni_tmp = nullptr; ctx->d_uni_order = nullptr; ctx->uni_items = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_uni_tmp, items * sizeof(BriskKeyPoint)));
+        HIPCHK(ctx, hipMalloc(&ctx->d_uni_order, items * sizeof(int)));
+        ctx->uni_items = items;
+      }
     }
   }
+  if (bucketing && (ctx->bk_u >= A.w || ctx->bk_v >= A.h))
+    return fail(ctx, BRISK_HIP_ERR_ARG, "bucketing: more buckets than pixels (key-point-bucketing-inl.h:82-83)");
   rc = workspace_acquire(ctx, s);
   if (rc) return fail(ctx, rc, "hipStreamWaitEvent failed");
   ctx->img_cache.valid = false;  // slot 0 is rewritten (detect_host sets it again for its own image)
@@ -594,6 +608,11 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
     const long occ_frame = ((long)oh * ow + 255) / 256 * 256;
     brisk_launch_uniformity(Bi.kp_out, Bi.counters, ctx->d_uni_order + f0 * Bi.kp_cap, ctx->d_uni_tmp + f0 * Bi.kp_cap,
                             ctx->d_occ + f0 * occ_frame, occ_frame, ow, Bi.kp_cap, scaling, A.uni_max, nf, si);
+  }
+  if (A.do_detect && !(A.uni_radius > 0.0) && ctx->bk_u > 0) {
+    // KeyPointBucketing as a post-filter of the detected keypoints (brisk_uniformity.hip)
+    brisk_launch_bucketing(Bi.kp_out, Bi.counters, ctx->d_uni_order + f0 * Bi.kp_cap, ctx->d_uni_tmp + f0 * Bi.kp_cap, Bi.kp_cap,
+                           A.h, A.w, ctx->bk_u, ctx->bk_v, ctx->bk_max, nf, si);
   }
   if (A.do_describe) {
     BriskPatternDev P = A.pat->dev;
@@ -1172,6 +1191,68 @@ int brisk_hip_set_uniformity(brisk_hip_ctx* ctx, double radius, int max_keypoint
   ctx->uni_radius = radius;
   ctx->uni_max = max_keypoints;
   return BRISK_HIP_OK;
+}
+
+int brisk_hip_set_bucketing(brisk_hip_ctx* ctx, int num_buckets_u, int num_buckets_v, int max_keypoints) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (num_buckets_u == 0 && num_buckets_v == 0) { ctx->bk_u = ctx->bk_v = ctx->bk_max = 0; return BRISK_HIP_OK; }
+  // key-point-bucketing-inl.h:78-86: at least one bucket each way, at least one keypoint
+  if (num_buckets_u < 1 || num_buckets_v < 1 || max_keypoints < 1 || (long)num_buckets_u * num_buckets_v > (1 << 24))
+    return fail(ctx, BRISK_HIP_ERR_ARG, "bucketing: buckets >= 1 each way (0, 0 = off), max_keypoints >= 1");
+  ctx->bk_u = num_buckets_u; ctx->bk_v = num_buckets_v; ctx->bk_max = max_keypoints;
+  return BRISK_HIP_OK;
+}
+
+// ---- 16-bit image functions (stand-alone: host buffers in, host buffers out) -------------------------------------
+static int image16_call(brisk_hip_ctx* ctx, int which, const uint16_t* src, int w, int h, int src_stride, void* dst, int dst_stride) {
+  if (!ctx || !src || !dst) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (w <= 0 || h <= 0 || w > 8191 || h > 8191 || src_stride < w) return fail(ctx, BRISK_HIP_ERR_ARG, "bad image description");
+  int dw, dh;
+  size_t delem;
+  if (which == 0) {
+    dw = w / 2; dh = h / 2; delem = 2;
+    if (dw * 2 < 16 || dh < 1) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "Halfsample16: fewer than 16 usable columns (the reference's loop writes nothing, image-down-sampling.cc:69-74)");
+  } else if (which == 1) {
+    dw = w / 3 * 2; dh = h / 3 * 2; delem = 2;
+    if (w / 3 * 3 < 12 || dh < 2) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "Twothirdsample16: fewer than 12 usable columns (the reference's loop writes nothing, image-down-sampling.cc:407-413)");
+  } else {
+    dw = w + 1; dh = h + 1; delem = 4;
+  }
+  if (dst_stride < dw) return fail(ctx, BRISK_HIP_ERR_ARG, "destination stride too small");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint16_t* d_src = nullptr;
+  void* d_dst = nullptr;
+  float* d_tmp = nullptr;
+  hipStream_t s = ctx->stream;
+  int rc = BRISK_HIP_OK;
+  auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == BRISK_HIP_OK) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); rc = BRISK_HIP_ERR_HIP; } };
+  chk(hipMalloc(&d_src, (size_t)w * h * 2), "hipMalloc");
+  chk(hipMalloc(&d_dst, (size_t)dw * dh * delem), "hipMalloc");
+  if (which == 2) chk(hipMalloc(&d_tmp, (size_t)w * h * 4), "hipMalloc");
+  if (rc == BRISK_HIP_OK) {
+    chk(hipMemcpy2DAsync(d_src, (size_t)w * 2, src, (size_t)src_stride * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, s), "hipMemcpy2DAsync");
+    if (which == 0) brisk_launch_halfsample16(d_src, w, w, h, (uint16_t*)d_dst, dw, s);
+    else if (which == 1) brisk_launch_twothirdsample16(d_src, w, w, h, (uint16_t*)d_dst, dw, s);
+    else brisk_launch_integral16(d_src, w, w, h, d_tmp, (float*)d_dst, dw, s);
+    chk(hipGetLastError(), "launch");
+    chk(hipMemcpy2DAsync(dst, (size_t)dst_stride * delem, d_dst, (size_t)dw * delem, (size_t)dw * delem, dh, hipMemcpyDeviceToHost, s), "hipMemcpy2DAsync");
+    chk(hipStreamSynchronize(s), "hipStreamSynchronize");
+  }
+  if (d_src) (void)hipFree(d_src);
+  if (d_dst) (void)hipFree(d_dst);
+  if (d_tmp) (void)hipFree(d_tmp);
+  return rc;
+}
+int brisk_hip_halfsample16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, uint16_t* dst, int dst_stride) {
+  return image16_call(ctx, 0, src, w, h, src_stride, dst, dst_stride);
+}
+int brisk_hip_twothirdsample16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, uint16_t* dst, int dst_stride) {
+  return image16_call(ctx, 1, src, w, h, src_stride, dst, dst_stride);
+}
+int brisk_hip_integral_image16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, float* dst, int dst_stride) {
+  return image16_call(ctx, 2, src, w, h, src_stride, dst, dst_stride);
 }
 
 int brisk_hip_profile_enable(brisk_hip_ctx* ctx, int enable) {

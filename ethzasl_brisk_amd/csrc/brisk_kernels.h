@@ -115,6 +115,14 @@ void brisk_launch_match_radius(const uint16_t* dist, long dist_pitch, int q0, in
 bool brisk_launch_match_knn_fused(const uint8_t* query, int q_pitch, int nq, const uint8_t* train, int t_pitch, int nt,
                                   int words32, int k, BriskDMatch* out, int* out_count, hipStream_t s);
 
-// ---- uniformity enforcement (brisk_uniformity.hip): optional post-filter of the detector's keypoints ----
+// ---- uniformity enforcement / keypoint bucketing (brisk_uniformity.hip): optional post-filters of the detector's keypoints ----
+void brisk_launch_bucketing(BriskKeyPoint* kp, BriskFrameCounters* counters, int* order, BriskKeyPoint* tmp, int kp_cap, int rows,
+                            int cols, int nbu, int nbv, int max_keypoints, int nframes, hipStream_t s);
 void brisk_launch_uniformity(BriskKeyPoint* kp, BriskFrameCounters* counters, int* order, BriskKeyPoint* tmp, uint8_t* occ,
                              long occ_frame, int ow, int kp_cap, float scaling, int max_keypoints, int nframes, hipStream_t s);
+
+// ---- 16-bit image functions (brisk_image16.hip); strides in elements ----
+void brisk_launch_halfsample16(const uint16_t* src, int sstride, int w, int h, uint16_t* dst, int dstride, hipStream_t s);
+void brisk_launch_twothirdsample16(const uint16_t* src, int sstride, int w, int h, uint16_t* dst, int dstride, hipStream_t s);
+// rowsum: w x h floats of scratch; out: (h + 1) x (w + 1) floats at row stride ostride
+void brisk_launch_integral16(const uint16_t* src, int sstride, int w, int h, float* rowsum, float* out, int ostride, hipStream_t s);

@@ -248,3 +248,103 @@ void brisk_launch_uniformity(BriskKeyPoint* kp, BriskFrameCounters* counters, in
   hipLaunchKernelGGL(k_uniformity_seq, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, occ, occ_frame, ow,
                      kp_cap, scaling, max_keypoints);
 }
+
+// ------------------------------------------------------------------------------------------------
+// KeyPointBucketing (brisk/include/brisk/internal/key-point-bucketing-inl.h:40-112, key-point-bucketing.h:50-67): the
+// reference's other way to limit and spread the keypoints of a layer (scale-space-layer-inl.h:372-378: used when
+// uniformity enforcement is off).  Points sorted by score, descending; with one bucket in either direction the best
+// `max_keypoints` are kept (:87-98), otherwise the image is divided into nbu x nbv buckets of
+// (1 + (cols - 1) / nbu) x (1 + (rows - 1) / nbv) pixels and a point is kept while its bucket holds fewer than
+// max_keypoints / (nbu * nbv) points (:48-63).  A point's fate depends only on how many better points share its bucket,
+// so there is no sequential pass: rank by counting, rank inside the bucket by counting, stable compaction.
+// Output order = descending score (equal scores keep the detector's (layer, y, x) order; the reference's std::sort leaves
+// it open).  Like the uniformity filter this is offered as a post-filter of BriskFeatureDetector: parity unpinned.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(UF_THREADS) k_bucketing(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
+                                                          int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap,
+                                                          int rows, int cols, int nbu, int nbv, int max_keypoints) {
+  __shared__ float tile[UF_THREADS];
+  __shared__ int btile[UF_THREADS];
+  __shared__ int wsum[UF_THREADS / 64];
+  __shared__ int kept_s;
+  const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = min(counters[frame].nkp, kp_cap);
+  BriskKeyPoint* K = kp + (long)frame * kp_cap;
+  BriskKeyPoint* T = tmp + (long)frame * kp_cap;
+  int* ord = order + (long)frame * kp_cap;  // ord[i]: bit 31 = kept, low bits = output position of keypoint i among the kept
+  if (n == 0) return;
+  const bool single = (nbu == 1 || nbv == 1);
+  const int cap = single ? max_keypoints : max_keypoints / (nbu * nbv);
+  const unsigned step_u = 1u + (unsigned)(cols - 1) / (unsigned)nbu, step_v = 1u + (unsigned)(rows - 1) / (unsigned)nbv;
+  // pass 1: is keypoint j kept?  (rank among the points of its bucket - of all points with one bucket - below the cap)
+  for (int j0 = 0; j0 < n; j0 += UF_THREADS) {
+    const int j = j0 + tid;
+    float mine = 0.f;
+    int mybucket = -1;
+    if (j < n) {
+      mine = K[j].response;
+      mybucket = single ? 0 : (int)((unsigned)(int)K[j].x / step_u) * nbv + (int)((unsigned)(int)K[j].y / step_v);
+    }
+    int better = 0;
+    for (int t0 = 0; t0 < n; t0 += UF_THREADS) {
+      __syncthreads();
+      if (t0 + tid < n) {
+        tile[tid] = K[t0 + tid].response;
+        btile[tid] = single ? 0 : (int)((unsigned)(int)K[t0 + tid].x / step_u) * nbv + (int)((unsigned)(int)K[t0 + tid].y / step_v);
+      }
+      __syncthreads();
+      const int m = min(UF_THREADS, n - t0);
+      if (j < n)
+        for (int q = 0; q < m; ++q) {
+          const float s = tile[q];
+          better += (btile[q] == mybucket && (s > mine || (s == mine && t0 + q < j))) ? 1 : 0;
+        }
+    }
+    if (j < n) ord[j] = (better < cap) ? (int)0x80000000 : 0;
+  }
+  __threadfence();
+  __syncthreads();
+  // pass 2: output position of a kept keypoint = kept keypoints with a better score
+  for (int j0 = 0; j0 < n; j0 += UF_THREADS) {
+    const int j = j0 + tid;
+    const float mine = (j < n) ? K[j].response : 0.f;
+    const bool kept = (j < n) && (__hip_atomic_load(&ord[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0);
+    int pos = 0;
+    for (int t0 = 0; t0 < n; t0 += UF_THREADS) {
+      __syncthreads();
+      if (t0 + tid < n) {
+        tile[tid] = K[t0 + tid].response;
+        btile[tid] = __hip_atomic_load(&ord[t0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0 ? 1 : 0;
+      }
+      __syncthreads();
+      const int m = min(UF_THREADS, n - t0);
+      if (kept)
+        for (int q = 0; q < m; ++q) {
+          const float s = tile[q];
+          pos += (btile[q] && (s > mine || (s == mine && t0 + q < j))) ? 1 : 0;
+        }
+    }
+    if (kept) T[pos] = K[j];
+    const unsigned long long bal = __ballot(kept);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+      int t = (j0 == 0) ? 0 : kept_s;
+      for (int q = 0; q < UF_THREADS / 64; ++q) t += wsum[q];
+      kept_s = t;
+    }
+    __syncthreads();
+  }
+  __threadfence();
+  __syncthreads();
+  const int nkept = kept_s;
+  for (int i = tid; i < nkept; i += UF_THREADS) K[i] = T[i];
+  if (tid == 0) counters[frame].nkp = nkept;
+}
+
+void brisk_launch_bucketing(BriskKeyPoint* kp, BriskFrameCounters* counters, int* order, BriskKeyPoint* tmp, int kp_cap, int rows,
+                            int cols, int nbu, int nbv, int max_keypoints, int nframes, hipStream_t s) {
+  if (nframes <= 0) return;
+  hipLaunchKernelGGL(k_bucketing, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, kp_cap, rows, cols, nbu, nbv,
+                     max_keypoints);
+}

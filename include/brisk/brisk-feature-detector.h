@@ -50,6 +50,14 @@ class BriskFeatureDetector {
     m_maxNumKpt = maxNumKpt > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)maxNumKpt;
   }
 
+  // Engine option as well: KeyPointBucketing (brisk/include/brisk/internal/key-point-bucketing-inl.h:40-112), what the
+  // reference's ScaleSpaceLayer applies when uniformity enforcement is off (scale-space-layer-inl.h:376-378).  Takes
+  // effect while the uniformity radius is 0; (0, 0) switches it off.
+  void SetKeyPointBucketing(size_t numBucketsU, size_t numBucketsV, size_t maxNumKpt) {
+    m_bucketsU = (int)numBucketsU; m_bucketsV = (int)numBucketsV;
+    m_bucketMax = maxNumKpt > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)maxNumKpt;
+  }
+
   // brisk-feature-detector.cc:87-92: scores and scales for provided keypoints (`keypoints` is replaced by the result,
   // up to one entry per layer that admits a point).  Runs the reference's sequential algorithm on the device; throws
   // where the reference has no defined result (a point within a few rows of a layer's bottom border makes it read
@@ -87,6 +95,7 @@ class BriskFeatureDetector {
     if (image.empty()) throw std::runtime_error("BriskFeatureDetector: empty image");
     if (image.type() != CV_8UC1) throw std::runtime_error("BriskFeatureDetector: image must be CV_8UC1");
     brisk_hip_ctx* ctx = hip::DefaultContext();  // this thread's workspace
+    hip::Check(ctx, brisk_hip_set_bucketing(ctx, m_bucketsU, m_bucketsV, m_bucketMax), "brisk_hip_set_bucketing");  // (context state: set per call)
     size_t cap = 16384;
     for (;;) {
       keypoints.resize(cap);
@@ -110,6 +119,7 @@ class BriskFeatureDetector {
   bool m_suppressScaleNonmaxima;
   double m_uniformityRadius = 0.0;
   int m_maxNumKpt = 0x7FFFFFFF;
+  int m_bucketsU = 0, m_bucketsV = 0, m_bucketMax = 0;
 };
 
 }  // namespace brisk

@@ -151,6 +151,24 @@ int brisk_hip_set_streams(brisk_hip_ctx* ctx, int n);
  * ScaleSpaceFeatureDetector (scale-space-layer-inl.h:372-375), so this is an engine option, not reference behaviour of
  * BriskFeatureDetector; equal responses keep their (layer, y, x) order (the reference's std::sort is unstable). */
 int brisk_hip_set_uniformity(brisk_hip_ctx* ctx, double radius, int max_keypoints);
+/* KeyPointBucketing (brisk/include/brisk/internal/key-point-bucketing-inl.h:40-112; what the reference's
+ * ScaleSpaceLayer uses when uniformity enforcement is off, scale-space-layer-inl.h:372-378), applied like the uniformity
+ * filter to the detector's keypoints of every following detect call while uniformity is off: keypoints in descending
+ * response order; with one bucket in either direction the best max_keypoints are kept, otherwise a keypoint is kept while
+ * its bucket of (1 + (cols - 1) / num_buckets_u) x (1 + (rows - 1) / num_buckets_v) pixels holds fewer than
+ * max_keypoints / (num_buckets_u * num_buckets_v).  Output in descending response order.  (0, 0, *) switches it off.
+ * The reference requires num_buckets_u < cols and num_buckets_v < rows (CHECK_LT, :82-83): checked per call. */
+int brisk_hip_set_bucketing(brisk_hip_ctx* ctx, int num_buckets_u, int num_buckets_v, int max_keypoints);
+
+/* ---- 16-bit image functions (not on the 8-bit detect + describe path) --------------- */
+/* Halfsample16 (brisk/src/image-down-sampling.cc:56-139): dst is (w / 2) x (h / 2); Twothirdsample16 (:394-548): dst is
+ * (w / 3 * 2) x (h / 3 * 2); IntegralImage16 (brisk/include/brisk/internal/integral-image.h:163-218): dst is
+ * (h + 1) x (w + 1) floats.  Host buffers, strides in ELEMENTS; the reference's arithmetic bit for bit (saturating adds,
+ * signed pack to 32767, float sums in the reference's order incl. its unscaled last 0..3 columns).  Images with fewer
+ * than 16 (half) / 12 (two thirds) usable columns, where the reference's loops write nothing: BRISK_HIP_ERR_UNSUPPORTED. */
+int brisk_hip_halfsample16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, uint16_t* dst, int dst_stride);
+int brisk_hip_twothirdsample16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, uint16_t* dst, int dst_stride);
+int brisk_hip_integral_image16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, float* dst, int dst_stride);
 
 /* ---- Hamming brute-force matcher (the step after the path) ----------------------- */
 /* binary-identical to cv::DMatch */

@@ -45,6 +45,12 @@ int bo_oast9_16_detect(const uint8_t* img, int w, int h, const uint8_t* thrmap, 
 /* brisk/include/brisk/internal/integral-image.h:56-161 ; out is (h+1) x (w+1) int32 */
 void bo_integral_image8(const uint8_t* img, int w, int h, int32_t* out);
 
+/* 16-bit image functions (brisk_oracle_16bit.c): image-down-sampling.cc:56-139, :394-548, integral-image.h:163-218.
+ * The down-samplers return -1 where the reference's loops write nothing (fewer than 16 / 12 usable columns). */
+int bo_halfsample16(const uint16_t* src, int w, int h, uint16_t* dst);
+int bo_twothirdsample16(const uint16_t* src, int w, int h, uint16_t* dst);
+void bo_integral_image16(const uint16_t* src, int w, int h, float* out);
+
 /* ---- detector: brisk/src/brisk-feature-detector.cc:77-85 ---- */
 typedef struct bo_scale_space bo_scale_space;
 /* BriskScaleSpace(octaves, suppress) + ConstructPyramid(image, threshold) */
@@ -104,6 +110,9 @@ bo_dmatch* bo_match_radius(const uint8_t* query, int nq, int q_pitch, int dim, i
 /* ---- uniformity enforcement (brisk_oracle_uniformity.c; PARITY UNPINNED for AGAST keypoints, see there) ---- */
 int bo_enforce_uniformity(const bo_keypoint* kps, int n, int rows, int cols, double radius, int max_keypoints,
                           bo_keypoint* out);
+/* KeyPointBucketing (key-point-bucketing-inl.h:40-112): kept points in descending score order; -1 = arguments the reference CHECKs */
+int bo_key_point_bucketing(const bo_keypoint* kps, int n, int rows, int cols, int max_keypoints, int nbu, int nbv,
+                           bo_keypoint* out);
 
 #ifdef __cplusplus
 }

@@ -73,3 +73,39 @@ int bo_enforce_uniformity(const bo_keypoint* kps, int n, int rows, int cols, dou
   free(order);
   return kept;
 }
+
+/* KeyPointBucketing (brisk/include/brisk/internal/key-point-bucketing-inl.h:74-112) + KeyPointBuckets::filterKeyPoints
+ * (:40-72) + KeyPointBuckets' constructor (key-point-bucketing.h:50-67), applied to (x, y, response) of AGAST keypoints
+ * (x, y truncated to the integer pixel as PointWithScore holds them, score-calculator.h:66-85).  PARITY UNPINNED for the
+ * same reason as the uniformity filter: the reference only reaches it through the Harris ScaleSpaceLayer.
+ *   - points sorted by score, descending (std::sort / std::partial_sort on `score > other.score`: not stable; here equal
+ *     scores keep their input order);
+ *   - one bucket in either direction: the first max_keypoints points are kept (:87-98);
+ *   - otherwise max per bucket = max_keypoints / (nbu * nbv), step_u = 1 + (cols - 1) / nbu, step_v = 1 + (rows - 1) / nbv,
+ *     a point is kept while the counter of bucket (x / step_u, y / step_v) is below the maximum (:54-63).
+ * Returns the number of kept points (written to out in descending score order), -1 for arguments the reference CHECKs. */
+int bo_key_point_bucketing(const bo_keypoint* kps, int n, int rows, int cols, int max_keypoints, int nbu, int nbv,
+                           bo_keypoint* out) {
+  if (rows <= 0 || cols <= 0 || nbu <= 0 || nbv <= 0 || nbu >= cols || nbv >= rows || max_keypoints <= 0) return -1;
+  if (n <= 0) return 0;
+  scored* order = (scored*)malloc(sizeof(scored) * (size_t)n);
+  for (int i = 0; i < n; ++i) { order[i].score = kps[i].response; order[i].index = i; }
+  qsort(order, (size_t)n, sizeof(scored), cmp_scored);
+  int kept = 0;
+  if (nbu == 1 || nbv == 1) {
+    for (int i = 0; i < n && kept < max_keypoints; ++i) out[kept++] = kps[order[i].index];
+  } else {
+    const unsigned max_per_bucket = (unsigned)max_keypoints / ((unsigned)nbu * (unsigned)nbv);
+    const unsigned step_u = 1u + ((unsigned)cols - 1u) / (unsigned)nbu, step_v = 1u + ((unsigned)rows - 1u) / (unsigned)nbv;
+    unsigned* counter = (unsigned*)calloc((size_t)nbu * nbv, sizeof(unsigned));
+    for (int i = 0; i < n; ++i) {
+      const bo_keypoint* p = &kps[order[i].index];
+      const unsigned cu = (unsigned)(int)p->x / step_u, cv = (unsigned)(int)p->y / step_v;
+      unsigned* c = &counter[(size_t)cu * nbv + cv];
+      if (*c < max_per_bucket) { ++*c; out[kept++] = *p; }
+    }
+    free(counter);
+  }
+  free(order);
+  return kept;
+}

@@ -55,6 +55,10 @@ def lib():
         L.bo_extractor_compute.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
         L.bo_hamming.argtypes = [vp, vp, C.c_int]
         L.bo_enforce_uniformity.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+        L.bo_halfsample16.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.bo_twothirdsample16.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.bo_integral_image16.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.bo_key_point_bucketing.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         L.bo_match_knn.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         L.bo_match_knn.restype = None
         L.bo_match_radius.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp]
@@ -260,3 +264,33 @@ def enforce_uniformity(kps, rows, cols, radius, max_keypoints=0x7FFFFFFF):
     out = np.zeros(max(len(kps), 1), KP)
     n = lib().bo_enforce_uniformity(_p(kps), len(kps), rows, cols, float(radius), int(max_keypoints), _p(out))
     return out[:n].copy()
+
+
+def key_point_bucketing(kps, rows, cols, max_keypoints, nbu, nbv):
+    """KeyPointBucketing (key-point-bucketing-inl.h:40-112) on (x, y, response); None for arguments the reference CHECKs"""
+    kps = np.ascontiguousarray(kps, KP)
+    out = np.zeros(max(len(kps), 1), KP)
+    n = lib().bo_key_point_bucketing(_p(kps), len(kps), rows, cols, int(max_keypoints), int(nbu), int(nbv), _p(out))
+    return None if n < 0 else out[:n].copy()
+
+
+def halfsample16(img):
+    img = np.ascontiguousarray(img, np.uint16)
+    h, w = img.shape
+    out = np.zeros((h // 2, w // 2), np.uint16)
+    return out if lib().bo_halfsample16(_p(img), w, h, _p(out)) == 0 else None
+
+
+def twothirdsample16(img):
+    img = np.ascontiguousarray(img, np.uint16)
+    h, w = img.shape
+    out = np.zeros((h // 3 * 2, w // 3 * 2), np.uint16)
+    return out if lib().bo_twothirdsample16(_p(img), w, h, _p(out)) == 0 else None
+
+
+def integral16(img):
+    img = np.ascontiguousarray(img, np.uint16)
+    h, w = img.shape
+    out = np.zeros((h + 1, w + 1), np.float32)
+    lib().bo_integral_image16(_p(img), w, h, _p(out))
+    return out

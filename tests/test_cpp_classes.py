@@ -61,3 +61,22 @@ def test_set_container_cpp_round_trip(tmp_path):
     r = subprocess.run([b, os.path.join(ROOT, "tests", "golden"), str(tmp_path / "rt.set")], capture_output=True, text=True)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and r.stdout.count("OK") == 3
+
+
+def test_image16_header_compiles_and_fails_loudly_without_gpu():
+    import ethzasl_brisk_amd as B
+    b = build_binary("test_image16")
+    if B.load_library().brisk_hip_device_count() > 0:
+        pytest.skip("GPU present")
+    r = subprocess.run([b], capture_output=True, text=True)
+    assert r.returncode == 2 and "exception" in r.stdout   # no CPU fallback behind the functions
+
+
+@pytest.mark.gpu
+def test_image16_functions_through_the_cpp_header():
+    """brisk::Halfsample16 / Twothirdsample16 / IntegralImage16 (include/brisk/internal/image-functions-16.h) against
+    per-pixel readings of the reference arithmetic"""
+    b = build_binary("test_image16")
+    r = subprocess.run([b], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout.count("OK") == 3

@@ -154,3 +154,64 @@ def test_detect_then_compute_on_the_same_buffer_uploads_once_and_notices_changes
         ko5, do5 = X.compute(other, k)
         assert ctx.debug_image_reuse() == h0 + 2 and same_kps(k5, ko5) and np.array_equal(d5, do5), name
     ctx.close()
+
+
+@pytest.mark.parametrize("nbu,nbv,mx", [(8, 6, 480), (1, 4, 300), (16, 16, 256), (3, 2, 100000)])
+def test_key_point_bucketing_vs_oracle(B, nbu, nbv, mx):
+    """KeyPointBucketing (key-point-bucketing-inl.h:40-112) as a post-filter of the detector: host-buffer call and a batch
+    (bucketing inside, descriptors of the kept keypoints), against the oracle's restatement (parity unpinned)."""
+    import torch
+    imgs = [synth.frame_1080p(500 + i) for i in range(3)]
+    ctx = B.Context(0)
+    det = B.BriskFeatureDetector(60, 4, context=ctx, maxNumKpt=mx, numBucketsU=nbu, numBucketsV=nbv)
+    X = O.Extractor()
+    want = []
+    for img in imgs:
+        ko = O.detect(img, 60, 4)
+        kb = O.key_point_bucketing(ko, 1080, 1920, mx, nbu, nbv)
+        assert kb is not None and (len(kb) < len(ko) or mx > len(ko))
+        want.append((kb,) + X.compute(img, kb))
+    kg = det.detect(imgs[0])
+    assert same_kps(kg, want[0][0]), explain(kg, want[0][0])
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    ctx.detect_describe_batch(ext, d.data_ptr(), 3, 1920, 1080, 1920 * 1080, 1920, 60, 4, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.batch_status(3) == 0
+    for f in range(3):
+        kd, _ = ctx.batch_download(f, described=False)
+        k2, d2 = ctx.batch_download(f, described=True)
+        assert same_kps(kd, want[f][0]), (f, explain(kd, want[f][0]))
+        assert same_kps(k2, want[f][1]) and np.array_equal(d2, want[f][2]), f
+    # off again: plain detection
+    ctx.set_bucketing(0, 0, 0)
+    assert same_kps(B.BriskFeatureDetector(60, 4, context=ctx).detect(imgs[0]), O.detect(imgs[0], 60, 4))
+    with pytest.raises(B.BriskHipError):
+        B.BriskFeatureDetector(60, 4, context=ctx, maxNumKpt=10, numBucketsU=4000, numBucketsV=2).detect(imgs[0])
+    ctx.close()
+
+
+def test_16bit_image_functions_vs_oracle(B):
+    """Halfsample16 / Twothirdsample16 / IntegralImage16 on the device, bit-equal to the oracle's restatements (which are
+    pinned by per-pixel readings of the reference arithmetic); sizes with a re-done last block, saturating values, the
+    unscaled tail columns of the integral, and the sizes the reference cannot handle."""
+    ctx = B.Context(0)
+    rng = np.random.default_rng(21)
+    for (h, w) in ((480, 752), (37, 53), (1080, 1920), (19, 16), (21, 13), (65, 130)):
+        img = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+        img[::5, ::3] = 65535
+        for fn, ofn in ((ctx.halfsample16, O.halfsample16), (ctx.twothirdsample16, O.twothirdsample16)):
+            want = ofn(img)
+            if want is None:   # the reference's loop writes nothing at this width
+                with pytest.raises(B.BriskHipError):
+                    fn(img)
+            else:
+                assert np.array_equal(fn(img), want), (h, w)
+        assert np.array_equal(ctx.integral_image16(img).view(np.uint32), O.integral16(img).view(np.uint32)), (h, w)
+    small = rng.integers(0, 65536, (20, 11), dtype=np.uint16)
+    assert O.halfsample16(small) is None and O.twothirdsample16(small) is None
+    for fn in (ctx.halfsample16, ctx.twothirdsample16):
+        with pytest.raises(B.BriskHipError):
+            fn(small)
+    assert np.array_equal(ctx.integral_image16(small).view(np.uint32), O.integral16(small).view(np.uint32))
+    ctx.close()

@@ -325,3 +325,78 @@ def test_set_file_round_trip(tmp_path):
         dst = str(tmp_path / name)
         write_set(dst, read_set(src))
         assert open(dst, "rb").read() == open(src, "rb").read()
+
+
+def test_key_point_bucketing_restatement():
+    """KeyPointBucketing (key-point-bucketing-inl.h:40-112) as restated in the oracle, against a direct Python reading of
+    the reference on random points: descending score order, per-bucket cap max / (nbu * nbv), bucket steps
+    1 + (size - 1) / buckets, the single-bucket branch keeps the best max, the CHECKed argument ranges."""
+    import oracle_lib as O
+    rng = np.random.default_rng(7)
+    rows, cols = 480, 640
+    for n, mx, nbu, nbv in ((500, 100, 4, 3), (500, 100, 1, 5), (37, 1000, 8, 8), (2000, 64, 8, 8), (300, 7, 2, 2), (10, 3, 1, 1)):
+        k = np.zeros(n, O.KP)
+        k["x"] = rng.uniform(0, cols - 0.01, n).astype(np.float32)
+        k["y"] = rng.uniform(0, rows - 0.01, n).astype(np.float32)
+        k["response"] = rng.integers(1, 60, n).astype(np.float32)   # many equal scores
+        got = O.key_point_bucketing(k, rows, cols, mx, nbu, nbv)
+        order = sorted(range(n), key=lambda i: (-k["response"][i], i))
+        if nbu == 1 or nbv == 1:
+            want = order[:mx]
+        else:
+            cap, su, sv = mx // (nbu * nbv), 1 + (cols - 1) // nbu, 1 + (rows - 1) // nbv
+            cnt, want = {}, []
+            for i in order:
+                b = (int(k["x"][i]) // su, int(k["y"][i]) // sv)
+                assert b[0] < nbu and b[1] < nbv
+                if cnt.get(b, 0) < cap:
+                    cnt[b] = cnt.get(b, 0) + 1
+                    want.append(i)
+        assert len(got) == len(want) and all(got[j].tobytes() == k[i].tobytes() for j, i in enumerate(want)), (n, mx, nbu, nbv)
+    assert O.key_point_bucketing(k, rows, cols, 10, cols, 2) is None and O.key_point_bucketing(k, rows, cols, 0, 2, 2) is None
+
+
+def test_16bit_functions_against_per_pixel_restatements():
+    """Halfsample16 / Twothirdsample16 / IntegralImage16 (image-down-sampling.cc:56-139, 394-548, integral-image.h:163-218):
+    the oracle's block-structured restatements against per-pixel readings of the same arithmetic, the way
+    test-downsampling.cc:67-142 checks the 8-bit functions against plain loops; sizes that exercise the re-done last block,
+    values that exercise the saturating add and the signed pack."""
+    import oracle_lib as O
+    rng = np.random.default_rng(11)
+    for (h, w) in ((48, 64), (37, 53), (480, 752), (19, 16), (21, 12), (40, 17)):
+        img = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+        img[::7, ::5] = 65535
+        img[1::9, 2::3] = 65534
+        a = img.astype(np.int64)
+        if w // 2 * 2 >= 16:
+            hh, ww = h // 2, w // 2
+            i00, i01 = a[0:2 * hh:2, 0:2 * ww:2], a[0:2 * hh:2, 1:2 * ww:2]
+            i10, i11 = np.minimum(a[1:2 * hh:2, 0:2 * ww:2] + 2, 65535), a[1:2 * hh:2, 1:2 * ww:2]
+            want = ((((i00 + i01 + 1) >> 1) + ((i10 + i11 + 1) >> 1) + 1) >> 1).astype(np.uint16)
+            assert np.array_equal(O.halfsample16(img), want), (h, w)
+        else:
+            assert O.halfsample16(img) is None
+        if w // 3 * 3 >= 12:
+            hh, ww = h // 3, w // 3
+            s = lambda r, c: a[r:3 * hh:3, c:3 * ww:3]  # noqa: E731
+            want = np.zeros((2 * hh, 2 * ww), np.int64)
+            want[0::2, 0::2] = (4 * s(0, 0) + 2 * s(0, 1) + 2 * s(1, 0) + s(1, 1)) // 9
+            want[0::2, 1::2] = (4 * s(0, 2) + 2 * s(0, 1) + 2 * s(1, 2) + s(1, 1)) // 9
+            want[1::2, 0::2] = (4 * s(2, 0) + 2 * s(2, 1) + 2 * s(1, 0) + s(1, 1)) // 9
+            want[1::2, 1::2] = (4 * s(2, 2) + 2 * s(2, 1) + 2 * s(1, 2) + s(1, 1)) // 9
+            assert np.array_equal(O.twothirdsample16(img), np.minimum(want, 32767).astype(np.uint16)), (h, w)
+        else:
+            assert O.twothirdsample16(img) is None
+        # integral: sequential float32 row sums (value / 65536 for the columns taken four at a time, the raw value for the rest)
+        want = np.zeros((h + 1, w + 1), np.float32)
+        n4 = w // 4 * 4
+        for y in range(h):
+            s_ = np.float32(0)
+            for x in range(w):
+                s_ = np.float32(s_ + (np.float32(img[y, x]) * np.float32(1.0 / 65536.0) if x < n4 else np.float32(img[y, x])))
+                want[y + 1, x + 1] = np.float32(want[y, x + 1] + s_)
+            if h * w > 4096 and y > 40:
+                break
+        got = O.integral16(img)
+        rows = (h + 1) if not (h * w > 4096) else 42
+        assert np.array_equal(got[:rows].view(np.uint32), want[:rows].view(np.uint32)), (h, w)

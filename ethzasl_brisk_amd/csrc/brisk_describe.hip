@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   };
   // one sampling pass over the run: one sample per lane and round, lane = (keypoint, pattern point); the parameters of
   // the next round are requested before the current round's gathers.  (Measured and dropped: all rounds of a pass in
-  // flight together - parameters of every round, then every round's gathers, then the combines: 234 VGPRs, no faster.)
+  // flight together - parameters of every round, then every round's gathers, then the combines: 234 VGPRs, no faster;
+  // dedicated sampler waves fed by helper waves through LDS: profiles/r03_describe_roles_experiment.txt.)
   auto pass = [&](const DsFrame& F, int total, bool rotated) {
     DsLane Lc = fetch(total, lane, rotated);
     for (int s0 = 0; s0 < total; s0 += 64) {

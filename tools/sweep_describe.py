@@ -1,5 +1,6 @@
 """GPU box: k_describe launch knobs (debug bits 8-11 = keypoints per ticket, 12-15 = workgroups per CU) through bench.py."""
 import json
+import os
 import subprocess
 import sys
 
@@ -11,7 +12,7 @@ extra = sys.argv[5:]
 for order in orders:
   for run in runs:
     for bpc in bpcs:
-        flags = (run << 8) | (bpc << 12) | (stage0 << 20) | ((order & 15) << 4) | ((order >> 4) << 29)
+        flags = (run << 8) | (bpc << 12) | (stage0 << 20) | ((order & 15) << 4) | ((order >> 4) << 29) | int(os.environ.get("SWEEP_EXTRA_FLAGS", "0"), 0)
         out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-host-fed", "--steps", "3", "--warmup", "1",
                               "--inner", "8", "--debug-flags", str(flags)] + extra, capture_output=True, text=True)
         try:

@@ -32,5 +32,5 @@ rev=$(python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import eth
 python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $out/pmc_fetch_b64.csv $out/pmc_write_b64.csv 64 1920 1080 $out/traffic.json $rev > /dev/null
 cd $GRAFT_REPO_ROOT && bash tools/pmc_sq.sh $tag/sq > /dev/null 2>&1
 cp $out/sq/summary_all.txt $out/sq_counters.txt
-rm -rf $out/ks $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/sq
+rm -rf $out/ks $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/sq; bash $GRAFT_REPO_ROOT/tools/pmc_describe.sh $tag/describe > /dev/null 2>&1; cp $out/describe/summary_describe.txt $out/describe_tcp_counters.txt
 cat $out/bench.json | cut -c1-600

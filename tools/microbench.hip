@@ -27,21 +27,18 @@
 #define ITERS 1024
 #define UNROLL 16
 
+// One asm block per 16 instructions (two passes over 8 independent accumulators).  Round 2 issued every instruction
+// from its own asm statement: hipcc's hazard recognizer then pads each one with `s_nop 0` (29 s_nop per 32 VALU in the
+// ISA of every k_op_* loop, tools/kernel ISA dump in DESIGN.md 5), which is what made one wave alone look like 8.5 clocks
+// per instruction and `v_lshlrev_b32 v, 1, v` look half rate.  Inside one asm string nothing is inserted.
 #define STREAM8(ASM)                                                                                        \
   for (int it = 0; it < ITERS; ++it) {                                                                      \
-    _Pragma("unroll") for (int u = 0; u < UNROLL / 8; ++u) {                                                \
-      asm volatile(ASM : "+v"(a0) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");                    \
-      asm volatile(ASM : "+v"(a1) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");                    \
-      asm volatile(ASM : "+v"(a2) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");                    \
-      asm volatile(ASM : "+v"(a3) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");                    \
-      asm volatile(ASM : "+v"(a4) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");                    \
-      asm volatile(ASM : "+v"(a5) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");                    \
-      asm volatile(ASM : "+v"(a6) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");                    \
-      asm volatile(ASM : "+v"(a7) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");                    \
-    }                                                                                                       \
+    asm volatile(ASM8(ASM) ASM8(ASM)                                                                        \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)           \
+                 : "v"(x), "v"(y) : "vcc");                                                                 \
   }
-
 // one workgroup per CU (dynamic LDS > half of the CU's), 4*W waves: W waves per SIMD, every wave runs the stream
+#define ASM8(A) A
 #define DEF_OP(ID, ASM)                                                                                     \
   __global__ void __launch_bounds__(1024) k_op_##ID(unsigned long long* cyc, int* sink, int seed) {         \
     extern __shared__ int dyn[];                                                                            \
@@ -57,43 +54,43 @@
     if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345678) sink[0] = 1;                                 \
   }
 
-DEF_OP(0, "v_and_b32 %0, %0, %1")
-DEF_OP(1, "v_or_b32 %0, %0, %1")
-DEF_OP(2, "v_add_u32 %0, %0, %1")
-DEF_OP(3, "v_sub_u32 %0, %0, %1")
-DEF_OP(4, "v_lshlrev_b32 %0, 1, %0")
-DEF_OP(5, "v_lshrrev_b32 %0, %1, %0")
-DEF_OP(6, "v_max_i32 %0, %0, %1")
-DEF_OP(7, "v_max_u32 %0, %0, %1")
-DEF_OP(8, "v_min_u32 %0, %0, %1")
-DEF_OP(9, "v_max_f32 %0, %0, %1")
-DEF_OP(10, "v_add_f32 %0, %0, %1")
-DEF_OP(11, "v_fma_f32 %0, %0, %1, %2")
-DEF_OP(12, "v_max3_i32 %0, %0, %1, %2")
-DEF_OP(13, "v_max3_u32 %0, %0, %1, %2")
-DEF_OP(14, "v_max3_f32 %0, %0, %1, %2")
-DEF_OP(15, "v_min3_f32 %0, %0, %1, %2")
-DEF_OP(16, "v_med3_i32 %0, %0, %1, %2")
-DEF_OP(17, "v_bfe_u32 %0, %1, 8, 8")
-DEF_OP(18, "v_perm_b32 %0, %1, %2, %0")
-DEF_OP(19, "v_alignbit_b32 %0, %1, %2, %0")
-DEF_OP(20, "v_cndmask_b32 %0, %0, %1, vcc")
-DEF_OP(21, "v_add3_u32 %0, %0, %1, %2")
-DEF_OP(22, "v_lshl_or_b32 %0, %0, 1, %1")
-DEF_OP(23, "v_and_or_b32 %0, %0, %1, %2")
-DEF_OP(24, "v_or3_b32 %0, %0, %1, %2")
-DEF_OP(25, "v_sad_u8 %0, %1, %2, %0")
-DEF_OP(26, "v_mul_u32_u24 %0, %0, %1")
-DEF_OP(27, "v_mad_u32_u24 %0, %0, %1, %2")
-DEF_OP(28, "v_mul_lo_u32 %0, %0, %1")
-DEF_OP(29, "v_cvt_f32_ubyte1 %0, %1")
-DEF_OP(30, "v_cvt_f32_u32 %0, %0")
-DEF_OP(31, "v_bcnt_u32_b32 %0, %1, %0")
-DEF_OP(32, "v_pk_max_u16 %0, %0, %1")
-DEF_OP(33, "v_pk_min_u16 %0, %0, %1")
-DEF_OP(34, "v_pk_max_i16 %0, %0, %1")
-DEF_OP(35, "v_pk_add_u16 %0, %0, %1")
-DEF_OP(36, "v_pk_sub_i16 %0, %0, %1")
+DEF_OP(0, "v_and_b32 %0, %0, %8\n" "v_and_b32 %1, %1, %8\n" "v_and_b32 %2, %2, %8\n" "v_and_b32 %3, %3, %8\n" "v_and_b32 %4, %4, %8\n" "v_and_b32 %5, %5, %8\n" "v_and_b32 %6, %6, %8\n" "v_and_b32 %7, %7, %8\n")
+DEF_OP(1, "v_or_b32 %0, %0, %8\n" "v_or_b32 %1, %1, %8\n" "v_or_b32 %2, %2, %8\n" "v_or_b32 %3, %3, %8\n" "v_or_b32 %4, %4, %8\n" "v_or_b32 %5, %5, %8\n" "v_or_b32 %6, %6, %8\n" "v_or_b32 %7, %7, %8\n")
+DEF_OP(2, "v_add_u32 %0, %0, %8\n" "v_add_u32 %1, %1, %8\n" "v_add_u32 %2, %2, %8\n" "v_add_u32 %3, %3, %8\n" "v_add_u32 %4, %4, %8\n" "v_add_u32 %5, %5, %8\n" "v_add_u32 %6, %6, %8\n" "v_add_u32 %7, %7, %8\n")
+DEF_OP(3, "v_sub_u32 %0, %0, %8\n" "v_sub_u32 %1, %1, %8\n" "v_sub_u32 %2, %2, %8\n" "v_sub_u32 %3, %3, %8\n" "v_sub_u32 %4, %4, %8\n" "v_sub_u32 %5, %5, %8\n" "v_sub_u32 %6, %6, %8\n" "v_sub_u32 %7, %7, %8\n")
+DEF_OP(4, "v_lshlrev_b32 %0, 1, %0\n" "v_lshlrev_b32 %1, 1, %1\n" "v_lshlrev_b32 %2, 1, %2\n" "v_lshlrev_b32 %3, 1, %3\n" "v_lshlrev_b32 %4, 1, %4\n" "v_lshlrev_b32 %5, 1, %5\n" "v_lshlrev_b32 %6, 1, %6\n" "v_lshlrev_b32 %7, 1, %7\n")
+DEF_OP(5, "v_lshrrev_b32 %0, %8, %0\n" "v_lshrrev_b32 %1, %8, %1\n" "v_lshrrev_b32 %2, %8, %2\n" "v_lshrrev_b32 %3, %8, %3\n" "v_lshrrev_b32 %4, %8, %4\n" "v_lshrrev_b32 %5, %8, %5\n" "v_lshrrev_b32 %6, %8, %6\n" "v_lshrrev_b32 %7, %8, %7\n")
+DEF_OP(6, "v_max_i32 %0, %0, %8\n" "v_max_i32 %1, %1, %8\n" "v_max_i32 %2, %2, %8\n" "v_max_i32 %3, %3, %8\n" "v_max_i32 %4, %4, %8\n" "v_max_i32 %5, %5, %8\n" "v_max_i32 %6, %6, %8\n" "v_max_i32 %7, %7, %8\n")
+DEF_OP(7, "v_max_u32 %0, %0, %8\n" "v_max_u32 %1, %1, %8\n" "v_max_u32 %2, %2, %8\n" "v_max_u32 %3, %3, %8\n" "v_max_u32 %4, %4, %8\n" "v_max_u32 %5, %5, %8\n" "v_max_u32 %6, %6, %8\n" "v_max_u32 %7, %7, %8\n")
+DEF_OP(8, "v_min_u32 %0, %0, %8\n" "v_min_u32 %1, %1, %8\n" "v_min_u32 %2, %2, %8\n" "v_min_u32 %3, %3, %8\n" "v_min_u32 %4, %4, %8\n" "v_min_u32 %5, %5, %8\n" "v_min_u32 %6, %6, %8\n" "v_min_u32 %7, %7, %8\n")
+DEF_OP(9, "v_max_f32 %0, %0, %8\n" "v_max_f32 %1, %1, %8\n" "v_max_f32 %2, %2, %8\n" "v_max_f32 %3, %3, %8\n" "v_max_f32 %4, %4, %8\n" "v_max_f32 %5, %5, %8\n" "v_max_f32 %6, %6, %8\n" "v_max_f32 %7, %7, %8\n")
+DEF_OP(10, "v_add_f32 %0, %0, %8\n" "v_add_f32 %1, %1, %8\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %8\n" "v_add_f32 %4, %4, %8\n" "v_add_f32 %5, %5, %8\n" "v_add_f32 %6, %6, %8\n" "v_add_f32 %7, %7, %8\n")
+DEF_OP(11, "v_fma_f32 %0, %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n" "v_fma_f32 %2, %2, %8, %9\n" "v_fma_f32 %3, %3, %8, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_fma_f32 %5, %5, %8, %9\n" "v_fma_f32 %6, %6, %8, %9\n" "v_fma_f32 %7, %7, %8, %9\n")
+DEF_OP(12, "v_max3_i32 %0, %0, %8, %9\n" "v_max3_i32 %1, %1, %8, %9\n" "v_max3_i32 %2, %2, %8, %9\n" "v_max3_i32 %3, %3, %8, %9\n" "v_max3_i32 %4, %4, %8, %9\n" "v_max3_i32 %5, %5, %8, %9\n" "v_max3_i32 %6, %6, %8, %9\n" "v_max3_i32 %7, %7, %8, %9\n")
+DEF_OP(13, "v_max3_u32 %0, %0, %8, %9\n" "v_max3_u32 %1, %1, %8, %9\n" "v_max3_u32 %2, %2, %8, %9\n" "v_max3_u32 %3, %3, %8, %9\n" "v_max3_u32 %4, %4, %8, %9\n" "v_max3_u32 %5, %5, %8, %9\n" "v_max3_u32 %6, %6, %8, %9\n" "v_max3_u32 %7, %7, %8, %9\n")
+DEF_OP(14, "v_max3_f32 %0, %0, %8, %9\n" "v_max3_f32 %1, %1, %8, %9\n" "v_max3_f32 %2, %2, %8, %9\n" "v_max3_f32 %3, %3, %8, %9\n" "v_max3_f32 %4, %4, %8, %9\n" "v_max3_f32 %5, %5, %8, %9\n" "v_max3_f32 %6, %6, %8, %9\n" "v_max3_f32 %7, %7, %8, %9\n")
+DEF_OP(15, "v_min3_f32 %0, %0, %8, %9\n" "v_min3_f32 %1, %1, %8, %9\n" "v_min3_f32 %2, %2, %8, %9\n" "v_min3_f32 %3, %3, %8, %9\n" "v_min3_f32 %4, %4, %8, %9\n" "v_min3_f32 %5, %5, %8, %9\n" "v_min3_f32 %6, %6, %8, %9\n" "v_min3_f32 %7, %7, %8, %9\n")
+DEF_OP(16, "v_med3_i32 %0, %0, %8, %9\n" "v_med3_i32 %1, %1, %8, %9\n" "v_med3_i32 %2, %2, %8, %9\n" "v_med3_i32 %3, %3, %8, %9\n" "v_med3_i32 %4, %4, %8, %9\n" "v_med3_i32 %5, %5, %8, %9\n" "v_med3_i32 %6, %6, %8, %9\n" "v_med3_i32 %7, %7, %8, %9\n")
+DEF_OP(17, "v_bfe_u32 %0, %8, 8, 8\n" "v_bfe_u32 %1, %8, 8, 8\n" "v_bfe_u32 %2, %8, 8, 8\n" "v_bfe_u32 %3, %8, 8, 8\n" "v_bfe_u32 %4, %8, 8, 8\n" "v_bfe_u32 %5, %8, 8, 8\n" "v_bfe_u32 %6, %8, 8, 8\n" "v_bfe_u32 %7, %8, 8, 8\n")
+DEF_OP(18, "v_perm_b32 %0, %8, %9, %0\n" "v_perm_b32 %1, %8, %9, %1\n" "v_perm_b32 %2, %8, %9, %2\n" "v_perm_b32 %3, %8, %9, %3\n" "v_perm_b32 %4, %8, %9, %4\n" "v_perm_b32 %5, %8, %9, %5\n" "v_perm_b32 %6, %8, %9, %6\n" "v_perm_b32 %7, %8, %9, %7\n")
+DEF_OP(19, "v_alignbit_b32 %0, %8, %9, %0\n" "v_alignbit_b32 %1, %8, %9, %1\n" "v_alignbit_b32 %2, %8, %9, %2\n" "v_alignbit_b32 %3, %8, %9, %3\n" "v_alignbit_b32 %4, %8, %9, %4\n" "v_alignbit_b32 %5, %8, %9, %5\n" "v_alignbit_b32 %6, %8, %9, %6\n" "v_alignbit_b32 %7, %8, %9, %7\n")
+DEF_OP(20, "v_cndmask_b32 %0, %0, %8, vcc\n" "v_cndmask_b32 %1, %1, %8, vcc\n" "v_cndmask_b32 %2, %2, %8, vcc\n" "v_cndmask_b32 %3, %3, %8, vcc\n" "v_cndmask_b32 %4, %4, %8, vcc\n" "v_cndmask_b32 %5, %5, %8, vcc\n" "v_cndmask_b32 %6, %6, %8, vcc\n" "v_cndmask_b32 %7, %7, %8, vcc\n")
+DEF_OP(21, "v_add3_u32 %0, %0, %8, %9\n" "v_add3_u32 %1, %1, %8, %9\n" "v_add3_u32 %2, %2, %8, %9\n" "v_add3_u32 %3, %3, %8, %9\n" "v_add3_u32 %4, %4, %8, %9\n" "v_add3_u32 %5, %5, %8, %9\n" "v_add3_u32 %6, %6, %8, %9\n" "v_add3_u32 %7, %7, %8, %9\n")
+DEF_OP(22, "v_lshl_or_b32 %0, %0, 1, %8\n" "v_lshl_or_b32 %1, %1, 1, %8\n" "v_lshl_or_b32 %2, %2, 1, %8\n" "v_lshl_or_b32 %3, %3, 1, %8\n" "v_lshl_or_b32 %4, %4, 1, %8\n" "v_lshl_or_b32 %5, %5, 1, %8\n" "v_lshl_or_b32 %6, %6, 1, %8\n" "v_lshl_or_b32 %7, %7, 1, %8\n")
+DEF_OP(23, "v_and_or_b32 %0, %0, %8, %9\n" "v_and_or_b32 %1, %1, %8, %9\n" "v_and_or_b32 %2, %2, %8, %9\n" "v_and_or_b32 %3, %3, %8, %9\n" "v_and_or_b32 %4, %4, %8, %9\n" "v_and_or_b32 %5, %5, %8, %9\n" "v_and_or_b32 %6, %6, %8, %9\n" "v_and_or_b32 %7, %7, %8, %9\n")
+DEF_OP(24, "v_or3_b32 %0, %0, %8, %9\n" "v_or3_b32 %1, %1, %8, %9\n" "v_or3_b32 %2, %2, %8, %9\n" "v_or3_b32 %3, %3, %8, %9\n" "v_or3_b32 %4, %4, %8, %9\n" "v_or3_b32 %5, %5, %8, %9\n" "v_or3_b32 %6, %6, %8, %9\n" "v_or3_b32 %7, %7, %8, %9\n")
+DEF_OP(25, "v_sad_u8 %0, %8, %9, %0\n" "v_sad_u8 %1, %8, %9, %1\n" "v_sad_u8 %2, %8, %9, %2\n" "v_sad_u8 %3, %8, %9, %3\n" "v_sad_u8 %4, %8, %9, %4\n" "v_sad_u8 %5, %8, %9, %5\n" "v_sad_u8 %6, %8, %9, %6\n" "v_sad_u8 %7, %8, %9, %7\n")
+DEF_OP(26, "v_mul_u32_u24 %0, %0, %8\n" "v_mul_u32_u24 %1, %1, %8\n" "v_mul_u32_u24 %2, %2, %8\n" "v_mul_u32_u24 %3, %3, %8\n" "v_mul_u32_u24 %4, %4, %8\n" "v_mul_u32_u24 %5, %5, %8\n" "v_mul_u32_u24 %6, %6, %8\n" "v_mul_u32_u24 %7, %7, %8\n")
+DEF_OP(27, "v_mad_u32_u24 %0, %0, %8, %9\n" "v_mad_u32_u24 %1, %1, %8, %9\n" "v_mad_u32_u24 %2, %2, %8, %9\n" "v_mad_u32_u24 %3, %3, %8, %9\n" "v_mad_u32_u24 %4, %4, %8, %9\n" "v_mad_u32_u24 %5, %5, %8, %9\n" "v_mad_u32_u24 %6, %6, %8, %9\n" "v_mad_u32_u24 %7, %7, %8, %9\n")
+DEF_OP(28, "v_mul_lo_u32 %0, %0, %8\n" "v_mul_lo_u32 %1, %1, %8\n" "v_mul_lo_u32 %2, %2, %8\n" "v_mul_lo_u32 %3, %3, %8\n" "v_mul_lo_u32 %4, %4, %8\n" "v_mul_lo_u32 %5, %5, %8\n" "v_mul_lo_u32 %6, %6, %8\n" "v_mul_lo_u32 %7, %7, %8\n")
+DEF_OP(29, "v_cvt_f32_ubyte1 %0, %8\n" "v_cvt_f32_ubyte1 %1, %8\n" "v_cvt_f32_ubyte1 %2, %8\n" "v_cvt_f32_ubyte1 %3, %8\n" "v_cvt_f32_ubyte1 %4, %8\n" "v_cvt_f32_ubyte1 %5, %8\n" "v_cvt_f32_ubyte1 %6, %8\n" "v_cvt_f32_ubyte1 %7, %8\n")
+DEF_OP(30, "v_cvt_f32_u32 %0, %0\n" "v_cvt_f32_u32 %1, %1\n" "v_cvt_f32_u32 %2, %2\n" "v_cvt_f32_u32 %3, %3\n" "v_cvt_f32_u32 %4, %4\n" "v_cvt_f32_u32 %5, %5\n" "v_cvt_f32_u32 %6, %6\n" "v_cvt_f32_u32 %7, %7\n")
+DEF_OP(31, "v_bcnt_u32_b32 %0, %8, %0\n" "v_bcnt_u32_b32 %1, %8, %1\n" "v_bcnt_u32_b32 %2, %8, %2\n" "v_bcnt_u32_b32 %3, %8, %3\n" "v_bcnt_u32_b32 %4, %8, %4\n" "v_bcnt_u32_b32 %5, %8, %5\n" "v_bcnt_u32_b32 %6, %8, %6\n" "v_bcnt_u32_b32 %7, %8, %7\n")
+DEF_OP(32, "v_pk_max_u16 %0, %0, %8\n" "v_pk_max_u16 %1, %1, %8\n" "v_pk_max_u16 %2, %2, %8\n" "v_pk_max_u16 %3, %3, %8\n" "v_pk_max_u16 %4, %4, %8\n" "v_pk_max_u16 %5, %5, %8\n" "v_pk_max_u16 %6, %6, %8\n" "v_pk_max_u16 %7, %7, %8\n")
+DEF_OP(33, "v_pk_min_u16 %0, %0, %8\n" "v_pk_min_u16 %1, %1, %8\n" "v_pk_min_u16 %2, %2, %8\n" "v_pk_min_u16 %3, %3, %8\n" "v_pk_min_u16 %4, %4, %8\n" "v_pk_min_u16 %5, %5, %8\n" "v_pk_min_u16 %6, %6, %8\n" "v_pk_min_u16 %7, %7, %8\n")
+DEF_OP(34, "v_pk_max_i16 %0, %0, %8\n" "v_pk_max_i16 %1, %1, %8\n" "v_pk_max_i16 %2, %2, %8\n" "v_pk_max_i16 %3, %3, %8\n" "v_pk_max_i16 %4, %4, %8\n" "v_pk_max_i16 %5, %5, %8\n" "v_pk_max_i16 %6, %6, %8\n" "v_pk_max_i16 %7, %7, %8\n")
+DEF_OP(35, "v_pk_add_u16 %0, %0, %8\n" "v_pk_add_u16 %1, %1, %8\n" "v_pk_add_u16 %2, %2, %8\n" "v_pk_add_u16 %3, %3, %8\n" "v_pk_add_u16 %4, %4, %8\n" "v_pk_add_u16 %5, %5, %8\n" "v_pk_add_u16 %6, %6, %8\n" "v_pk_add_u16 %7, %7, %8\n")
+DEF_OP(36, "v_pk_sub_i16 %0, %0, %8\n" "v_pk_sub_i16 %1, %1, %8\n" "v_pk_sub_i16 %2, %2, %8\n" "v_pk_sub_i16 %3, %3, %8\n" "v_pk_sub_i16 %4, %4, %8\n" "v_pk_sub_i16 %5, %5, %8\n" "v_pk_sub_i16 %6, %6, %8\n" "v_pk_sub_i16 %7, %7, %8\n")
 
 typedef void (*op_kernel_t)(unsigned long long*, int*, int);
 struct OpDesc { const char* name; op_kernel_t fn; int ninstr; };

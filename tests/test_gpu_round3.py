@@ -215,3 +215,34 @@ def test_16bit_image_functions_vs_oracle(B):
             fn(small)
     assert np.array_equal(ctx.integral_image16(small).view(np.uint32), O.integral16(small).view(np.uint32))
     ctx.close()
+
+
+def test_describe_work_queues_beyond_2048_frames(B):
+    """More than 8 x 256 frames in one launch: k_describe's frames are then dealt to more than eight queues (one queue
+    holds at most 256 frames).  2100 small frames, a sample of slots - first, last, around the queue boundaries - against the
+    oracle; then 5 and 9 frames on the same context (one queue / eight queues with almost empty groups)."""
+    import torch
+    w, h = 192, 128
+    distinct = [synth.gen(w, h, 700 + s, 24) for s in range(7)]
+    X = O.Extractor()
+    want = []
+    for img in distinct:
+        ko = O.detect(img, 50, 2)
+        want.append((ko,) + X.compute(img, ko))
+    assert sum(len(k[1]) for k in want) > 50
+    ctx = B.Context(0, 4096, 1024)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    for n in (2100, 5, 9):
+        stack = np.stack([distinct[f % 7] for f in range(n)])
+        d = torch.from_numpy(stack).cuda()
+        ctx.detect_describe_batch(ext, d.data_ptr(), n, w, h, w * h, w, 50, 2, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ctx.batch_status(n) == 0
+        slots = sorted(set([f for f in (0, 1, 7, 8, 9, 255, 256, 257, 1023, 1024, 2047, 2048, 2049, 2090, 2098, 2099) if f < n] + list(range(min(n, 12)))))
+        for f in slots:
+            ko, ko2, do = want[f % 7]
+            kd, _ = ctx.batch_download(f, described=False)
+            kg, dg = ctx.batch_download(f, described=True)
+            assert same_kps(kd, ko), (n, f, explain(kd, ko))
+            assert same_kps(kg, ko2) and np.array_equal(dg, do), (n, f)
+    ctx.close()

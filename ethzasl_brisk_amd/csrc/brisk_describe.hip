@@ -143,9 +143,6 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
 #endif
 #define DS_MAXRUN 8
 #define DS_MAXQ 256        // frames per work queue (more frames per launch: more queues)
-#ifndef DS_RUN_BATCH
-#define DS_RUN_BATCH 2   // keypoints per ticket in batches of >= 8 frames
-#endif
 #ifndef DS_BLOCKS_PER_CU
 #define DS_BLOCKS_PER_CU 3
 #endif
@@ -264,7 +261,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
                                                             const uint32_t* __restrict__ integral, int istride,
                                                             long iframe_elems, BriskFrameCounters* counters,
                                                             BriskKeyPoint* dkp, uint4* __restrict__ drec,
-                                                            uint8_t* desc, int kp_cap, int desc_pitch, int nframes) {
+                                                            uint8_t* desc, int kp_cap, int desc_pitch, int nframes, int run_fixed) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ds_lds[];
   // LDS: long pairs {i, j, wdx, wdy} | short pairs i | j << 16 | per wave: records and rotations of a run, values, the
   // work queue's cumulative run / keypoint counts
@@ -395,12 +392,24 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
     for (int j0 = 0; j0 < m; j0 += 64) {
       const int j = j0 + lane;
       const int nkp = j < m ? counters[g + (m - 1 - j) * ngroups].ndesc : 0;
-      int r = (nkp + RUN - 1) / RUN;
+      // keypoints per ticket of this frame (RUN is the kernel's maximum): sparse frames small runs - the stretch of
+      // keypoints an XCD has in flight must stay local (2 at BASELINE config 2's ~480 keypoints per megapixel) -, dense
+      // frames larger ones (fuller sampling rounds, fewer tickets: 30 k keypoints per frame 6.6 -> 5.8 ms per 64 frames),
+      // and never fewer tickets than there are waves to take them (one frame per call: 1 keypoint per ticket)
+      int runf = run_fixed;
+      if (runf == 0) {
+        const long density = (long)nkp * (1 << 20) / ((long)cols * G.L[0].h);  // keypoints per megapixel
+        runf = density < 1500 ? 2 : density < 6000 ? 4 : 8;
+        const int waves_serving = (int)(gridDim.x * DS_WAVES) / ngroups;
+        runf = min(runf, max(1, nkp / max(waves_serving, 1)));
+      }
+      runf = min(max(runf, 1), RUN);
+      int r = (nkp + runf - 1) / runf;
       for (int off = 1; off < 64; off <<= 1) {
         const int t = __shfl_up(r, off, 64);
         if (lane >= off) r += t;
       }
-      if (j < m) { cum[j] = carry + r; cnt_q[j] = nkp; }
+      if (j < m) { cum[j] = carry + r; cnt_q[j] = nkp | (runf << 24); }
       carry += __shfl(r, 63, 64);
     }
     wave_sync();
@@ -416,8 +425,10 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
         qj = __builtin_amdgcn_readfirstlane(qj);
         T.frame = g + (m - 1 - qj) * ngroups;
         const int run = __builtin_amdgcn_readfirstlane(tk - (qj ? cum[qj - 1] : 0));
-        T.k0 = run * RUN;
-        T.cnt = min(RUN, __builtin_amdgcn_readfirstlane(cnt_q[qj]) - T.k0);
+        const int cq = __builtin_amdgcn_readfirstlane(cnt_q[qj]);
+        const int runf = cq >> 24;
+        T.k0 = run * runf;
+        T.cnt = min(runf, (cq & 0xFFFFFF) - T.k0);
         T.total = T.cnt * np;
       }
       return T;
@@ -543,7 +554,7 @@ static size_t describe_lds_bytes(const BriskPatternDev& P, int run, bool regtab)
 }
 
 typedef void (*ds_kernel_t)(BriskGeom, BriskPatternDev, const uint8_t*, const uint32_t*, int, long, BriskFrameCounters*, BriskKeyPoint*, uint4*,
-                            uint8_t*, int, int, int);
+                            uint8_t*, int, int, int, int);
 
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
@@ -569,22 +580,23 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
       (void)hipGetDevice(&dev);
       ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
     }
-    int run = (G.debug_flags >> 8) & 0xF;
-    if (!run) run = nframes >= 8 ? DS_RUN_BATCH : 1;
-    if (P.has_bilinear) run = 1;
-    run = run >= 8 ? 8 : run >= 4 ? 4 : run >= 2 ? 2 : 1;
+    // keypoints per ticket: chosen per frame inside the kernel (from the frame's keypoint density) up to DS_MAXRUN;
+    // debug bits 8-11 fix it (tuning experiments)
+    int run_fixed = (G.debug_flags >> 8) & 0xF;
+    if (P.has_bilinear) run_fixed = 1;
+    if (run_fixed > DS_MAXRUN) run_fixed = DS_MAXRUN;
     int bpc = (G.debug_flags >> 12) & 0xF;
     if (!bpc) bpc = DS_BLOCKS_PER_CU;
     const bool regtab = P.reg_tables && !P.has_bilinear;
-    size_t lds = describe_lds_bytes(P, run, regtab);
+    const int run_max = P.has_bilinear ? 1 : DS_MAXRUN;
+    size_t lds = describe_lds_bytes(P, run_max, regtab);
     const size_t lds_limit = 160 * 1024 / (size_t)(bpc + 1) + 512;  // bpc + 1 workgroups of this size do not fit a CU
     if (lds < lds_limit && !(G.debug_flags & (1 << 28))) lds = lds_limit;  // bit 28: no padding (other kernels share the CUs)
-    ds_kernel_t fn = run == 8 ? k_describe<8, false, true> : run == 4 ? k_describe<4, false, true> : run == 2 ? k_describe<2, false, true> : k_describe<1, false, true>;
-    if (!regtab) fn = run == 8 ? k_describe<8, false, false> : run == 4 ? k_describe<4, false, false> : run == 2 ? k_describe<2, false, false> : k_describe<1, false, false>;
+    ds_kernel_t fn = regtab ? k_describe<DS_MAXRUN, false, true> : k_describe<DS_MAXRUN, false, false>;
     if (P.has_bilinear) fn = k_describe<1, true, false>;
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fn, dim3(ncu * bpc), dim3(DS_WAVES * 64), lds, s, G, P, B.pyr, Dd.integral, Dd.istride, Dd.iframe_elems,
-                       B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, nframes);
+                       B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, nframes, run_fixed);
   }
   brisk_prof_mark(prof, BRISK_STG_DESCRIBE + 1, s);
 }

@@ -12,6 +12,7 @@ import ethzasl_brisk_amd as B
 import synth
 
 ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+ctx.debug_set_flags(int(os.environ.get("BRISK_DEBUG_FLAGS", "0"), 0))   # (k_describe launch knobs: tools/sweep_describe.py)
 ext = B.BriskDescriptorExtractor(context=ctx)
 frames = np.stack([synth.frame_1080p(i) for i in range(4)])
 d = torch.from_numpy(frames).cuda()

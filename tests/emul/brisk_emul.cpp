@@ -550,6 +550,34 @@ int emul_scale_index(void* p, float size, int scale_invariant) {
 }
 int emul_scale_index_host(float size) { return brisk_pattern_scale_index_host(size); }
 
+// brisk_div_by_magic (k_describe's division by scaling2) against C division: every scaling2 of the pattern's table, the
+// given numerators plus edge values; returns the number of mismatches
+long emul_div_magic_mismatches(void* p, const int* numerators, int n) {
+  const BriskPatternHost& H = ((EmulPattern*)p)->H;
+  long bad = 0;
+  const int edge[] = {0, 1, -1, 2147483647, -2147483647 - 1, -2147483647, 1073741824, 4095, 4096, 4097, -4096, 65535};
+  for (size_t i = 0; i < H.scaling.size() / 2; ++i) {
+    const int d = H.scaling[2 * i + 1];
+    if (d < 2) continue;
+    int M, sh;
+    brisk_div_magic(d, &M, &sh);
+    for (int k = 0; k < n; ++k) bad += (numerators[k] / d != brisk_div_by_magic(numerators[k], M, sh));
+    for (int e : edge) {
+      bad += (e / d != brisk_div_by_magic(e, M, sh));
+      bad += ((e - d) / d != brisk_div_by_magic(e - d, M, sh)) + ((d * 3 + e % 7) / d != brisk_div_by_magic(d * 3 + e % 7, M, sh));
+    }
+  }
+  return bad;
+}
+// the same for an arbitrary divisor
+long emul_div_magic_mismatches_d(int d, const int* numerators, int n) {
+  int M, sh;
+  brisk_div_magic(d, &M, &sh);
+  long bad = 0;
+  for (int k = 0; k < n; ++k) bad += (numerators[k] / d != brisk_div_by_magic(numerators[k], M, sh));
+  return bad;
+}
+
 // mirrors k_integral_* + k_desc_prepare + k_describe; returns surviving count
 int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kps, int n, uint8_t* desc, int desc_pitch,
                   int rotation_invariant, int scale_invariant) {

@@ -37,6 +37,10 @@ def lib():
         L.emul_pattern_point.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.emul_scale_index.argtypes = [vp, C.c_float, C.c_int]
         L.emul_scale_index_host.argtypes = [C.c_float]
+        L.emul_div_magic_mismatches.argtypes = [vp, vp, C.c_int]
+        L.emul_div_magic_mismatches.restype = C.c_long
+        L.emul_div_magic_mismatches_d.argtypes = [C.c_int, vp, C.c_int]
+        L.emul_div_magic_mismatches_d.restype = C.c_long
         L.emul_describe.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib

@@ -304,3 +304,18 @@ def test_describe_box_that_ends_in_the_last_column():
         ko, do = oext.compute(img, k)
         ke, de = pat.describe(img, k)
         assert len(ko) > 100 and same_kps(ke, ko) and np.array_equal(de, do)
+
+
+def test_division_by_multiplication_is_exact():
+    """k_describe divides the weighted box sum by scaling2 with a host-computed magic multiplier (brisk_div_magic /
+    brisk_div_by_magic, Hacker's Delight 10-1): equal to C's truncating division for every scaling2 of both built-in
+    patterns (and of small / large pattern scales) on random and edge numerators, and for assorted divisors."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    nums = np.concatenate([rng.integers(-2**31, 2**31, 20000, dtype=np.int64), rng.integers(0, 1 << 30, 20000, dtype=np.int64)]).astype(np.int32)
+    L = E.lib()
+    for version, scale in ((2, 1.0), (1, 1.0), (2, 0.4), (2, 3.0)):
+        p = E.Pattern(version, scale)
+        assert L.emul_div_magic_mismatches(p._h, nums.ctypes.data_as(C.c_void_p), len(nums)) == 0, (version, scale)
+    for d in (2, 3, 7, 4095, 4096, 4097, 65535, 65536, 1 << 30, (1 << 30) + 1, 2**31 - 1, 12345677):
+        assert L.emul_div_magic_mismatches_d(d, nums.ctypes.data_as(C.c_void_p), len(nums)) == 0, d

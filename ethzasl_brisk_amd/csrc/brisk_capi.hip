@@ -381,16 +381,7 @@ static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
     for (size_t i = 0; i < 64 * n; ++i) {
       memcpy(&tab[4 * i], &H.mult[i], 4);
       memcpy(&tab[4 * i + 1], &H.sigma[i], 4);
-      const int scaling = H.scaling[2 * i], scaling2 = H.scaling[2 * i + 1];
-      if (scaling2 >= 2 && scaling >= 0 && scaling < (1 << 24)) {
-        int M, sh;
-        brisk_div_magic(scaling2, &M, &sh);
-        tab[4 * i + 2] = scaling | (sh << 24);
-        tab[4 * i + 3] = M;
-      } else {  // degenerate boxes (never sampled through the box branch in practice): plain division on the device
-        tab[4 * i + 2] = (scaling & 0xFFFFFF) | (1 << 30);
-        tab[4 * i + 3] = scaling2;
-      }
+      brisk_pack_tab(H.scaling[2 * i], H.scaling[2 * i + 1], &tab[4 * i + 2], &tab[4 * i + 3]);
     }
     HIPCHK(ctx, hipMemcpy(b + o_tab, tab.data(), 64 * n * 16, hipMemcpyHostToDevice));
   }

@@ -160,39 +160,15 @@ struct DsLane {  // a lane's sample of one round
   double2 uv;    // unit offset of the point at the keypoint's rotation
   int slot;      // keypoint-in-run * npoints + point
 };
-struct DsPrep {
-  int x_left, y_top, x_right, y_bottom;
-  unsigned A, B, C, D, r_x_1_i, r_y_1_i, r_x1_i, r_y1_i;
-  int scaling, magic, shift;  // acc / scaling2 as a multiplication (brisk_div_by_magic); shift < 0: plain division by `magic`
-  bool quirk;
-};
+typedef BriskBoxPrep DsPrep;  // address / weight stage of a sample (brisk_device_describe.h)
 struct DsRaw {
   ds_u32x2 p00, p02, p10, p12, p20, p22, p30, p32;
   unsigned br, bl;
 };
-// SmoothedIntensity split into address / load / combine stages (device only; the arithmetic is that of
-// brisk_smoothed_intensity in brisk_device_describe.h, box branch)
+// SmoothedIntensity split into address / load / combine stages: the arithmetic is brisk_box_prep / brisk_box_acc /
+// brisk_box_divide of brisk_device_describe.h (host + device: tests/emul runs it on the CPU)
 __device__ __forceinline__ DsPrep ds_prep(float xf, float yf, float sigma_half, int tab_z, int tab_w) {
-  DsPrep p;
-  const int scaling = tab_z & 0xFFFFFF;
-  p.scaling = scaling; p.magic = tab_w; p.shift = (tab_z & (1 << 30)) ? -1 : ((tab_z >> 24) & 31);
-  const float x_1 = xf - sigma_half, x1 = xf + sigma_half, y_1 = yf - sigma_half, y1 = yf + sigma_half;
-  p.x_left = (int)(x_1 + 0.5); p.y_top = (int)(y_1 + 0.5); p.x_right = (int)(x1 + 0.5); p.y_bottom = (int)(y1 + 0.5);
-  const float r_x_1 = (float)((float)p.x_left - x_1 + 0.5);
-  const float r_y_1 = (float)((float)p.y_top - y_1 + 0.5);
-  const float r_x1 = (float)(x1 - (float)p.x_right + 0.5);
-  const float r_y1 = (float)(y1 - (float)p.y_bottom + 0.5);
-  const int dx = p.x_right - p.x_left - 1, dy = p.y_bottom - p.y_top - 1;
-  p.A = (unsigned)(int)((r_x_1 * r_y_1) * scaling);
-  p.B = (unsigned)(int)((r_x1 * r_y_1) * scaling);
-  p.C = (unsigned)(int)((r_x1 * r_y1) * scaling);
-  p.D = (unsigned)(int)((r_x_1 * r_y1) * scaling);
-  p.r_x_1_i = (unsigned)(int)(r_x_1 * scaling);
-  p.r_y_1_i = (unsigned)(int)(r_y_1 * scaling);
-  p.r_x1_i = (unsigned)(int)(r_x1 * scaling);
-  p.r_y1_i = (unsigned)(int)(r_y1 * scaling);
-  p.quirk = (dx + dy > 2);
-  return p;
+  return brisk_box_prep(xf, yf, sigma_half, tab_z, tab_w);
 }
 // The 4 x 4 integral samples as eight 8-byte gathers through a buffer descriptor of the frame's integral image: four
 // 32-bit offsets per lane (the corners), the second row of each pair through the scalar offset; plus the two displaced
@@ -219,22 +195,9 @@ __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, __amdgpu_buff
   r.bl = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xl + (xl >= cols ? wrap : 0), 0, 0);
 }
 __device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
-  const uint32_t i00 = r.p00.x, i01 = r.p00.y, i02 = r.p02.x, i03 = r.p02.y;
-  const uint32_t i10 = r.p10.x, i11 = r.p10.y, i12 = r.p12.x, i13 = r.p12.y;
-  const uint32_t i20 = r.p20.x, i21 = r.p20.y, i22 = r.p22.x, i23 = r.p22.y;
-  const uint32_t i30 = r.p30.x, i31 = r.p30.y, i32 = r.p32.x, i33 = r.p32.y;
-  const unsigned tl = i11 - i01 - i10 + i00;  // pixel (x_left, y_top)
-  const unsigned tr = i13 - i03 - i12 + i02;  // pixel (x_right, y_top)
-  const unsigned br = p.quirk ? r.br : (i33 - i23 - i32 + i22);
-  const unsigned bl = p.quirk ? r.bl : (i31 - i21 - i30 + i20);
-  const uint32_t top = i12 - i11 - i02 + i01;
-  const uint32_t bottom = i32 - i31 - i22 + i21;
-  const uint32_t left = i21 - i20 - i11 + i10;
-  const uint32_t right = i23 - i22 - i13 + i12;
-  const uint32_t middle = i22 - i21 - i12 + i11;
-  const uint32_t acc = p.A * tl + p.B * tr + p.C * br + p.D * bl + p.r_y_1_i * top + p.r_y1_i * bottom + p.r_x_1_i * left +
-                       p.r_x1_i * right + (unsigned)p.scaling * middle;
-  if (__any(p.shift < 0)) return p.shift < 0 ? (int)acc / p.magic : brisk_div_by_magic((int)acc, p.magic, p.shift);
+  const uint32_t acc = brisk_box_acc(p, r.p00.x, r.p00.y, r.p02.x, r.p02.y, r.p10.x, r.p10.y, r.p12.x, r.p12.y, r.p20.x, r.p20.y, r.p22.x,
+                                     r.p22.y, r.p30.x, r.p30.y, r.p32.x, r.p32.y, r.br, r.bl);
+  if (__any(p.shift < 0)) return brisk_box_divide(p, acc);  // (a pattern with degenerate boxes: the plain division is compiled in but skipped)
   return brisk_div_by_magic((int)acc, p.magic, p.shift);
 }
 // one sample: address stage + gathers (issue), and its combine stage

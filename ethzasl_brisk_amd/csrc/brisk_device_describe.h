@@ -184,6 +184,72 @@ BRISK_HD int brisk_div_by_magic(int n, int M, int sh) {
   return q + (int)((unsigned)q >> 31);
 }
 
+// ---- SmoothedIntensity, box branch (:410-530), split into the stages k_describe runs: address / weights, the 4 x 4
+// integral samples + the two displaced corner pixels (loaded by the caller), combination.  Same arithmetic as
+// brisk_smoothed_intensity above; tests/emul runs these on the CPU against the oracle.
+// tab_z / tab_w: BriskPatternDev::tab words 2 and 3 of the (scale, point): scaling | shift << 24 | plain << 30, and the
+// magic multiplier of scaling2 (plain: scaling2 itself) - brisk_pack_tab.
+BRISK_HD void brisk_pack_tab(int scaling, int scaling2, int* tab_z, int* tab_w) {
+  if (scaling2 >= 2 && scaling >= 0 && scaling < (1 << 24)) {
+    int M, sh;
+    brisk_div_magic(scaling2, &M, &sh);
+    *tab_z = scaling | (sh << 24);
+    *tab_w = M;
+  } else {  // degenerate boxes (never sampled through the box branch in practice): plain division on the device
+    *tab_z = (scaling & 0xFFFFFF) | (1 << 30);
+    *tab_w = scaling2;
+  }
+}
+struct BriskBoxPrep {
+  int x_left, y_top, x_right, y_bottom;
+  unsigned A, B, C, D, r_x_1_i, r_y_1_i, r_x1_i, r_y1_i;
+  int scaling, magic, shift;  // acc / scaling2 as a multiplication (brisk_div_by_magic); shift < 0: plain division by `magic`
+  bool quirk;                 // dx + dy > 2: the integral branch with its displaced bottom corners (:453)
+};
+BRISK_HD BriskBoxPrep brisk_box_prep(float xf, float yf, float sigma_half, int tab_z, int tab_w) {
+  BriskBoxPrep p;
+  const int scaling = tab_z & 0xFFFFFF;
+  p.scaling = scaling; p.magic = tab_w; p.shift = (tab_z & (1 << 30)) ? -1 : ((tab_z >> 24) & 31);
+  const float x_1 = xf - sigma_half, x1 = xf + sigma_half, y_1 = yf - sigma_half, y1 = yf + sigma_half;
+  p.x_left = (int)(x_1 + 0.5); p.y_top = (int)(y_1 + 0.5); p.x_right = (int)(x1 + 0.5); p.y_bottom = (int)(y1 + 0.5);
+  const float r_x_1 = (float)((float)p.x_left - x_1 + 0.5);
+  const float r_y_1 = (float)((float)p.y_top - y_1 + 0.5);
+  const float r_x1 = (float)(x1 - (float)p.x_right + 0.5);
+  const float r_y1 = (float)(y1 - (float)p.y_bottom + 0.5);
+  const int dx = p.x_right - p.x_left - 1, dy = p.y_bottom - p.y_top - 1;
+  p.A = (unsigned)(int)((r_x_1 * r_y_1) * scaling);
+  p.B = (unsigned)(int)((r_x1 * r_y_1) * scaling);
+  p.C = (unsigned)(int)((r_x1 * r_y1) * scaling);
+  p.D = (unsigned)(int)((r_x_1 * r_y1) * scaling);
+  p.r_x_1_i = (unsigned)(int)(r_x_1 * scaling);
+  p.r_y_1_i = (unsigned)(int)(r_y_1 * scaling);
+  p.r_x1_i = (unsigned)(int)(r_x1 * scaling);
+  p.r_y1_i = (unsigned)(int)(r_y1 * scaling);
+  p.quirk = (dx + dy > 2);
+  return p;
+}
+// i[r][c]: integral samples at rows {y_top, y_top + 1, y_bottom, y_bottom + 1} x columns {x_left, x_left + 1, x_right,
+// x_right + 1}; br / bl: image pixels (x_right + 1, y_bottom - 1) / (x_left + 1, y_bottom - 1) (used when p.quirk).
+// Returns the weighted sum before the division by scaling2.
+BRISK_HD uint32_t brisk_box_acc(const BriskBoxPrep& p, uint32_t i00, uint32_t i01, uint32_t i02, uint32_t i03, uint32_t i10,
+                                uint32_t i11, uint32_t i12, uint32_t i13, uint32_t i20, uint32_t i21, uint32_t i22, uint32_t i23,
+                                uint32_t i30, uint32_t i31, uint32_t i32, uint32_t i33, unsigned qbr, unsigned qbl) {
+  const unsigned tl = i11 - i01 - i10 + i00;  // pixel (x_left, y_top)
+  const unsigned tr = i13 - i03 - i12 + i02;  // pixel (x_right, y_top)
+  const unsigned br = p.quirk ? qbr : (i33 - i23 - i32 + i22);
+  const unsigned bl = p.quirk ? qbl : (i31 - i21 - i30 + i20);
+  const uint32_t top = i12 - i11 - i02 + i01;
+  const uint32_t bottom = i32 - i31 - i22 + i21;
+  const uint32_t left = i21 - i20 - i11 + i10;
+  const uint32_t right = i23 - i22 - i13 + i12;
+  const uint32_t middle = i22 - i21 - i12 + i11;
+  return p.A * tl + p.B * tr + p.C * br + p.D * bl + p.r_y_1_i * top + p.r_y1_i * bottom + p.r_x_1_i * left + p.r_x1_i * right +
+         (unsigned)p.scaling * middle;
+}
+BRISK_HD int brisk_box_divide(const BriskBoxPrep& p, uint32_t acc) {
+  return p.shift < 0 ? (int)acc / p.magic : brisk_div_by_magic((int)acc, p.magic, p.shift);
+}
+
 // long-pair contribution (:721-730): C integer division truncates toward zero
 BRISK_HD void brisk_long_pair(const int* values, const int* lp /* i, j, wdx, wdy */, int* d0, int* d1) {
   const int delta_t = values[lp[0]] - values[lp[1]];

@@ -578,6 +578,33 @@ long emul_div_magic_mismatches_d(int d, const int* numerators, int n) {
   return bad;
 }
 
+// one sample the way k_describe computes it: parameters from the packed table record (brisk_pack_tab) and the unit
+// offset, box corners / weights (brisk_box_prep), the 4 x 4 integral samples + the two displaced corner pixels, the
+// weighted sum (brisk_box_acc), the division by multiplication (brisk_box_divide); points on the bilinear branch through
+// the generic function (the kernel's GENERIC variant)
+static int emul_sample(const BriskPatternDev& P, const uint8_t* img, int stride, int cols, const uint32_t* integ, int istride, float kx,
+                       float ky, int scale, int theta, int i) {
+  const int ti = scale * P.npoints + i;
+  const float sigma = P.sigma[ti];
+  if (sigma < 0.5f) return brisk_smoothed_intensity(img, stride, cols, integ, istride, kx, ky, brisk_pattern_point(P, scale, theta, i));
+  int tz, tw;
+  brisk_pack_tab(P.scaling[2 * ti], P.scaling[2 * ti + 1], &tz, &tw);
+  const double mm = (double)P.mult[ti];
+  const double* uv = P.uv + ((long)theta * P.npoints + i) * 2;
+  const float xf = (float)(mm * uv[0]) + kx, yf = (float)(mm * uv[1]) + ky;
+  const BriskBoxPrep p = brisk_box_prep(xf, yf, sigma, tz, tw);
+  const uint32_t* r0 = integ + (long)p.y_top * istride;
+  const uint32_t* r1 = r0 + istride;
+  const uint32_t* r2 = integ + (long)p.y_bottom * istride;
+  const uint32_t* r3 = r2 + istride;
+  const int qy = p.y_bottom - 1 > 0 ? p.y_bottom - 1 : 0;
+  const unsigned qbr = brisk_linear_px(img, stride, cols, p.x_right + 1, qy), qbl = brisk_linear_px(img, stride, cols, p.x_left + 1, qy);
+  const uint32_t acc = brisk_box_acc(p, r0[p.x_left], r0[p.x_left + 1], r0[p.x_right], r0[p.x_right + 1], r1[p.x_left], r1[p.x_left + 1],
+                                     r1[p.x_right], r1[p.x_right + 1], r2[p.x_left], r2[p.x_left + 1], r2[p.x_right], r2[p.x_right + 1],
+                                     r3[p.x_left], r3[p.x_left + 1], r3[p.x_right], r3[p.x_right + 1], qbr, qbl);
+  return brisk_box_divide(p, acc);
+}
+
 // mirrors k_integral_* + k_desc_prepare + k_describe; returns surviving count
 int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kps, int n, uint8_t* desc, int desc_pitch,
                   int rotation_invariant, int scale_invariant) {
@@ -612,7 +639,7 @@ int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kp
     if (P.rotation_invariant) {
       if (kp->angle == -1.0f) {
         for (int i = 0; i < P.npoints; ++i) {
-          values[i] = brisk_smoothed_intensity(padded.data(), stride, w, integ.data(), istride, kp->x, kp->y, brisk_pattern_point(P, scale, 0, i));
+          values[i] = emul_sample(P, padded.data(), stride, w, integ.data(), istride, kp->x, kp->y, scale, 0, i);
         }
         int d0 = 0, d1 = 0;
         for (int p = 0; p < P.nlong; ++p) {
@@ -627,7 +654,7 @@ int emul_describe(void* pat, const uint8_t* img, int w, int h, BriskKeyPoint* kp
       }
     }
     for (int i = 0; i < P.npoints; ++i) {
-      values[i] = brisk_smoothed_intensity(padded.data(), stride, w, integ.data(), istride, kp->x, kp->y, brisk_pattern_point(P, scale, theta, i));
+      values[i] = emul_sample(P, padded.data(), stride, w, integ.data(), istride, kp->x, kp->y, scale, theta, i);
     }
     uint8_t* drow = desc + (size_t)k * desc_pitch;
     memset(drow, 0, P.strings);

@@ -179,6 +179,13 @@ __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, __amdgpu_buff
   const int rowb = istride * 4;
   const int o_t = p.y_top * rowb, o_b = p.y_bottom * rowb;
   const int o_tl = o_t + p.x_left * 4, o_tr = o_t + p.x_right * 4, o_bl = o_b + p.x_left * 4, o_br = o_b + p.x_right * 4;
+  int qy = max(p.y_bottom - 1, 0);
+  int xr = p.x_right + 1, xl = p.x_left + 1;
+  const int o_q = qy * stride;
+  const int wrap = stride - cols;  // x >= cols: first pixels of the next row
+  // (the image bytes first, then row by row: 1 % faster than bytes last, 4 % faster than left clusters before right ones)
+  r.br = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xr + (xr >= cols ? wrap : 0), 0, 0);
+  r.bl = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xl + (xl >= cols ? wrap : 0), 0, 0);
   r.p00 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, 0, 0);
   r.p02 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, 0, 0);
   r.p10 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, rowb, 0);
@@ -187,12 +194,6 @@ __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, __amdgpu_buff
   r.p22 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, 0, 0);
   r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl, rowb, 0);
   r.p32 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, rowb, 0);
-  int qy = max(p.y_bottom - 1, 0);
-  int xr = p.x_right + 1, xl = p.x_left + 1;
-  const int o_q = qy * stride;
-  const int wrap = stride - cols;  // x >= cols: first pixels of the next row
-  r.br = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xr + (xr >= cols ? wrap : 0), 0, 0);
-  r.bl = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xl + (xl >= cols ? wrap : 0), 0, 0);
 }
 __device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
   const uint32_t acc = brisk_box_acc(p, r.p00.x, r.p00.y, r.p02.x, r.p02.y, r.p10.x, r.p10.y, r.p12.x, r.p12.y, r.p20.x, r.p20.y, r.p22.x,
@@ -322,7 +323,9 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
       } else {
         const DsPrep pr = ds_prep(xf, yf, sigma, Lc.tab.z, Lc.tab.w);
         DsRaw raw;
+        __builtin_amdgcn_s_setprio(1);  // a wave that has its gathers to issue goes first (1 % of the kernel)
         if (valid) ds_load(raw, pr, F.rs_img, stride, cols, F.rs_int, istride);
+        __builtin_amdgcn_s_setprio(0);
         value = ds_combine(pr, raw);
       }
       if (valid) vals[Lc.slot] = value;

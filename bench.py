@@ -252,7 +252,7 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-fed (host frames) measurement")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL result gather even with one rank (self-test)")
-    ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results become wrong)")
+    ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="timing experiments only (results become wrong)")
     ap.add_argument("--pattern-version", type=int, default=2)
     ap.add_argument("--min-region-s", type=float, default=2.0,
                     help="--frames mode: the step is repeated until the timed region is at least this long")

@@ -649,6 +649,22 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
     ctx->sub_created = true;
   }
+  // timing experiments only (debug bits 20-23 = g with bit 27): the descriptor half in groups of 8 g frames, one after the
+  // other on `s` (integral image of a group -> its descriptors: is the integral still in the Infinity Cache?); bit 19: the
+  // integral images of all frames first, then the groups (the same launches with a stale cache)
+  const int grp = 8 * ((ctx->debug_flags >> 20) & 0xF);
+  if (grp > 0 && !do_detect && do_describe) {
+    if (ctx->debug_flags & (1 << 19))
+      brisk_launch_integral(ctx->G, ctx->B.pyr, ctx->B.bandsum, ctx->D.integral, ctx->D.istride, ctx->D.iframe_elems, ctx->B.band_h, nframes, s);
+    for (long f0 = 0; f0 < nframes; f0 += grp) {
+      const int nf = (int)((nframes - f0) < grp ? (nframes - f0) : grp);
+      if (f0 == 0) ctx->last_frames_per_launch = nf;
+      rc = batch_slice(ctx, A, d_frames + f0 * frame_pitch, f0, nf, s, (f0 == 0) ? &ctx->prof : nullptr, false);
+      if (rc) return rc;
+    }
+    guard.armed = false;
+    return batch_end(ctx, A, nframes, s);
+  }
   if (nsub > 1) HIPCHK(ctx, hipEventRecord(ctx->fork_ev, s));
   for (int i = 0; i < nsub; ++i) {
     const long f0 = (long)nframes * i / nsub, f1 = (long)nframes * (i + 1) / nsub;
@@ -787,7 +803,13 @@ static int overflow_to_rc(brisk_hip_ctx* ctx, int flags) {
   if (flags & 1) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "candidate capacity exceeded (brisk_hip_set_capacity)");
   if (flags & 2) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "tie-candidate capacity exceeded (brisk_hip_set_capacity)");
   if (flags & 4) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "keypoint capacity exceeded (brisk_hip_set_capacity)");
-  if (flags & 8) return fail(ctx, BRISK_HIP_ERR_HIP, "tie resolution gave up waiting for a decision (internal error)");
+  if (flags & 8) {
+    static const char* const site[8] = {"", " (the layer below)", " (a pending tie outside its chunk)", " (a neighbour's decision)",
+                                        " (the writer wave)", "", "", ""};
+    char msg[128];
+    snprintf(msg, sizeof(msg), "tie resolution gave up waiting for a decision%s (internal error)", site[(flags >> 8) & 7]);
+    return fail(ctx, BRISK_HIP_ERR_HIP, msg);
+  }
   if (flags & 16)
     return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED,
                 "no defined result in the reference on this input: suppressScaleNonmaxima=false indexes layer 0's point list "

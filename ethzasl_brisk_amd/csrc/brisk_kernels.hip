@@ -1055,6 +1055,12 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   // a frame whose candidate or tie list overflowed is reported as an error and its result discarded; its map holds
   // tie candidates that are in no list, which nobody would ever decide: do not wait for them
   const bool skip_frame = (counters[frame].overflow & 3) != 0;
+  // Safety net of the waits below (a wait that cannot end must not hang the GPU): a wait may legitimately last as long
+  // as all raster-earlier work of the frame - a frame of 150 k ties that all depend on each other decides one tie per
+  // 4 us, and the layer above waits at its front for most of that -, so the bound is 0.5 s + 20 us per tie of the frame
+  // on the 100 MHz wall clock, not a spin count.
+  long long wait_budget = 50000000ll;
+  for (int q = 0; q < nl; ++q) wait_budget += (long long)min(counters[frame].ntie[q], tie_cap) * 2000ll;
   for (int l = l0; l < l1; ++l) {
   int* const my_prog = &counters[frame].tie_prog[l];
   const int n = min(counters[frame].ntie[l], tie_cap);
@@ -1224,12 +1230,18 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       if (!valid) {  // pipeline front: wait for the layer below, then read the window
         int need;
         TR_NEED(key, need)
-        for (int spin = 0; seen < need && spin < (1 << 20); ++spin) {
+        long long t0 = 0;
+        for (int spin = 0; seen < need; ++spin) {
           TR_POLL(need)
           if (seen >= need || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
           __builtin_amdgcn_s_sleep(8);
+          if ((spin & 255) == 255) {
+            const long long now = (long long)wall_clock64();
+            if (!t0) t0 = now;
+            else if (now - t0 > wait_budget) break;
+          }
         }
-        if (seen < need) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+        if (seen < need) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (the layer below: never observed)
         const unsigned s0 = pw0, s1 = pw1;  // keep the next tie's prefetch
         TR_PREFETCH(j)
         v0 = pw0; v1 = pw1;
@@ -1261,7 +1273,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
           // (a pending raster-earlier tie of the window is always in this chunk: earlier chunks are complete and the
           // window was read after they were)
           if (!(lo < j && sxyd[lo] == k2)) {
-            __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+            __hip_atomic_store(&abort_s, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
             lo = -1;
           }
         }
@@ -1273,12 +1285,18 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       TR_T(5)
       if (lo >= 0) {
         int st = 0;
-        for (int spin = 0; spin < (1 << 22); ++spin) {
+        long long t0 = 0;
+        for (int spin = 0;; ++spin) {
           st = __hip_atomic_load(&tstat[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 3;
           if (st || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
           __builtin_amdgcn_s_sleep(1);
+          if ((spin & 4095) == 4095) {  // (the other wave may itself be waiting for the layer below)
+            const long long now = (long long)wall_clock64();
+            if (!t0) t0 = now;
+            else if (now - t0 > wait_budget) break;
+          }
         }
-        if (!st) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
+        if (!st && !__hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __hip_atomic_store(&abort_s, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
         if (st) wl[lane] = (uint16_t)((v0 & ~0x3000u) | ((unsigned)st << 12));
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1309,6 +1327,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     // The deciding waves never wait for a memory write this way (an agent-scope atomic takes microseconds).
     if (wave == dwaves) {
       int w = 0, row_pub = -1;
+      long long t0 = 0;
       for (int idle = 0; w < nc;) {
         const int i = w + lane;
         const int st = (i < nc) ? __hip_atomic_load(&tstat[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
@@ -1343,9 +1362,13 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
           }
           if (w < nc) row_pub = max(row_pub, (int)((sxyd[w] >> 13) & 0x1FFF));
         } else {
-          if (++idle > (1 << 22)) {  // (never observed)
-            __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            break;
+          if ((++idle & 4095) == 0) {  // (the deciding waves may be waiting for the layer below)
+            const long long now = (long long)wall_clock64();
+            if (idle == 4096) t0 = now;
+            else if (now - t0 > wait_budget) {  // (never observed)
+              __hip_atomic_store(&abort_s, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              break;
+            }
           }
           __builtin_amdgcn_s_sleep(2);
         }
@@ -1372,7 +1395,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   }
   }  // layers of this workgroup
   __syncthreads();
-  if (tid == 0 && abort_s) atomicOr(&counters[frame].overflow, 8);  // a wait ran into its bound: reported as an error
+  if (tid == 0 && abort_s) atomicOr(&counters[frame].overflow, 8 | (abort_s << 8));  // a wait ran into its bound: reported as an error (bits 8-10: which wait)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -80,3 +80,45 @@ def test_image16_functions_through_the_cpp_header():
     r = subprocess.run([b], capture_output=True, text=True)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and r.stdout.count("OK") == 3
+
+
+def test_capacity_test_compiles():
+    build_binary("test_capacity")
+
+
+CAPACITY_CASES = [
+    ("noise_vga_thr20", lambda np: np.random.default_rng(1).integers(0, 256, (480, 640), dtype=np.uint8), 20, 4),
+    ("tie_blocks_thr21", lambda np: np.kron(np.random.default_rng(1487 * 8).integers(0, 4, (739 // 3 + 1, 525 // 3 + 1)) * 80 + 7,
+                                            np.ones((3, 3)))[:739, :525].astype(np.uint8), 21, 2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mk,thr,octaves", CAPACITY_CASES, ids=[c[0] for c in CAPACITY_CASES])
+def test_drop_in_classes_grow_the_workspace(tmp_path, name, mk, thr, octaves):
+    """images with more candidates / ties / keypoints than the default workspace holds (every tenth pixel of a noise
+    image is a keypoint; block images are all ties): the C ABI answers BRISK_HIP_ERR_CAPACITY, the drop-in classes grow
+    the workspace and repeat the call - the caller sees the reference's result (which has no capacities)"""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import ethzasl_brisk_amd as B
+    b = build_binary("test_capacity")
+    img = np.ascontiguousarray(mk(np))
+    raw, out = tmp_path / "img.raw", tmp_path / "out.bin"
+    img.tofile(raw)
+    r = subprocess.run([b, str(raw), str(img.shape[1]), str(img.shape[0]), str(thr), str(octaves), str(out)], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0
+    blob = out.read_bytes()
+    ndet, ndesc, drows, dcols = np.frombuffer(blob[:16], np.int32)
+    KP = B.KEYPOINT
+    kd = np.frombuffer(blob[16:16 + ndet * KP.itemsize], KP)
+    kg = np.frombuffer(blob[16 + ndet * KP.itemsize:16 + (ndet + ndesc) * KP.itemsize], KP)
+    dg = np.frombuffer(blob[16 + (ndet + ndesc) * KP.itemsize:], np.uint8).reshape(drows, dcols)
+    ko = O.detect(img, thr, octaves)
+    ko2, do = O.Extractor().compute(img, ko)
+    assert len(ko) > 16384   # beyond the classes' first output capacity
+    assert kd.tobytes() == ko.tobytes()
+    assert kg.tobytes() == ko2.tobytes() and np.array_equal(dg, do)

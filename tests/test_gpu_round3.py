@@ -246,3 +246,18 @@ def test_describe_work_queues_beyond_2048_frames(B):
             assert same_kps(kd, ko), (n, f, explain(kd, ko))
             assert same_kps(kg, ko2) and np.array_equal(dg, do), (n, f)
     ctx.close()
+
+
+def test_random_sizes_thresholds_octaves_fuzz():
+    """tools/soak4.py in a process of its own (it forks its oracle workers before HIP is initialised): 250 random cases -
+    image sides 9 ... 1100, thresholds 1 ... 140 (ordered and fast path), 0 ... 6 octaves, five content kinds incl. all-tie
+    block images, host calls and small device batches - each bit-equal to the oracle (keypoints before and after
+    compute(), descriptors).  Cases the default workspace answers with BRISK_HIP_ERR_CAPACITY are repeated on a larger one."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak4.py"), "250", "11"], capture_output=True, text=True, timeout=900)
+    tail = [ln for ln in r.stdout.splitlines() if ln.startswith(("soak4", "ERROR", "MISMATCH"))]
+    print("\n".join(tail[-20:]), r.stderr[-2000:])
+    assert r.returncode == 0 and tail and tail[-1].startswith("soak4: 250 cases") and " 0 bad" in tail[-1]

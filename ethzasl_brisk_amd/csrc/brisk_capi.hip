@@ -31,6 +31,7 @@ struct brisk_hip_ctx {
   std::mutex mu;
   std::string err;
   int cand_cap = 65536, kp_cap = 16384, tie_cap = 8192;
+  int desc_pitch = 64;  // bytes per descriptor row on the device: grows with the longest descriptor a pattern of this context produced (generateKernel at pattern scales < 1: up to 224 bytes)
   // current allocation
   int slots = 0;
   long pyr_elems_alloc = 0;
@@ -217,7 +218,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   const int istride = brisk_align_up(G.w + 1, 16);
   const long iframe = (long)istride * (G.h + 1);
   if (nframes <= c->slots && G.pyr_elems <= c->pyr_elems_alloc && iframe <= c->iframe_elems_alloc &&
-      c->B.cand_cap == c->cand_cap && c->B.kp_cap == c->kp_cap) {
+      c->B.cand_cap == c->cand_cap && c->B.kp_cap == c->kp_cap && c->D.desc_pitch >= c->desc_pitch) {
     c->D.istride = istride;
     c->B.istride = istride;
     c->D.iframe_elems = iframe;
@@ -245,7 +246,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMalloc(&c->D.dscale, (size_t)slots * c->kp_cap * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->D.dperm, (size_t)slots * c->kp_cap * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->D.drec, ((size_t)slots * c->kp_cap + 4) * sizeof(uint4)));
-  c->D.desc_pitch = 64;
+  c->D.desc_pitch = c->desc_pitch;
   HIPCHK(c, hipMalloc(&c->D.desc, (size_t)slots * c->kp_cap * c->D.desc_pitch));
   HIPCHK(c, hipMalloc(&c->d_kp_in, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
   HIPCHK(c, hipMalloc(&c->d_n_in, (size_t)slots * sizeof(int)));
@@ -490,6 +491,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   ctx->G.debug_flags = ctx->debug_flags;
   ctx->G.no_scale_nms = (A.no_scale_nms && A.octaves != 0) ? 1 : 0;
   ctx->G.lower_threshold = A.lower_threshold;
+  if (A.do_describe && A.pat && A.pat->host.strings > ctx->desc_pitch) ctx->desc_pitch = brisk_align_up(A.pat->host.strings, 16);
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
   const bool bucketing = A.do_detect && !(A.uni_radius > 0.0) && ctx->bk_u > 0;
@@ -981,6 +983,7 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   int rc = ensure_stage(ctx, img_bytes * 2);
   if (rc) return rc;
   make_geometry(w, h, 20, 0, &ctx->G, &ctx->T);  // only layer 0 is needed
+  if (pat->host.strings > ctx->desc_pitch) ctx->desc_pitch = brisk_align_up(pat->host.strings, 16);
   rc = ensure_buffers(ctx, 1, ctx->G);
   if (rc) return rc;
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
@@ -1051,7 +1054,7 @@ static int match_host(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pi
   if (nq < 0 || nimg < 0 || k_or_cap < 0 || !out_count || (nq > 0 && (!query || (k_or_cap > 0 && !out))) ||
       (nimg > 0 && (!train || !ntrain || !t_pitch)))
     return fail(ctx, BRISK_HIP_ERR_ARG, "match: bad argument");
-  if (dim < 16 || dim > 64) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "match: descriptor size must be 16..64 bytes");
+  if (dim < 16 || dim > 224) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "match: descriptor size must be 16..224 bytes");
   if (q_pitch < dim) return fail(ctx, BRISK_HIP_ERR_ARG, "match: query pitch smaller than the descriptor");
   if (nq == 0) return BRISK_HIP_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1133,7 +1136,7 @@ static int match_host(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pi
       brisk_launch_match_knn(d_dist, dist_pitch, (int)q0, nqb, nt, d_start, nimg, masked, k_or_cap, d_out, d_cnt, s);
     else
       brisk_launch_match_radius(d_dist, dist_pitch, (int)q0, nqb, nt, d_start, nimg, masked, max_distance, k_or_cap, d_out,
-                                d_cnt, s);
+                                d_cnt, dim16, s);
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(out_count, d_cnt, sizeof(int) * (size_t)nq, hipMemcpyDeviceToHost, s));
@@ -1166,7 +1169,7 @@ int brisk_hip_match_knn_device(brisk_hip_ctx* ctx, const uint8_t* d_query, int n
   std::lock_guard<std::mutex> lock(ctx->mu);
   if (nq < 0 || nt < 0 || k < 0 || !d_out_count || (nq > 0 && (!d_query || (k > 0 && !d_out))) || (nt > 0 && !d_train))
     return fail(ctx, BRISK_HIP_ERR_ARG, "match: bad argument");
-  if (dim_bytes < 16 || dim_bytes > 64) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "match: descriptor size must be 16..64 bytes");
+  if (dim_bytes < 16 || dim_bytes > 224) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "match: descriptor size must be 16..224 bytes");
   if (q_pitch < dim_bytes || (nt > 0 && t_pitch < dim_bytes)) return fail(ctx, BRISK_HIP_ERR_ARG, "match: pitch smaller than the descriptor");
   if (nq == 0) return BRISK_HIP_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -49,7 +49,7 @@
 #define BRISK_SCALES 64
 #define BRISK_NROT 1024
 #define BRISK_MAX_POINTS 128
-#define BRISK_MAX_SHORT 512
+#define BRISK_MAX_SHORT 1792  // generateKernel with 60 points: up to 1770 pairs (pattern scales < 1 make most of them short: descriptors of up to 224 bytes)
 #define BRISK_MAX_LONG 2048
 
 struct BriskLayerGeom {

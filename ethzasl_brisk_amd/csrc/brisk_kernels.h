@@ -110,7 +110,7 @@ void brisk_launch_match_knn(const uint16_t* dist, long dist_pitch, int q0, int n
                             const int* masked, int k, BriskDMatch* out, int* out_count, hipStream_t s);
 void brisk_launch_match_radius(const uint16_t* dist, long dist_pitch, int q0, int nqb, int nt, const int* img_start,
                                int nimg, const int* masked, float max_distance, int cap, BriskDMatch* out, int* out_count,
-                               hipStream_t s);
+                               int dim_bytes, hipStream_t s);
 // k <= 2, one train set, no masks: fused distance + top-2 kernel; false = not covered, use the matrix path
 bool brisk_launch_match_knn_fused(const uint8_t* query, int q_pitch, int nq, const uint8_t* train, int t_pitch, int nt,
                                   int words32, int k, BriskDMatch* out, int* out_count, hipStream_t s);

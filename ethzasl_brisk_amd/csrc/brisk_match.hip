@@ -15,9 +15,10 @@
 
 #define MT_THREADS 256
 #define MT_QTILE 32
-#define MT_MAXWORDS 8  // descriptors up to 64 bytes (8 x u64); BRISK uses 48 and 64
+#define MT_MAXWORDS_LONG 28  // descriptors up to 224 bytes (generateKernel at small pattern scales); BRISK's own are 48 and 64 (8 x u64)
 
 // grid: (ceil(nt / 256), ceil(nqb / MT_QTILE)); thread = one train descriptor, loop over the query tile in LDS
+template <int MT_MAXWORDS>
 __global__ void __launch_bounds__(MT_THREADS) k_match_dist(const uint8_t* __restrict__ query, int q_pitch, int q0, int nqb,
                                                            const uint8_t* __restrict__ train, int t_pitch, int nt,
                                                            int words /* u64 per descriptor */,
@@ -144,11 +145,11 @@ __global__ void __launch_bounds__(64) k_match_knn(const uint16_t* __restrict__ d
 }
 
 // one wave per query.  out row = (q0 + q) * cap, at most cap matches are stored, out_count = matches found.
-#define MR_BINS 513
+#define MR_BINS 1793  // distances 0 ... 8 x 224 bytes (BRISK's own descriptors: 0 ... 512; the prefix below only walks the first 513 bins then)
 __global__ void __launch_bounds__(64) k_match_radius(const uint16_t* __restrict__ dist, long dist_pitch, int q0, int nt,
                                                      const int* __restrict__ img_start, int nimg,
                                                      const int* __restrict__ masked, float max_distance, int cap,
-                                                     BriskDMatch* __restrict__ out, int* __restrict__ out_count) {
+                                                     BriskDMatch* __restrict__ out, int* __restrict__ out_count, int nbins) {
   __shared__ int bins[MR_BINS + 1];
   const int q = blockIdx.x, lane = threadIdx.x;
   const uint16_t* row = dist + (long)q * dist_pitch;
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(64) k_match_radius(const uint16_t* __restrict_
     if (lane == 0) out_count[q0 + q] = 0;
     return;
   }
-  for (int b = lane; b <= MR_BINS; b += 64) bins[b] = 0;
+  for (int b = lane; b <= nbins; b += 64) bins[b] = 0;
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   for (int t = lane; t < nt; t += 64) {
@@ -166,14 +167,14 @@ __global__ void __launch_bounds__(64) k_match_radius(const uint16_t* __restrict_
   }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {  // exclusive prefix over the (at most 513) distance values
+  if (lane == 0) {  // exclusive prefix over the nbins (513 for a 64-byte descriptor) distance values
     int acc = 0;
-    for (int b = 0; b < MR_BINS; ++b) { const int c = bins[b]; bins[b] = acc; acc += c; }
-    bins[MR_BINS] = acc;
+    for (int b = 0; b < nbins; ++b) { const int c = bins[b]; bins[b] = acc; acc += c; }
+    bins[nbins] = acc;
   }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
-  const int total = bins[MR_BINS];
+  const int total = bins[nbins];
   // stable placement: chunks of 64 train entries in order; inside a chunk equal distances keep lane order
   for (int t0 = 0; t0 < nt; t0 += 64) {
     const int t = t0 + lane;
@@ -302,9 +303,13 @@ void brisk_launch_match_dist(const uint8_t* query, int q_pitch, int q0, int nqb,
                              int words, const uint8_t* mask, long mask_pitch, uint16_t* dist, long dist_pitch,
                              hipStream_t s) {
   if (nt <= 0 || nqb <= 0) return;
-  hipLaunchKernelGGL(k_match_dist, dim3((nt + MT_THREADS - 1) / MT_THREADS, (nqb + MT_QTILE - 1) / MT_QTILE),
-                     dim3(MT_THREADS), 0, s, query, q_pitch, q0, nqb, train, t_pitch, nt, words, mask, mask_pitch, dist,
-                     dist_pitch);
+  const dim3 grid((nt + MT_THREADS - 1) / MT_THREADS, (nqb + MT_QTILE - 1) / MT_QTILE);
+  if (words <= 8)
+    hipLaunchKernelGGL(k_match_dist<8>, grid, dim3(MT_THREADS), 0, s, query, q_pitch, q0, nqb, train, t_pitch, nt, words, mask,
+                       mask_pitch, dist, dist_pitch);
+  else
+    hipLaunchKernelGGL(k_match_dist<MT_MAXWORDS_LONG>, grid, dim3(MT_THREADS), 0, s, query, q_pitch, q0, nqb, train, t_pitch, nt,
+                       words, mask, mask_pitch, dist, dist_pitch);
 }
 void brisk_launch_match_masked_out(const uint8_t* mask, long mask_pitch, int q0, int nqb, const int* img_start,
                                    const int* has_mask, int nimg, int* masked, hipStream_t s) {
@@ -319,8 +324,8 @@ void brisk_launch_match_knn(const uint16_t* dist, long dist_pitch, int q0, int n
 }
 void brisk_launch_match_radius(const uint16_t* dist, long dist_pitch, int q0, int nqb, int nt, const int* img_start,
                                int nimg, const int* masked, float max_distance, int cap, BriskDMatch* out, int* out_count,
-                               hipStream_t s) {
+                               int dim_bytes, hipStream_t s) {
   if (nqb <= 0) return;
   hipLaunchKernelGGL(k_match_radius, dim3(nqb), dim3(64), 0, s, dist, dist_pitch, q0, nt, img_start, nimg, masked,
-                     max_distance, cap, out, out_count);
+                     max_distance, cap, out, out_count, min(dim_bytes * 8 + 1, MR_BINS));
 }

@@ -128,7 +128,8 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
 int brisk_hip_detect_batch(brisk_hip_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, long frame_pitch,
                            int row_pitch, int threshold, int octaves, void* stream);
 /* Device pointers of the last batch's results.  d_counts: per frame {detected, described} at
- * byte stride *count_stride (ints); keypoints [frame][kp_cap]; descriptors [frame][kp_cap][desc_pitch]. */
+ * byte stride *count_stride (ints); keypoints [frame][kp_cap]; descriptors [frame][kp_cap][desc_pitch] (desc_pitch is 64 until a pattern
+ * with longer descriptors was used on this context: read it after the call, not once). */
 int brisk_hip_batch_results(brisk_hip_ctx* ctx, const int** d_detected, const int** d_described, int* count_stride,
                             const brisk_hip_keypoint** d_detected_kps, const brisk_hip_keypoint** d_described_kps,
                             const uint8_t** d_desc, int* kp_cap, int* desc_pitch);
@@ -178,7 +179,7 @@ typedef struct brisk_hip_dmatch {
 } brisk_hip_dmatch;
 /* BruteForceMatcher::knnMatchImpl -> commonKnnMatchImpl (brisk/src/brute-force-matcher.cc:54-64, 80-162) with
  * brisk::Hamming (brisk/include/brisk/internal/hamming.h:98-112: popcount of a ^ b over dim_bytes / 16 128-bit
- * words).  query: nq rows of dim_bytes at pitch q_pitch; train[i]: ntrain[i] rows at pitch t_pitch[i] (the
+ * words; dim_bytes 16 ... 224).  query: nq rows of dim_bytes at pitch q_pitch; train[i]: ntrain[i] rows at pitch t_pitch[i] (the
  * trainDescCollection, nimg images).  masks: NULL, or nimg pointers (each NULL or an nq x ntrain[i] u8 matrix at
  * pitch mask_pitch[i]; 0 = pair not allowed).  out: nq * k matches, row q at out + q * k, sorted by
  * (distance, imgIdx, trainIdx); out_count[q] = entries of row q (0 for a masked-out query; rows with fewer

@@ -102,8 +102,9 @@ class Pattern:
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
         k = np.ascontiguousarray(kps, KP).copy()
-        desc = np.zeros((max(len(k), 1), 64), np.uint8)
-        n = lib().emul_describe(self._h, _p(img), w, h, _p(k), len(k), _p(desc), 64, int(rotation_invariant),
+        pitch = max(64, self.strings)
+        desc = np.zeros((max(len(k), 1), pitch), np.uint8)
+        n = lib().emul_describe(self._h, _p(img), w, h, _p(k), len(k), _p(desc), pitch, int(rotation_invariant),
                                 int(scale_invariant))
         return k[:n].copy(), desc[:n, :self.strings].copy()
 

@@ -120,6 +120,21 @@ def test_describe_matches_oracle(golden_ast, version):
         assert same_kps(ke, ko) and np.array_equal(de, do)
 
 
+@pytest.mark.parametrize("scale", [0.7, 1.3, 0.45])
+def test_generated_kernel_pattern_scales_change_the_descriptor_length(golden_ast, scale):
+    """generateKernel's pair thresholds are not scaled with the pattern (brisk-descriptor-extractor.cc:338: dMax 5.85,
+    dMin 8.2 whatever patternScale is), so a briskV1 extractor at another pattern scale has another number of short pairs
+    and another descriptor length (:176): 128 bytes at 0.7, 48 at 1.3, 192 at 0.45"""
+    P, X = E.Pattern(version=1, pattern_scale=scale), O.Extractor(version=1, pattern_scale=scale)
+    assert (P.strings, P.points) == (X.strings, X.points) and P.strings != 64
+    e = golden_ast[0]
+    k = O.detect(e["image"], 70, 3)
+    ko, do = X.compute(e["image"], k)
+    ke, de = P.describe(e["image"], k)
+    assert len(ko) > 100 and do.shape[1] == X.strings
+    assert same_kps(ke, ko) and np.array_equal(de, do)
+
+
 def test_describe_flags_and_custom_pattern(golden_harris):
     e = golden_harris[0]
     g = e["keypoints"]

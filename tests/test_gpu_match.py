@@ -44,7 +44,7 @@ def test_reference_match_test_on_gpu(B, golden_ast):
     assert len(m) == len(d1) and np.array_equal(m["trainIdx"], np.array([r[0]["trainIdx"] for r in rows]))
 
 
-@pytest.mark.parametrize("dim", [48, 64, 16, 40])
+@pytest.mark.parametrize("dim", [48, 64, 16, 40, 96, 224])
 def test_knn_and_radius_vs_oracle(B, dim):
     rng = np.random.default_rng(dim)
     # low-entropy descriptors: plenty of equal distances (tie order = (distance, image, train index))

@@ -261,3 +261,38 @@ def test_random_sizes_thresholds_octaves_fuzz():
     tail = [ln for ln in r.stdout.splitlines() if ln.startswith(("soak4", "ERROR", "MISMATCH"))]
     print("\n".join(tail[-20:]), r.stderr[-2000:])
     assert r.returncode == 0 and tail and tail[-1].startswith("soak4: 250 cases") and " 0 bad" in tail[-1]
+
+
+@pytest.mark.parametrize("scale", [0.7, 1.3])
+def test_generated_kernel_at_other_pattern_scales_has_other_descriptor_lengths(B, scale):
+    """briskV1 at patternScale != 1: generateKernel's pair thresholds are not scaled (brisk-descriptor-extractor.cc:338),
+    so the extractor has 128-byte (0.7) or 48-byte (1.3) descriptors; host call and device batch, then the default
+    extractor again on the same context (the descriptor rows of the workspace only ever grow)"""
+    import torch
+    img = synth.gen(640, 480, 31, 60)
+    ko = O.detect(img, 60, 3)
+    X = O.Extractor(version=1, pattern_scale=scale)
+    ko2, do = X.compute(img, ko)
+    assert X.strings == (128 if scale < 1 else 48) and len(ko2) > 100
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(version=1, patternScale=scale, context=ctx)
+    assert ext.descriptorSize() == X.strings
+    kg = B.BriskFeatureDetector(60, 3, context=ctx).detect(img)
+    kg2, dg = ext.compute(img, kg)
+    assert same_kps(kg2, ko2) and dg.shape == do.shape and np.array_equal(dg, do)
+    d = torch.from_numpy(np.stack([img, img[::-1].copy()])).cuda()
+    ctx.detect_describe_batch(ext, d.data_ptr(), 2, 640, 480, 640 * 480, 640, 60, 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.batch_status(2) == 0
+    kb, db = ctx.batch_download(0, described=True, strings=X.strings)
+    assert same_kps(kb, ko2) and np.array_equal(db, do)
+    ko3, do3 = O.Extractor().compute(img, ko)
+    kg3, dg3 = B.BriskDescriptorExtractor(context=ctx).compute(img, kg)
+    assert same_kps(kg3, ko3) and np.array_equal(dg3, do3)
+    # the matcher takes these lengths too
+    m = B.BruteForceMatcher(context=ctx)
+    m.add([dg])
+    got = m.knnMatch(dg[:50], 2)
+    want = O.match_knn(do[:50], [do], 2)
+    assert [[(x["trainIdx"], x["distance"]) for x in r] for r in got] == [[(x["trainIdx"], x["distance"]) for x in r] for r in want]
+    ctx.close()

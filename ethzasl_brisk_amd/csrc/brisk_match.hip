@@ -60,19 +60,20 @@ __global__ void __launch_bounds__(MT_THREADS) k_match_dist(const uint8_t* __rest
   }
 }
 
-// masked-out queries (OpenCV DescriptorMatcher::isMaskedOut): some image with a mask has an all-zero mask row.
+// masked-out queries (OpenCV DescriptorMatcher::isMaskedOut: `outCount == masks.size()`): EVERY image has a non-empty
+// mask whose row for this query is all zero - the query can match nothing anywhere.
 // grid: nqb blocks of 64 threads; img_start[nimg + 1] are the offsets of the images in the concatenated train set,
 // has_mask[i] != 0 if image i has a mask.
 __global__ void __launch_bounds__(64) k_match_masked_out(const uint8_t* __restrict__ mask, long mask_pitch, int q0,
                                                          const int* __restrict__ img_start, const int* __restrict__ has_mask,
                                                          int nimg, int* __restrict__ masked) {
   const int q = blockIdx.x, lane = threadIdx.x;
-  int out = 0;
-  for (int i = 0; i < nimg; ++i) {
-    if (!has_mask[i]) continue;
+  int out = nimg > 0 ? 1 : 0;
+  for (int i = 0; i < nimg && out; ++i) {
+    if (!has_mask[i]) { out = 0; break; }  // no mask, or no train descriptors (an empty cv::Mat): not counted
     bool any = false;
     for (int t = img_start[i] + lane; t < img_start[i + 1]; t += 64) any |= mask[(long)(q0 + q) * mask_pitch + t] != 0;
-    if (!__any(any)) out = 1;
+    if (__any(any)) out = 0;
   }
   if (lane == 0) masked[q] = out;
 }

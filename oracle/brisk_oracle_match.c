@@ -13,7 +13,9 @@
  * Third-party behaviour outside /root/reference (OpenCV 3, un-pinned: brisk/package.xml:22), restated from the
  * published cv::DescriptorMatcher source:
  *   isPossibleMatch(mask, q, t) = mask.empty() || mask(q, t) != 0
- *   isMaskedOut(masks, q)       = some non-empty mask has an all-zero row q
+ *   isMaskedOut(masks, q)       = !masks.empty() && every mask is non-empty and has an all-zero row q
+ *                                 (`outCount == masks.size()`: the query can match nothing in any image; an image
+ *                                 without a mask, or an empty mask - no train descriptors -, keeps the query alive)
  * Order of equal distances: the reference selects k times the first minimum (image order, then train index) and
  * then calls std::sort on DMatch::operator< (distance only), which is not stable.  The oracle (and the engine)
  * return the lexicographic (distance, imgIdx, trainIdx) order: what the selection produces, and what std::sort
@@ -41,14 +43,13 @@ int bo_hamming(const uint8_t* a, const uint8_t* b, int size) {
 static int possible(const uint8_t* mask, int mask_pitch, int q, int t) { return mask == NULL || mask[(size_t)q * mask_pitch + t] != 0; }
 
 static int masked_out(int nimg, const uint8_t* const* masks, const int* mask_pitch, const int* ntrain, int q) {
-  if (!masks) return 0;
+  if (!masks || nimg <= 0) return 0;
   for (int i = 0; i < nimg; ++i) {
-    if (!masks[i]) continue;
-    int nz = 0;
-    for (int t = 0; t < ntrain[i]; ++t) nz += masks[i][(size_t)q * mask_pitch[i] + t] != 0;
-    if (nz == 0) return 1;
+    if (!masks[i] || ntrain[i] <= 0) return 0;   /* cv::Mat::empty(): not counted, so outCount < masks.size() */
+    for (int t = 0; t < ntrain[i]; ++t)
+      if (masks[i][(size_t)q * mask_pitch[i] + t] != 0) return 0;
   }
-  return 0;
+  return 1;
 }
 
 static int cmp_match(const void* pa, const void* pb) {

@@ -76,15 +76,25 @@ def test_masks_topup_and_empty_sets(B):
     t1 = rng.integers(0, 256, (70, 48), dtype=np.uint8)
     m0 = (rng.random((40, 9)) > 0.3).astype(np.uint8)
     m1 = (rng.random((40, 70)) > 0.5).astype(np.uint8) * 255
-    m0[4, :] = 0                                # query 4 is masked out
-    m1[9, :] = 0                                # query 9 too
+    m0[4, :] = 0                                # query 4 can match nothing in image 0 ...
+    m1[4, :] = 0                                # ... nor in image 1: masked out (isMaskedOut: every mask has a zero row)
+    m1[9, :] = 0                                # query 9 is only barred from image 1
     bf = B.BruteForceMatcher()
     bf.add([t0, t1])
     for masks in ([m0, m1], [m0, None], [None, m1]):
         same_rows(bf.knnMatch(q, 3, masks), O.match_knn(q, [t0, t1], 3, masks))
         same_rows(bf.knnMatch(q, 100, masks), O.match_knn(q, [t0, t1], 100, masks))   # k > possible matches
         same_rows(bf.radiusMatch(q, 190.0, masks), O.match_radius(q, [t0, t1], 190.0, masks))
-    assert len(bf.knnMatch(q, 3, [m0, m1], compactResult=True)) == 38
+    assert len(bf.knnMatch(q, 3, [m0, m1], compactResult=True)) == 39
+    assert len(bf.knnMatch(q, 3, [m0, None], compactResult=True)) == 40   # an image without a mask keeps every query alive
+    # an empty image with an (empty) mask is not counted either: nobody is masked out, query 4 gets pseudo matches only
+    e = np.zeros((0, 48), np.uint8)
+    bfe = B.BruteForceMatcher()
+    bfe.add([t0, t1, e])
+    me = [m0, m1, np.zeros((40, 0), np.uint8)]
+    same_rows(bfe.knnMatch(q, 3, me), O.match_knn(q, [t0, t1, e], 3, me))
+    same_rows(bfe.radiusMatch(q, 190.0, me), O.match_radius(q, [t0, t1, e], 190.0, me))
+    assert len(bfe.knnMatch(q, 3, me, compactResult=True)) == 40
     # k larger than the train set, trailing empty image
     bf2 = B.BruteForceMatcher()
     bf2.add([t0[:2], t1[:1], np.zeros((0, 48), np.uint8)])

@@ -263,6 +263,22 @@ def test_random_sizes_thresholds_octaves_fuzz():
     assert r.returncode == 0 and tail and tail[-1].startswith("soak4: 250 cases") and " 0 bad" in tail[-1]
 
 
+@pytest.mark.parametrize("tool,cases", [("soak5", 200), ("soak6", 200)])
+def test_option_and_matcher_fuzz(tool, cases):
+    """tools/soak5.py (options of the two classes: masks, suppressScaleNonmaxima = false incl. the inputs without a defined
+    result, uniformity / bucketing parameters, invariance flags, both pattern versions at three pattern scales) and
+    tools/soak6.py (the matcher: set sizes incl. empty ones, 1 ... 6 train images, descriptor lengths 16 ... 224, masks,
+    k, radii), each in a process of its own, every case equal to the oracle"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool + ".py"), str(cases), "13"], capture_output=True, text=True, timeout=900)
+    tail = [ln for ln in r.stdout.splitlines() if ln.startswith((tool, "ERROR", "MISMATCH"))]
+    print("\n".join(tail[-20:]), r.stderr[-2000:])
+    assert r.returncode == 0 and tail and tail[-1].startswith("%s: %d cases" % (tool, cases)) and " 0 bad" in tail[-1]
+
+
 @pytest.mark.parametrize("scale", [0.7, 1.3])
 def test_generated_kernel_at_other_pattern_scales_has_other_descriptor_lengths(B, scale):
     """briskV1 at patternScale != 1: generateKernel's pair thresholds are not scaled (brisk-descriptor-extractor.cc:338),

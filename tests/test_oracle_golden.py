@@ -267,15 +267,23 @@ def test_match_oracle_semantics():
     r = rows[0]
     assert len(r) == 5 and list(r["distance"][3:]) == [2147483648.0, 2147483648.0]
     assert list(r["imgIdx"][3:]) == [1, 1] and list(r["trainIdx"][3:]) == [0, 0]
-    # masks: a query whose mask row is empty in some masked image is dropped; masked pairs are skipped
+    # masks: masked pairs are skipped; a query is dropped only when EVERY image has a mask whose row is all zero
+    # (cv::DescriptorMatcher::isMaskedOut: outCount == masks.size()) - an image without a mask keeps it alive
     m0 = np.ones((7, 5), np.uint8)
     m0[2, :] = 0
     m0[3, 1] = 0
     rows = O.match_knn(q, [t0, t1], 10, [m0, None])
-    assert len(rows[2]) == 0 and len(rows[0]) == 10
+    assert len(rows[2]) == 10 and all(m["imgIdx"] == 1 for m in rows[2] if m["distance"] < 1e9) and len(rows[0]) == 10
     assert not any((m["imgIdx"] == 0 and m["trainIdx"] == 1 and m["distance"] < 1e9) for m in rows[3])
+    m1 = np.ones((7, t1.shape[0]), np.uint8)
+    m1[2, :] = 0
+    m1[4, :] = 0
+    rows2 = O.match_knn(q, [t0, t1], 10, [m0, m1])
+    assert len(rows2[2]) == 0 and len(rows2[4]) == 10          # query 2 can match nothing, query 4 still has image 0
+    assert len(O.match_knn(q, [t0, t1, np.zeros((0, 48), np.uint8)], 10, [m0, m1, np.zeros((7, 0), np.uint8)])[2]) == 10   # an empty mask is not counted
     rr = O.match_radius(q, [t0, t1], 200.0, [m0, None])
-    assert len(rr[2]) == 0
+    assert all(m["imgIdx"] == 1 for m in rr[2])
+    assert len(O.match_radius(q, [t0, t1], 200.0, [m0, m1])[2]) == 0
     for i in (0, 3):
         d = [(int(np.unpackbits(q[i] ^ t).sum()), im, j) for im, tt in enumerate((t0, t1)) for j, t in enumerate(tt)
              if not (im == 0 and m0[i, j] == 0)]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off fuzz (GPU box): random image sizes (9 ... 1100 px a side, every residue of the tile / down-sampling column
 classes), thresholds (1 ... 140: fast and ordered path), octave counts (0 ... 6), content kinds and call shapes (single
-host call, device batch of 1 ... 5 frames), each compared bit-exactly with the oracle.
+host call; device batch of 1 ... 5 frames, tight / in-place eligible / padded / unaligned layouts; host-fed batch), each
+compared bit-exactly with the oracle.
 usage: python3 tools/soak4.py [cases] [seed]"""
 import os
 import sys
@@ -45,12 +46,17 @@ def make_case(i, seed):
         thr = max(thr, 60)   # (noise images: keep the candidate lists inside the context's capacity)
     octaves = int(rng.integers(0, 7))
     nfr = int(rng.integers(1, 6)) if rng.random() < 0.5 else 0   # 0: host call on one frame
-    return (i, w, h, kind, thr, octaves, nfr, seed * 1000 + i)
+    # memory layout of a device batch: 0 tight, 1 width a multiple of 64 (layer 0 is then read in place), 2 padded rows,
+    # 3 padded rows + padded frames + a base address that is not 16-byte aligned, 4 frames in host memory (host-fed entry)
+    lay = int(rng.integers(0, 5)) if nfr else 0
+    if lay == 1:
+        w = max(64, w // 64 * 64)
+    return (i, w, h, kind, thr, octaves, nfr, seed * 1000 + i, lay)
 
 
 def oracle_case(c):
     import oracle_lib as O
-    i, w, h, kind, thr, octaves, nfr, s = c
+    i, w, h, kind, thr, octaves, nfr, s, lay = c
     out = []
     for f in range(max(nfr, 1)):
         img = make_image(kind, w, h, s * 8 + f)
@@ -76,7 +82,7 @@ def main():
         big = None
 
         def run(c, cx, ex_):
-            i, w, h, kind, thr, octaves, nfr, s = c
+            i, w, h, kind, thr, octaves, nfr, s, lay = c
             have = []
             if nfr == 0:
                 img = make_image(kind, w, h, s * 8)
@@ -86,8 +92,22 @@ def main():
                 have.append((k.tobytes(), k2.tobytes(), d.tobytes()))
             else:
                 frames = np.stack([make_image(kind, w, h, s * 8 + f) for f in range(nfr)])
-                d = torch.from_numpy(frames).cuda()
-                cx.detect_describe_batch(ex_, d.data_ptr(), nfr, w, h, w * h, w, thr, octaves, st)
+                if lay == 4:
+                    hbuf = torch.from_numpy(frames).pin_memory()
+                    cx.detect_describe_batch_host(ex_, hbuf.data_ptr(), nfr, w, h, w * h, w, thr, octaves)
+                elif lay >= 2:
+                    rp = w + int(1 + (s * 7 + i) % 90) if lay == 3 else (w + 63) // 64 * 64 + 64 * (i % 2)
+                    fp = rp * h + (0 if lay == 2 else 16 * (i % 5) + (i % 3))
+                    off = 0 if lay == 2 else 1 + i % 15
+                    buf = np.full(off + fp * nfr + 64, 0xA5, np.uint8)
+                    for f in range(nfr):
+                        v = buf[off + f * fp: off + f * fp + rp * h].reshape(h, rp)
+                        v[:, :w] = frames[f]
+                    d = torch.from_numpy(buf).cuda()
+                    cx.detect_describe_batch(ex_, d.data_ptr() + off, nfr, w, h, fp, rp, thr, octaves, st)
+                else:
+                    d = torch.from_numpy(frames).cuda()
+                    cx.detect_describe_batch(ex_, d.data_ptr(), nfr, w, h, w * h, w, thr, octaves, st)
                 torch.cuda.synchronize()
                 assert cx.batch_status(nfr) == 0   # (raises BRISK_HIP_ERR_CAPACITY itself)
                 for f in range(nfr):

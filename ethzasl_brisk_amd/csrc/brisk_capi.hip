@@ -1229,10 +1229,12 @@ static int image16_call(brisk_hip_ctx* ctx, int which, const uint16_t* src, int 
   size_t delem;
   if (which == 0) {
     dw = w / 2; dh = h / 2; delem = 2;
-    if (dw * 2 < 16 || dh < 1) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "Halfsample16: fewer than 16 usable columns (the reference's loop writes nothing, image-down-sampling.cc:69-74)");
+    if (dw * 2 >= 16 && dh < 1) return BRISK_HIP_OK;  // a single row: the reference's row loop does not run, nothing to write
+    if (dw * 2 < 16) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "Halfsample16: fewer than 16 usable columns (the reference's loop writes nothing, image-down-sampling.cc:69-74)");
   } else if (which == 1) {
     dw = w / 3 * 2; dh = h / 3 * 2; delem = 2;
-    if (w / 3 * 3 < 12 || dh < 2) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "Twothirdsample16: fewer than 12 usable columns (the reference's loop writes nothing, image-down-sampling.cc:407-413)");
+    if (w / 3 * 3 >= 12 && dh < 2) return BRISK_HIP_OK;  // fewer than three rows: nothing to write
+    if (w / 3 * 3 < 12) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "Twothirdsample16: fewer than 12 usable columns (the reference's loop writes nothing, image-down-sampling.cc:407-413)");
   } else {
     dw = w + 1; dh = h + 1; delem = 4;
   }

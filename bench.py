@@ -505,8 +505,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom_stage, "achieved": round(dom_gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(dom_gb / HBM_PEAK_GBS, 5), "traffic": dom_traffic,
                      "algorithmic_bytes_per_launch": dom_alg, "avg_launch_ms": round(dom_ms, 4), "launches_timed": ncalls,
-                     "note": ("k_describe is bound by outstanding cache-line requests x latency (gathers), not by HBM "
-                              "bandwidth: DESIGN.md 5, profiles/r02_describe_tcp_counters.txt; " if dom_stage == "k_describe" else "")
+                     "note": ("k_describe is bound by the L2 misses / L1 line fills of its gathers at the compulsory-miss level, "
+                              "not by HBM bandwidth, occupancy or instruction issue: DESIGN.md 5, profiles/r03_microbench_gather.json, "
+                              "profiles/r03_describe_tcp_counters.txt; " if dom_stage == "k_describe" else "")
                              + "every kernel group: config.kernel_groups"},
     }
     if rank == 0:

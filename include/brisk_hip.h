@@ -63,7 +63,7 @@ int brisk_hip_pattern_create(brisk_hip_ctx* ctx, int version, float pattern_scal
 int brisk_hip_pattern_create_from_text(brisk_hip_ctx* ctx, const char* ptn_text, float pattern_scale,
                                        brisk_hip_pattern** out);
 void brisk_hip_pattern_destroy(brisk_hip_pattern* p);
-int brisk_hip_pattern_descriptor_size(const brisk_hip_pattern* p); /* descriptorSize() :780-782 (48 / 64) */
+int brisk_hip_pattern_descriptor_size(const brisk_hip_pattern* p); /* descriptorSize() :780-782 (48; 64 for briskV1; 16 ... 224 for briskV1 at other pattern scales) */
 int brisk_hip_pattern_points(const brisk_hip_pattern* p);
 /* host copies of the derived tables, for inspection / tests: 64 entries each */
 int brisk_hip_pattern_tables(const brisk_hip_pattern* p, float* scale_list, int* size_list, float* size_thresh);

@@ -120,7 +120,7 @@ def test_describe_matches_oracle(golden_ast, version):
         assert same_kps(ke, ko) and np.array_equal(de, do)
 
 
-@pytest.mark.parametrize("scale", [0.7, 1.3, 0.45])
+@pytest.mark.parametrize("scale", [0.7, 1.3, 0.45, 2.5])
 def test_generated_kernel_pattern_scales_change_the_descriptor_length(golden_ast, scale):
     """generateKernel's pair thresholds are not scaled with the pattern (brisk-descriptor-extractor.cc:338: dMax 5.85,
     dMin 8.2 whatever patternScale is), so a briskV1 extractor at another pattern scale has another number of short pairs
@@ -131,7 +131,7 @@ def test_generated_kernel_pattern_scales_change_the_descriptor_length(golden_ast
     k = O.detect(e["image"], 70, 3)
     ko, do = X.compute(e["image"], k)
     ke, de = P.describe(e["image"], k)
-    assert len(ko) > 100 and do.shape[1] == X.strings
+    assert len(ko) > (100 if scale < 2 else 20) and do.shape[1] == X.strings
     assert same_kps(ke, ko) and np.array_equal(de, do)
 
 

@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -115,6 +116,36 @@ __global__ void __launch_bounds__(1024) k_box(const uint32_t* __restrict__ integ
     const uint32_t* r3 = r2 + iw;
     u32x2 v0, v1, v2, v3, v4, v5, v6, v7;
 #define LD(p) (*reinterpret_cast<const u32x2*>(p))
+    if (ORDER == 2) {
+      // rows 2k and 2k + 1 interleaved dword by dword (element (y, x) at (y >> 1) * 2 iw + 2 x + (y & 1)): the 2 x 2 cluster
+      // of (y, x) is ONE 16-byte group when y is even and two (pair rows y >> 1 and (y + 1) >> 1) when it is odd; the
+      // code always loads both groups (the second repeats the first for an even y)
+      const long pr = 2L * iw;
+      unsigned t = 0;
+      const int ys[2] = {yt, yb}, xs[2] = {xl, xr};
+      uint4 A[4], B[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int y = ys[q >> 1], x = xs[q & 1];
+        A[q] = *reinterpret_cast<const uint4*>(I + (long)(y >> 1) * pr + 2 * x);
+        B[q] = *reinterpret_cast<const uint4*>(I + (long)((y + 1) >> 1) * pr + 2 * x);
+      }
+      unsigned b0 = 0, b1 = 0;
+      if (bytes) {
+        b0 = P[(long)(yb - 1) * (iw - 1) + xr + 1];
+        b1 = P[(long)(yb - 1) * (iw - 1) + xl + 1];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool odd = ys[q >> 1] & 1;
+        t += (odd ? A[q].y : A[q].x) ^ (odd ? B[q].x : A[q].y);
+        t += (odd ? A[q].w : A[q].z) ^ (odd ? B[q].z : A[q].w);
+      }
+      t += b0 + b1;
+      for (int k = 0; k < valu; ++k) t = t * 1664525u + 1013904223u;
+      acc += t;
+      continue;
+    }
     if (ORDER == 0) {
       v0 = LD(r0 + xl); v1 = LD(r0 + xr); v2 = LD(r1 + xl); v3 = LD(r1 + xr);
       v4 = LD(r2 + xl); v5 = LD(r2 + xr); v6 = LD(r3 + xl); v7 = LD(r3 + xr);
@@ -249,27 +280,34 @@ int main(int argc, char** argv) {
     // describe-shaped passes: 8 integral images of 1921 x 1081 u32 (one per XCD group) + their u8 images
     const int iw = 1921, ih = 1081;
     const long fd = (long)iw * ih;
-    uint8_t* img = (uint8_t*)(tbl + 8 * fd);
+    const long fd2 = (long)iw * (ih + 1);  // the row-pair interleaved layout: (ih + 1) / 2 pair rows
+    uint8_t* img = (uint8_t*)(tbl + 8 * fd2);
     struct Cfg { int radius, order, align, bytes, valu, band; };
     const Cfg cfgs[] = {{50, 0, 0, 1, 0, 0},   {50, 0, 0, 0, 0, 0},    {50, 1, 0, 0, 0, 0},   {50, 0, 1, 0, 0, 0},   {50, 0, 0, 1, 100, 0},
                         {50, 0, 0, 1, 400, 0}, {50, 0, 0, 1, 1000, 0}, {20, 0, 0, 1, 0, 0},   {120, 0, 0, 1, 0, 0},  {300, 0, 0, 1, 0, 0},
                         {50, 0, 0, 1, 0, 32},  {50, 0, 0, 1, 0, 64},   {50, 0, 0, 1, 0, 128}, {50, 0, 0, 1, 0, 256}, {50, 0, 0, 1, 0, 512},
-                        {50, 0, 0, 0, 0, 64},  {50, 0, 0, 0, 0, 256},  {20, 0, 0, 1, 0, 64},  {120, 0, 0, 1, 0, 64}, {120, 0, 0, 1, 0, 256}};
+                        {50, 0, 0, 0, 0, 64},  {50, 0, 0, 0, 0, 256},  {20, 0, 0, 1, 0, 64},  {120, 0, 0, 1, 0, 64}, {120, 0, 0, 1, 0, 256},
+                        // order 2: the row-pair interleaved layout (two 16-byte groups per 2 x 2 cluster) beside order 0
+                        {50, 2, 0, 1, 0, 0},   {50, 2, 0, 1, 0, 64},   {50, 2, 0, 1, 0, 256}, {120, 2, 0, 1, 0, 64}, {120, 2, 0, 1, 0, 256},
+                        {120, 2, 0, 1, 0, 0},  {20, 2, 0, 1, 0, 64},   {50, 2, 0, 1, 400, 64}, {50, 0, 0, 1, 400, 64}};
+    const bool layout_only = argc > 1 && !strcmp(argv[1], "layout");  // only the rows needed for the layout comparison
     const int Wb[] = {1, 2, 3, 4, 5, 6, 8};
     bool firstb = true;
     for (const Cfg& c : cfgs) {
+      if (layout_only && !(c.order == 2 || (c.order == 0 && c.bytes == 1 && c.align == 0 && (c.valu == 0 || c.valu == 400) && (c.band == 0 || c.band == 64 || c.band == 256)))) continue;
       for (int W : Wb) {
+        if (layout_only && W != 2 && W != 3) continue;
         const int bpc = W > 4 ? 2 : 1;
         const int threads = 64 * 4 * W / bpc;
         const size_t lds = bpc == 1 ? 100 * 1024 : 70 * 1024;
-        auto fn = c.order ? k_box<1> : k_box<0>;
+        auto fn = c.order == 2 ? k_box<2> : c.order ? k_box<1> : k_box<0>;
         CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int grid = ncu * bpc;
         const int iters = std::max(8, 2048 / W);
         double best_ms = 1e30;
         for (int rep = 0; rep < 3; ++rep) {
           CHECK(hipEventRecord(e0, 0));
-          hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, 0, tbl, img, iw, ih, fd, c.radius, c.align, c.bytes, c.valu, c.band, iters, d_cyc,
+          hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, 0, tbl, img, iw, ih, c.order == 2 ? fd2 : fd, c.radius, c.align, c.bytes, c.valu, c.band, iters, d_cyc,
                              d_sink);
           CHECK(hipEventRecord(e1, 0));
           CHECK(hipEventSynchronize(e1));

@@ -147,12 +147,14 @@ __device__ __forceinline__ void pyramid_tile_level(const uint8_t* so, int stw, i
       if (gx + 3 < fast_cols) {
         if (TWOTHIRD) {
           // source columns 3 (gx / 2) .. + 5 (2-byte aligned) of the outer row (A or C) and the middle row B
-          const uint8_t* pa = so + (long)(3 * (gy >> 1) + ((gy & 1) ? 2 : 0)) * stw + 3 * (gx >> 1);
-          const uint8_t* pb = so + (long)(3 * (gy >> 1) + 1) * stw + 3 * (gx >> 1);
-          const uint16_t* ha = reinterpret_cast<const uint16_t*>(pa);
-          const uint16_t* hb = reinterpret_cast<const uint16_t*>(pb);
-          const unsigned a_lo = (unsigned)ha[0] | ((unsigned)ha[1] << 16), a_hi = ha[2];
-          const unsigned b_lo = (unsigned)hb[0] | ((unsigned)hb[1] << 16), b_hi = hb[2];
+          // (the six bytes start at a multiple of 6: two ALIGNED dwords hold them, shifted by 0 or 2 bytes - reads at a
+          // 2-byte alignment stall the LDS pipeline: SQ_LDS_UNALIGNED_STALL was 70 % of this kernel's LDS time)
+          const int sx = 3 * (gx >> 1), sh = sx & 2;
+          const unsigned* wa = reinterpret_cast<const unsigned*>(so + (long)(3 * (gy >> 1) + ((gy & 1) ? 2 : 0)) * stw + (sx & ~3));
+          const unsigned* wb = reinterpret_cast<const unsigned*>(so + (long)(3 * (gy >> 1) + 1) * stw + (sx & ~3));
+          const unsigned a0 = wa[0], a1 = wa[1], b0 = wb[0], b1 = wb[1];
+          const unsigned a_lo = __builtin_amdgcn_alignbyte(a1, a0, sh), a_hi = (a1 >> (8 * sh)) & 0xFFFFu;
+          const unsigned b_lo = __builtin_amdgcn_alignbyte(b1, b0, sh), b_hi = (b1 >> (8 * sh)) & 0xFFFFu;
           const unsigned u_lo = swar_avg(swar_avg(a_lo, b_lo), a_lo), u_hi = swar_avg(swar_avg(a_hi, b_hi), a_hi);  // u0..u3, u4 u5
           const unsigned X = __builtin_amdgcn_perm(u_hi, u_lo, 0x05030200u);  // u0 u2 u3 u5: the outer columns
           const unsigned M = __builtin_amdgcn_perm(u_hi, u_lo, 0x04040101u);  // u1 u1 u4 u4: the middle columns

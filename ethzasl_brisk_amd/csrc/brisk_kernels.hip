@@ -464,25 +464,25 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   // addresses.  What lands in the tile for positions outside the image is irrelevant: no valid centre (3 px inside
   // the border) reads it, and phase B rejects the invalid centres phase A may let through.
   {
+    // thread = (dword column, row group): DT_ROWDW columns x DT_RG row groups (256 / 18 = 14: threads 252 .. 255 idle), rows
+    // rg, rg + 14, ... - the column clamp and the LDS address are computed once, the row clamp is three operations per
+    // dword (the staging was 100 VALU instructions per thread, a quarter of the kernel's, with a running (row, column)
+    // pair per dword)
+    constexpr int DT_RG = 256 / DT_ROWDW;
+    static_assert(DT_RG * DT_NLD >= DT_LH, "the row groups cover the halo tile");
     unsigned stg[DT_NLD];
-    // dword i = threadIdx.x + 256 k of the tile: (row, dword in row) advances by (256 / DT_ROWDW, 256 % DT_ROWDW) per k
-    const int r0 = threadIdx.x / DT_ROWDW, c0 = threadIdx.x % DT_ROWDW;
-    int r = r0, c = c0;
+    const int col = threadIdx.x % DT_ROWDW, rg = threadIdx.x / DT_ROWDW;
+    const uint8_t* colp = img + min(max(x0 - 4 + col * 4, 0), stride - 4);
 #pragma unroll
     for (int k = 0; k < DT_NLD; ++k) {
-      const int rr = min(r, DT_LH - 1);  // (the last round's surplus threads reload the last row)
-      const int cy = min(max(y0 - 3 + rr, 0), h - 1), cx = min(max(x0 - 4 + c * 4, 0), stride - 4);
-      stg[k] = *reinterpret_cast<const unsigned*>(img + (long)cy * stride + cx);
-      r += 256 / DT_ROWDW; c += 256 % DT_ROWDW;
-      if (c >= DT_ROWDW) { c -= DT_ROWDW; ++r; }
+      const int rr = min(rg + DT_RG * k, DT_LH - 1);  // (surplus rows reload the last one)
+      const int cy = min(max(y0 - 3 + rr, 0), h - 1);
+      stg[k] = *reinterpret_cast<const unsigned*>(colp + (long)cy * stride);
     }
-    r = r0; c = c0;
+    uint8_t* tp = &tile[rg * DT_PITCH + col * 4];
 #pragma unroll
-    for (int k = 0; k < DT_NLD; ++k) {
-      if (r < DT_LH) *reinterpret_cast<unsigned*>(&tile[r * DT_PITCH + c * 4]) = stg[k];
-      r += 256 / DT_ROWDW; c += 256 % DT_ROWDW;
-      if (c >= DT_ROWDW) { c -= DT_ROWDW; ++r; }
-    }
+    for (int k = 0; k < DT_NLD; ++k)
+      if (rg < DT_RG && rg + DT_RG * k < DT_LH) *reinterpret_cast<unsigned*>(tp + DT_RG * k * DT_PITCH) = stg[k];
   }
   if (threadIdx.x == 0) qcount = 0;
   __syncthreads();

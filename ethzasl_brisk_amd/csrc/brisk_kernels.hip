@@ -679,7 +679,9 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
     bool ok[SB_PER_WAVE], is8[SB_PER_WAVE];
 #pragma unroll
     for (int k = 0; k < SB_PER_WAVE; ++k) {
-      const int x = hdr[k].x & 0xFFFF, y = hdr[k].x >> 16;
+      // (the header is the same in every lane: as scalars, the anchors and patch origins below are scalar arithmetic)
+      const int hx = __builtin_amdgcn_readfirstlane((int)hdr[k].x);
+      const int x = hx & 0xFFFF, y = (int)((unsigned)hx >> 16);
       const int l = __builtin_amdgcn_readfirstlane((int)(hdr[k].y & 0xFF));
       const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
       const bool has_below = !G.single_layer && (l > 0);

@@ -153,6 +153,17 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
 
 typedef uint32_t __attribute__((ext_vector_type(2))) ds_u32x2;
 
+// sum over the 64 lanes, returned in every lane (DPP inclusive scan, lane 63 holds the total)
+__device__ __forceinline__ int ds_wave_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 struct DsLane {  // a lane's sample of one round
   float kx, ky;
   int4 tab;      // {mult, sigma (float bits), scaling | shift << 24, magic} of (scale, point): BriskPatternDev::tab
@@ -463,10 +474,10 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
               d1 += b;
             }
           }
-          for (int off = 32; off > 0; off >>= 1) {
-            d0 += __shfl_xor(d0, off, 64);
-            d1 += __shfl_xor(d1, off, 64);
-          }
+          // wave sums (integers: order independent) by DPP row shifts / broadcasts - six dependent LDS permutes per sum
+          // (__shfl_xor) cost ~0.25 us per keypoint of a wave's time
+          d0 = ds_wave_sum(d0);
+          d1 = ds_wave_sum(d1);
           if (lane == kq) { md0 = d0; md1 = d1; }
         }
         if (estimate) {  // one fp64 atan2 for the whole run

@@ -807,7 +807,7 @@ static int overflow_to_rc(brisk_hip_ctx* ctx, int flags) {
   if (flags & 4) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "keypoint capacity exceeded (brisk_hip_set_capacity)");
   if (flags & 8) {
     static const char* const site[8] = {"", " (the layer below)", " (a pending tie outside its chunk)", " (a neighbour's decision)",
-                                        " (the writer wave)", "", "", ""};
+                                        " (the writer wave)", " (the sorted tie list of the layer below)", "", ""};
     char msg[128];
     snprintf(msg, sizeof(msg), "tie resolution gave up waiting for a decision%s (internal error)", site[(flags >> 8) & 7]);
     return fail(ctx, BRISK_HIP_ERR_HIP, msg);
@@ -1427,7 +1427,7 @@ int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlaye
   out[0] = c.ncand; out[1] = c.nkp; out[2] = c.ndesc; out[3] = c.overflow;
   *nlayers = ctx->G.nlayers;
   for (int l = 0; l < ctx->G.nlayers; ++l) out[4 + l] = c.ntie[l];
-  for (int i = 0; i < 5; ++i) out[20 + i] = c.pad[i];
+  for (int i = 0; i < 4; ++i) out[20 + i] = c.pad[i];
   out[25] = c.nestimate;
   out[26] = c.orient_ticket; out[27] = c.desc_ticket;
   return BRISK_HIP_OK;

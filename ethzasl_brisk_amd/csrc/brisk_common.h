@@ -107,7 +107,8 @@ struct BriskFrameCounters {
   int tie_prog[BRISK_MAX_LAYERS];   // k_tie_resolve: rows of layer l whose ties are decided and whose touches are performed
   int orient_ticket, desc_ticket;   // k_describe (stage 0 / 1): next run of keypoints (in processing order) to be handed out
   int nestimate;                    // kept keypoints that came without an angle (k_describe stage 0 skips frames that have none)
-  int pad[5];
+  int tie_sorted;                   // k_tie_resolve: bit l = layer l's tie list has been rewritten in raster order (layers beyond the on-chip capacity)
+  int pad[4];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)

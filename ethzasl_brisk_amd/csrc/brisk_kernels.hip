@@ -1022,17 +1022,114 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 #define TR_T(i)
 #endif
 
+// Raster order of a layer's ties beyond the on-chip capacity, in O(n) (ranking by counting smaller keys took n^2 / 1024
+// steps per thread: 24 s for the 970 k ties of an all-tie 3645 x 2524 frame, 0.4 s now): ties counted per image row (LDS
+// histogram, two 16-bit counters per word), rows prefix-summed, ties scattered into their row's bucket in global scratch,
+// every bucket ordered by x (a wave per row, rank by counting - 64 keys per load, handed round by lane broadcasts; a row
+// holds at most its width) and written back over the layer's list, which is then in raster order.  pool: 12288 words of
+// LDS (4096 words of row counters + 8192 row offsets).  Not inlined: a cold path, and the tie kernel must stay at 104
+// VGPRs at most (k_tie_resolve).
+__device__ __noinline__ void tie_sort_large(const BriskCand* C, int* list, int n, int h, unsigned* gkey, unsigned* gci, unsigned* pool,
+                                            unsigned* wsum) {
+  const int tid = threadIdx.x, nthreads = blockDim.x, wave = tid >> 6, lane = tid & 63;
+  unsigned* cnt32 = pool;            // [4096]
+  unsigned* rowstart = pool + 4096;  // [8192]
+  int* wlist = list;
+  #pragma unroll 1
+  for (int i = tid; i < 4096; i += nthreads) cnt32[i] = 0;
+  __syncthreads();
+  #pragma unroll 1
+  for (int j = tid; j < n; j += nthreads) {
+    const unsigned y = (C[list[j]].key >> 13) & 0x1FFFu;
+    atomicAdd(&cnt32[y >> 1], (y & 1) ? 0x10000u : 1u);
+  }
+  __syncthreads();
+  {  // exclusive prefix over the 8192 rows: a contiguous stretch of rows per thread, wave scan, wave totals
+    const int rpt = (8192 + nthreads - 1) / nthreads;
+    const int r0 = min(tid * rpt, 8192), r1 = min(r0 + rpt, 8192);
+    unsigned local = 0;
+    #pragma unroll 1
+    for (int r = r0; r < r1; ++r) local += (cnt32[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+    const unsigned incl = (unsigned)wave_inclusive_scan((int)local);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned base = incl - local;
+    #pragma unroll 1
+    for (int q = 0; q < wave; ++q) base += wsum[q];
+    #pragma unroll 1
+    for (int r = r0; r < r1; ++r) {
+      rowstart[r] = base;
+      base += (cnt32[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+    }
+  }
+  __syncthreads();
+  #pragma unroll 1
+  for (int i = tid; i < 4096; i += nthreads) cnt32[i] = 0;
+  __syncthreads();
+  #pragma unroll 1
+  for (int j = tid; j < n; j += nthreads) {
+    const int ci = list[j];
+    const unsigned key = C[ci].key;
+    const unsigned y = (key >> 13) & 0x1FFFu;
+    const unsigned old = atomicAdd(&cnt32[y >> 1], (y & 1) ? 0x10000u : 1u);
+    const unsigned pos = rowstart[y] + ((old >> (16 * (y & 1))) & 0xFFFFu);
+    gkey[pos] = key;
+    gci[pos] = (unsigned)ci;
+  }
+  // (the buckets are read by other waves of this workgroup: stores acknowledged, then the barrier; L1-bypassing loads)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  #pragma unroll 1
+  for (int y = wave; y < h; y += (nthreads >> 6)) {
+    const int b0 = (int)rowstart[y], nb = (int)((cnt32[y >> 1] >> (16 * (y & 1))) & 0xFFFFu);
+    #pragma unroll 1
+    for (int e0 = 0; e0 < nb; e0 += 64) {
+      const bool mine = e0 + lane < nb;
+      const unsigned myk = mine ? __hip_atomic_load(&gkey[b0 + e0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const int ci = mine ? (int)__hip_atomic_load(&gci[b0 + e0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      int r = 0;
+      #pragma unroll 1
+      for (int i0 = 0; i0 < nb; i0 += 64) {  // 64 keys of the bucket per load, handed round by lane broadcasts
+        const unsigned kk = (i0 + lane < nb) ? __hip_atomic_load(&gkey[b0 + i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+#pragma unroll 8
+        for (int t = 0; t < 64; ++t) r += ((unsigned)__builtin_amdgcn_readlane((int)kk, t) < myk) ? 1 : 0;
+      }
+      // (read by the workgroup of the layer above, possibly on another XCD: through memory, like the score-state map)
+      if (mine) __hip_atomic_store(&wlist[b0 + r], ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// (at most 104 VGPRs: beside this kernel's 16 waves a CU must still have room for one 512-thread workgroup of the
+// integral kernel - 2 waves x 40 allocated VGPRs per SIMD -, or the two stop overlapping: 0.74 -> 0.84 ms for the window.
+// tie_sort_large is called, not inlined, at a point where little is live: 95 VGPRs.)
 __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                              BriskFrameCounters* counters, const int* tie_idx,
                                                              const uint8_t* blocks, unsigned* gscratch, int cand_cap,
                                                              int tie_cap, int nframes, int lpw) {
   __shared__ uint8_t kp5s[TR_WAVES][32];
   __shared__ uint16_t win[TR_WAVES][TR_WIN * TR_WIN + 1];  // per-wave window of the tie being decided
-  __shared__ unsigned skey[TR_CHUNK > TR_THREADS ? TR_CHUNK : TR_THREADS];
-  __shared__ int sorder[TR_CHUNK];      // candidate index of the tie with raster rank r
-  __shared__ unsigned sxyd[TR_CHUNK];   // its key (layer, y, x)
+  // the four TR_CHUNK-sized arrays as ONE block of LDS: the raster sort of a layer beyond the on-chip capacity
+  // (tie_sort_large) uses all of it for its row tables (4096 words of row counters + 8192 row offsets) before any of
+  // them holds live data
+  constexpr int TR_SK = TR_CHUNK > TR_THREADS ? TR_CHUNK : TR_THREADS;
+  struct TiePool {
+    unsigned skey[TR_SK];
+    int sorder[TR_CHUNK];      // candidate index of the tie with raster rank r
+    unsigned sxyd[TR_CHUNK];   // its key (layer, y, x)
+    int vals_ci[TR_CHUNK];     // candidate index of the tie (unsorted order)
+    unsigned pad[(TR_SK + 3 * TR_CHUNK) < 12288 ? 12288 - (TR_SK + 3 * TR_CHUNK) : 1];
+  };
+  __shared__ TiePool tp;
+  __shared__ unsigned wsum[TR_WAVES];
+  unsigned (&skey)[TR_SK] = tp.skey;
+  int (&sorder)[TR_CHUNK] = tp.sorder;
+  unsigned (&sxyd)[TR_CHUNK] = tp.sxyd;
+  unsigned* const pool = reinterpret_cast<unsigned*>(&tp);
   __shared__ int vals[TR_WAVES][40];
-  __shared__ int vals_ci[TR_CHUNK];     // candidate index of the tie (unsorted order)
+  int (&vals_ci)[TR_CHUNK] = tp.vals_ci;
   __shared__ uint16_t sfpm[TR_CHUNK];   // e3 footprint mask of the tie with raster rank r
   __shared__ unsigned below_bm[TR_BM_WORDS];  // cells of this layer that a tie of the layer below can touch
   __shared__ int ticket_s, abort_s, seen_s;
@@ -1064,7 +1161,13 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   // 4 us, and the layer above waits at its front for most of that -, so the bound is 0.5 s + 20 us per tie of the frame
   // on the 100 MHz wall clock, not a spin count.
   long long wait_budget = 50000000ll;
-  for (int q = 0; q < nl; ++q) wait_budget += (long long)min(counters[frame].ntie[q], tie_cap) * 2000ll;
+  for (int q = 0; q < nl; ++q) {
+    const long long nq = min(counters[frame].ntie[q], tie_cap);
+    wait_budget += nq * 2000ll;
+    // (a layer beyond the on-chip capacity is first put into raster order through global scratch: O(n), at most a
+    // row's width of steps per tie)
+    if (nq > TR_CHUNK) wait_budget += nq * 2000ll;
+  }
   for (int l = l0; l < l1; ++l) {
   int* const my_prog = &counters[frame].tie_prog[l];
   const int n = min(counters[frame].ntie[l], tie_cap);
@@ -1072,6 +1175,16 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   if (n == 0 || skip_frame) {
     if (tid == 0) __hip_atomic_fetch_max(my_prog, TR_PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     continue;
+  }
+  if (n > TR_CHUNK) {
+    // raster order in O(n) through global scratch (this layer's share: the ties of all layers together are at most the
+    // candidates), before the per-layer state below is built: the tie kernel must stay at 104 VGPRs
+    int off = 0;
+    for (int q = 0; q < l; ++q) off += min(counters[frame].ntie[q], tie_cap);
+    unsigned* gk = gscratch + (long)frame * cand_cap * 2 + off;
+    tie_sort_large(C, const_cast<int*>(tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap), n, G.L[l].h, gk, gk + cand_cap, pool, wsum);
+    // the list was rewritten in place: the workgroup of the layer above reads it (for its bitmap) only after this flag
+    if (tid == 0) __hip_atomic_fetch_or(&counters[frame].tie_sorted, 1 << l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid == 0) seen_s = 0;
   const BriskLayerView L = make_view(G, pyr, smap, frame, l);
@@ -1095,8 +1208,20 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     __syncthreads();
     const int nb = min(counters[frame].ntie[l - 1], tie_cap);
     const int* listb = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l - 1) * tie_cap;
+    if (nb > TR_CHUNK) {  // that list is rewritten in raster order by its workgroup (tie_sort_large): not before it is done
+      long long t0 = 0;
+      for (int spin = 0; !(__hip_atomic_load(&counters[frame].tie_sorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1 << (l - 1))); ++spin) {
+        if (__hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        __builtin_amdgcn_s_sleep(8);
+        if ((spin & 255) == 255) {
+          const long long now = (long long)wall_clock64();
+          if (!t0) t0 = now;
+          else if (now - t0 > wait_budget) { __hip_atomic_store(&abort_s, 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+        }
+      }
+    }
     for (int j = tid; j < nb; j += nthreads) {
-      const BriskCand* c = &C[listb[j]];
+      const BriskCand* c = &C[__hip_atomic_load(&listb[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
       if (!c->fp_mask) continue;
       const int x0 = max((int)c->fp_x0 - 2, 0) >> bm_shift, x1 = min((int)c->fp_x0 + 5, L.w - 1) >> bm_shift;
       const int y0 = max((int)c->fp_y0 - 2, 0) >> bm_shift, y1 = min((int)c->fp_y0 + 5, L.h - 1) >> bm_shift;
@@ -1108,8 +1233,6 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
 
   // ---- raster order of the layer's ties
   const bool on_chip = n <= TR_CHUNK;
-  unsigned* gkey = nullptr;
-  unsigned* gci = nullptr;
   if (on_chip) {
     for (int j = tid; j < n; j += nthreads) {
       const int ci = list[j];
@@ -1125,30 +1248,8 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       sxyd[r] = k;
     }
     __syncthreads();
-  } else {
-    // the sorted list goes to global scratch (this layer's share: the ties of all layers together are at most the
-    // candidates), ranked by counting smaller keys through LDS tiles
-    int off = 0;
-    for (int q = 0; q < l; ++q) off += min(counters[frame].ntie[q], tie_cap);
-    gkey = gscratch + (long)frame * cand_cap * 2 + off;
-    gci = gkey + cand_cap;
-    unsigned* tilek = skey;
-    for (int j0 = 0; j0 < n; j0 += nthreads) {
-      const int j = j0 + tid;
-      const int ci = (j < n) ? list[j] : 0;
-      const unsigned myk = (j < n) ? C[ci].key : 0xFFFFFFFFu;
-      int rank = 0;
-      for (int t0 = 0; t0 < n; t0 += nthreads) {
-        __syncthreads();
-        tilek[tid] = (t0 + tid < n) ? C[list[t0 + tid]].key : 0xFFFFFFFFu;
-        __syncthreads();
-        const int m = min(nthreads, n - t0);
-        for (int q = 0; q < m; ++q) rank += (tilek[q] < myk) ? 1 : 0;
-      }
-      if (j < n) { gkey[rank] = myk; gci[rank] = (unsigned)ci; }
-    }
-    __syncthreads();  // (same workgroup reads them back below: the barrier orders the plain stores)
   }
+  // (a layer beyond the on-chip capacity was put into raster order at the top of the layer loop: tie_sort_large)
 
   uint16_t* wl = win[wave];
   for (int c0 = 0; c0 < n; c0 += TR_CHUNK) {
@@ -1156,8 +1257,9 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     if (!on_chip) {
       __syncthreads();
       for (int r = tid; r < nc; r += nthreads) {
-        sxyd[r] = gkey[c0 + r];
-        sorder[r] = (int)gci[c0 + r];
+        const int ci = __hip_atomic_load(&list[c0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (rewritten above: not from L1)
+        sorder[r] = ci;
+        sxyd[r] = C[ci].key;
       }
       __syncthreads();
     }
@@ -1393,7 +1495,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     __syncthreads();
     if (tid == 0 && !last) {
       const int c1 = c0 + nc;
-      const int row = (c1 < n) ? (int)((gkey[c1] >> 13) & 0x1FFF) : TR_PROG_DONE;
+      const int row = (c1 < n) ? (int)((C[__hip_atomic_load(&list[c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)].key >> 13) & 0x1FFF) : TR_PROG_DONE;
       __hip_atomic_fetch_max(my_prog, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -97,6 +97,17 @@ def _cpu_worker(idx, conn, nframes):
         conn.send(("done", n, dt, kp))
 
 
+def gen_frames(fn, seeds, sharers=1):
+    """synthetic frames on a thread pool (NumPy releases the GIL in the array passes: 0.4 s per 1080p frame, 1.4 s per 4K
+    frame on one thread); `sharers` ranks of one node split the CPU quota"""
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(len(seeds), usable_cores() // max(sharers, 1)))
+    if nthreads == 1:
+        return [fn(s) for s in seeds]
+    with ThreadPoolExecutor(nthreads) as ex:
+        return list(ex.map(fn, seeds))
+
+
 def usable_cores():
     """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (cpu.max) - on the GPU
     boxes 256 hardware threads are visible but the container's quota is 16 CPUs."""
@@ -256,6 +267,10 @@ def parse_args(argv):
     ap.add_argument("--pattern-version", type=int, default=2)
     ap.add_argument("--min-region-s", type=float, default=2.0,
                     help="--frames mode: the step is repeated until the timed region is at least this long")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 1 / 4 / 5 and the dense regimes (config.other_configs)")
+    ap.add_argument("--config", default="", help="profiling: run ONLY this entry of config.other_configs (1, 4, 4_uniform, 5, dense30, dense50) "
+                                                 "for --config-seconds and print its object")
+    ap.add_argument("--config-seconds", type=float, default=0.5)
     ap.add_argument("--fail-rank", type=int, default=-1, help="launcher self-test: this rank exits with code 7 at start-up")
     return ap.parse_args(argv)
 
@@ -331,10 +346,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.config:
+        o = other_configs(local_rank, only=args.config, seconds=args.config_seconds)
+        os.write(real_stdout, (json.dumps(o) + "\n").encode())
+        return
     # ---- synthetic frame ring, resident in HBM before the timed region (frame seed = global frame index)
     nd = max(1, min(args.distinct, chunk))
     seeds = [(mine[i] if args.frames else rank * 100000 + i) for i in range(nd)]
-    host = np.stack([synth.frame_1080p(s) for s in seeds])
+    host = np.stack(gen_frames(synth.frame_1080p, seeds, world))
     ring = torch.from_numpy(host).to(dev)
     idx = torch.arange(chunk, device=dev) % nd
     frames = ring[idx].contiguous()          # [chunk, H, W] u8 in HBM
@@ -467,7 +486,7 @@ def main():
     # the dominant KERNEL (largest HIP-event interval of a single stage) carries the roofline object; its algorithmic
     # bytes are those of its SURVEY 8(d) stage
     group_of_stage = {"k_pyramid": "pyramid", "k_detect": "detect", "k_classify_refine": "nms", "k_tie_resolve": "nms",
-                      "k_finalize": "nms", "k_integral_final": "integral", "k_desc_prepare": "describe", "k_describe": "describe"}
+                      "k_finalize": "nms", "k_postfilter": "nms", "k_integral_final": "integral", "k_desc_prepare": "describe", "k_describe": "describe"}
     dom_stage = max(stage_ms, key=lambda k: stage_ms[k])
     dom = group_of_stage[dom_stage]
     dom_ms = stage_ms[dom_stage]
@@ -519,6 +538,11 @@ def main():
             out["config"]["box_streaming_ceiling_GBps"] = "failed: %r" % (e,)
         if world == 1 and not args.no_host_fed and hasattr(ctx, "detect_describe_batch_host"):
             out["config"]["pcie_fed"] = host_fed(ctx, ext, host, chunk, strings)
+        if world == 1 and not args.no_other_configs:
+            try:
+                out["config"]["other_configs"] = other_configs(local_rank, traffic_rev=ctx.kernel_revision())
+            except Exception as e:  # reported, never fatal for the bench line
+                out["config"]["other_configs"] = "failed: %r" % (e,)
         if cpu is not None:
             out["cpu_baseline"] = cpu.measure()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
@@ -528,11 +552,190 @@ def main():
         dist.destroy_process_group()
 
 
+def _timed_calls(fn, sync, seconds, min_reps=3):
+    """fn() repeated for about `seconds` (after one untimed call); returns seconds per call"""
+    fn()
+    sync()
+    t0 = time.perf_counter()
+    fn()
+    sync()
+    one = max(time.perf_counter() - t0, 1e-6)
+    reps = max(min_reps, int(seconds / one))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps, reps
+
+
+def config5_keypoints(n=100000, seed=7):
+    """x, y uniform, size log-uniform in [8.64, 200] (scale indices 5..63), angle -1"""
+    import numpy as np
+    import ethzasl_brisk_amd as B
+    rng = np.random.default_rng(seed)
+    kp = np.zeros(n, B.KEYPOINT)
+    kp["size"] = np.exp(rng.uniform(np.log(8.64), np.log(200.0), n)).astype(np.float32)
+    kp["x"] = rng.uniform(0, W, n).astype(np.float32)
+    kp["y"] = rng.uniform(0, H, n).astype(np.float32)
+    kp["angle"] = -1
+    kp["class_id"] = -1
+    return kp
+
+
+def other_configs(device, only="", seconds=0.4, traffic_rev=None):
+    try:
+        return _other_configs(device, only, seconds)
+    finally:
+        import torch
+        torch.cuda.empty_cache()
+
+
+def _other_configs(device, only="", seconds=0.4):
+    """The BASELINE configurations that are not the bench line, and the dense regimes of config 2 - measured after the
+    timed region, never part of `value`.  Every entry: workload, rate, algorithmic MB (SURVEY 8(d) model), fraction of
+    the 8 TB/s peak that rate x bytes is, and the engine's HIP-event stage intervals."""
+    import numpy as np
+    import torch
+    import synth
+    import ethzasl_brisk_amd as B
+    dev = torch.device("cuda", device)
+    sync = torch.cuda.synchronize
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+
+    def want(name):
+        return not only or only == name
+
+    def entry(workload, per_s, unit, alg_bytes, units_per_call, stage_ms, extra=None):
+        gb = alg_bytes * per_s / 1e9
+        e = {"workload": workload, "value": round(per_s, 1), "unit": unit, "algorithmic_MB": round(alg_bytes / 1e6, 3),
+             "achieved_GBps": round(gb, 1), "frac": round(gb / HBM_PEAK_GBS, 5),
+             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0}, "units_per_call": units_per_call}
+        if extra:
+            e.update(extra)
+        return e
+
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:  # one configuration failing must not hide the others
+            return {"failed": repr(e)}
+
+    def batch_config(name, frames_np, w, h, octaves, thr, radius, nbatch, workload):
+        ctx = B.Context(device, max_candidates=262144 if name.startswith("dense") else 65536,
+                        max_keypoints=65536 if name.startswith("dense") else 16384)
+        ext = B.BriskDescriptorExtractor(context=ctx)
+        d = torch.from_numpy(frames_np).to(dev)
+        batch = d[torch.arange(nbatch, device=dev) % len(frames_np)].contiguous()
+        del d
+        ctx.set_uniformity(radius)
+        call = lambda: ctx.detect_describe_batch(ext, batch.data_ptr(), nbatch, w, h, w * h, w, thr, octaves, stream)
+        call()
+        sync()
+        assert ctx.batch_status(nbatch) == 0
+        kp = float(np.mean([ctx.debug_counters(f)["described"] for f in range(min(nbatch, 16))]))
+        det = float(np.mean([ctx.debug_counters(f)["keypoints"] for f in range(min(nbatch, 16))]))
+        cand = float(np.mean([ctx.debug_counters(f)["candidates"] for f in range(min(nbatch, 16))]))
+        ctx.profile_enable(True)
+        dt, reps = _timed_calls(call, sync, seconds)
+        stage_ms, _ = ctx.profile_read()
+        ctx.profile_enable(False)
+        alg = sum(algorithmic_bytes(w, h, octaves, int(round(kp))).values())
+        e = entry(workload, nbatch / dt, "frames/s", alg, nbatch, stage_ms,
+                  {"ms_per_frame": round(dt / nbatch * 1e3, 4), "distinct_frames": len(frames_np), "calls_timed": reps,
+                   "mean_candidates": round(cand, 1), "mean_keypoints_detected": round(det, 1), "mean_keypoints_described": round(kp, 1)})
+        ctx.close()
+        del batch
+        torch.cuda.empty_cache()
+        return e
+
+    if want("1"):
+        # config 1: one 640 x 480 frame through the host-buffer calls (what the drop-in classes do)
+        ctx = B.Context(device)
+        ext = B.BriskDescriptorExtractor(context=ctx)
+        det = B.BriskFeatureDetector(70, 4, context=ctx)
+        img = synth.frame_vga(1)
+        k = det.detect(img)
+        k2, _ = ext.compute(img, k)
+        ctx.profile_enable(True)
+        dt, reps = _timed_calls(lambda: ext.compute(img, det.detect(img)), sync, seconds)
+        stage_ms, _ = ctx.profile_read()   # (average over both kinds of call: a stage only counts in the call that runs it)
+        ctx.profile_enable(False)
+        alg = sum(algorithmic_bytes(640, 480, 4, len(k2)).values())
+        res["1"] = entry("BASELINE config 1: one 640x480 frame, threshold 70, 4 octaves, host-buffer detect() + compute() "
+                         "(upload, kernels, download; one frame per call: latency-bound)", 1.0 / dt, "frames/s", alg, 1, stage_ms,
+                         {"ms_per_frame": round(dt * 1e3, 4), "keypoints_described": int(len(k2)), "calls_timed": reps})
+        ctx.close()
+    if want("4") or want("4_uniform") or want("4_uniform_single"):
+        frames4 = np.stack(gen_frames(synth.frame_4k, [2 + i for i in range(16)]))
+        for name, radius in (("4", 0.0), ("4_uniform", 8.0)):
+            if want(name):
+                res[name] = guarded(batch_config, name, frames4, 3840, 2160, 6, 80, radius, 64,
+                                         "BASELINE config 4: 3840x2160, 6 octaves (12 layers), threshold 80, 64 resident frames per call "
+                                         "(16 distinct)" + (", uniformity enforcement radius 8 px" if radius else ", no post-filter"))
+        if want("4_uniform_single"):  # latency of ONE 4K frame per call (the post-filter is one workgroup per frame)
+            res["4_uniform_single"] = guarded(batch_config, "4_uniform_single", frames4[:1], 3840, 2160, 6, 80, 8.0, 1,
+                                                   "BASELINE config 4, ONE resident 3840x2160 frame per call, uniformity enforcement radius 8 px "
+                                                   "(latency: stage_ms.k_postfilter is the filter alone)")
+        del frames4
+    if want("dense30") or want("dense50"):
+        framesd = np.stack(gen_frames(synth.frame_1080p, [700000 + i for i in range(16)]))
+        for name, thr in (("dense50", 50), ("dense30", 30)):
+            if want(name):
+                res[name] = guarded(batch_config, name, framesd, W, H, OCTAVES, thr, 0.0, 64,
+                                         "dense regime: config 2's frames at AGAST threshold %d, 64 resident frames per call (16 distinct)" % thr)
+        del framesd
+    if want("5"):
+        # config 5: descriptor only, 100 000 provided keypoints on one 1080p frame, orientation estimated
+        ctx = B.Context(device, max_candidates=65536, max_keypoints=131072)
+        ext = B.BriskDescriptorExtractor(context=ctx)
+        img = synth.frame_1080p(0)
+        kp = config5_keypoints()
+        k2, dd = ext.compute(img, kp)
+        nd = len(k2)
+        dt_py, _ = _timed_calls(lambda: ext.compute(img, kp), sync, seconds / 2)
+        # the C ABI itself (include/brisk_hip.h: brisk_hip_describe) on buffers the caller reuses, as a C++ caller's
+        # vectors would be: keypoints in / out in one array, packed 48-byte descriptor rows
+        import ctypes as C
+        kbuf = kp.copy()
+        dbuf = np.empty((len(kp), ext.descriptorSize()), np.uint8)
+        nio = C.c_int()
+
+        def raw():
+            kbuf.view(np.uint8)[:] = kp.view(np.uint8)   # (byte views: NumPy copies structured arrays field by field, 25 x slower)
+            nio.value = len(kp)
+            ctx.check(ctx._L.brisk_hip_describe(ctx._h, ext._h, img.ctypes.data_as(C.c_void_p), W, H, W, kbuf.ctypes.data_as(C.c_void_p),
+                                                C.byref(nio), dbuf.ctypes.data_as(C.c_void_p), dbuf.shape[1], 1, 1))
+        raw()
+        assert nio.value == nd and np.array_equal(dbuf[:nd], dd)
+        ctx.profile_enable(True)
+        dt, reps = _timed_calls(raw, sync, seconds)
+        stage_ms, _ = ctx.profile_read()
+        ctx.profile_enable(False)
+        dev_ms = sum(stage_ms.values())
+        # SURVEY 8(d): integral build 10.38 + one read of image and integral 10.38 + kp / descriptor I/O (the reference's 51.9 MB
+        # LUT is 1.2 MB of factorised tables here and not counted)
+        alg = (W * H + 4 * (W + 1) * (H + 1)) * 2 + len(kp) * 28 + nd * (28 + 48)
+        res["5"] = entry("BASELINE config 5: descriptor only, 100000 provided keypoints (size log-uniform 8.64..200, angle -1) on one "
+                         "1080p frame, brisk_hip_describe on host buffers incl. transfers", nd / dt, "descriptors/s", alg / max(nd, 1), nd, stage_ms,
+                         {"ms_per_call": round(dt * 1e3, 4), "described": nd, "calls_timed": reps,
+                          "device_ms_per_call": round(dev_ms, 4),
+                          "device_descriptors_per_s": round(nd / (dev_ms * 1e-3), 1) if dev_ms > 0 else None,
+                          "device_frac": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dev_ms > 0 else None,
+                          "python_wrapper_ms_per_call": round(dt_py * 1e3, 4),
+                          "note": "value / frac: the whole C-ABI call on pageable host buffers (refilling the 2.8 MB keypoint array, H2D of "
+                                  "the 2 MB image + keypoints, kernels, D2H of keypoints + descriptors); device_*: the HIP-event stage "
+                                  "intervals only; python_wrapper: the same through ethzasl_brisk_amd.BriskDescriptorExtractor.compute "
+                                  "(fresh numpy arrays per call)"})
+        ctx.close()
+    return res
+
+
 def kernel_groups(stage_ms, groups, fpl, traffic):
     """{group: {alg_bytes, ms, GBps, frac, hbm_bytes}} per launch (fpl frames), from the engine's per-stage HIP-event
     intervals.  Stage names -> groups of SURVEY 8(d)."""
     stage_of = {"pyramid": ["k_pyramid"], "detect": ["k_detect"],
-                "nms": ["k_classify_refine", "k_tie_resolve", "k_finalize"],
+                "nms": ["k_classify_refine", "k_tie_resolve", "k_finalize", "k_postfilter"],
                 "integral": ["k_integral_final"], "describe": ["k_desc_prepare", "k_describe"]}
     out = {}
     for g, stages in stage_of.items():
@@ -542,8 +745,12 @@ def kernel_groups(stage_ms, groups, fpl, traffic):
         hb = None
         if traffic and g in traffic.get("groups", {}):
             hb = round(traffic["groups"][g] * fpl / traffic["frames_per_launch"])
+        # frac: algorithmic bytes / interval / peak; hbm_frac: the counter-measured HBM bytes instead (what the memory
+        # system really moved: below frac where the model charges a re-read the kernel does not do, above it where
+        # gathers fetch whole lines)
         out[g] = {"alg_bytes": alg, "ms": round(ms, 4), "GBps": round(gb, 2), "frac": round(gb / HBM_PEAK_GBS, 5),
-                  "hbm_bytes": hb}
+                  "hbm_bytes": hb,
+                  "hbm_frac": None if (hb is None or ms <= 0) else round(hb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     return out
 
 

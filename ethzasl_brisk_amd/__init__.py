@@ -122,6 +122,15 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _kcopy(a, n=None):
+    """copy of the first n records of a contiguous KEYPOINT array through a byte view (NumPy copies structured arrays
+    field by field: 2.8 ms per 100 000 keypoints instead of 0.1 ms)"""
+    n = len(a) if n is None else n
+    out = np.empty(n, KEYPOINT)
+    out.view(np.uint8)[:] = a.view(np.uint8)[:n * KEYPOINT.itemsize]
+    return out
+
+
 class Context:
     """Device workspace (one per GPU).  Shared by detector and extractor objects."""
 
@@ -266,7 +275,7 @@ class Context:
         desc = np.zeros((max(n.value, 1), strings), np.uint8)
         self.check(self._L.brisk_hip_batch_download(self._h, frame, int(described), _ptr(kps), len(kps), C.byref(n),
                                                     _ptr(desc) if described else None, strings))
-        return kps[:n.value].copy(), (desc[:n.value].copy() if described else None)
+        return _kcopy(kps, n.value), (desc[:n.value].copy() if described else None)
 
 
 _default_ctx = {}
@@ -310,7 +319,7 @@ class BriskFeatureDetector:
         c.check(c._L.brisk_hip_detect_uniform(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
                                               int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0,
                                               self.uniformityRadius, self.maxNumKpt, _ptr(out), capacity, C.byref(n)))
-        return out[:n.value].copy()
+        return _kcopy(out, n.value)
 
 
     def ComputeScale(self, image, keypoints, capacity=None):
@@ -330,7 +339,7 @@ class BriskFeatureDetector:
         c.check(c._L.brisk_hip_compute_scale(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
                                              int(self.m_suppressScaleNonmaxima), _ptr(k) if len(k) else None, len(k),
                                              _ptr(out), cap, C.byref(n)))
-        return out[:n.value].copy()
+        return _kcopy(out, n.value)
 
 
 class BriskDescriptorExtractor:
@@ -377,16 +386,16 @@ class BriskDescriptorExtractor:
         if img.dtype != np.uint8 or img.ndim != 2:
             raise RuntimeError("Unsupported image format. Must be CV_16UC1 or CV_8UC1.")  # :678 (8-bit only here)
         h, w = img.shape
-        k = np.ascontiguousarray(keypoints, KEYPOINT).copy()
+        k = _kcopy(np.ascontiguousarray(keypoints, KEYPOINT))
         n = C.c_int(len(k))
         s = self.descriptorSize()
-        desc = np.zeros((max(len(k), 1), s), np.uint8)
+        desc = np.empty((max(len(k), 1), s), np.uint8)   # (rows [0, n) are written by the call, the others dropped below)
         if len(k) == 0:
             k = np.zeros(1, KEYPOINT)
         c = self._ctx
         c.check(c._L.brisk_hip_describe(c._h, self._h, _ptr(img), w, h, w, _ptr(k), C.byref(n), _ptr(desc), s,
                                         int(self.rotationInvariance), int(self.scaleInvariance)))
-        return k[:n.value].copy(), desc[:n.value].copy()
+        return k[:n.value], desc[:n.value]
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):

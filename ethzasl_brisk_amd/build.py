@@ -16,6 +16,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
+LINK_LIBS = []
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -44,6 +47,38 @@ def build_variant(name, defines):
     return out
 
 
+def _compile_objects(hipcc, flags, objdir, verbose, force):
+    """one hipcc -c per source, all at once (independent translation units); an object is kept when neither its source,
+    a header of csrc/ or include/, nor the command line changed (brisk_capi.hip alone carries the kernel revision)"""
+    import hashlib
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    hdrs.append(os.path.join(HERE, "..", "include", "brisk_hip.h"))
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
+    procs, objs = [], []
+    for s in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        src = os.path.join(CSRC, s)
+        fl = list(flags)
+        if s == "brisk_capi.hip":
+            fl.append('-DBRISK_KERNEL_REV="%s"' % kernel_revision())
+        cmd = [hipcc] + fl + ["-c", "-o", obj, src]
+        stamp = obj + ".cmd"
+        sig = hashlib.sha1(" ".join(cmd).encode()).hexdigest()
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == sig
+                and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t)):
+            continue
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, stamp, sig, subprocess.Popen(cmd)))
+    for s, stamp, sig, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, "hipcc -c " + s)
+        open(stamp, "w").write(sig)
+    return objs
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
@@ -51,7 +86,9 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     extra = os.environ.get("BRISK_HIPCC_EXTRA", "").split()  # tuning experiments only (e.g. -DBRISK_DETECT_ROWS_PER_THREAD=2)
-    cmd = [hipcc] + FLAGS + extra + ['-DBRISK_KERNEL_REV="%s"' % kernel_revision(), "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cflags = [f for f in FLAGS if f != "-shared"] + extra
+    objs = _compile_objects(hipcc, cflags, os.path.join(HERE, "..", "build", "obj"), verbose, force)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + LINK_LIBS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -47,6 +47,7 @@ struct brisk_hip_ctx {
   BriskTileTable T{};
   int last_nframes = 0;
   bool last_has_desc = false;
+  int last_desc_pitch = 0;  // device pitch of the descriptor rows the last call wrote (a host describe call packs them at the caller's pitch)
   const uint8_t* last_l0_ext = nullptr;  // layer 0 of the last batch was read in place from the caller's frames (debug_layer)
   long last_l0_pitch = 0;
   BriskProfiler prof;
@@ -206,7 +207,7 @@ static void make_geometry(int w, int h, int threshold, int octaves, BriskGeom* G
 
 static void free_buffers(brisk_hip_ctx* c) {
   hipFree(c->B.pyr); hipFree(c->B.smap); hipFree(c->B.cand); hipFree(c->B.blocks); hipFree(c->B.tie_idx); hipFree(c->B.keys);
-  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->B.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale); hipFree(c->D.dperm); hipFree(c->D.drec);
+  hipFree(c->B.counters); hipFree(c->B.kp_out); hipFree(c->D.integral); hipFree(c->B.bandsum); hipFree(c->D.dkp); hipFree(c->D.dscale); hipFree(c->D.dperm); hipFree(c->D.drec); hipFree(c->D.dp_work);
   hipFree(c->D.desc); hipFree(c->d_kp_in); hipFree(c->d_n_in);
   c->B = BriskDetectBuffers{};
   c->D = BriskDescribeBuffers{};
@@ -246,6 +247,8 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   HIPCHK(c, hipMalloc(&c->D.dscale, (size_t)slots * c->kp_cap * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->D.dperm, (size_t)slots * c->kp_cap * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->D.drec, ((size_t)slots * c->kp_cap + 4) * sizeof(uint4)));
+  c->D.dp_work_stride = brisk_dp_work_ints(c->kp_cap);
+  HIPCHK(c, hipMalloc(&c->D.dp_work, (size_t)slots * c->D.dp_work_stride * sizeof(int)));
   c->D.desc_pitch = c->desc_pitch;
   HIPCHK(c, hipMalloc(&c->D.desc, (size_t)slots * c->kp_cap * c->D.desc_pitch));
   HIPCHK(c, hipMalloc(&c->d_kp_in, (size_t)slots * c->kp_cap * sizeof(BriskKeyPoint)));
@@ -555,6 +558,7 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
   Di.dscale += f0 * Bi.kp_cap;
   Di.dperm += f0 * Bi.kp_cap;
   Di.drec += f0 * Bi.kp_cap;
+  Di.dp_work += f0 * Di.dp_work_stride;
   Di.desc += f0 * Bi.kp_cap * Di.desc_pitch;
   BriskOverlap ov{};
   const BriskOverlap* ovp = nullptr;
@@ -607,6 +611,7 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
     brisk_launch_bucketing(Bi.kp_out, Bi.counters, ctx->d_uni_order + f0 * Bi.kp_cap, ctx->d_uni_tmp + f0 * Bi.kp_cap, Bi.kp_cap,
                            A.h, A.w, ctx->bk_u, ctx->bk_v, ctx->bk_max, nf, si);
   }
+  if (A.do_detect) brisk_prof_mark(prof, BRISK_STG_INTEGRAL, si);  // end of the post-filter interval
   if (A.do_describe) {
     BriskPatternDev P = A.pat->dev;
     brisk_launch_describe(Gs, P, Bi, Di, nf, Bi.kp_out, &Bi.counters[0].nkp, sizeof(BriskFrameCounters), si, prof, ovp);
@@ -619,6 +624,7 @@ static int batch_end(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipStr
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = nframes;
   ctx->last_has_desc = A.do_describe;
+  ctx->last_desc_pitch = ctx->D.desc_pitch;
   const int rc = workspace_release(ctx, s);
   if (rc) return fail(ctx, rc, "hipEventRecord failed");
   return BRISK_HIP_OK;
@@ -835,7 +841,8 @@ int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags)
 }
 
 static int download_locked(brisk_hip_ctx* ctx, int frame, int which, brisk_hip_keypoint* kps, int cap, int* n,
-                           uint8_t* desc, int desc_stride, int strings) {
+                           uint8_t* desc, int desc_stride, int strings, int dev_pitch = 0) {
+  if (!dev_pitch) dev_pitch = ctx->D.desc_pitch;
   if (frame < 0 || frame >= ctx->slots) return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame index");
   HIPCHK(ctx, wait_own_work(ctx));
   BriskFrameCounters c;
@@ -851,8 +858,11 @@ static int download_locked(brisk_hip_ctx* ctx, int frame, int which, brisk_hip_k
   }
   if (desc && which && cnt) {
     if (cnt > cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "output descriptor buffer too small");
-    HIPCHK(ctx, hipMemcpy2D(desc, desc_stride, ctx->D.desc + (size_t)frame * ctx->B.kp_cap * ctx->D.desc_pitch,
-                            ctx->D.desc_pitch, strings, cnt, hipMemcpyDeviceToHost));
+    const uint8_t* src = ctx->D.desc + (size_t)frame * ctx->B.kp_cap * ctx->D.desc_pitch;
+    if (dev_pitch == desc_stride && strings == desc_stride)  // rows packed on both sides: one linear copy (a pitched one of 75 k rows takes 4 x as long)
+      HIPCHK(ctx, hipMemcpy(desc, src, (size_t)cnt * strings, hipMemcpyDeviceToHost));
+    else
+      HIPCHK(ctx, hipMemcpy2D(desc, desc_stride, src, dev_pitch, strings, cnt, hipMemcpyDeviceToHost));
   }
   return BRISK_HIP_OK;
 }
@@ -863,8 +873,8 @@ int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which, brisk_hip
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   // descriptor width of the last describe is not stored per call: copy the full pitch-limited row
-  return download_locked(ctx, frame, which, kps, cap, n, desc, desc_stride,
-                         desc_stride < ctx->D.desc_pitch ? desc_stride : ctx->D.desc_pitch);
+  const int pitch = ctx->last_desc_pitch ? ctx->last_desc_pitch : ctx->D.desc_pitch;
+  return download_locked(ctx, frame, which, kps, cap, n, desc, desc_stride, desc_stride < pitch ? desc_stride : pitch, pitch);
 }
 
 // ---- host-buffer calls ---------------------------------------------------------------------------
@@ -1003,6 +1013,8 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   }
   HIPCHK(ctx, hipMemsetAsync(ctx->B.counters, 0, sizeof(BriskFrameCounters), ctx->stream));
   BriskDetectBuffers Bd = ctx->B;
+  brisk_prof_begin_call(&ctx->prof);
+  brisk_prof_mark(&ctx->prof, BRISK_STG_PYRAMID, ctx->stream);  // (the layer-0 pass, if any, shows as k_pyramid)
   if (reuse) {
     // layer 0 (in the pyramid buffer, or read in place from the staging buffer) and the pyramid kernel's 96-row band
     // sums are what the detect call left
@@ -1015,15 +1027,22 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
     brisk_launch_layer0_only(ctx->G, ctx->B, 1, ctx->d_stage, (long)img_bytes, pitch, ctx->stream);
     Bd.band_h = 64;  // brisk_launch_layer0_only: k_pyramid_even's 64-row band sums
   }
+  brisk_prof_mark(&ctx->prof, BRISK_STG_DETECT, ctx->stream);
   BriskPatternDev P = pat->dev;
   P.rotation_invariant = rotation_invariant ? 1 : 0;
   P.scale_invariant = scale_invariant ? 1 : 0;
-  brisk_launch_describe(ctx->G, P, Bd, ctx->D, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, nullptr);
+  // descriptor rows of this call at the caller's pitch when the caller's rows are packed (a cv::Mat of K x strings bytes):
+  // the download is then one linear copy
+  BriskDescribeBuffers Dd = ctx->D;
+  if (desc_stride == pat->host.strings && pat->host.strings % 8 == 0 && pat->host.strings <= ctx->D.desc_pitch) Dd.desc_pitch = pat->host.strings;
+  brisk_launch_describe(ctx->G, P, Bd, Dd, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, &ctx->prof);
+  if (ctx->prof.on) ctx->prof.calls++;
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;
   ctx->last_has_desc = true;
+  ctx->last_desc_pitch = Dd.desc_pitch;
   if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
-  return download_locked(ctx, 0, 1, kps, n_in, n, desc, desc_stride, pat->host.strings);
+  return download_locked(ctx, 0, 1, kps, n_in, n, desc, desc_stride, pat->host.strings, Dd.desc_pitch);
 }
 
 // ---- per-stage timing (HIP events on the launch stream) -----------------------------------------------

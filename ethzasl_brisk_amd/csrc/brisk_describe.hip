@@ -14,6 +14,14 @@
 #ifndef DP_THREADS
 #define DP_THREADS 1024
 #endif
+// Frames with more input keypoints than this take the multi-workgroup path (k_dp_count / k_dp_scan / k_dp_scatter): the
+// one-workgroup kernel below ranks its keys by counting (n^2 / 1024 steps per thread) and walks its inputs 1024 at a time.
+#define DP_SMALL_N 2048
+// work area of the multi-workgroup path, ints per frame: [0] keypoints without an angle, [DP_W_HIST ..] bucket histogram /
+// cursors (DP_MAXBUCKETS + 1), [DP_W_BLK ..] kept keypoints per block of 1024 inputs (then their exclusive prefix)
+#define DP_MAXBUCKETS 4096
+#define DP_W_HIST 16
+#define DP_W_BLK (DP_W_HIST + DP_MAXBUCKETS + 16)
 // k_desc_prepare: per frame, scale index + border filter (brisk-descriptor-extractor.cc:636-662),
 // stable compaction into dkp (keypoints) / dscale.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------------
@@ -43,13 +51,19 @@ __device__ __forceinline__ unsigned dp_order_key(int x, int y, int sc, int j, in
 
 __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskPatternDev P, const BriskKeyPoint* kp_in,
                                                        const int* n_in_ptr, long n_in_stride, BriskFrameCounters* counters,
-                                                       BriskKeyPoint* dkp, int* dscale, int* dperm, uint4* drec, int kp_cap) {
+                                                       BriskKeyPoint* dkp, int* dscale, int* dperm, uint4* drec, int kp_cap,
+                                                       int* work, long work_stride) {
   __shared__ int wtot[DP_THREADS / 64];
   __shared__ int base, nest;
   __shared__ __attribute__((aligned(16))) unsigned pkey[DP_MAXSORT + 4];
   const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
   const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;
+  if (n > DP_SMALL_N) {  // the multi-workgroup path takes this frame: its histogram starts from zero
+    int* wk = work + (long)frame * work_stride;
+    for (int q = tid; q < DP_W_BLK; q += DP_THREADS) wk[q] = 0;
+    return;
+  }
   if (tid == 0) { base = 0; nest = 0; }
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
@@ -119,6 +133,119 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
     drec[(long)frame * kp_cap + r] = make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.angle),
                                                  (unsigned)dscale[(long)frame * kp_cap + j] | ((unsigned)j << 8));
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same preparation for frames with many keypoints (BASELINE config 5: 100 000 provided keypoints on one frame; 4K
+// frames with several thousand), any count, several workgroups per frame, O(n):
+//   k_dp_count    block b of a frame takes inputs [1024 b, 1024 b + 1024): scale index + border filter, kept keypoints per
+//                 block, histogram of the kept keypoints over square tiles of the frame (at most DP_MAXBUCKETS)
+//   k_dp_scan     one workgroup per frame: exclusive prefix over the block counts (-> stable compaction offsets) and over
+//                 the tile histogram (-> start of every tile's stretch of the processing order), frame counters
+//   k_dp_scatter  keypoint j (input order, filtered: the OUTPUT order of the reference) -> dkp[j]; its record goes to the
+//                 next free place of its tile's stretch.  The processing order is tile after tile in raster order - the
+//                 spatial locality k_describe's L2 hit rate rests on - and unordered inside a tile (an atomic cursor):
+//                 results are written by index j, so they do not depend on it.
+// ------------------------------------------------------------------------------------------------
+struct DpTiles { int shift, tiles_x, w, h; };
+__device__ __forceinline__ int dp_bucket(const DpTiles& T, float x, float y) {
+  const int xi = min(max((int)x, 0), T.w - 1), yi = min(max((int)y, 0), T.h - 1);
+  return (yi >> T.shift) * T.tiles_x + (xi >> T.shift);
+}
+// keep flag, scale index and wave-level position of input i
+struct DpItem { bool keep; int sc; BriskKeyPoint kp; };
+__device__ __forceinline__ DpItem dp_item(const BriskGeom& G, const BriskPatternDev& P, const BriskKeyPoint* K, int i, int n) {
+  DpItem it;
+  it.keep = false; it.sc = 0;
+  if (i < n) {
+    it.kp = K[i];
+    it.sc = brisk_scale_index(P, it.kp.size);
+    it.keep = brisk_inside_border(P, it.sc, it.kp.x, it.kp.y, G.L[0].w, G.L[0].h);
+  }
+  return it;
+}
+
+__global__ void __launch_bounds__(DP_THREADS) k_dp_count(BriskGeom G, BriskPatternDev P, DpTiles T, const BriskKeyPoint* kp_in,
+                                                          const int* n_in_ptr, long n_in_stride, int kp_cap, int* work, long work_stride) {
+  __shared__ int wtot[DP_THREADS / 64];
+  const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
+  if (n <= DP_SMALL_N || (int)blockIdx.x * DP_THREADS >= n) return;
+  int* wk = work + (long)frame * work_stride;
+  const DpItem it = dp_item(G, P, kp_in + (long)frame * kp_cap, blockIdx.x * DP_THREADS + tid, n);
+  const unsigned long long bal = __ballot(it.keep);
+  if (lane == 0) wtot[wave] = __popcll(bal);
+  const unsigned long long bal_e = __ballot(it.keep && it.kp.angle == -1.0f);
+  if (lane == 0 && bal_e) atomicAdd(&wk[0], __popcll(bal_e));
+  if (it.keep) atomicAdd(&wk[DP_W_HIST + dp_bucket(T, it.kp.x, it.kp.y)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+#pragma unroll
+    for (int k = 0; k < DP_THREADS / 64; ++k) t += wtot[k];
+    wk[DP_W_BLK + blockIdx.x] = t;
+  }
+}
+
+// exclusive prefix of v[0 .. n) in place, returns the total (one workgroup of DP_THREADS threads; sh: DP_THREADS / 64 + 1 ints)
+__device__ __forceinline__ int dp_scan_inplace(int* v, int n, int* sh) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int carry = 0;
+  for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
+    const int i = i0 + tid;
+    const int x = i < n ? v[i] : 0;
+    int incl = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < DP_THREADS / 64; ++k) { const int t = sh[k]; woff += (k < wave) ? t : 0; tot += t; }
+    if (i < n) v[i] = carry + woff + incl - x;
+    carry += tot;
+    __syncthreads();
+  }
+  return carry;
+}
+
+__global__ void __launch_bounds__(DP_THREADS) k_dp_scan(const int* n_in_ptr, long n_in_stride, int kp_cap, int nbuckets,
+                                                         BriskFrameCounters* counters, int* work, long work_stride) {
+  __shared__ int sh[DP_THREADS / 64 + 1];
+  const int frame = blockIdx.x;
+  const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
+  if (n <= DP_SMALL_N) return;
+  int* wk = work + (long)frame * work_stride;
+  const int m = dp_scan_inplace(wk + DP_W_BLK, (n + DP_THREADS - 1) / DP_THREADS, sh);
+  (void)dp_scan_inplace(wk + DP_W_HIST, nbuckets, sh);
+  if (threadIdx.x == 0) {
+    counters[frame].ndesc = m; counters[frame].nestimate = wk[0]; counters[frame].desc_ticket = 0; counters[frame].orient_ticket = 0;
+  }
+}
+
+__global__ void __launch_bounds__(DP_THREADS) k_dp_scatter(BriskGeom G, BriskPatternDev P, DpTiles T, const BriskKeyPoint* kp_in,
+                                                            const int* n_in_ptr, long n_in_stride, int kp_cap, int* work,
+                                                            long work_stride, BriskKeyPoint* dkp, uint4* drec) {
+  __shared__ int wtot[DP_THREADS / 64];
+  const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
+  if (n <= DP_SMALL_N || (int)blockIdx.x * DP_THREADS >= n) return;
+  int* wk = work + (long)frame * work_stride;
+  const DpItem it = dp_item(G, P, kp_in + (long)frame * kp_cap, blockIdx.x * DP_THREADS + tid, n);
+  const unsigned long long bal = __ballot(it.keep);
+  if (lane == 0) wtot[wave] = __popcll(bal);
+  __syncthreads();
+  if (!it.keep) return;
+  int j = wk[DP_W_BLK + blockIdx.x] + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+  for (int k = 0; k < DP_THREADS / 64; ++k) j += (k < wave) ? wtot[k] : 0;
+  dkp[(long)frame * kp_cap + j] = it.kp;
+  const int pos = atomicAdd(&wk[DP_W_HIST + dp_bucket(T, it.kp.x, it.kp.y)], 1);
+  drec[(long)frame * kp_cap + pos] = make_uint4(__float_as_uint(it.kp.x), __float_as_uint(it.kp.y), __float_as_uint(it.kp.angle),
+                                                (unsigned)it.sc | ((unsigned)j << 8));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -524,6 +651,8 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   }
 }
 
+long brisk_dp_work_ints(int kp_cap) { return DP_W_BLK + (kp_cap + DP_THREADS - 1) / DP_THREADS + 16; }
+
 static size_t describe_lds_bytes(const BriskPatternDev& P, int run, bool regtab) {
   const size_t table = regtab ? 0 : (P.nlong <= DS_LP_LDS ? (size_t)P.nlong * 16 : 0) + (((size_t)P.nshort * 4 + 15) & ~(size_t)15);
   const size_t per_wave = (size_t)run * 16 + (((size_t)run * 4 + 15) & ~(size_t)15) + (((size_t)run * P.npoints * 4 + 15) & ~(size_t)15) + 2 * DS_MAXQ * 4;
@@ -541,7 +670,20 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
     brisk_launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
-                     Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap);
+                     Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap, Dd.dp_work, Dd.dp_work_stride);
+  if (B.kp_cap > DP_SMALL_N) {  // frames with more keypoints than the one-workgroup kernel takes (the others exit at once)
+    DpTiles T;
+    T.w = G.L[0].w; T.h = G.L[0].h; T.shift = 6;
+    while ((((T.w - 1) >> T.shift) + 1) * (((T.h - 1) >> T.shift) + 1) > DP_MAXBUCKETS) ++T.shift;
+    T.tiles_x = ((T.w - 1) >> T.shift) + 1;
+    const int nbuckets = T.tiles_x * (((T.h - 1) >> T.shift) + 1);
+    const dim3 grid((B.kp_cap + DP_THREADS - 1) / DP_THREADS, nframes);
+    hipLaunchKernelGGL(k_dp_count, grid, dim3(DP_THREADS), 0, s, G, P, T, kp_in, n_in, n_in_stride, B.kp_cap, Dd.dp_work, Dd.dp_work_stride);
+    hipLaunchKernelGGL(k_dp_scan, dim3(nframes), dim3(DP_THREADS), 0, s, n_in, n_in_stride, B.kp_cap, nbuckets, B.counters, Dd.dp_work,
+                       Dd.dp_work_stride);
+    hipLaunchKernelGGL(k_dp_scatter, grid, dim3(DP_THREADS), 0, s, G, P, T, kp_in, n_in, n_in_stride, B.kp_cap, Dd.dp_work,
+                       Dd.dp_work_stride, Dd.dkp, Dd.drec);
+  }
   // with `ov` the integral image is already running beside the detector's tail (brisk_launch_detect) and
   // k_desc_prepare (one workgroup per frame, does not read it): join only in front of the sampling kernel
   if (ov) (void)hipStreamWaitEvent(s, ov->join, 0);

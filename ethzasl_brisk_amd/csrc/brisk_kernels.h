@@ -42,10 +42,13 @@ struct BriskDescribeBuffers {
   uint4* drec;         // [slots][kp_cap] the keypoints in processing order: {x, y, angle (float bits), scale | index << 8}
   uint8_t* desc;       // [slots][kp_cap][desc_pitch]
   int desc_pitch;
+  int* dp_work;        // [slots][dp_work_stride] work area of the multi-workgroup keypoint preparation (brisk_dp_work_ints)
+  long dp_work_stride;
 };
+long brisk_dp_work_ints(int kp_cap);
 
 // Optional per-stage timing with HIP events on the launch stream (bench.py roofline leg).
-#define BRISK_PROF_STAGES 8
+#define BRISK_PROF_STAGES 9
 #define BRISK_PROF_MAX_CALLS 64
 struct BriskProfiler {
   bool on = false;
@@ -59,6 +62,7 @@ struct BriskProfiler {
 };
 // stage ids
 enum { BRISK_STG_PYRAMID = 0, BRISK_STG_DETECT, BRISK_STG_CLASSIFY, BRISK_STG_TIES, BRISK_STG_FINALIZE,
+       BRISK_STG_POSTFILTER /* uniformity enforcement / bucketing (empty interval when both are off) */,
        BRISK_STG_INTEGRAL, BRISK_STG_DESC_PREPARE, BRISK_STG_DESCRIBE };
 const char* brisk_stage_name(int i);
 void brisk_prof_begin_call(BriskProfiler* P);

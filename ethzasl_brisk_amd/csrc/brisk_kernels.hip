@@ -1824,7 +1824,7 @@ static inline int grid_for(long items, int per_block, int cap) {
 
 const char* brisk_stage_name(int i) {
   static const char* n[BRISK_PROF_STAGES] = {"k_pyramid", "k_detect", "k_classify_refine", "k_tie_resolve", "k_finalize",
-                                             "k_integral_final", "k_desc_prepare", "k_describe"};
+                                             "k_postfilter", "k_integral_final", "k_desc_prepare", "k_describe"};
   return (i >= 0 && i < BRISK_PROF_STAGES) ? n[i] : "?";
 }
 
@@ -1938,7 +1938,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     hipLaunchKernelGGL(k_ordered_keypoints, dim3(nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.keys, B.kp_out,
                        B.cand_cap, B.kp_cap, mask, mask_frame_pitch, mask_row_pitch, G.no_scale_nms);
     brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
-    brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
+    brisk_prof_mark(prof, BRISK_STG_POSTFILTER, s);
     return;
   }
   // blocks per frame: few for large batches (every block then walks several rounds of its frame's candidates on one
@@ -1979,7 +1979,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                      B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);
   hipLaunchKernelGGL(k_finalize_large, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys,
                      reinterpret_cast<unsigned*>(B.tie_idx), (long)BRISK_MAX_LAYERS * B.tie_cap, B.kp_out, B.cand_cap, B.kp_cap);
-  brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
+  brisk_prof_mark(prof, BRISK_STG_POSTFILTER, s);
 }
 
 void brisk_launch_compute_scale(const BriskGeom& G, const BriskDetectBuffers& B, const uint8_t* frame, int row_pitch,

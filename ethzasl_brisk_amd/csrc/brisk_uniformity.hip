@@ -6,9 +6,10 @@
 // BriskFeatureDetector for BASELINE config 4 ("uniformity-enforced").  The algorithm is a greedy pass over the
 // keypoints in descending score order against an occupancy image.  What a point reads from that image is
 //   min(255, sum of the mask values that the ACCEPTED earlier points within 15 cells added at its cell)
-// (saturating adds of non-negative values commute), so no image is needed: k_uniformity decides the points in score
-// order with one wave per point, a wave waits (in LDS) only for the decisions of the earlier points within 15 cells of
-// its own and sums their contributions directly.  Frames with more points than the on-chip arrays hold take the
+// (saturating adds of non-negative values commute), so no image is needed: k_uf_rank puts the points into score order,
+// k_uf_decide decides all points of a frame at once - a point waits (in LDS) only for the decisions of the better points
+// within 15 cells of its own, found through a hash of 16 x 16-cell bins, and sums their contributions directly.
+// Frames with more points than the on-chip arrays hold take the
 // literal walk over an occupancy image in global memory (k_uniformity_seq: one workgroup per frame, the 31 x 31 update
 // of an accepted point spread over the workgroup).
 #include <hip/hip_runtime.h>
@@ -141,82 +142,194 @@ __device__ __forceinline__ int uf_contribution(int dx, int dy, float nsc) {
   return (int)(uint8_t)(int)ceilf(lut * nsc99);
 }
 
-__global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
-                                                           int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap,
-                                                           float scaling, int max_keypoints) {
-  __shared__ float tile[UF_THREADS];
-  __shared__ int pcell[UF_LDS_POINTS];     // cy << 16 | cx of the point with score rank r
-  __shared__ float pnsc[UF_LDS_POINTS];    // its normalised score
-  __shared__ int dec[UF_LDS_POINTS];       // 0 pending, 1 accepted, 2 rejected
-  __shared__ int wsum[UF_THREADS / 64];
-  const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// ---- frames with up to UF_LDS_POINTS points: two kernels --------------------------------------------------------
+// k_uf_rank    (several workgroups per frame) score rank of every point by counting - (score descending, input index
+//              ascending), the walk order of the reference - and, at its rank, the point's occupancy cell and normalised
+//              score.  n^2 comparisons, but spread over n / 256 workgroups and two instructions each: 45 us for the 4 745
+//              points of a 4K frame, where ONE workgroup ranking and then scanning all earlier points of every point
+//              took 3 ms.
+// k_uf_decide  (one workgroup per frame) the points of a frame hashed by 16 x 16-cell bins; a point looks at the better
+//              points of the 3 x 3 bins around its own (what lies within 15 cells is in there), waits until those within
+//              reach are decided and sums what the accepted ones contributed - O(n k) for k neighbours, all points at
+//              once.  One lane per point, ranks dealt round-robin: a lane only ever waits for smaller ranks, and the
+//              decision is published INSIDE the polling loop (lanes of one wave wait for each other), so the smallest
+//              undecided rank always gets decided.
+#define UR_THREADS 256
+#define UF_TILE 1024
+#define UF_HASH 8192
+struct UfSorted { int cx, cy; float nsc; };  // (scratch in the first 12 bytes of tmp[rank])
+
+__global__ void __launch_bounds__(UR_THREADS) k_uf_rank(const BriskKeyPoint* __restrict__ kp, const BriskFrameCounters* __restrict__ counters,
+                                                        int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap, float scaling) {
+  __shared__ __attribute__((aligned(16))) float tile[UF_TILE];
+  __shared__ float wmax[UR_THREADS / 64];
+  const int frame = blockIdx.y, tid = threadIdx.x;
   const int n = min(counters[frame].nkp, kp_cap);
-  BriskKeyPoint* K = kp + (long)frame * kp_cap;
-  BriskKeyPoint* T = tmp + (long)frame * kp_cap;
-  int* ord = order + (long)frame * kp_cap;
-  if (n == 0 || n > UF_LDS_POINTS) return;  // (the larger frames: k_uniformity_seq)
-  // rank by (score descending, input index ascending)
-  for (int j0 = 0; j0 < n; j0 += UF_THREADS) {
-    const int j = j0 + tid;
-    const float mine = (j < n) ? K[j].response : 0.f;
-    int rank = 0;
-    for (int t0 = 0; t0 < n; t0 += UF_THREADS) {
-      __syncthreads();
-      tile[tid] = (t0 + tid < n) ? K[t0 + tid].response : 0.f;
-      __syncthreads();
-      const int m = min(UF_THREADS, n - t0);
-      if (j < n)
-        for (int q = 0; q < m; ++q) {
-          const float s = tile[q];
-          rank += (s > mine || (s == mine && t0 + q < j)) ? 1 : 0;
-        }
+  const int j0 = blockIdx.x * UR_THREADS;
+  if (n == 0 || n > UF_LDS_POINTS || j0 >= n) return;
+  const BriskKeyPoint* K = kp + (long)frame * kp_cap;
+  const int j = j0 + tid;
+  BriskKeyPoint me;
+  me.x = me.y = 0.f; me.response = 0.f;
+  if (j < n) me = K[j];
+  const float mine = me.response;
+  const int own = j0 / UF_TILE * UF_TILE;  // the tile that holds this workgroup's own points
+  int rank = 0;
+  float mx = 0.f;
+  for (int t0 = 0; t0 < n; t0 += UF_TILE) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < UF_TILE / UR_THREADS; ++k) {
+      const int q = t0 + k * UR_THREADS + tid;
+      const float v = q < n ? K[q].response : -3.0e38f;  // (never counted)
+      tile[k * UR_THREADS + tid] = v;
+      mx = fmaxf(mx, v);
     }
-    if (j < n) ord[rank] = j;
-  }
-  __threadfence();
-  __syncthreads();
-  const float maxScore = K[__hip_atomic_load(&ord[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)].response;
-  for (int r = tid; r < n; r += UF_THREADS) {
-    const BriskKeyPoint p = K[__hip_atomic_load(&ord[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
-    pcell[r] = ((int)(p.y * scaling + 16) << 16) | (int)(p.x * scaling + 16);
-    pnsc[r] = sqrtf(sqrtf(p.response / maxScore)) * 255.0f;
-    dec[r] = 0;
-  }
-  __syncthreads();
-  // decisions in score order, one wave per point: the wave's lanes scan the earlier points, a lane that finds one
-  // within reach waits for its decision (the earliest undecided point never waits) and adds what it contributed
-  for (int r = wave; r < n; r += UF_THREADS / 64) {
-    const int cyr = pcell[r] >> 16, cxr = pcell[r] & 0xFFFF;
-    int sum = 0;
-    for (int j0 = 0; j0 < r; j0 += 64) {
-      const int j = j0 + lane;
-      if (j < r) {
-        const int c = pcell[j];
-        const int dy = cyr - (c >> 16), dx = cxr - (c & 0xFFFF);
-        if (dx >= -15 && dx <= 15 && dy >= -15 && dy <= 15) {
-          int d = 0;
-          for (int spin = 0; spin < (1 << 24); ++spin) {
-            d = __hip_atomic_load(&dec[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (d) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (d == 0) atomicOr(&counters[frame].overflow, 8);  // (never observed) reported as an internal error
-          if (d == 1) sum += uf_contribution(dx, dy, pnsc[j]);
-        }
+    __syncthreads();
+    // equal scores: the smaller input index first - all of an earlier tile's equals count, none of a later tile's
+    if (t0 < own) {
+      for (int q = 0; q < UF_TILE; q += 4) {
+        const float4 s = *reinterpret_cast<const float4*>(&tile[q]);
+        rank += (s.x >= mine ? 1 : 0) + (s.y >= mine ? 1 : 0) + (s.z >= mine ? 1 : 0) + (s.w >= mine ? 1 : 0);
+      }
+    } else if (t0 > own) {
+      for (int q = 0; q < UF_TILE; q += 4) {
+        const float4 s = *reinterpret_cast<const float4*>(&tile[q]);
+        rank += (s.x > mine ? 1 : 0) + (s.y > mine ? 1 : 0) + (s.z > mine ? 1 : 0) + (s.w > mine ? 1 : 0);
+      }
+    } else {
+      for (int q = 0; q < UF_TILE; ++q) {
+        const float sq = tile[q];
+        rank += (sq > mine || (sq == mine && t0 + q < j)) ? 1 : 0;
       }
     }
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    const double s0 = (double)(sum > 255 ? 255 : sum);
-    const bool acc = !(pnsc[r] < s0);
-    if (lane == 0) __hip_atomic_store(&dec[r], acc ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  // the best score of the frame (every workgroup has seen all of them)
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+  __syncthreads();
+  float maxScore = wmax[0];
+#pragma unroll
+  for (int k = 1; k < UR_THREADS / 64; ++k) maxScore = fmaxf(maxScore, wmax[k]);
+  if (j < n) {
+    order[(long)frame * kp_cap + rank] = j;
+    UfSorted rec;
+    rec.cy = (int)(me.y * scaling + 16);
+    rec.cx = (int)(me.x * scaling + 16);
+    rec.nsc = sqrtf(sqrtf(mine / maxScore)) * 255.0f;
+    *reinterpret_cast<UfSorted*>(tmp + (long)frame * kp_cap + rank) = rec;
+  }
+}
+
+__device__ __forceinline__ unsigned uf_hash(int bx, int by) {
+  return (((unsigned)by * 73856093u) ^ ((unsigned)bx * 19349663u)) & (UF_HASH - 1);
+}
+
+__global__ void __launch_bounds__(UF_THREADS) k_uf_decide(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
+                                                          int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap,
+                                                          int max_keypoints) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char uf_lds[];
+  int2* pcell = reinterpret_cast<int2*>(uf_lds);                                   // [UF_LDS_POINTS] (cx, cy) of rank r
+  int* hcur = reinterpret_cast<int*>(pcell + UF_LDS_POINTS);                       // [UF_HASH] bucket counts, then fill cursors
+  unsigned short* hstart = reinterpret_cast<unsigned short*>(hcur + UF_HASH);      // [UF_HASH + 2] first list entry of a bucket
+  unsigned short* blist = hstart + UF_HASH + 2;                                    // [UF_LDS_POINTS] ranks grouped by bucket
+  volatile unsigned char* dec = reinterpret_cast<volatile unsigned char*>(blist + UF_LDS_POINTS);  // [UF_LDS_POINTS] 0 pending, 1 accepted, 2 rejected
+  __shared__ int wsum[UF_THREADS / 64];
+  __shared__ int kept_s, giveup_s;
+  const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = min(counters[frame].nkp, kp_cap);
+  if (n == 0 || n > UF_LDS_POINTS) return;  // (the larger frames: k_uniformity_seq)
+  BriskKeyPoint* K = kp + (long)frame * kp_cap;
+  BriskKeyPoint* T = tmp + (long)frame * kp_cap;
+  const int* ord = order + (long)frame * kp_cap;
+  for (int b = tid; b < UF_HASH; b += UF_THREADS) hcur[b] = 0;
+  if (tid == 0) giveup_s = 0;
+  __syncthreads();
+  for (int r = tid; r < n; r += UF_THREADS) {
+    const UfSorted rec = *reinterpret_cast<const UfSorted*>(T + r);
+    pcell[r] = make_int2(rec.cx, rec.cy);
+    dec[r] = 0;
+    atomicAdd(&hcur[uf_hash(rec.cx >> 4, rec.cy >> 4)], 1);
   }
   __syncthreads();
-  // the accepted points in score order, at most max_keypoints of them
+  {  // exclusive prefix over the buckets: UF_HASH / UF_THREADS consecutive buckets per thread
+    constexpr int PER = UF_HASH / UF_THREADS;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { loc[q] = hcur[tid * PER + q]; sum += loc[q]; }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < UF_THREADS / 64; ++q) run += (q < wave) ? wsum[q] : 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { hstart[tid * PER + q] = (unsigned short)run; hcur[tid * PER + q] = run; run += loc[q]; }
+    if (tid == UF_THREADS - 1) hstart[UF_HASH] = (unsigned short)run;  // (n <= 8192 < 65536)
+  }
+  __syncthreads();
+  for (int r = tid; r < n; r += UF_THREADS) {
+    const int2 c = pcell[r];
+    blist[atomicAdd(&hcur[uf_hash(c.x >> 4, c.y >> 4)], 1)] = (unsigned short)r;
+  }
+  __syncthreads();
+  // decisions: rank r on thread r % UF_THREADS, in increasing order
+  for (int r0 = 0; r0 < n; r0 += UF_THREADS) {
+    const int r = r0 + tid;
+    bool done = r >= n;
+    int2 c = make_int2(0, 0);
+    float mynsc = 0.f;
+    if (!done) { c = pcell[r]; mynsc = reinterpret_cast<const UfSorted*>(T + r)->nsc; }
+    const int bx = c.x >> 4, by = c.y >> 4;
+    int spins = 0;
+    while (__any(!done)) {
+      if (!done) {
+        bool pending = false;
+        int sum = 0;
+        for (int k = 0; k < 9 && !pending; ++k) {
+          const int nbx = bx + k % 3 - 1, nby = by + k / 3 - 1;
+          const unsigned b = uf_hash(nbx, nby);
+          const int e1 = hstart[b + 1];
+          for (int e = hstart[b]; e < e1; ++e) {
+            const int q = blist[e];
+            if (q >= r) continue;  // only better points count
+            const int2 cq = pcell[q];
+            if ((cq.x >> 4) != nbx || (cq.y >> 4) != nby) continue;  // another bin in the same bucket (it has its own turn)
+            const int dx = c.x - cq.x, dy = c.y - cq.y;
+            if (dx < -15 || dx > 15 || dy < -15 || dy > 15) continue;
+            const unsigned d = dec[q];
+            if (d == 0) { pending = true; break; }
+            if (d == 1) sum += uf_contribution(dx, dy, reinterpret_cast<const UfSorted*>(T + q)->nsc);
+          }
+        }
+        if (!pending) {
+          const double s0 = (double)(sum > 255 ? 255 : sum);
+          dec[r] = !(mynsc < s0) ? 1 : 2;
+          done = true;
+        } else if (++spins > (1 << 22)) {  // (never observed) reported as an internal error instead of a hang
+          giveup_s = 1;
+          dec[r] = 2;
+          done = true;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && giveup_s) atomicOr(&counters[frame].overflow, 8);
+  // the accepted points in score order, at most max_keypoints of them.  T[] held the sorted cells and scores until here.
   int run = 0;
-  __shared__ int kept_s;
+  __syncthreads();
   for (int r0 = 0; r0 < n; r0 += UF_THREADS) {
     const int r = r0 + tid;
     const bool a = (r < n) && dec[r] == 1;
+    BriskKeyPoint mine;
+    if (a) mine = K[ord[r]];
     const unsigned long long bal = __ballot(a);
     if (lane == 0) wsum[wave] = __popcll(bal);
     __syncthreads();
@@ -227,7 +340,8 @@ __global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __rest
       total += t;
     }
     const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (a && pos < max_keypoints) T[pos] = K[__hip_atomic_load(&ord[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    // (T[pos] with pos <= r: the sorted record at pos is no longer needed - every decision has been taken)
+    if (a && pos < max_keypoints) T[pos] = mine;
     run += total;
     __syncthreads();
   }
@@ -239,12 +353,19 @@ __global__ void __launch_bounds__(UF_THREADS) k_uniformity(BriskKeyPoint* __rest
   if (tid == 0) counters[frame].nkp = kept;
 }
 
+static size_t uf_decide_lds() {
+  return (size_t)UF_LDS_POINTS * 8 + (size_t)UF_HASH * 4 + (size_t)(UF_HASH + 2) * 2 + (size_t)UF_LDS_POINTS * 2 + (size_t)UF_LDS_POINTS + 64;
+}
+
 void brisk_launch_uniformity(BriskKeyPoint* kp, BriskFrameCounters* counters, int* order, BriskKeyPoint* tmp, uint8_t* occ,
                              long occ_frame, int ow, int kp_cap, float scaling, int max_keypoints, int nframes, hipStream_t s) {
   if (nframes <= 0) return;
-  hipLaunchKernelGGL(k_uniformity, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, kp_cap, scaling,
-                     max_keypoints);
-  // frames with more points than k_uniformity's on-chip arrays hold (it left them untouched; clears its own image)
+  const int cap = kp_cap < UF_LDS_POINTS ? kp_cap : UF_LDS_POINTS;
+  hipLaunchKernelGGL(k_uf_rank, dim3((cap + UR_THREADS - 1) / UR_THREADS, nframes), dim3(UR_THREADS), 0, s, kp, counters, order, tmp,
+                     kp_cap, scaling);
+  (void)hipFuncSetAttribute((const void*)k_uf_decide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)uf_decide_lds());
+  hipLaunchKernelGGL(k_uf_decide, dim3(nframes), dim3(UF_THREADS), uf_decide_lds(), s, kp, counters, order, tmp, kp_cap, max_keypoints);
+  // frames with more points than the on-chip arrays hold (left untouched above; clears its own image)
   hipLaunchKernelGGL(k_uniformity_seq, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, occ, occ_frame, ow,
                      kp_cap, scaling, max_keypoints);
 }

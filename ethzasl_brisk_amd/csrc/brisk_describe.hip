@@ -299,8 +299,23 @@ struct DsLane {  // a lane's sample of one round
   int slot;      // keypoint-in-run * npoints + point
 };
 typedef BriskBoxPrep DsPrep;  // address / weight stage of a sample (brisk_device_describe.h)
+// DS_NO_IMAGE (default): the two displaced corner pixels of the reference quirk (brisk-descriptor-extractor.cc:453) come out
+// of the integral image as well - pixel (u, v) = I[v+1][u+1] - I[v+1][u] - I[v][u+1] + I[v][u], exact in wrap-around
+// arithmetic: the bottom row pair's first row is loaded three columns wide and row y_bottom - 1 adds one 8-byte gather per
+// side - instead of two byte gathers from the frame, which then is no part of the kernel's working set (2.1 MB per 1080p
+// frame, a fifth of the compulsory misses).  Only a box that ends in the image's last column still reads the frame (the
+// reference's linear address is the first pixel of the next row): a rare, separate pair of loads.
+#ifndef DS_NO_IMAGE
+#define DS_NO_IMAGE 1
+#endif
+typedef uint32_t __attribute__((ext_vector_type(3))) ds_u32x3;
 struct DsRaw {
+#if DS_NO_IMAGE
+  ds_u32x2 p00, p02, p10, p12, p30, p32, ql, qr;
+  ds_u32x3 p20, p22;
+#else
   ds_u32x2 p00, p02, p10, p12, p20, p22, p30, p32;
+#endif
   unsigned br, bl;
 };
 // SmoothedIntensity split into address / load / combine stages: the arithmetic is brisk_box_prep / brisk_box_acc /
@@ -308,15 +323,34 @@ struct DsRaw {
 __device__ __forceinline__ DsPrep ds_prep(float xf, float yf, float sigma_half, int tab_z, int tab_w) {
   return brisk_box_prep(xf, yf, sigma_half, tab_z, tab_w);
 }
-// The 4 x 4 integral samples as eight 8-byte gathers through a buffer descriptor of the frame's integral image: four
-// 32-bit offsets per lane (the corners), the second row of each pair through the scalar offset; plus the two displaced
-// bottom corners of the reference quirk (brisk-descriptor-extractor.cc:453) from the image (linear addressing of the
-// reference: a box that ends in the last column reads the first pixel of the next row).
+// The 4 x 4 integral samples as eight gathers through a buffer descriptor of the frame's integral image: four 32-bit
+// offsets per lane (the corners), the second row of each pair through the scalar offset; plus what the two displaced
+// bottom corners of the reference quirk need (above).
 __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, __amdgpu_buffer_rsrc_t rs_img, int stride, int cols,
                                         __amdgpu_buffer_rsrc_t rs_int, int istride) {
   const int rowb = istride * 4;
   const int o_t = p.y_top * rowb, o_b = p.y_bottom * rowb;
   const int o_tl = o_t + p.x_left * 4, o_tr = o_t + p.x_right * 4, o_bl = o_b + p.x_left * 4, o_br = o_b + p.x_right * 4;
+#if DS_NO_IMAGE
+  r.p00 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, 0, 0);
+  r.p02 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, 0, 0);
+  r.p10 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, rowb, 0);
+  r.p12 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, rowb, 0);
+  r.ql = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl - rowb + 4, 0, 0);   // row y_bottom - 1, columns x_left + 1, + 2
+  r.qr = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br - rowb + 4, 0, 0);   // row y_bottom - 1, columns x_right + 1, + 2
+  r.p20 = __builtin_amdgcn_raw_buffer_load_b96(rs_int, o_bl, 0, 0);
+  r.p22 = __builtin_amdgcn_raw_buffer_load_b96(rs_int, o_br, 0, 0);
+  r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl, rowb, 0);
+  r.p32 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, rowb, 0);
+  r.br = 0; r.bl = 0;
+  const bool wrap = p.quirk && (p.x_right + 1 >= cols || p.x_left + 1 >= cols);
+  if (__builtin_expect(wrap, 0)) {
+    const int qy = max(p.y_bottom - 1, 0), xr = p.x_right + 1, xl = p.x_left + 1, o_q = qy * stride, wr = stride - cols;
+    r.br = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xr + (xr >= cols ? wr : 0), 0, 0);
+    r.bl = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xl + (xl >= cols ? wr : 0), 0, 0);
+    r.br |= 0x100u; r.bl |= 0x100u;  // (marks "from the frame")
+  }
+#else
   int qy = max(p.y_bottom - 1, 0);
   int xr = p.x_right + 1, xl = p.x_left + 1;
   const int o_q = qy * stride;
@@ -332,10 +366,18 @@ __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, __amdgpu_buff
   r.p22 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, 0, 0);
   r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl, rowb, 0);
   r.p32 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, rowb, 0);
+#endif
 }
 __device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
+#if DS_NO_IMAGE
+  unsigned qbr = r.p22.z - r.p22.y - r.qr.y + r.qr.x;  // pixel (x_right + 1, y_bottom - 1)
+  unsigned qbl = r.p20.z - r.p20.y - r.ql.y + r.ql.x;  // pixel (x_left + 1, y_bottom - 1)
+  if (r.br & 0x100u) { qbr = r.br & 0xFFu; qbl = r.bl & 0xFFu; }
+#else
+  const unsigned qbr = r.br, qbl = r.bl;
+#endif
   const uint32_t acc = brisk_box_acc(p, r.p00.x, r.p00.y, r.p02.x, r.p02.y, r.p10.x, r.p10.y, r.p12.x, r.p12.y, r.p20.x, r.p20.y, r.p22.x,
-                                     r.p22.y, r.p30.x, r.p30.y, r.p32.x, r.p32.y, r.br, r.bl);
+                                     r.p22.y, r.p30.x, r.p30.y, r.p32.x, r.p32.y, qbr, qbl);
   if (__any(p.shift < 0)) return brisk_box_divide(p, acc);  // (a pattern with degenerate boxes: the plain division is compiled in but skipped)
   return brisk_div_by_magic((int)acc, p.magic, p.shift);
 }

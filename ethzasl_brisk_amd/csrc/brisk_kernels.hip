@@ -446,9 +446,16 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so blocks with equal blockIdx.x % 8
   // share an XCD (and its L2) within a frame.  Give each residue a contiguous eighth of the frame's tile list so
   // that the halo rows/columns shared by neighbouring tiles are fetched into one L2 instead of eight.
+  // WHICH eighth an XCD takes rotates with the frame: the eighths differ in cost (layer 0's full tiles first, the small
+  // layers' partial tiles last; texture), workgroups are dealt to the XCDs in strict rotation, and with the same eighth
+  // on the same XCD frame after frame the XCD with the cheapest one idles while the dispatcher waits for the others -
+  // 64 4K frames (3960 tiles: a multiple of 8, so nothing rotated by itself): 1.15 -> 0.78 ms.  gridDim.x is the tile count
+  // rounded up to a multiple of 8, so blockIdx.x & 7 IS the XCD for every frame; the surplus workgroups exit.
   const int nt = T.total_tiles;
-  const int res = blockIdx.x & 7;
-  const int tid_sw = res * (nt >> 3) + min(res, nt & 7) + (blockIdx.x >> 3);
+  const int res = ((blockIdx.x & 7) + frame) & 7;
+  const int slot = blockIdx.x >> 3;
+  if (slot >= (nt >> 3) + (res < (nt & 7) ? 1 : 0)) return;
+  const int tid_sw = res * (nt >> 3) + min(res, nt & 7) + slot;
   int l = 0;
   while (l + 1 < G.nlayers && tid_sw >= T.first_tile[l + 1]) ++l;
   const int t = tid_sw - T.first_tile[l];
@@ -1108,7 +1115,7 @@ __device__ __noinline__ void tie_sort_large(const BriskCand* C, int* list, int n
 __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
                                                              BriskFrameCounters* counters, const int* tie_idx,
                                                              const uint8_t* blocks, unsigned* gscratch, int cand_cap,
-                                                             int tie_cap, int nframes, int lpw) {
+                                                             int tie_cap, int nframes, int lpw, int persist) {
   __shared__ uint8_t kp5s[TR_WAVES][32];
   __shared__ uint16_t win[TR_WAVES][TR_WIN * TR_WIN + 1];  // per-wave window of the tie being decided
   // the four TR_CHUNK-sized arrays as ONE block of LDS: the raster sort of a layer beyond the on-chip capacity
@@ -1138,7 +1145,11 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nthreads = blockDim.x, dwaves = (nthreads >> 6) - 1;  // deciding waves; the last wave writes the decisions to memory
   const int nl = G.nlayers;
-  const int ngroups = (nl + lpw - 1) / lpw;  // workgroups per frame, `lpw` consecutive layers each
+  const int ngroups = (nl + lpw - 1) / lpw;  // tickets per frame, `lpw` consecutive layers each
+  // persist: the grid is one workgroup per CU and a workgroup draws ticket after ticket (frames whose layers differ a lot
+  // in ties - 4K: 23 ... 1026 per layer - then balance by themselves; a ticket still only waits for tickets drawn before it)
+  for (;;) {
+  __syncthreads();  // (the previous ticket's use of the on-chip arrays and of ticket_s is over)
   if (tid == 0) {
     abort_s = 0;
     if (nframes >= 8) {  // one ticket counter per XCD residue: frames g * 8 + xcd, layer groups in ascending order
@@ -1499,9 +1510,11 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
       __hip_atomic_fetch_max(my_prog, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  }  // layers of this workgroup
+  }  // layers of this ticket
   __syncthreads();
   if (tid == 0 && abort_s) atomicOr(&counters[frame].overflow, 8 | (abort_s << 8));  // a wait ran into its bound: reported as an error (bits 8-10: which wait)
+  if (!persist) return;
+  }  // tickets of this workgroup
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1925,7 +1938,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   };
   if (ov && fork_at == 1) fork_integral();
   brisk_prof_mark(prof, BRISK_STG_DETECT, s);
-  hipLaunchKernelGGL(k_detect, dim3(T.total_tiles, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,
+  hipLaunchKernelGGL(k_detect, dim3((T.total_tiles + 7) / 8 * 8, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,
                      B.cand_cap);
   if (ov && fork_at == 2) fork_integral();
   brisk_prof_mark(prof, BRISK_STG_CLASSIFY, s);
@@ -1964,15 +1977,21 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     // (128 frames: 0.69 ms with one layer per workgroup, 0.35 with four, 0.45 with eight).  With 8 or more frames
     // every XCD residue of blockIdx gets whole frames.
     static const int lpw_knob = env_knob("BRISK_TR_LPW", 0);
+    // (pyramids of more than 8 layers - 4K frames with 6 octaves: 23 ... 1026 ties per layer - in groups that leave a
+    // quarter of the CUs to the integral kernel beside them: 64 frames x 12 layers 1.03 -> 0.89 ms)
+    const int per_wg = G.nlayers > 8 ? 192 : 256;
     const int lpw = lpw_knob ? min(lpw_knob, G.nlayers)
-                             : (nframes * G.nlayers <= 512 ? 1 : min((nframes * G.nlayers + 255) / 256, G.nlayers));
-    const int tr_grid = (nframes >= 8 ? (nframes + 7) / 8 * 8 : nframes) * ((G.nlayers + lpw - 1) / lpw);
+                             : (nframes * G.nlayers <= 512 ? 1 : min((nframes * G.nlayers + per_wg - 1) / per_wg, G.nlayers));
+    int tr_grid = (nframes >= 8 ? (nframes + 7) / 8 * 8 : nframes) * ((G.nlayers + lpw - 1) / lpw);
+    static const int persist_knob = env_knob("BRISK_TR_PERSIST", -1), pgrid_knob = env_knob("BRISK_TR_PGRID", 256);
+    const int persist = persist_knob >= 0 ? persist_knob : (tr_grid > pgrid_knob ? 1 : 0);
+    if (persist && tr_grid > pgrid_knob) tr_grid = pgrid_knob;
     // waves per workgroup: 16 (15 deciding).  (12 leave room for a third integral workgroup per CU on the side stream
     // of a large batch: the batch gets 1 % faster, the tie kernel itself 40 % slower - not taken.)
     static const int waves_knob = env_knob("BRISK_TR_WAVES", 0);
     const int tr_waves = waves_knob ? min(max(waves_knob, 2), TR_WAVES) : TR_WAVES;
     hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                       B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw);
+                       B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist);
   }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,

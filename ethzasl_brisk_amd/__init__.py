@@ -32,8 +32,14 @@ ABI_SYMBOLS = [
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
     "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
     "brisk_hip_reserve", "brisk_hip_detect_uniform", "brisk_hip_detect_describe_batch_host", "brisk_hip_stream_ceiling",
-    "brisk_hip_kernel_revision", "brisk_hip_compute_scale",
+    "brisk_hip_kernel_revision", "brisk_hip_compute_scale", "brisk_hip_describe_same_image", "brisk_hip_detect_filtered",
 ]
+
+
+class PostFilter(C.Structure):
+    """brisk_hip_postfilter: the optional post-filters of one detect call"""
+    _fields_ = [("uniformity_radius", C.c_double), ("uniformity_max_keypoints", C.c_int), ("num_buckets_u", C.c_int),
+                ("num_buckets_v", C.c_int), ("bucket_max_keypoints", C.c_int)]
 
 
 class BriskHipError(RuntimeError):
@@ -78,6 +84,7 @@ def load_library():
     L.brisk_hip_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp,
                                    C.c_int, ip]
     L.brisk_hip_describe.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, C.c_int, C.c_int, C.c_int]
+    L.brisk_hip_describe_same_image.argtypes = L.brisk_hip_describe.argtypes
     L.brisk_hip_detect_describe_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
                                                   C.c_int, vp]
     L.brisk_hip_detect_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, vp]
@@ -107,6 +114,8 @@ def load_library():
     L.brisk_hip_reserve.argtypes = [vp, C.c_int, C.c_int]
     L.brisk_hip_detect_uniform.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                            C.c_double, C.c_int, vp, C.c_int, ip]
+    L.brisk_hip_detect_filtered.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
+                                            C.POINTER(PostFilter), vp, C.c_int, ip]
     L.brisk_hip_compute_scale.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp,
                                           C.c_int, ip]
     L.brisk_hip_detect_describe_batch_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
@@ -315,10 +324,11 @@ class BriskFeatureDetector:
         out = np.zeros(capacity, KEYPOINT)
         n = C.c_int()
         c = self._ctx
-        c.set_bucketing(self.numBucketsU, self.numBucketsV, self.maxNumKpt)  # (context state: set per call; (0, 0) = off)
-        c.check(c._L.brisk_hip_detect_uniform(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
-                                              int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0,
-                                              self.uniformityRadius, self.maxNumKpt, _ptr(out), capacity, C.byref(n)))
+        # the object's post-filter settings travel with the call (the context's own settings are neither used nor changed)
+        pf = PostFilter(self.uniformityRadius, self.maxNumKpt, self.numBucketsU, self.numBucketsV, self.maxNumKpt)
+        c.check(c._L.brisk_hip_detect_filtered(c._h, _ptr(img), w, h, w, self.threshold, self.octaves,
+                                               int(self.m_suppressScaleNonmaxima), _ptr(m), w if m is not None else 0,
+                                               C.byref(pf), _ptr(out), capacity, C.byref(n)))
         return _kcopy(out, n.value)
 
 
@@ -380,8 +390,10 @@ class BriskDescriptorExtractor:
         self._ctx.check(self._ctx._L.brisk_hip_pattern_tables(self._h, _ptr(a), _ptr(b), _ptr(t)))
         return a, b, t
 
-    def compute(self, image, keypoints):
-        """compute() (brisk-descriptor-extractor.cc:612-778): returns (filtered keypoints, descriptors)."""
+    def compute(self, image, keypoints, same_image=False):
+        """compute() (brisk-descriptor-extractor.cc:612-778): returns (filtered keypoints, descriptors).
+        same_image: the caller states that `image` is the very buffer the context's last detect() call was given and
+        that it has not changed (brisk_hip_describe_same_image: no second upload)."""
         img = np.ascontiguousarray(image)
         if img.dtype != np.uint8 or img.ndim != 2:
             raise RuntimeError("Unsupported image format. Must be CV_16UC1 or CV_8UC1.")  # :678 (8-bit only here)
@@ -393,8 +405,9 @@ class BriskDescriptorExtractor:
         if len(k) == 0:
             k = np.zeros(1, KEYPOINT)
         c = self._ctx
-        c.check(c._L.brisk_hip_describe(c._h, self._h, _ptr(img), w, h, w, _ptr(k), C.byref(n), _ptr(desc), s,
-                                        int(self.rotationInvariance), int(self.scaleInvariance)))
+        fn = c._L.brisk_hip_describe_same_image if same_image else c._L.brisk_hip_describe
+        c.check(fn(c._h, self._h, _ptr(img), w, h, w, _ptr(k), C.byref(n), _ptr(desc), s,
+                   int(self.rotationInvariance), int(self.scaleInvariance)))
         return k[:n.value], desc[:n.value]
 
     def close(self):

@@ -90,8 +90,11 @@ struct brisk_hip_ctx {
   hipEvent_t copied_ev[2] = {nullptr, nullptr}, consumed_ev[2] = {nullptr, nullptr};
   // The image of the last host-buffer detect call is still on the device (staging buffer, layer 0 and the pyramid
   // kernel's 96-row band sums of slot 0).  The reference API forces detect() and compute() to be two calls on the same
-  // cv::Mat (test-binary-equal.cc:215,237), not two uploads: a describe call that names the same host buffer - same
-  // pointer, size, stride and the same 64-bit hash over a 1/16 sample of its pixels - reuses the device copy.
+  // cv::Mat (test-binary-equal.cc:215,237); a caller who KNOWS that the pixels did not change in between says so
+  // (brisk_hip_describe_same_image) and the second upload and layer-0 pass are skipped.  brisk_hip_describe itself always
+  // uses the pixels it is given, like the reference's compute() - unless BRISK_HIP_IMAGE_CACHE=1 opts in to recognising
+  // the buffer by pointer, size, stride and a 64-bit hash over a 1/16 sample of its pixels (a change that avoids every
+  // sampled word goes unnoticed: off by default).
   struct {
     bool valid = false;
     const uint8_t* ptr = nullptr;
@@ -119,8 +122,9 @@ static uint64_t image_sample_hash(const uint8_t* img, int w, int h, int stride) 
   }
   return hsh;
 }
-static bool image_cache_enabled() {
-  static const bool on = !(getenv("BRISK_HIP_IMAGE_CACHE") && atoi(getenv("BRISK_HIP_IMAGE_CACHE")) == 0);
+// the sampled-hash recognition of an unchanged buffer: opt-in (a change that misses every sampled word is not seen)
+static bool image_hash_reuse_enabled() {
+  static const bool on = getenv("BRISK_HIP_IMAGE_CACHE") && atoi(getenv("BRISK_HIP_IMAGE_CACHE")) == 1;
   return on;
 }
 
@@ -346,6 +350,8 @@ const char* brisk_hip_last_error(const brisk_hip_ctx* ctx) { return ctx ? ctx->e
 int brisk_hip_set_capacity(brisk_hip_ctx* ctx, int max_candidates, int max_keypoints) {
   if (!ctx) return BRISK_HIP_ERR_ARG;
   if (max_candidates < 256 || max_keypoints < 16) return fail(ctx, BRISK_HIP_ERR_ARG, "capacity too small");
+  // (k_describe's keypoint records carry the keypoint index in 23 bits beside the scale index)
+  if (max_keypoints >= (1 << 23)) return fail(ctx, BRISK_HIP_ERR_ARG, "keypoint capacity must be below 2^23");
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->cand_cap = max_candidates;
   ctx->kp_cap = max_keypoints;
@@ -356,6 +362,7 @@ int brisk_hip_set_capacity(brisk_hip_ctx* ctx, int max_candidates, int max_keypo
 int brisk_hip_reserve(brisk_hip_ctx* ctx, int min_candidates, int min_keypoints) {
   if (!ctx) return BRISK_HIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (min_keypoints >= (1 << 23)) return fail(ctx, BRISK_HIP_ERR_ARG, "keypoint capacity must be below 2^23");
   if (min_candidates > ctx->cand_cap) {
     ctx->cand_cap = min_candidates;
     if (min_candidates / 4 > ctx->tie_cap) ctx->tie_cap = min_candidates / 4;
@@ -480,6 +487,7 @@ struct BatchArgs {
   bool do_detect, do_describe;
   double uni_radius;  // uniformity enforcement of this call (0 = off)
   int uni_max;
+  int bk_u = 0, bk_v = 0, bk_max = 0;  // KeyPointBucketing of this call (0 buckets = off)
   bool no_scale_nms = false;  // suppressScaleNonmaxima == false with octaves > 0
   int lower_threshold = BRISK_LOWER_THRESHOLD;  // 0: ComputeScale's pyramid (brisk-feature-detector.cc:90)
   bool inplace_ok = true;  // layer 0 may be read from the frame buffer (not for the host-fed path's recycled staging buffers)
@@ -497,7 +505,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   if (A.do_describe && A.pat && A.pat->host.strings > ctx->desc_pitch) ctx->desc_pitch = brisk_align_up(A.pat->host.strings, 16);
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
-  const bool bucketing = A.do_detect && !(A.uni_radius > 0.0) && ctx->bk_u > 0;
+  const bool bucketing = A.do_detect && !(A.uni_radius > 0.0) && A.bk_u > 0;
   if ((A.do_detect && A.uni_radius > 0.0) || bucketing) {
     size_t need = 0;
     if (!bucketing) {
@@ -524,7 +532,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
       }
     }
   }
-  if (bucketing && (ctx->bk_u >= A.w || ctx->bk_v >= A.h))
+  if (bucketing && (A.bk_u >= A.w || A.bk_v >= A.h))
     return fail(ctx, BRISK_HIP_ERR_ARG, "bucketing: more buckets than pixels (key-point-bucketing-inl.h:82-83)");
   rc = workspace_acquire(ctx, s);
   if (rc) return fail(ctx, rc, "hipStreamWaitEvent failed");
@@ -606,10 +614,10 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
     brisk_launch_uniformity(Bi.kp_out, Bi.counters, ctx->d_uni_order + f0 * Bi.kp_cap, ctx->d_uni_tmp + f0 * Bi.kp_cap,
                             ctx->d_occ + f0 * occ_frame, occ_frame, ow, Bi.kp_cap, scaling, A.uni_max, nf, si);
   }
-  if (A.do_detect && !(A.uni_radius > 0.0) && ctx->bk_u > 0) {
+  if (A.do_detect && !(A.uni_radius > 0.0) && A.bk_u > 0) {
     // KeyPointBucketing as a post-filter of the detected keypoints (brisk_uniformity.hip)
     brisk_launch_bucketing(Bi.kp_out, Bi.counters, ctx->d_uni_order + f0 * Bi.kp_cap, ctx->d_uni_tmp + f0 * Bi.kp_cap, Bi.kp_cap,
-                           A.h, A.w, ctx->bk_u, ctx->bk_v, ctx->bk_max, nf, si);
+                           A.h, A.w, A.bk_u, A.bk_v, A.bk_max, nf, si);
   }
   if (A.do_detect) brisk_prof_mark(prof, BRISK_STG_INTEGRAL, si);  // end of the post-filter interval
   if (A.do_describe) {
@@ -634,7 +642,7 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
                      long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* d_mask,
                      long mask_frame_pitch, int mask_row_pitch, hipStream_t s, bool do_detect, bool do_describe,
                      double uni_radius = -1.0, int uni_max = 0, bool no_scale_nms = false,
-                     int lower_threshold = BRISK_LOWER_THRESHOLD) {
+                     int lower_threshold = BRISK_LOWER_THRESHOLD, const int* bucketing = nullptr) {
   if (!d_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   // timing experiments only (debug bit 27): the descriptor half of a batch alone, on the keypoints the previous batch left
@@ -643,6 +651,9 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
               do_describe, uni_radius < 0.0 ? ctx->uni_radius : uni_radius, uni_radius < 0.0 ? ctx->uni_max : uni_max};
   A.no_scale_nms = no_scale_nms;
   A.lower_threshold = lower_threshold;
+  // post-filters given per call (uni_radius >= 0 / bucketing != null) never read or write the context's settings
+  if (bucketing) { A.bk_u = bucketing[0]; A.bk_v = bucketing[1]; A.bk_max = bucketing[2]; }
+  else if (uni_radius < 0.0) { A.bk_u = ctx->bk_u; A.bk_v = ctx->bk_v; A.bk_max = ctx->bk_max; }
   int rc = batch_begin(ctx, A, nframes, s);
   if (rc) return rc;
   WorkspaceGuard guard(ctx, s);
@@ -709,6 +720,7 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
   if (!h_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   BatchArgs A{pat, w, h, threshold, octaves, 0, 0, nullptr, 0, 0, true, true, ctx->uni_radius, ctx->uni_max};
+  A.bk_u = ctx->bk_u; A.bk_v = ctx->bk_v; A.bk_max = ctx->bk_max;
   A.inplace_ok = false;  // the staging buffers are recycled slice after slice: the engine keeps its own layer-0 copy (the link, not the engine, bounds this path)
   hipStream_t s = ctx->stream;
   int rc = batch_begin(ctx, A, nframes, s);
@@ -880,7 +892,7 @@ int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which, brisk_hip
 // ---- host-buffer calls ---------------------------------------------------------------------------
 static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
                        int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, double uni_radius, int uni_max,
-                       brisk_hip_keypoint* out, int cap, int* n) {
+                       brisk_hip_keypoint* out, int cap, int* n, const int* bucketing = nullptr) {
   if (!ctx || !img || !n || (cap > 0 && !out) || cap < 0) return BRISK_HIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   *n = 0;
@@ -907,14 +919,12 @@ static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int
     d_mask = ctx->d_stage + img_bytes;
   }
   rc = run_batch(ctx, nullptr, ctx->d_stage, 1, w, h, (long)img_bytes, pitch, threshold, octaves, d_mask, (long)img_bytes,
-                 pitch, ctx->stream, true, false, uni_radius, uni_max, !suppress_scale_nonmaxima);
+                 pitch, ctx->stream, true, false, uni_radius, uni_max, !suppress_scale_nonmaxima, BRISK_LOWER_THRESHOLD, bucketing);
   if (rc) return rc;
-  if (image_cache_enabled()) {
-    ctx->img_cache.valid = true;
-    ctx->img_cache.ptr = img; ctx->img_cache.w = w; ctx->img_cache.h = h; ctx->img_cache.stride = stride;
-    ctx->img_cache.hash = image_sample_hash(img, w, h, stride);  // (while the GPU works)
-    ctx->img_cache.l0_ext = ctx->last_l0_ext;
-  }
+  ctx->img_cache.valid = true;
+  ctx->img_cache.ptr = img; ctx->img_cache.w = w; ctx->img_cache.h = h; ctx->img_cache.stride = stride;
+  ctx->img_cache.hash = image_hash_reuse_enabled() ? image_sample_hash(img, w, h, stride) : 0;  // (while the GPU works)
+  ctx->img_cache.l0_ext = ctx->last_l0_ext;
   return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
 }
 
@@ -931,6 +941,20 @@ int brisk_hip_detect_uniform(brisk_hip_ctx* ctx, const uint8_t* img, int w, int 
   if (uniformity_radius < 0.0) return ctx ? fail(ctx, BRISK_HIP_ERR_ARG, "uniformity: negative radius") : BRISK_HIP_ERR_ARG;
   return detect_host(ctx, img, w, h, stride, threshold, octaves, suppress_scale_nonmaxima, mask, mask_stride,
                      uniformity_radius, max_keypoints, out, cap, n);
+}
+
+int brisk_hip_detect_filtered(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                              int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride,
+                              const brisk_hip_postfilter* pf, brisk_hip_keypoint* out, int cap, int* n) {
+  if (!pf) return ctx ? fail(ctx, BRISK_HIP_ERR_ARG, "null post-filter description") : BRISK_HIP_ERR_ARG;
+  if (pf->uniformity_radius < 0.0) return ctx ? fail(ctx, BRISK_HIP_ERR_ARG, "uniformity: negative radius") : BRISK_HIP_ERR_ARG;
+  const bool bk_off = pf->num_buckets_u == 0 && pf->num_buckets_v == 0;
+  if (!bk_off && (pf->num_buckets_u < 1 || pf->num_buckets_v < 1 || pf->bucket_max_keypoints < 1 ||
+                  (long)pf->num_buckets_u * pf->num_buckets_v > (1 << 24)))
+    return ctx ? fail(ctx, BRISK_HIP_ERR_ARG, "bucketing: buckets >= 1 each way (0, 0 = off), max_keypoints >= 1") : BRISK_HIP_ERR_ARG;
+  const int bk[3] = {bk_off ? 0 : pf->num_buckets_u, bk_off ? 0 : pf->num_buckets_v, bk_off ? 0 : pf->bucket_max_keypoints};
+  return detect_host(ctx, img, w, h, stride, threshold, octaves, suppress_scale_nonmaxima, mask, mask_stride,
+                     pf->uniformity_radius, pf->uniformity_radius > 0.0 ? pf->uniformity_max_keypoints : 0x7FFFFFFF, out, cap, n, bk);
 }
 
 int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
@@ -979,9 +1003,9 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
   return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
 }
 
-int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
-                       brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
-                       int scale_invariant) {
+static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
+                         brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
+                         int scale_invariant, bool same_image) {
   if (!ctx || !pat || !img || !n || *n < 0 || (*n > 0 && (!kps || !desc))) return BRISK_HIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (w <= 0 || h <= 0 || w > 8191 || h > 8191 || stride < w) return fail(ctx, BRISK_HIP_ERR_ARG, "bad image description");
@@ -998,9 +1022,11 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   if (rc) return rc;
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   WorkspaceGuard guard(ctx, ctx->stream);
-  // the image of the last detect call, still on the device?  (same host buffer, same sampled hash)
+  // the image of the last detect call, still on the device?  Only on the caller's word (same_image) - or, opted in through
+  // the environment, when the sampled hash of the buffer has not changed
   const bool reuse = ctx->img_cache.valid && ctx->img_cache.ptr == img && ctx->img_cache.w == w && ctx->img_cache.h == h &&
-                     ctx->img_cache.stride == stride && ctx->img_cache.hash == image_sample_hash(img, w, h, stride);
+                     ctx->img_cache.stride == stride &&
+                     (same_image || (image_hash_reuse_enabled() && ctx->img_cache.hash == image_sample_hash(img, w, h, stride)));
   ctx->img_cache.valid = reuse;  // an uploaded image overwrites the staging buffer (and is not remembered itself)
   if (reuse) ctx->img_cache.hits++;
   if (!reuse) HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
@@ -1043,6 +1069,18 @@ int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const u
   ctx->last_desc_pitch = Dd.desc_pitch;
   if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
   return download_locked(ctx, 0, 1, kps, n_in, n, desc, desc_stride, pat->host.strings, Dd.desc_pitch);
+}
+
+int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
+                       brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
+                       int scale_invariant) {
+  return describe_host(ctx, pat, img, w, h, stride, kps, n, desc, desc_stride, rotation_invariant, scale_invariant, false);
+}
+
+int brisk_hip_describe_same_image(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
+                                  brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
+                                  int scale_invariant) {
+  return describe_host(ctx, pat, img, w, h, stride, kps, n, desc, desc_stride, rotation_invariant, scale_invariant, true);
 }
 
 // ---- per-stage timing (HIP events on the launch stream) -----------------------------------------------
@@ -1248,12 +1286,13 @@ static int image16_call(brisk_hip_ctx* ctx, int which, const uint16_t* src, int 
   size_t delem;
   if (which == 0) {
     dw = w / 2; dh = h / 2; delem = 2;
-    if (dw * 2 >= 16 && dh < 1) return BRISK_HIP_OK;  // a single row: the reference's row loop does not run, nothing to write
-    if (dw * 2 < 16) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "Halfsample16: fewer than 16 usable columns (the reference's loop writes nothing, image-down-sampling.cc:69-74)");
+    // a single row, or fewer than 16 usable columns: the reference's loops do not run and nothing is written
+    // (image-down-sampling.cc:69-74) - the same here, for both degenerate shapes
+    if (dh < 1 || dw * 2 < 16) return BRISK_HIP_OK;
   } else if (which == 1) {
     dw = w / 3 * 2; dh = h / 3 * 2; delem = 2;
-    if (w / 3 * 3 >= 12 && dh < 2) return BRISK_HIP_OK;  // fewer than three rows: nothing to write
-    if (w / 3 * 3 < 12) return fail(ctx, BRISK_HIP_ERR_UNSUPPORTED, "Twothirdsample16: fewer than 12 usable columns (the reference's loop writes nothing, image-down-sampling.cc:407-413)");
+    // fewer than three rows or fewer than 12 usable columns: nothing to write (image-down-sampling.cc:407-413)
+    if (dh < 2 || w / 3 * 3 < 12) return BRISK_HIP_OK;
   } else {
     dw = w + 1; dh = h + 1; delem = 4;
   }

@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
       // bit p = values[i] > values[j], LSB first in little-endian u32 words (:538-564)
       for (int kq = 0; kq < cur.cnt; ++kq) {
         const int* v = vals + kq * np;
-        const int k = (int)(__builtin_amdgcn_readfirstlane((int)krec[kq].w) >> 8);
+        const int k = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)krec[kq].w) >> 8);  // (index < 2^23: brisk_hip_set_capacity)
         unsigned long long mine = 0;
         if (REGTAB) {
           int va[DS_REG_SHORT], vb[DS_REG_SHORT];

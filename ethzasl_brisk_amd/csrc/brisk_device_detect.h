@@ -829,121 +829,71 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
     return true;
   }
 
-  // Refine3D
-  const int center = brisk_V<DIRECT>(tl, x_layer, y_layer);
+  // ---- a layer with neighbours on both sides (brisk-scale-space.cc:534-754) --------------------------------------------
+  // Three layer classes share one body; what differs is tabulated:
+  //   class            neighbour below                      scale fit      own-layer weight towards above | towards below
+  //   0  octave 0      virtual: AGAST 5_8 scores, 3 x 3     Refine1D_2     (1.5 - s) / 0.5                | (s - 0.5) / 0.5
+  //   1  octave c > 0  intra-octave below (window map 8/6)  Refine1D       (1.5 - s) / 0.5                | (s - 0.75) / 0.25
+  //   2  intra-octave  octave below (window map 6/4)        Refine1D_1     4 - 3 s                        | 3 s - 2
+  // with s the fitted relative scale; the weight is evaluated as (a + b s) / c in double (the reference's expressions are
+  // these with the operands in another order - same roundings), the other neighbour gets 1 - weight.
+  const int cls = (layer == 0) ? 0 : ((layer & 1) ? 2 : 1);
+  const bool intra = (cls == 2);
+  const int own_score = brisk_V<DIRECT>(tl, x_layer, y_layer);
   bool ismax = true;
-  float delta_x_above = 0, delta_y_above = 0;
+  float up_dx = 0, up_dy = 0;
   touch->on = true;
-  const float max_above = brisk_score_max_other<DIRECT>(Labove, true, (layer & 1) != 0, x_layer, y_layer, center,
-                                                ismax, delta_x_above, delta_y_above, touch);
+  const float up_peak = brisk_score_max_other<DIRECT>(Labove, true, intra, x_layer, y_layer, own_score, ismax, up_dx, up_dy, touch);
   if (!ismax) return false;
 
-  float x, y, scale, max;
-  bool doScaleRefinement = true;
-  if ((layer & 1) == 0) {
-    float delta_x_below, delta_y_below;
-    float max_below_float;
-    if (layer == 0) {  // virtual layer below octave 0 via AGAST 5_8 (:558-592)
-      const int s_0_0 = brisk_V58<DIRECT>(tl, x_layer - 1, y_layer - 1);
-      const int s_1_0 = brisk_V58<DIRECT>(tl, x_layer, y_layer - 1);
-      const int s_2_0 = brisk_V58<DIRECT>(tl, x_layer + 1, y_layer - 1);
-      const int s_2_1 = brisk_V58<DIRECT>(tl, x_layer + 1, y_layer);
-      const int s_1_1 = brisk_V58<DIRECT>(tl, x_layer, y_layer);
-      const int s_0_1 = brisk_V58<DIRECT>(tl, x_layer - 1, y_layer);
-      const int s_0_2 = brisk_V58<DIRECT>(tl, x_layer - 1, y_layer + 1);
-      const int s_1_2 = brisk_V58<DIRECT>(tl, x_layer, y_layer + 1);
-      const int s_2_2 = brisk_V58<DIRECT>(tl, x_layer + 1, y_layer + 1);
-      int mb = s_0_0;
-      mb = brisk_max(mb, s_1_0); mb = brisk_max(mb, s_2_0); mb = brisk_max(mb, s_2_1); mb = brisk_max(mb, s_1_1);
-      mb = brisk_max(mb, s_0_1); mb = brisk_max(mb, s_0_2); mb = brisk_max(mb, s_1_2); mb = brisk_max(mb, s_2_2);
-      brisk_subpixel2d(s_0_0, s_0_1, s_0_2, s_1_0, s_1_1, s_1_2, s_2_0, s_2_1, s_2_2, delta_x_below, delta_y_below);
-      max_below_float = (float)mb;
-    } else {
-      max_below_float = brisk_score_max_other<DIRECT>(Lbelow, false, false, x_layer, y_layer, center, ismax,
-                                              delta_x_below, delta_y_below, &none);
-      if (!ismax) return false;
-    }
-    *e5 = true;
-    float delta_x_layer, delta_y_layer;
-    int s_1_1;
-    const float max_layer = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x_layer, delta_y_layer, &s_1_1);
-    if (layer == 0) {
-      if (s_1_1 - BRISK_MAX_THRESHOLD <= (int)max_above) doScaleRefinement = false;
-    } else {
-      if ((s_1_1 - BRISK_MAX_THRESHOLD < (max_above)) || (s_1_1 - BRISK_MAX_THRESHOLD < (max_below_float))) {
-        if ((s_1_1 - BRISK_MIN_DROP > (max_above)) || (s_1_1 - BRISK_MIN_DROP > (max_below_float))) {
-          doScaleRefinement = false;
-        } else {
-          return false;
-        }
-      }
-    }
-    const float s0 = ((float)center < max_layer) ? max_layer : (float)center;  // std::max(float(center), max_layer)
-    if (doScaleRefinement) {
-      if (layer == 0) scale = brisk_refine1d_2(max_below_float, s0, max_above, max);
-      else scale = brisk_refine1d(max_below_float, s0, max_above, max);
-    } else {
-      scale = 1.0f;
-      max = max_layer;
-    }
-    if (scale > 1.0) {
-      const float r0 = (float)((1.5 - scale) / .5);
-      const float r1 = (float)(1.0 - r0);
-      x = (r0 * delta_x_layer + r1 * delta_x_above + (float)x_layer) * lscale + loffset;
-      y = (r0 * delta_y_layer + r1 * delta_y_above + (float)y_layer) * lscale + loffset;
-    } else {
-      if (layer == 0) {
-        const float r0 = (float)((scale - 0.5) / 0.5);
-        const float r_1 = (float)(1.0 - r0);
-        x = r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer;
-        y = r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer;
-      } else {
-        const float r0 = (float)((scale - 0.75) / 0.25);
-        const float r_1 = (float)(1.0 - r0);
-        x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer) * lscale + loffset;
-        y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer) * lscale + loffset;
-      }
-    }
+  float dn_peak, dn_dx, dn_dy;
+  if (cls == 0) {  // (:558-592) the layer below octave 0 does not exist: 5_8 scores of the 3 x 3 block around the point
+    int q[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q[i] = brisk_V58<DIRECT>(tl, x_layer + i % 3 - 1, y_layer + i / 3 - 1);
+    int best = q[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) best = brisk_max(best, q[i]);
+    // (brisk_subpixel2d takes the block column by column: s_x_y)
+    brisk_subpixel2d(q[0], q[3], q[6], q[1], q[4], q[7], q[2], q[5], q[8], dn_dx, dn_dy);
+    dn_peak = (float)best;
   } else {
-    float delta_x_below, delta_y_below;
-    const float max_below = brisk_score_max_other<DIRECT>(Lbelow, false, true, x_layer, y_layer, center, ismax,
-                                                  delta_x_below, delta_y_below, &none);
+    dn_peak = brisk_score_max_other<DIRECT>(Lbelow, false, intra, x_layer, y_layer, own_score, ismax, dn_dx, dn_dy, &none);
     if (!ismax) return false;
-    *e5 = true;
-    float delta_x_layer, delta_y_layer;
-    int s_1_1;
-    const float max_layer = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, delta_x_layer, delta_y_layer, &s_1_1);
-    if ((s_1_1 - BRISK_MAX_THRESHOLD < (max_above)) || (s_1_1 - BRISK_MAX_THRESHOLD < (max_below))) {
-      if ((s_1_1 - BRISK_MIN_DROP > (max_above)) || (s_1_1 - BRISK_MIN_DROP > (max_below))) {
-        doScaleRefinement = false;
-      } else {
-        return false;
-      }
-    }
-    const float s0 = ((float)center < max_layer) ? max_layer : (float)center;
-    if (doScaleRefinement) {
-      scale = brisk_refine1d_1(max_below, s0, max_above, max);
-    } else {
-      scale = 1.0f;
-      max = max_layer;
-    }
-    if (scale > 1.0) {
-      const float r0 = (float)(4.0 - scale * 3.0);
-      const float r1 = (float)(1.0 - r0);
-      x = (r0 * delta_x_layer + r1 * delta_x_above + (float)x_layer) * lscale + loffset;
-      y = (r0 * delta_y_layer + r1 * delta_y_above + (float)y_layer) * lscale + loffset;
-    } else {
-      const float r0 = (float)(scale * 3.0 - 2.0);
-      const float r_1 = (float)(1.0 - r0);
-      x = (r0 * delta_x_layer + r_1 * delta_x_below + (float)x_layer) * lscale + loffset;
-      y = (r0 * delta_y_layer + r_1 * delta_y_below + (float)y_layer) * lscale + loffset;
-    }
   }
-  scale *= lscale;
-  kp->x = x;
-  kp->y = y;
-  kp->size = BRISK_BASIC_SIZE * scale;
-  kp->response = max;
+  *e5 = true;
+  float own_dx, own_dy;
+  int patch_centre;
+  const float own_peak = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, own_dx, own_dy, &patch_centre);
+
+  // maximum along the scale axis?  (kMaxThreshold_ = 1, kMinDrop_ = 15; ints against floats, as the reference compares them)
+  const int near_margin = patch_centre - BRISK_MAX_THRESHOLD, far_margin = patch_centre - BRISK_MIN_DROP;
+  bool fit_scale = true;
+  if (cls == 0) {
+    if (near_margin <= (int)up_peak) fit_scale = false;  // (:600-602: octave 0 only looks up, and never rejects)
+  } else if (near_margin < up_peak || near_margin < dn_peak) {
+    if (far_margin > up_peak || far_margin > dn_peak) fit_scale = false;
+    else return false;
+  }
+  const float mid = ((float)own_score < own_peak) ? own_peak : (float)own_score;  // std::max(float(center), max_layer)
+  float rel_scale = 1.0f, response = own_peak;
+  if (fit_scale) {
+    rel_scale = cls == 0 ? brisk_refine1d_2(dn_peak, mid, up_peak, response)
+              : cls == 1 ? brisk_refine1d(dn_peak, mid, up_peak, response)
+                         : brisk_refine1d_1(dn_peak, mid, up_peak, response);
+  }
+  const bool upwards = rel_scale > 1.0;
+  const double wa = upwards ? (intra ? 4.0 : 1.5) : (cls == 0 ? -0.5 : intra ? -2.0 : -0.75);
+  const double wb = upwards ? (intra ? -3.0 : -1.0) : (intra ? 3.0 : 1.0);
+  const double wc = intra ? 1.0 : ((upwards || cls == 0) ? 0.5 : 0.25);
+  const float w_own = (float)((wa + wb * rel_scale) / wc);
+  const float w_nb = (float)(1.0 - w_own);
+  const float nb_dx = upwards ? up_dx : dn_dx, nb_dy = upwards ? up_dy : dn_dy;
+  // (octave 0: scale 1, offset 0 - the reference leaves them out where it interpolates downwards, the same value)
+  kp->x = (w_own * own_dx + w_nb * nb_dx + (float)x_layer) * lscale + loffset;
+  kp->y = (w_own * own_dy + w_nb * nb_dy + (float)y_layer) * lscale + loffset;
+  kp->size = BRISK_BASIC_SIZE * (rel_scale * lscale);
+  kp->response = response;
   return true;
 }
 

@@ -379,7 +379,7 @@ void brisk_launch_uniformity(BriskKeyPoint* kp, BriskFrameCounters* counters, in
 // max_keypoints / (nbu * nbv) points (:48-63).  A point's fate depends only on how many better points share its bucket,
 // so there is no sequential pass: rank by counting, rank inside the bucket by counting, stable compaction.
 // Output order = descending score (equal scores keep the detector's (layer, y, x) order; the reference's std::sort leaves
-// it open).  Like the uniformity filter this is offered as a post-filter of BriskFeatureDetector: parity unpinned.
+// it open) - except for one bucket with no more than max_keypoints points, which the reference leaves untouched.  Like the uniformity filter this is offered as a post-filter of BriskFeatureDetector: parity unpinned.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(UF_THREADS) k_bucketing(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
                                                           int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap,
@@ -395,6 +395,7 @@ __global__ void __launch_bounds__(UF_THREADS) k_bucketing(BriskKeyPoint* __restr
   int* ord = order + (long)frame * kp_cap;  // ord[i]: bit 31 = kept, low bits = output position of keypoint i among the kept
   if (n == 0) return;
   const bool single = (nbu == 1 || nbv == 1);
+  if (single && n <= max_keypoints) return;  // :87-88: one bucket sorts and cuts only when there are too many points - else the vector stays as the detector left it
   const int cap = single ? max_keypoints : max_keypoints / (nbu * nbv);
   const unsigned step_u = 1u + (unsigned)(cols - 1) / (unsigned)nbu, step_v = 1u + (unsigned)(rows - 1) / (unsigned)nbv;
   // pass 1: is keypoint j kept?  (rank among the points of its bucket - of all points with one bucket - below the cap)

@@ -96,10 +96,12 @@ class BriskDescriptorExtractor {
     agast::Mat tmp = agast::Mat::zeros(n > 0 ? n : 1, strings, CV_8UC1);
     brisk_hip_ctx* ctx = hip::DefaultContext();
     brisk_hip_reserve(ctx, 4 * n, n);  // grows the workspace when needed, never shrinks it
+    // (hip::ScopedSameImage: the caller's word that this is the unchanged buffer of the thread's last detect() call)
     hip::Check(ctx,
-               brisk_hip_describe(ctx, pattern_, image.data, image.cols, image.rows, (int)image.step,
-                                  reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), &n, tmp.data, (int)tmp.step,
-                                  rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0),
+               (hip::SameImageHint() ? brisk_hip_describe_same_image : brisk_hip_describe)(
+                   ctx, pattern_, image.data, image.cols, image.rows, (int)image.step,
+                   reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), &n, tmp.data, (int)tmp.step,
+                   rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0),
                "brisk_hip_describe");
     keypoints.resize((size_t)n);
     descriptors = agast::Mat::zeros(n, strings, CV_8UC1);

@@ -95,15 +95,18 @@ class BriskFeatureDetector {
     if (image.empty()) throw std::runtime_error("BriskFeatureDetector: empty image");
     if (image.type() != CV_8UC1) throw std::runtime_error("BriskFeatureDetector: image must be CV_8UC1");
     brisk_hip_ctx* ctx = hip::DefaultContext();  // this thread's workspace
-    hip::Check(ctx, brisk_hip_set_bucketing(ctx, m_bucketsU, m_bucketsV, m_bucketMax), "brisk_hip_set_bucketing");  // (context state: set per call)
+    // the object's post-filter settings travel with the call: the thread's context keeps whatever a user set on it
+    brisk_hip_postfilter pf;
+    pf.uniformity_radius = m_uniformityRadius; pf.uniformity_max_keypoints = m_maxNumKpt;
+    pf.num_buckets_u = m_bucketsU; pf.num_buckets_v = m_bucketsV; pf.bucket_max_keypoints = m_bucketMax;
     size_t cap = 16384;
     for (;;) {
       keypoints.resize(cap);
       int n = 0;
-      const int rc = brisk_hip_detect_uniform(ctx, image.data, image.cols, image.rows, (int)image.step, threshold, octaves,
-                                              m_suppressScaleNonmaxima ? 1 : 0, mask.empty() ? nullptr : mask.data,
-                                              mask.empty() ? 0 : (int)mask.step, m_uniformityRadius, m_maxNumKpt,
-                                              reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), (int)cap, &n);
+      const int rc = brisk_hip_detect_filtered(ctx, image.data, image.cols, image.rows, (int)image.step, threshold, octaves,
+                                               m_suppressScaleNonmaxima ? 1 : 0, mask.empty() ? nullptr : mask.data,
+                                               mask.empty() ? 0 : (int)mask.step, &pf,
+                                               reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), (int)cap, &n);
       if (rc == BRISK_HIP_ERR_CAPACITY && cap < (1u << 22)) {  // output buffer too small: retry larger
         keypoints.clear();
         cap *= 4;

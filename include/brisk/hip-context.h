@@ -21,30 +21,74 @@ inline void Check(brisk_hip_ctx* ctx, int rc, const char* what) {
   throw std::runtime_error(msg);
 }
 
-// One workspace per THREAD (device taken from BRISK_HIP_DEVICE, default 0): the reference's classes are re-entrant
-// (detectImpl is const and builds its state per call, brisk-feature-detector.cc:77-85), so concurrent calls from
-// several threads must not serialise on one workspace or race on its settings.  Every thread that uses the classes
-// gets its own context (stream + lazily sized buffers, ~30 MB per 1080p frame slot), destroyed when the thread ends.
-// Pattern tables (BriskDescriptorExtractor) are plain device memory and are shared by all contexts of the device.
+// One workspace per THREAD: the reference's classes are re-entrant (detectImpl is const and builds its state per call,
+// brisk-feature-detector.cc:77-85), so concurrent calls from several threads must not serialise on one workspace or race
+// on its settings.  Every thread that uses the classes gets its own context (stream + lazily sized buffers, ~30 MB per
+// 1080p frame slot), destroyed when the thread ends.  Pattern tables (BriskDescriptorExtractor) are plain device memory
+// and are shared by all contexts of the device.
+// Device of a thread's context: SetThreadDevice(d) (one host thread per GPU of a node: call it first thing in the
+// thread), else the BRISK_HIP_DEVICE environment variable, else device 0.
+inline int& ThreadDeviceRequest() {
+  static thread_local int dev = -1;
+  return dev;
+}
 struct ThreadContext {
   brisk_hip_ctx* ctx = nullptr;
   int rc = BRISK_HIP_OK;
+  int device = 0;
   ThreadContext() {
     const char* dev = std::getenv("BRISK_HIP_DEVICE");
-    rc = brisk_hip_create(dev ? std::atoi(dev) : 0, &ctx);
+    device = ThreadDeviceRequest() >= 0 ? ThreadDeviceRequest() : (dev ? std::atoi(dev) : 0);
+    rc = brisk_hip_create(device, &ctx);
   }
   ~ThreadContext() {
     if (ctx) brisk_hip_destroy(ctx);
+  }
+  void Recreate(int dev) {
+    if (ctx) brisk_hip_destroy(ctx);
+    ctx = nullptr;
+    device = dev;
+    rc = brisk_hip_create(device, &ctx);
   }
   ThreadContext(const ThreadContext&) = delete;
   ThreadContext& operator=(const ThreadContext&) = delete;
 };
 
-inline brisk_hip_ctx* DefaultContext() {
+inline ThreadContext& ThisThread() {
   static thread_local ThreadContext tc;
+  return tc;
+}
+
+inline brisk_hip_ctx* DefaultContext() {
+  ThreadContext& tc = ThisThread();
   if (tc.rc != BRISK_HIP_OK || !tc.ctx) Check(nullptr, tc.rc ? tc.rc : BRISK_HIP_ERR_NO_DEVICE, "brisk_hip_create");
   return tc.ctx;
 }
+
+// Selects the GPU of the calling thread's context.  Call it before the thread constructs a BriskDescriptorExtractor or
+// uses a detector: extractor objects keep pattern tables on the device of the context they were built with.  A context the
+// thread already has on another device is destroyed (its workspace with it) and re-created.
+inline void SetThreadDevice(int device) {
+  ThreadDeviceRequest() = device;
+  ThreadContext& tc = ThisThread();
+  if (tc.device != device || !tc.ctx) tc.Recreate(device);
+  if (tc.rc != BRISK_HIP_OK || !tc.ctx) Check(nullptr, tc.rc ? tc.rc : BRISK_HIP_ERR_NO_DEVICE, "brisk_hip_create");
+}
+
+// Engine option (per thread, off by default): while set, BriskDescriptorExtractor::compute() tells the engine that its
+// image is the very cv::Mat buffer the thread's last detect() call was given and that the pixels have not changed in
+// between - the usual detect() -> compute() pair (test-binary-equal.cc:215,237) - so the image is not uploaded a second
+// time (brisk_hip_describe_same_image).  Without it compute() always uploads, as the reference always reads the current
+// pixels.
+inline bool& SameImageHint() {
+  static thread_local bool on = false;
+  return on;
+}
+struct ScopedSameImage {
+  bool prev;
+  ScopedSameImage() : prev(SameImageHint()) { SameImageHint() = true; }
+  ~ScopedSameImage() { SameImageHint() = prev; }
+};
 
 }  // namespace hip
 }  // namespace brisk

@@ -49,7 +49,7 @@ typedef struct brisk_hip_pattern brisk_hip_pattern;  /* sampling pattern tables 
 int brisk_hip_create(int device, brisk_hip_ctx** out);
 void brisk_hip_destroy(brisk_hip_ctx* ctx);
 const char* brisk_hip_last_error(const brisk_hip_ctx* ctx);
-/* per-frame capacities: AGAST candidates (default 65536) and keypoints (default 16384) */
+/* per-frame capacities: AGAST candidates (default 65536) and keypoints (default 16384; below 2^23) */
 int brisk_hip_set_capacity(brisk_hip_ctx* ctx, int max_candidates, int max_keypoints);
 int brisk_hip_device_count(void);
 /* raises the capacities to at least these values; never lowers them (no reallocation for smaller requests) */
@@ -85,6 +85,17 @@ int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int s
 int brisk_hip_detect_uniform(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
                              int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, double uniformity_radius,
                              int max_keypoints, brisk_hip_keypoint* out, int cap, int* n);
+/* The same call with BOTH optional post-filters given per call: nothing is read from or written to the context's settings
+ * (brisk_hip_set_uniformity / brisk_hip_set_bucketing), so detector objects with different settings can share a
+ * context.  uniformity_radius 0 = off, else >= 1; bucketing takes effect while uniformity is off, (0, 0) buckets = off. */
+typedef struct brisk_hip_postfilter {
+  double uniformity_radius;
+  int uniformity_max_keypoints;
+  int num_buckets_u, num_buckets_v, bucket_max_keypoints;
+} brisk_hip_postfilter;
+int brisk_hip_detect_filtered(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                              int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride,
+                              const brisk_hip_postfilter* pf, brisk_hip_keypoint* out, int cap, int* n);
 /* BriskFeatureDetector::ComputeScale (brisk-feature-detector.cc:87-92; brisk-scale-space.cc:104-123 and the branches
  * behind it): scores / scales for PROVIDED keypoints on a pyramid with lower threshold 0.  Every provided keypoint yields
  * up to one output per layer that admits it (layer order, provided order inside a layer; class_id is kept).  Sequential
@@ -100,6 +111,18 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
 int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
                        brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
                        int scale_invariant);
+/* The same call for the usual detect() -> compute() pair on one image (test-binary-equal.cc:215,237): the caller STATES
+ * that `img` is the buffer the context's last brisk_hip_detect / _detect_uniform call was given and that its pixels have
+ * not changed since.  The upload and the layer-0 pass are then skipped (the device still holds the image).  If pointer,
+ * size or stride differ from that call's, or another call used the context in between, the image is uploaded as in
+ * brisk_hip_describe.  A caller whose pixels DID change gets the descriptors of the old pixels: brisk_hip_describe never
+ * makes that assumption (it always uploads, as the reference's compute() always reads the current pixels), unless the
+ * environment opts in with BRISK_HIP_IMAGE_CACHE=1 - the buffer is then recognised by pointer, size, stride and a 64-bit
+ * hash over one 8-byte word per 128 bytes of every row, and a change that avoids every sampled word (a small overlay, rows
+ * narrower than 8 + the row's phase) goes unnoticed. */
+int brisk_hip_describe_same_image(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
+                                  brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
+                                  int scale_invariant);
 
 /* ---- device-resident batch path (frames already in HBM; results stay in HBM) ----------------- */
 /* d_frames: nframes images, frame f at d_frames + f*frame_pitch, row pitch row_pitch.  Runs
@@ -157,7 +180,9 @@ int brisk_hip_set_uniformity(brisk_hip_ctx* ctx, double radius, int max_keypoint
  * filter to the detector's keypoints of every following detect call while uniformity is off: keypoints in descending
  * response order; with one bucket in either direction the best max_keypoints are kept, otherwise a keypoint is kept while
  * its bucket of (1 + (cols - 1) / num_buckets_u) x (1 + (rows - 1) / num_buckets_v) pixels holds fewer than
- * max_keypoints / (num_buckets_u * num_buckets_v).  Output in descending response order.  (0, 0, *) switches it off.
+ * max_keypoints / (num_buckets_u * num_buckets_v).  Output in descending response order - except with one bucket in either
+ * direction and no more than max_keypoints keypoints: the reference then leaves the vector untouched (:87-88), and so
+ * does the engine (detector order).  (0, 0, *) switches it off.
  * The reference requires num_buckets_u < cols and num_buckets_v < rows (CHECK_LT, :82-83): checked per call. */
 int brisk_hip_set_bucketing(brisk_hip_ctx* ctx, int num_buckets_u, int num_buckets_v, int max_keypoints);
 
@@ -166,7 +191,8 @@ int brisk_hip_set_bucketing(brisk_hip_ctx* ctx, int num_buckets_u, int num_bucke
  * (w / 3 * 2) x (h / 3 * 2); IntegralImage16 (brisk/include/brisk/internal/integral-image.h:163-218): dst is
  * (h + 1) x (w + 1) floats.  Host buffers, strides in ELEMENTS; the reference's arithmetic bit for bit (saturating adds,
  * signed pack to 32767, float sums in the reference's order incl. its unscaled last 0..3 columns).  Images with fewer
- * than 16 (half) / 12 (two thirds) usable columns, where the reference's loops write nothing: BRISK_HIP_ERR_UNSUPPORTED. */
+ * than 16 (half) / 12 (two thirds) usable columns or without an output row, where the reference's loops write nothing:
+ * BRISK_HIP_OK, dst untouched. */
 int brisk_hip_halfsample16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, uint16_t* dst, int dst_stride);
 int brisk_hip_twothirdsample16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, uint16_t* dst, int dst_stride);
 int brisk_hip_integral_image16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, float* dst, int dst_stride);
@@ -228,8 +254,8 @@ int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, u
 int brisk_hip_debug_set_flags(brisk_hip_ctx* ctx, int flags);
 /* integral image of frame slot `frame` after the last describe: (h+1) x (w+1) u32, tightly packed */
 int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out);
-/* number of brisk_hip_describe calls that found their image still on the device (left there by brisk_hip_detect on the
- * same host buffer: same pointer, size, stride and sampled hash) and skipped the upload and the layer-0 pass */
+/* number of describe calls that reused the image a detect call had left on the device (brisk_hip_describe_same_image, or
+ * brisk_hip_describe under BRISK_HIP_IMAGE_CACHE=1) and skipped the upload and the layer-0 pass */
 int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx);
 /* per-frame work counts of the last batch (tools only): out[0] candidates, out[1] keypoints, out[2] described
  * keypoints, out[3] overflow flags, out[4 + l] tie candidates of layer l, out[20 .. 27] experiment words; out holds 28 ints. */

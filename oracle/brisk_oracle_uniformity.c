@@ -88,6 +88,10 @@ int bo_key_point_bucketing(const bo_keypoint* kps, int n, int rows, int cols, in
                            bo_keypoint* out) {
   if (rows <= 0 || cols <= 0 || nbu <= 0 || nbv <= 0 || nbu >= cols || nbv >= rows || max_keypoints <= 0) return -1;
   if (n <= 0) return 0;
+  if ((nbu == 1 || nbv == 1) && n <= max_keypoints) {  /* :87-88: sorted and cut only when there are too many - else untouched */
+    for (int i = 0; i < n; ++i) out[i] = kps[i];
+    return n;
+  }
   scored* order = (scored*)malloc(sizeof(scored) * (size_t)n);
   for (int i = 0; i < n; ++i) { order[i].score = kps[i].response; order[i].index = i; }
   qsort(order, (size_t)n, sizeof(scored), cmp_scored);

@@ -338,11 +338,13 @@ def test_set_file_round_trip(tmp_path):
 def test_key_point_bucketing_restatement():
     """KeyPointBucketing (key-point-bucketing-inl.h:40-112) as restated in the oracle, against a direct Python reading of
     the reference on random points: descending score order, per-bucket cap max / (nbu * nbv), bucket steps
-    1 + (size - 1) / buckets, the single-bucket branch keeps the best max, the CHECKed argument ranges."""
+    1 + (size - 1) / buckets, the single-bucket branch keeps the best max (and leaves a vector of no more than max points
+    untouched, in detector order), the CHECKed argument ranges."""
     import oracle_lib as O
     rng = np.random.default_rng(7)
     rows, cols = 480, 640
-    for n, mx, nbu, nbv in ((500, 100, 4, 3), (500, 100, 1, 5), (37, 1000, 8, 8), (2000, 64, 8, 8), (300, 7, 2, 2), (10, 3, 1, 1)):
+    for n, mx, nbu, nbv in ((500, 100, 4, 3), (500, 100, 1, 5), (37, 1000, 8, 8), (2000, 64, 8, 8), (300, 7, 2, 2), (10, 3, 1, 1),
+                            (40, 100, 1, 3), (100, 100, 5, 1)):
         k = np.zeros(n, O.KP)
         k["x"] = rng.uniform(0, cols - 0.01, n).astype(np.float32)
         k["y"] = rng.uniform(0, rows - 0.01, n).astype(np.float32)
@@ -350,7 +352,7 @@ def test_key_point_bucketing_restatement():
         got = O.key_point_bucketing(k, rows, cols, mx, nbu, nbv)
         order = sorted(range(n), key=lambda i: (-k["response"][i], i))
         if nbu == 1 or nbv == 1:
-            want = order[:mx]
+            want = order[:mx] if n > mx else list(range(n))   # :87-88: not too many points -> the vector is left untouched
         else:
             cap, su, sv = mx // (nbu * nbv), 1 + (cols - 1) // nbu, 1 + (rows - 1) // nbv
             cnt, want = {}, []

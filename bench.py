@@ -263,6 +263,9 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-fed (host frames) measurement")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL result gather even with one rank (self-test)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "capi"],
+                    help="result gather of the N-GPU batch path: torch.distributed (RCCL through torch) or the engine's own "
+                         "C-ABI communicator (brisk_hip_comm_*: RCCL directly, what a C++ host uses)")
     ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="timing experiments only (results become wrong)")
     ap.add_argument("--pattern-version", type=int, default=2)
     ap.add_argument("--min-region-s", type=float, default=2.0,
@@ -378,7 +381,10 @@ def main():
     if use_dist:
         run_chunk()                          # allocates the engine's result buffers
         torch.cuda.synchronize()
-        gather = ResultGather(ctx, chunk, strings, dev, rank, world, chunk_max)
+        if args.gather == "capi":
+            gather = CapiGather(ctx, chunk, strings, dev, rank, world, chunk_max, ctl, stream)
+        else:
+            gather = ResultGather(ctx, chunk, strings, dev, rank, world, chunk_max)
 
     def step():
         for _ in range(inner):
@@ -511,7 +517,7 @@ def main():
                    "gather_note": None if gather_ms is None else "result gather of one step run alone after the timed region (inside it the transfers overlap the next chunk's kernels)",
                    "stream_slices": args.streams, "frames_per_kernel_launch": fpl, "distinct_frames_per_gpu": nd,
                    "mean_keypoints_per_frame": round(mean_kp, 1),
-                   "parallelism": "frames sharded over %d rank(s)%s" % (world, (", asynchronous RCCL gather of keypoints+descriptors to rank 0 after every chunk (overlaps the next chunk)" if (world > 1 and gather) else "") + gather_note),
+                   "parallelism": "frames sharded over %d rank(s)%s" % (world, ((", asynchronous RCCL gather of keypoints+descriptors to rank 0 after every chunk (overlaps the next chunk; %s)" % ("C-ABI communicator brisk_hip_comm_*" if args.gather == "capi" else "torch.distributed")) if (world > 1 and gather) else "") + gather_note),
                    "algorithmic_MB_per_frame": round(per_frame_bytes / 1e6, 3),
                    "pipeline_achieved_GBps": round(per_frame_bytes * fps / 1e9, 2),
                    "pipeline_frac_of_hbm_peak": round(per_frame_bytes * fps / 1e9 / (HBM_PEAK_GBS * world), 5),
@@ -935,6 +941,61 @@ class ResultGather:
             import torch.distributed as dist
             dist.all_reduce(m, op=dist.ReduceOp.MAX, group=ctl)
         self.kpad = min(self.cap, (int(m.item()) + 127) // 128 * 128)
+
+
+class CapiGather(ResultGather):
+    """The same exchange through the engine's C ABI (include/brisk_hip.h: brisk_hip_comm_*): RCCL directly, no
+    torch.distributed on the data path - torch only provides the destination buffers on rank 0 and, through the gloo
+    control group, carries the 128-byte unique id to the other ranks."""
+
+    def __init__(self, ctx, batch, strings, dev, rank, world, frames_max, ctl, stream):
+        import ctypes as C
+        super().__init__(ctx, batch, strings, dev, rank, world, frames_max)
+        torch = self.torch
+        self.ctx, self.stream, self.C = ctx, stream, C
+        L = ctx._L
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            ctx.check(L.brisk_hip_comm_unique_id(uid))
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor(list(uid), dtype=torch.uint8)
+            dist.broadcast(t, 0, group=ctl)
+            uid = (C.c_uint8 * 128)(*[int(v) for v in t])
+        self.comm = C.c_void_p()
+        ctx.check(L.brisk_hip_comm_create(ctx._h, rank, world, uid, C.byref(self.comm)))
+        self.slots = [None, None]
+        self.i = 0
+
+    def _dst(self):
+        torch = self.torch
+        j = self.i & 1
+        sl = self.slots[j]
+        if self.rank != 0:
+            return None
+        if sl is None or sl["kpad"] != self.kpad:
+            b = self.frames_max
+            sl = self.slots[j] = {"kpad": self.kpad,
+                                  "ac": torch.zeros((self.world, b), device=self.dev, dtype=torch.int32),
+                                  "gk": torch.zeros((self.world, b, self.kpad, 7), device=self.dev, dtype=torch.float32),
+                                  "gd": torch.zeros((self.world, b, self.kpad, self.strings), device=self.dev, dtype=torch.uint8)}
+        return sl
+
+    def run(self):
+        C = self.C
+        sl = self._dst()
+        p = (lambda t: C.c_void_p(t.data_ptr())) if sl else (lambda t: None)
+        self.ctx.check(self.ctx._L.brisk_hip_comm_gather_results(
+            self.ctx._h, self.comm, 0, self.frames_max, self.kpad, self.strings,
+            p(sl["ac"]) if sl else None, p(sl["gk"]) if sl else None, p(sl["gd"]) if sl else None, C.c_void_p(self.stream)))
+        self.cur = sl
+        self.i += 1
+
+    def finish(self):
+        if self.i:
+            self.ctx.check(self.ctx._L.brisk_hip_comm_wait(self.comm, None))
+            sl = getattr(self, "cur", None)
+            self.last = (sl["ac"], sl["gk"], sl["gd"]) if sl else None
 
 
 if __name__ == "__main__":

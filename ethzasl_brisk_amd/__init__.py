@@ -33,6 +33,8 @@ ABI_SYMBOLS = [
     "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
     "brisk_hip_reserve", "brisk_hip_detect_uniform", "brisk_hip_detect_describe_batch_host", "brisk_hip_stream_ceiling",
     "brisk_hip_kernel_revision", "brisk_hip_compute_scale", "brisk_hip_describe_same_image", "brisk_hip_detect_filtered",
+    "brisk_hip_comm_unique_id", "brisk_hip_comm_create", "brisk_hip_comm_destroy", "brisk_hip_comm_rank", "brisk_hip_comm_world",
+    "brisk_hip_comm_gather_results", "brisk_hip_comm_wait", "brisk_hip_debug_filter_keypoints",
 ]
 
 
@@ -116,6 +118,15 @@ def load_library():
                                            C.c_double, C.c_int, vp, C.c_int, ip]
     L.brisk_hip_detect_filtered.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                             C.POINTER(PostFilter), vp, C.c_int, ip]
+    L.brisk_hip_debug_filter_keypoints.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, ip]
+    L.brisk_hip_comm_unique_id.argtypes = [vp]
+    L.brisk_hip_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.brisk_hip_comm_destroy.argtypes = [vp]
+    L.brisk_hip_comm_destroy.restype = None
+    L.brisk_hip_comm_rank.argtypes = [vp]
+    L.brisk_hip_comm_world.argtypes = [vp]
+    L.brisk_hip_comm_gather_results.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.brisk_hip_comm_wait.argtypes = [vp, vp]
     L.brisk_hip_compute_scale.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp,
                                           C.c_int, ip]
     L.brisk_hip_detect_describe_batch_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbrisk_hip.so")
-SOURCES = ["brisk_kernels.hip", "brisk_describe.hip", "brisk_image16.hip", "brisk_match.hip", "brisk_uniformity.hip", "brisk_capi.hip", "brisk_pattern.cpp"]
+SOURCES = ["brisk_kernels.hip", "brisk_describe.hip", "brisk_image16.hip", "brisk_match.hip", "brisk_uniformity.hip", "brisk_comm.hip", "brisk_capi.hip", "brisk_pattern.cpp"]
 # -ffp-contract=off: the reference binary has no FMA contraction (built with -mssse3 only); the
 # sub-pixel / sub-scale float expressions must round after every operation to stay bit-exact.
 # -simplifycfg-sink-common=false: sinking the common tails of the per-layer-class branches of the refinement code
@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
-LINK_LIBS = []
+LINK_LIBS = ["-ldl"]
 
 
 def needs_build():

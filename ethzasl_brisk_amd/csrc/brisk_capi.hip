@@ -156,6 +156,28 @@ static hipError_t wait_own_work(brisk_hip_ctx* c) {
   return c->done_valid ? hipEventSynchronize(c->done_ev) : hipSuccess;
 }
 
+// ---- what brisk_comm.hip needs from a context (not part of the C ABI) -----------------------------------------------
+int brisk_hip_internal_fail(brisk_hip_ctx* ctx, int code, const char* msg) {
+  if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->err = msg; }
+  return code;
+}
+// device pointers / geometry of the last batch's described results (null pointers when no described batch exists)
+int brisk_hip_internal_batch_view(brisk_hip_ctx* ctx, const BriskFrameCounters** counters, const BriskKeyPoint** dkp,
+                                  const uint8_t** desc, int* kp_cap, int* desc_pitch, int* nframes, int* device, hipStream_t* stream) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const bool have = ctx->last_has_desc && ctx->last_nframes > 0;
+  if (counters) *counters = have ? ctx->B.counters : nullptr;
+  if (dkp) *dkp = have ? ctx->D.dkp : nullptr;
+  if (desc) *desc = have ? ctx->D.desc : nullptr;
+  if (kp_cap) *kp_cap = ctx->B.kp_cap;
+  if (desc_pitch) *desc_pitch = ctx->last_desc_pitch ? ctx->last_desc_pitch : ctx->D.desc_pitch;
+  if (nframes) *nframes = ctx->last_nframes;
+  if (device) *device = ctx->device;
+  if (stream) *stream = ctx->stream;
+  return BRISK_HIP_OK;
+}
+
 #define HIPCHK(ctx, call)                                                                       \
   do {                                                                                          \
     hipError_t e_ = (call);                                                                     \
@@ -493,6 +515,36 @@ struct BatchArgs {
   bool inplace_ok = true;  // layer 0 may be read from the frame buffer (not for the host-fed path's recycled staging buffers)
 };
 
+// scratch of the post-filters (uniformity enforcement: occupancy images for the frames beyond the on-chip capacity; both:
+// order / keypoint scratch per slot)
+static int ensure_filter_buffers(brisk_hip_ctx* ctx, int w, int h, int nframes, double uni_radius) {
+  size_t need = 0;
+  if (uni_radius > 0.0) {
+    const float scaling = (float)(15.0 / (float)uni_radius);
+    const int oh = (int)(h * ceil(scaling) + 32), ow = (int)(w * ceil(scaling) + 32);
+    need = (size_t)(((long)oh * ow + 255) / 256 * 256) * nframes + 64;
+  }
+  const size_t items = (size_t)ctx->slots * ctx->kp_cap;
+  if (need > ctx->occ_bytes || items > ctx->uni_items) {
+    HIPCHK(ctx, hipDeviceSynchronize());
+    if (need > ctx->occ_bytes) {
+      if (ctx->d_occ) (void)hipFree(ctx->d_occ);
+      ctx->d_occ = nullptr; ctx->occ_bytes = 0;
+      HIPCHK(ctx, hipMalloc(&ctx->d_occ, need));
+      ctx->occ_bytes = need;
+    }
+    if (items > ctx->uni_items) {
+      if (ctx->d_uni_tmp) (void)hipFree(ctx->d_uni_tmp);
+      if (ctx->d_uni_order) (void)hipFree(ctx->d_uni_order);
+      ctx->d_uni_tmp = nullptr; ctx->d_uni_order = nullptr; ctx->uni_items = 0;
+      HIPCHK(ctx, hipMalloc(&ctx->d_uni_tmp, items * sizeof(BriskKeyPoint)));
+      HIPCHK(ctx, hipMalloc(&ctx->d_uni_order, items * sizeof(int)));
+      ctx->uni_items = items;
+    }
+  }
+  return BRISK_HIP_OK;
+}
+
 // geometry, workspace, restoring the all-zero score-state map, profiler bookkeeping: once per batch, on stream s
 static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipStream_t s) {
   int rc = check_detect_args(ctx, A.w, A.h, A.threshold, A.octaves);
@@ -507,30 +559,8 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   if (rc) return rc;
   const bool bucketing = A.do_detect && !(A.uni_radius > 0.0) && A.bk_u > 0;
   if ((A.do_detect && A.uni_radius > 0.0) || bucketing) {
-    size_t need = 0;
-    if (!bucketing) {
-      const float scaling = (float)(15.0 / (float)A.uni_radius);
-      const int oh = (int)(A.h * ceil(scaling) + 32), ow = (int)(A.w * ceil(scaling) + 32);
-      need = (size_t)(((long)oh * ow + 255) / 256 * 256) * nframes + 64;
-    }
-    const size_t items = (size_t)ctx->slots * ctx->kp_cap;
-    if (need > ctx->occ_bytes || items > ctx->uni_items) {
-      HIPCHK(ctx, hipDeviceSynchronize());
-      if (need > ctx->occ_bytes) {
-        if (ctx->d_occ) (void)hipFree(ctx->d_occ);
-        ctx->d_occ = nullptr; ctx->occ_bytes = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_occ, need));
-        ctx->occ_bytes = need;
-      }
-      if (items > ctx->uni_items) {
-        if (ctx->d_uni_tmp) (void)hipFree(ctx->d_uni_tmp);
-        if (ctx->d_uni_order) (void)hipFree(ctx->d_uni_order);
-        ctx->d_uni_tmp = nullptr; ctx->d_uni_order = nullptr; ctx->uni_items = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_uni_tmp, items * sizeof(BriskKeyPoint)));
-        HIPCHK(ctx, hipMalloc(&ctx->d_uni_order, items * sizeof(int)));
-        ctx->uni_items = items;
-      }
-    }
+    rc = ensure_filter_buffers(ctx, A.w, A.h, nframes, bucketing ? 0.0 : A.uni_radius);
+    if (rc) return rc;
   }
   if (bucketing && (A.bk_u >= A.w || A.bk_v >= A.h))
     return fail(ctx, BRISK_HIP_ERR_ARG, "bucketing: more buckets than pixels (key-point-bucketing-inl.h:82-83)");
@@ -1460,6 +1490,41 @@ int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, u
 }
 
 int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx) { return ctx ? ctx->img_cache.hits : 0; }
+
+// the uniformity filter alone on a given keypoint list (parity tests of the filter kernels on lists no detector produces)
+int brisk_hip_debug_filter_keypoints(brisk_hip_ctx* ctx, const brisk_hip_keypoint* in, int n_in, int rows, int cols, double radius,
+                                     int max_keypoints, brisk_hip_keypoint* out, int* n) {
+  if (!ctx || !in || !out || !n || n_in < 0 || rows <= 0 || cols <= 0 || rows > 8191 || cols > 8191 || radius < 1.0 || max_keypoints < 1)
+    return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n_in > ctx->kp_cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "more keypoints than the configured capacity");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  make_geometry(cols, rows, 20, 0, &ctx->G, &ctx->T);
+  int rc = ensure_buffers(ctx, 1, ctx->G);
+  if (rc) return rc;
+  rc = ensure_filter_buffers(ctx, cols, rows, 1, radius);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  if (workspace_acquire(ctx, s)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
+  WorkspaceGuard guard(ctx, s);
+  ctx->img_cache.valid = false;
+  BriskFrameCounters c0;
+  memset(&c0, 0, sizeof(c0));
+  c0.nkp = n_in;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->B.counters, &c0, sizeof(c0), hipMemcpyHostToDevice, s));
+  if (n_in) HIPCHK(ctx, hipMemcpyAsync(ctx->B.kp_out, in, sizeof(BriskKeyPoint) * (size_t)n_in, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));  // (c0 lives on this stack frame)
+  const float scaling = (float)(15.0 / (float)radius);
+  const int oh = (int)(rows * ceil(scaling) + 32), ow = (int)(cols * ceil(scaling) + 32);
+  const long occ_frame = ((long)oh * ow + 255) / 256 * 256;
+  brisk_launch_uniformity(ctx->B.kp_out, ctx->B.counters, ctx->d_uni_order, ctx->d_uni_tmp, ctx->d_occ, occ_frame, ow, ctx->B.kp_cap, scaling,
+                          max_keypoints, 1, s);
+  HIPCHK(ctx, hipGetLastError());
+  ctx->last_nframes = 1;
+  ctx->last_has_desc = false;
+  if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
+  return download_locked(ctx, 0, 0, out, n_in, n, nullptr, 0, 0);
+}
 
 int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out) {
   if (!ctx || !out) return BRISK_HIP_ERR_ARG;

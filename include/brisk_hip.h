@@ -166,6 +166,36 @@ int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags)
  * caller's stream with events, so the call stays asynchronous and ordered on that stream. */
 int brisk_hip_set_streams(brisk_hip_ctx* ctx, int n);
 
+/* ---- multi-GPU: result gather of the batch path (BASELINE config 3) --------------------------------------
+ * Frames are independent units (brisk-feature-detector.cc:77-85 builds all state per call): one process or host thread
+ * per GPU, each with its own context, runs brisk_hip_detect_describe_batch on its shard of the frame stream - there is no
+ * collective inside detect + describe.  The only exchange is this gather of the results to one rank, on RCCL directly
+ * (grouped ncclSend / ncclRecv over xGMI; librccl is opened at run time, BRISK_HIP_ERR_UNSUPPORTED where it is missing).
+ *   rank 0:      brisk_hip_comm_unique_id(id); pass the 128 bytes to the other ranks (file, socket, MPI, ...)
+ *   every rank:  brisk_hip_comm_create(ctx, rank, world, id, &comm)         (collective: all ranks call it)
+ *   per batch:   brisk_hip_detect_describe_batch(ctx, ...); brisk_hip_comm_gather_results(ctx, comm, root, ...)
+ *   root:        brisk_hip_comm_wait(comm, stream or NULL) before reading the destination buffers
+ * The gather is asynchronous and double-buffered: the rank's rows are packed into a slab on the batch's stream, the
+ * transfer runs on the communicator's own stream beside the next batch's kernels. */
+#define BRISK_HIP_COMM_ID_BYTES 128
+typedef struct brisk_hip_comm brisk_hip_comm;
+int brisk_hip_comm_unique_id(uint8_t* id /* BRISK_HIP_COMM_ID_BYTES */);
+int brisk_hip_comm_create(brisk_hip_ctx* ctx, int rank, int world, const uint8_t* id, brisk_hip_comm** out);
+void brisk_hip_comm_destroy(brisk_hip_comm* comm);
+int brisk_hip_comm_rank(const brisk_hip_comm* comm);
+int brisk_hip_comm_world(const brisk_hip_comm* comm);
+/* Collective over the communicator: every rank contributes the DESCRIBED results of its context's last batch as fixed
+ * slabs - per-frame counts [frames_max] (0 for the frames beyond its own batch), keypoints [frames_max][kpad] and
+ * descriptors [frames_max][kpad][strings] (the first kpad rows of every frame; strings = descriptor bytes) - and `root`
+ * receives them, rank after rank, in d_counts [world][frames_max], d_kps [world][frames_max][kpad],
+ * d_desc [world][frames_max][kpad][strings] (device memory of the root's GPU; ignored on the other ranks).  frames_max,
+ * kpad and strings must be the same on every rank; a frame with more than kpad keypoints is cut (its count is not: the
+ * root can tell).  stream: the stream the batch ran on (NULL = the context's stream). */
+int brisk_hip_comm_gather_results(brisk_hip_ctx* ctx, brisk_hip_comm* comm, int root, int frames_max, int kpad, int strings,
+                                  int* d_counts, brisk_hip_keypoint* d_kps, uint8_t* d_desc, void* stream);
+/* orders `stream` behind every gather issued so far on this rank (NULL: blocks the host until they are done) */
+int brisk_hip_comm_wait(brisk_hip_comm* comm, void* stream);
+
 /* ---- optional post-filter: keypoint uniformity enforcement (BASELINE config 4) ---- */
 /* EnforceKeyPointUniformity (brisk/include/brisk/internal/uniformity-enforcement-inl.h:44-194, mask LUT
  * scale-space-layer-inl.h:88-97) applied to the detector's keypoints (x, y, response) in every following detect call
@@ -257,6 +287,10 @@ int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out);
 /* number of describe calls that reused the image a detect call had left on the device (brisk_hip_describe_same_image, or
  * brisk_hip_describe under BRISK_HIP_IMAGE_CACHE=1) and skipped the upload and the layer-0 pass */
 int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx);
+/* the uniformity filter of brisk_hip_set_uniformity alone, on a GIVEN keypoint list of a rows x cols image (tests of the
+ * filter kernels on lists no detector produces: tight clusters, the smallest radii); out holds n_in keypoints */
+int brisk_hip_debug_filter_keypoints(brisk_hip_ctx* ctx, const brisk_hip_keypoint* in, int n_in, int rows, int cols, double radius,
+                                     int max_keypoints, brisk_hip_keypoint* out, int* n);
 /* per-frame work counts of the last batch (tools only): out[0] candidates, out[1] keypoints, out[2] described
  * keypoints, out[3] overflow flags, out[4 + l] tie candidates of layer l, out[20 .. 27] experiment words; out holds 28 ints. */
 int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlayers);

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "test_binary_equal")
 
 
-def build_binary(name="test_binary_equal"):
+def build_binary(name="test_binary_equal", hip_runtime=False, defines=(), extra_flags=()):
     from ethzasl_brisk_amd import build
     build.build()
     src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
@@ -17,9 +17,12 @@ def build_binary(name="test_binary_equal"):
     hdrs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs]
     hdrs.append(os.path.join(ROOT, "tests", "cpp", "set_serialization.h"))
     if not os.path.exists(out) or any(os.path.getmtime(p) > os.path.getmtime(out) for p in [src] + hdrs):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", out,
-                               src, "-L" + os.path.join(ROOT, "ethzasl_brisk_amd"), "-lbrisk_hip",
-                               "-Wl,-rpath," + os.path.join(ROOT, "ethzasl_brisk_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+        # hip_runtime: the test itself allocates device memory (plain g++ against the HIP runtime's C API)
+        hip = ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lamdhip64"] if hip_runtime else []
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include")] +
+                              ["-D" + d for d in defines] + list(extra_flags) + ["-o", out, src,
+                               "-L" + os.path.join(ROOT, "ethzasl_brisk_amd"), "-lbrisk_hip"] + hip +
+                              ["-Wl,-rpath," + os.path.join(ROOT, "ethzasl_brisk_amd"), "-Wl,-rpath,/opt/rocm/lib"])
     return out
 
 
@@ -39,6 +42,26 @@ def test_reference_golden_through_cpp_classes():
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "Verification success" in r.stdout
     assert r.stdout.count("OK") == 5
+
+
+def test_gather_test_compiles_and_fails_loudly_without_gpu():
+    """tests/cpp/test_gather.cc: the C++ side of the multi-GPU batch path (brisk_hip_comm_* on RCCL, no torch)"""
+    import ethzasl_brisk_amd as B
+    b = build_binary("test_gather", hip_runtime=True)
+    if B.load_library().brisk_hip_device_count() > 0:
+        pytest.skip("GPU present")
+    r = subprocess.run([b], capture_output=True, text=True)
+    assert r.returncode == 2 and "brisk_hip_create failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_result_gather_through_the_c_abi_world_1():
+    """three host-fed batches, gathered with brisk_hip_comm_gather_results on a one-rank RCCL communicator (both send
+    slabs in use), every row compared with brisk_hip_batch_download"""
+    b = build_binary("test_gather", hip_runtime=True)
+    r = subprocess.run([b], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "gather OK" in r.stdout
 
 
 def test_thread_test_compiles():

@@ -613,8 +613,10 @@ def _other_configs(device, only="", seconds=0.4):
         return not only or only == name
 
     def entry(workload, per_s, unit, alg_bytes, units_per_call, stage_ms, extra=None):
+        # alg_bytes: SURVEY 8(d) bytes per unit (frame or descriptor); algorithmic_MB: per call
         gb = alg_bytes * per_s / 1e9
-        e = {"workload": workload, "value": round(per_s, 1), "unit": unit, "algorithmic_MB": round(alg_bytes / 1e6, 3),
+        e = {"workload": workload, "value": round(per_s, 1), "unit": unit, "algorithmic_MB": round(alg_bytes * units_per_call / 1e6, 3),
+             "algorithmic_MB_per": "call of %d %s" % (units_per_call, unit.split("/")[0]),
              "achieved_GBps": round(gb, 1), "frac": round(gb / HBM_PEAK_GBS, 5),
              "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0}, "units_per_call": units_per_call}
         if extra:

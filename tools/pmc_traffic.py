@@ -48,7 +48,8 @@ def main():
                 "k_score_blocks": "nms", "k_classify_refine": "nms", "k_classify_refine_direct": "nms", "k_tie_resolve": "nms",
                 "k_finalize": "nms", "k_finalize_large": "nms", "k_smap_clear": "nms", "k_order_candidates": "nms",
                 "k_ordered_keypoints": "nms", "k_nms": "nms", "k_integral_final": "integral", "k_desc_prepare": "describe",
-                "k_describe": "describe"}
+                "k_describe": "describe", "k_dp_count": "describe", "k_dp_scan": "describe", "k_dp_scatter": "describe",
+                "k_uf_rank": "nms", "k_uf_decide": "nms", "k_uniformity_seq": "nms", "k_bucketing": "nms"}
     groups = {}
     for k, v in out["kernels"].items():
         g = group_of.get(k)
@@ -56,7 +57,8 @@ def main():
             groups[g] = groups.get(g, 0.0) + v["hbm_bytes_per_launch"]
     out["groups"] = groups
     out["kernel_revision"] = sys.argv[7] if len(sys.argv) > 7 else None
-    out["hbm_bytes_per_launch"] = out["kernels"]["k_detect"]["hbm_bytes_per_launch"]
+    out["hbm_bytes_per_launch"] = out["kernels"].get("k_detect", {}).get("hbm_bytes_per_launch")  # (descriptor-only runs have no detector)
+    out["hbm_bytes_all_kernels_per_launch"] = sum(v["hbm_bytes_per_launch"] for v in out["kernels"].values())
     txt = json.dumps(out, indent=1)
     if len(sys.argv) > 6:
         open(sys.argv[6], "w").write(txt + "\n")

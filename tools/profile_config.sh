@@ -26,6 +26,11 @@ w.writerows(keep)
 PY
       rm -rf $out/pmc_${c}_$m
     done
+    # HBM bytes per launch and kernel (FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_traffic.py); frames per launch: 64 for the batches, 1 otherwise
+    case $c in 4|4_uniform|dense30|dense50) fpl=64; geo="3840 2160";; *) fpl=1; geo="1920 1080";; esac
+    case $c in dense30|dense50) geo="1920 1080";; 4_uniform_single) geo="3840 2160";; 1) geo="640 480";; esac
+    rev=$(python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import ethzasl_brisk_amd as B; print(B.load_library().brisk_hip_kernel_revision().decode())" 2>/dev/null)
+    python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $out/config${c}_pmc_fetch.csv $out/config${c}_pmc_write.csv $fpl $geo $out/config${c}_traffic.json $rev > /dev/null
   fi
   rm -rf $out/ks_$c
 done

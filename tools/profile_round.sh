@@ -11,10 +11,10 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/bench.py > $out/bench.json 2> $out/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --steps 2 --warmup 1 --inner 8 > $out/ks.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --no-other-configs --steps 2 --warmup 1 --inner 8 > $out/ks.log 2>&1
 cp $(find $out/ks -name "*kernel_stats.csv" | head -1) $out/kernel_stats_b256.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c -d $out/pmc_$c -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --batch 64 --inner 2 --steps 2 --warmup 1 > $out/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c -d $out/pmc_$c -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --no-other-configs --batch 64 --inner 2 --steps 2 --warmup 1 > $out/pmc_$c.log 2>&1
 done
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)

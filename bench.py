@@ -301,7 +301,7 @@ def main():
 
     # the CPU baseline workers are forked before torch / HIP exist in this process (rank 0, N=1 only)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry and not args.config:
         cpu = CpuBaseline()
 
     import numpy as np

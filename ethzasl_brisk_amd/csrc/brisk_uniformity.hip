@@ -157,68 +157,80 @@ __device__ __forceinline__ int uf_contribution(int dx, int dy, float nsc) {
 #define UR_THREADS 256
 #define UF_TILE 1024
 #define UF_HASH 8192
+#define UF_NB 6   // neighbours a point keeps in registers (k_uf_decide)
 struct UfSorted { int cx, cy; float nsc; };  // (scratch in the first 12 bytes of tmp[rank])
 
+// UR_POINTS points per workgroup, one per lane; the UR_THREADS / 64 waves split the comparison range between them (wave w
+// takes tiles w, w + 4, ... of 1024 scores, staged in its own LDS region: no workgroup barrier in the loop), the partial
+// ranks are added up in LDS.  A single 4K frame (4 745 points): 75 workgroups, ~2 tiles per wave.
+#define UR_POINTS 64
 __global__ void __launch_bounds__(UR_THREADS) k_uf_rank(const BriskKeyPoint* __restrict__ kp, const BriskFrameCounters* __restrict__ counters,
                                                         int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap, float scaling) {
-  __shared__ __attribute__((aligned(16))) float tile[UF_TILE];
+  __shared__ __attribute__((aligned(16))) float tile[UR_THREADS / 64][UF_TILE];
+  __shared__ int srank[UR_POINTS];
   __shared__ float wmax[UR_THREADS / 64];
-  const int frame = blockIdx.y, tid = threadIdx.x;
+  const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = min(counters[frame].nkp, kp_cap);
-  const int j0 = blockIdx.x * UR_THREADS;
+  const int j0 = blockIdx.x * UR_POINTS;
   if (n == 0 || n > UF_LDS_POINTS || j0 >= n) return;
   const BriskKeyPoint* K = kp + (long)frame * kp_cap;
-  const int j = j0 + tid;
+  const int j = j0 + lane;
   BriskKeyPoint me;
   me.x = me.y = 0.f; me.response = 0.f;
   if (j < n) me = K[j];
   const float mine = me.response;
   const int own = j0 / UF_TILE * UF_TILE;  // the tile that holds this workgroup's own points
+  if (tid < UR_POINTS) srank[tid] = 0;
+  __syncthreads();
   int rank = 0;
   float mx = 0.f;
-  for (int t0 = 0; t0 < n; t0 += UF_TILE) {
-    __syncthreads();
+  float* tl = tile[wave];
+  for (int t0 = wave * UF_TILE; t0 < n; t0 += (UR_THREADS / 64) * UF_TILE) {
 #pragma unroll
-    for (int k = 0; k < UF_TILE / UR_THREADS; ++k) {
-      const int q = t0 + k * UR_THREADS + tid;
+    for (int k = 0; k < UF_TILE / 64; ++k) {
+      const int q = t0 + k * 64 + lane;
       const float v = q < n ? K[q].response : -3.0e38f;  // (never counted)
-      tile[k * UR_THREADS + tid] = v;
+      tl[k * 64 + lane] = v;
       mx = fmaxf(mx, v);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // equal scores: the smaller input index first - all of an earlier tile's equals count, none of a later tile's
     if (t0 < own) {
       for (int q = 0; q < UF_TILE; q += 4) {
-        const float4 s = *reinterpret_cast<const float4*>(&tile[q]);
+        const float4 s = *reinterpret_cast<const float4*>(&tl[q]);
         rank += (s.x >= mine ? 1 : 0) + (s.y >= mine ? 1 : 0) + (s.z >= mine ? 1 : 0) + (s.w >= mine ? 1 : 0);
       }
     } else if (t0 > own) {
       for (int q = 0; q < UF_TILE; q += 4) {
-        const float4 s = *reinterpret_cast<const float4*>(&tile[q]);
+        const float4 s = *reinterpret_cast<const float4*>(&tl[q]);
         rank += (s.x > mine ? 1 : 0) + (s.y > mine ? 1 : 0) + (s.z > mine ? 1 : 0) + (s.w > mine ? 1 : 0);
       }
     } else {
       for (int q = 0; q < UF_TILE; ++q) {
-        const float sq = tile[q];
+        const float sq = tl[q];
         rank += (sq > mine || (sq == mine && t0 + q < j)) ? 1 : 0;
       }
     }
+    __builtin_amdgcn_wave_barrier();  // (the tile is overwritten by the wave's next one)
   }
-  // the best score of the frame (every workgroup has seen all of them)
+  if (rank) atomicAdd(&srank[lane], rank);
+  // the best score of the frame (the workgroup's waves have seen all of them between them)
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-  if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+  if (lane == 0) wmax[wave] = mx;
   __syncthreads();
+  if (wave != 0 || j >= n) return;
   float maxScore = wmax[0];
 #pragma unroll
   for (int k = 1; k < UR_THREADS / 64; ++k) maxScore = fmaxf(maxScore, wmax[k]);
-  if (j < n) {
-    order[(long)frame * kp_cap + rank] = j;
-    UfSorted rec;
-    rec.cy = (int)(me.y * scaling + 16);
-    rec.cx = (int)(me.x * scaling + 16);
-    rec.nsc = sqrtf(sqrtf(mine / maxScore)) * 255.0f;
-    *reinterpret_cast<UfSorted*>(tmp + (long)frame * kp_cap + rank) = rec;
-  }
+  rank = srank[lane];
+  order[(long)frame * kp_cap + rank] = j;
+  UfSorted rec;
+  rec.cy = (int)(me.y * scaling + 16);
+  rec.cx = (int)(me.x * scaling + 16);
+  rec.nsc = sqrtf(sqrtf(mine / maxScore)) * 255.0f;
+  *reinterpret_cast<UfSorted*>(tmp + (long)frame * kp_cap + rank) = rec;
 }
 
 __device__ __forceinline__ unsigned uf_hash(int bx, int by) {
@@ -242,6 +254,12 @@ __global__ void __launch_bounds__(UF_THREADS) k_uf_decide(BriskKeyPoint* __restr
   BriskKeyPoint* K = kp + (long)frame * kp_cap;
   BriskKeyPoint* T = tmp + (long)frame * kp_cap;
   const int* ord = order + (long)frame * kp_cap;
+#ifdef UF_TIMING
+  const long long t_start = (long long)wall_clock64();
+#define UF_T(i) if (tid == 0) counters[frame].pad[i] = (int)((long long)wall_clock64() - t_start);
+#else
+#define UF_T(i)
+#endif
   for (int b = tid; b < UF_HASH; b += UF_THREADS) hcur[b] = 0;
   if (tid == 0) giveup_s = 0;
   __syncthreads();
@@ -278,33 +296,78 @@ __global__ void __launch_bounds__(UF_THREADS) k_uf_decide(BriskKeyPoint* __restr
     blist[atomicAdd(&hcur[uf_hash(c.x >> 4, c.y >> 4)], 1)] = (unsigned short)r;
   }
   __syncthreads();
+  // the bucket cursors are done with: their LDS now holds the normalised scores (a neighbour's contribution is read in
+  // the decision loop, where a global load per accepted neighbour cost microseconds)
+  float* pnsc = reinterpret_cast<float*>(hcur);
+  static_assert(UF_HASH >= UF_LDS_POINTS, "the scores alias the bucket cursors");
+  for (int r = tid; r < n; r += UF_THREADS) pnsc[r] = reinterpret_cast<const UfSorted*>(T + r)->nsc;
+  __syncthreads();
+  UF_T(0)
   // decisions: rank r on thread r % UF_THREADS, in increasing order
   for (int r0 = 0; r0 < n; r0 += UF_THREADS) {
     const int r = r0 + tid;
     bool done = r >= n;
     int2 c = make_int2(0, 0);
     float mynsc = 0.f;
-    if (!done) { c = pcell[r]; mynsc = reinterpret_cast<const UfSorted*>(T + r)->nsc; }
+    if (!done) { c = pcell[r]; mynsc = pnsc[r]; }
     const int bx = c.x >> 4, by = c.y >> 4;
+    // The better points within reach, found ONCE (the bins do not change): rank and what the point adds if accepted, in
+    // registers.  The polling loop below then costs a few LDS reads per pass instead of a walk over nine buckets - the
+    // passes are what a chain of dependent decisions multiplies (186 -> 30 us for the 4 012 points of a 4K frame).  A point
+    // with more than UF_NB such neighbours (tight clusters) walks the buckets on every pass as before.
+    int nq[UF_NB], nc[UF_NB];
+#pragma unroll
+    for (int i = 0; i < UF_NB; ++i) { nq[i] = 0; nc[i] = 0; }
+    int cnt = 0;
+    if (!done) {
+      for (int k = 0; k < 9; ++k) {
+        const int nbx = bx + k % 3 - 1, nby = by + k / 3 - 1;
+        const unsigned b = uf_hash(nbx, nby);
+        const int e1 = hstart[b + 1];
+        for (int e = hstart[b]; e < e1; ++e) {
+          const int q = blist[e];
+          if (q >= r) continue;  // only better points count
+          const int2 cq = pcell[q];
+          if ((cq.x >> 4) != nbx || (cq.y >> 4) != nby) continue;  // another bin in the same bucket (it has its own turn)
+          const int dx = c.x - cq.x, dy = c.y - cq.y;
+          if (dx < -15 || dx > 15 || dy < -15 || dy > 15) continue;
+          const int contrib = uf_contribution(dx, dy, pnsc[q]);
+#pragma unroll
+          for (int i = 0; i < UF_NB; ++i)
+            if (cnt == i) { nq[i] = q; nc[i] = contrib; }
+          ++cnt;
+        }
+      }
+    }
+    const bool listed = cnt <= UF_NB;
     int spins = 0;
     while (__any(!done)) {
       if (!done) {
         bool pending = false;
         int sum = 0;
-        for (int k = 0; k < 9 && !pending; ++k) {
-          const int nbx = bx + k % 3 - 1, nby = by + k / 3 - 1;
-          const unsigned b = uf_hash(nbx, nby);
-          const int e1 = hstart[b + 1];
-          for (int e = hstart[b]; e < e1; ++e) {
-            const int q = blist[e];
-            if (q >= r) continue;  // only better points count
-            const int2 cq = pcell[q];
-            if ((cq.x >> 4) != nbx || (cq.y >> 4) != nby) continue;  // another bin in the same bucket (it has its own turn)
-            const int dx = c.x - cq.x, dy = c.y - cq.y;
-            if (dx < -15 || dx > 15 || dy < -15 || dy > 15) continue;
-            const unsigned d = dec[q];
-            if (d == 0) { pending = true; break; }
-            if (d == 1) sum += uf_contribution(dx, dy, reinterpret_cast<const UfSorted*>(T + q)->nsc);
+        if (listed) {
+#pragma unroll
+          for (int i = 0; i < UF_NB; ++i) {
+            const unsigned d = (i < cnt) ? (unsigned)dec[nq[i]] : 2u;
+            pending = pending || d == 0;
+            sum += (d == 1) ? nc[i] : 0;
+          }
+        } else {
+          for (int k = 0; k < 9 && !pending; ++k) {
+            const int nbx = bx + k % 3 - 1, nby = by + k / 3 - 1;
+            const unsigned b = uf_hash(nbx, nby);
+            const int e1 = hstart[b + 1];
+            for (int e = hstart[b]; e < e1; ++e) {
+              const int q = blist[e];
+              if (q >= r) continue;
+              const int2 cq = pcell[q];
+              if ((cq.x >> 4) != nbx || (cq.y >> 4) != nby) continue;
+              const int dx = c.x - cq.x, dy = c.y - cq.y;
+              if (dx < -15 || dx > 15 || dy < -15 || dy > 15) continue;
+              const unsigned d = dec[q];
+              if (d == 0) { pending = true; break; }
+              if (d == 1) sum += uf_contribution(dx, dy, pnsc[q]);
+            }
           }
         }
         if (!pending) {
@@ -321,6 +384,7 @@ __global__ void __launch_bounds__(UF_THREADS) k_uf_decide(BriskKeyPoint* __restr
     }
   }
   __syncthreads();
+  UF_T(1)
   if (tid == 0 && giveup_s) atomicOr(&counters[frame].overflow, 8);
   // the accepted points in score order, at most max_keypoints of them.  T[] held the sorted cells and scores until here.
   int run = 0;
@@ -348,9 +412,11 @@ __global__ void __launch_bounds__(UF_THREADS) k_uf_decide(BriskKeyPoint* __restr
   if (tid == 0) kept_s = min(run, max_keypoints);
   __threadfence();
   __syncthreads();
+  UF_T(2)
   const int kept = kept_s;
   for (int i = tid; i < kept; i += UF_THREADS) K[i] = T[i];
   if (tid == 0) counters[frame].nkp = kept;
+  UF_T(3)
 }
 
 static size_t uf_decide_lds() {
@@ -361,7 +427,7 @@ void brisk_launch_uniformity(BriskKeyPoint* kp, BriskFrameCounters* counters, in
                              long occ_frame, int ow, int kp_cap, float scaling, int max_keypoints, int nframes, hipStream_t s) {
   if (nframes <= 0) return;
   const int cap = kp_cap < UF_LDS_POINTS ? kp_cap : UF_LDS_POINTS;
-  hipLaunchKernelGGL(k_uf_rank, dim3((cap + UR_THREADS - 1) / UR_THREADS, nframes), dim3(UR_THREADS), 0, s, kp, counters, order, tmp,
+  hipLaunchKernelGGL(k_uf_rank, dim3((cap + UR_POINTS - 1) / UR_POINTS, nframes), dim3(UR_THREADS), 0, s, kp, counters, order, tmp,
                      kp_cap, scaling);
   (void)hipFuncSetAttribute((const void*)k_uf_decide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)uf_decide_lds());
   hipLaunchKernelGGL(k_uf_decide, dim3(nframes), dim3(UF_THREADS), uf_decide_lds(), s, kp, counters, order, tmp, kp_cap, max_keypoints);

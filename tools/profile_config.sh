@@ -9,12 +9,12 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do
-  python3 $GRAFT_REPO_ROOT/bench.py --config $c > $out/config$c.json 2> $out/config$c.err
-  timeout 600 rocprofv3 --kernel-trace --stats -d $out/ks_$c -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --config $c --config-seconds 0.2 > $out/ks_$c.log 2>&1
+  python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config $c > $out/config$c.json 2> $out/config$c.err
+  timeout 240 rocprofv3 --kernel-trace --stats -d $out/ks_$c -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config $c --config-seconds 0.2 > $out/ks_$c.log 2>&1
   cp $(find $out/ks_$c -name "*kernel_stats.csv" | head -1) $out/config${c}_kernel_stats.csv
   if [ -z "$NO_PMC" ]; then
     for m in FETCH_SIZE WRITE_SIZE; do
-      timeout 600 rocprofv3 --pmc $m -d $out/pmc_${c}_$m -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --config $c --config-seconds 0.05 > $out/pmc_${c}_$m.log 2>&1
+      timeout 240 rocprofv3 --pmc $m -d $out/pmc_${c}_$m -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config $c --config-seconds 0.05 > $out/pmc_${c}_$m.log 2>&1
       f=$(find $out/pmc_${c}_$m -name "*counter_collection.csv" | head -1)
       python3 - "$f" "$out/config${c}_pmc_$(echo $m | tr A-Z a-z | sed s/_size//).csv" <<'PY'
 import csv, sys

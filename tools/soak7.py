@@ -93,7 +93,14 @@ def main():
                     bad += 1
                     print("ERROR 16-bit", name, img.shape, repr(e)[:200], flush=True)
                     continue
-                if want is None or got.shape != want.shape or got.tobytes() != want.tobytes():
+                if want is None:  # the reference's loops write nothing at this shape: the engine returns OK and leaves dst untouched
+                    if got.any():
+                        bad += 1
+                        print("MISMATCH 16-bit", name, img.shape, "written although the reference writes nothing", flush=True)
+                    else:
+                        refused += 1
+                    continue
+                if got.shape != want.shape or got.tobytes() != want.tobytes():
                     bad += 1
                     print("MISMATCH 16-bit", name, img.shape, "oracle refuses" if want is None else "", flush=True)
         ext = B.BriskDescriptorExtractor(context=ctx)

@@ -307,6 +307,13 @@ static int ensure_stage(brisk_hip_ctx* c, size_t bytes) {
   return BRISK_HIP_OK;
 }
 
+// host image -> device staging (rows at `pitch`): one linear copy when neither side has row padding (a pitched copy is
+// issued row by row: 1080 short rows take several times as long as 2 MB in one piece, profiles/r04_microbench_copy.json)
+static hipError_t upload_rows(uint8_t* dst, int pitch, const uint8_t* src, int stride, int w, int h, hipStream_t s) {
+  if (pitch == w && stride == w) return hipMemcpyAsync(dst, src, (size_t)w * h, hipMemcpyHostToDevice, s);
+  return hipMemcpy2DAsync(dst, pitch, src, stride, w, h, hipMemcpyHostToDevice, s);
+}
+
 static int check_detect_args(brisk_hip_ctx* ctx, int w, int h, int threshold, int octaves) {
   if (w <= 0 || h <= 0 || w > 8191 || h > 8191) return fail(ctx, BRISK_HIP_ERR_ARG, "image size must be in [1, 8191]");
   if (octaves < 0 || 2 * octaves > BRISK_MAX_LAYERS) return fail(ctx, BRISK_HIP_ERR_ARG, "octaves must be in [0, 8]");
@@ -941,11 +948,10 @@ static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int
   const int pitch = brisk_align_up(w, 64);
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   WorkspaceGuard guard(ctx, ctx->stream);  // (run_batch records the event again at its own end: harmless)
-  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, upload_rows(ctx->d_stage, pitch, img, stride, w, h, ctx->stream));
   const uint8_t* d_mask = nullptr;
   if (mask) {
-    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage + img_bytes, pitch, mask, mask_stride, w, h, hipMemcpyHostToDevice,
-                                 ctx->stream));
+    HIPCHK(ctx, upload_rows(ctx->d_stage + img_bytes, pitch, mask, mask_stride, w, h, ctx->stream));
     d_mask = ctx->d_stage + img_bytes;
   }
   rc = run_batch(ctx, nullptr, ctx->d_stage, 1, w, h, (long)img_bytes, pitch, threshold, octaves, d_mask, (long)img_bytes,
@@ -1005,7 +1011,7 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
   if (workspace_acquire(ctx, ctx->stream)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   WorkspaceGuard guard(ctx, ctx->stream);
   ctx->img_cache.valid = false;
-  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, upload_rows(ctx->d_stage, pitch, img, stride, w, h, ctx->stream));
   if (n_in == 0) {
     // an empty list makes GetKeypoints detect (brisk-scale-space.cc:104): plain detection on the pyramid ComputeScale
     // builds (lowerThreshold_ = 0, brisk-feature-detector.cc:90), without the mask filter
@@ -1059,7 +1065,7 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
                      (same_image || (image_hash_reuse_enabled() && ctx->img_cache.hash == image_sample_hash(img, w, h, stride)));
   ctx->img_cache.valid = reuse;  // an uploaded image overwrites the staging buffer (and is not remembered itself)
   if (reuse) ctx->img_cache.hits++;
-  if (!reuse) HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, pitch, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  if (!reuse) HIPCHK(ctx, upload_rows(ctx->d_stage, pitch, img, stride, w, h, ctx->stream));
   const int n_in = *n;
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, &n_in, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   if (n_in) HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in, kps, sizeof(BriskKeyPoint) * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
@@ -1091,7 +1097,7 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
   // the download is then one linear copy
   BriskDescribeBuffers Dd = ctx->D;
   if (desc_stride == pat->host.strings && pat->host.strings % 8 == 0 && pat->host.strings <= ctx->D.desc_pitch) Dd.desc_pitch = pat->host.strings;
-  brisk_launch_describe(ctx->G, P, Bd, Dd, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, &ctx->prof);
+  brisk_launch_describe(ctx->G, P, Bd, Dd, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, &ctx->prof, nullptr, n_in);
   if (ctx->prof.on) ctx->prof.calls++;
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;

@@ -706,14 +706,16 @@ typedef void (*ds_kernel_t)(BriskGeom, BriskPatternDev, const uint8_t*, const ui
 
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
-                           long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov) {
+                           long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov, int n_in_max) {
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
   if (!ov && !((G.debug_flags & (1 << 19)) && (G.debug_flags & (1 << 27))))  // (bits 19 + 27: brisk_capi.hip, timing experiments)
     brisk_launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap, Dd.dp_work, Dd.dp_work_stride);
-  if (B.kp_cap > DP_SMALL_N) {  // frames with more keypoints than the one-workgroup kernel takes (the others exit at once)
+  // frames with more keypoints than the one-workgroup kernel takes (the others exit at once; a host call knows its
+  // count - n_in_max - and does not launch them for nothing: three launches are 15 us of a single frame's latency)
+  if (B.kp_cap > DP_SMALL_N && (n_in_max < 0 || n_in_max > DP_SMALL_N)) {
     DpTiles T;
     T.w = G.L[0].w; T.h = G.L[0].h; T.shift = 6;
     while ((((T.w - 1) >> T.shift) + 1) * (((T.h - 1) >> T.shift) + 1) > DP_MAXBUCKETS) ++T.shift;

@@ -95,7 +95,8 @@ void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_
 // kp_in: [slots][kp_cap]; n_in: per-frame counts at byte stride n_in_stride
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
-                           long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov = nullptr);
+                           long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov = nullptr,
+                           int n_in_max = -1 /* largest per-frame count if the host knows it, else -1 */);
 
 // streaming probe (brisk_hip_stream_ceiling): mode 0 copies `bytes` from a to b with 16-byte loads/stores, mode 1 only reads a
 void brisk_launch_stream_probe(const void* a, void* b, size_t bytes, int mode, hipStream_t s);

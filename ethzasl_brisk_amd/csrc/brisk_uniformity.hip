@@ -447,85 +447,128 @@ void brisk_launch_uniformity(BriskKeyPoint* kp, BriskFrameCounters* counters, in
 // Output order = descending score (equal scores keep the detector's (layer, y, x) order; the reference's std::sort leaves
 // it open) - except for one bucket with no more than max_keypoints points, which the reference leaves untouched.  Like the uniformity filter this is offered as a post-filter of BriskFeatureDetector: parity unpinned.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(UF_THREADS) k_bucketing(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
-                                                          int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap,
-                                                          int rows, int cols, int nbu, int nbv, int max_keypoints) {
-  __shared__ float tile[UF_THREADS];
-  __shared__ int btile[UF_THREADS];
+// Three kernels (round 4; round 3 did both counting passes in ONE workgroup per frame: n^2 / 1024 steps per thread, twice -
+// about 2 ms for the 4 600 keypoints of a 4K frame).  k_bk_count<0>: 64 points per workgroup, the comparison range split
+// over its four waves (as in k_uf_rank): better points in the same bucket -> kept flag.  k_bk_count<1>: better KEPT points
+// -> output position, the keypoint goes to tmp[position].  k_bk_finish: one workgroup per frame copies the kept
+// keypoints back and sets the count.
+#define BK_POINTS 64
+struct BkBuckets { int nbu, nbv, cap, single; unsigned step_u, step_v; };
+__device__ __forceinline__ int bk_bucket(const BkBuckets& b, float x, float y) {
+  return b.single ? 0 : (int)((unsigned)(int)x / b.step_u) * b.nbv + (int)((unsigned)(int)y / b.step_v);
+}
+// bucket of every point, once (the divisions by the run-time bucket steps are ~40 instructions each): order[j] = bucket
+__global__ void __launch_bounds__(256) k_bk_keys(const BriskKeyPoint* __restrict__ kp, const BriskFrameCounters* __restrict__ counters,
+                                                 int* __restrict__ order, int kp_cap, BkBuckets B, int max_keypoints) {
+  const int frame = blockIdx.y;
+  const int n = min(counters[frame].nkp, kp_cap);
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || (B.single && n <= max_keypoints)) return;
+  const BriskKeyPoint p = kp[(long)frame * kp_cap + j];
+  order[(long)frame * kp_cap + j] = bk_bucket(B, p.x, p.y);
+}
+// MODE 0: key = bucket of a point (order[q], bits 0-30), result = kept flag in bit 31 of order[j]; MODE 1: key = kept flag,
+// result = tmp[position]
+template <int MODE>
+__global__ void __launch_bounds__(UR_THREADS) k_bk_count(const BriskKeyPoint* __restrict__ kp, const BriskFrameCounters* __restrict__ counters,
+                                                         int* __restrict__ order, BriskKeyPoint* __restrict__ tmp, int kp_cap, BkBuckets B,
+                                                         int max_keypoints) {
+  __shared__ __attribute__((aligned(16))) float tsc[UR_THREADS / 64][UF_TILE];
+  __shared__ __attribute__((aligned(16))) int tkey[UR_THREADS / 64][UF_TILE];
+  __shared__ int scount[BK_POINTS];
+  const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = min(counters[frame].nkp, kp_cap);
+  const int j0 = blockIdx.x * BK_POINTS;
+  if (j0 >= n || (B.single && n <= max_keypoints)) return;  // (:87-88: one bucket sorts and cuts only when there are too many points)
+  const BriskKeyPoint* K = kp + (long)frame * kp_cap;
+  int* ord = order + (long)frame * kp_cap;
+  const int j = j0 + lane;
+  BriskKeyPoint me;
+  me.x = me.y = 0.f; me.response = 0.f;
+  if (j < n) me = K[j];
+  const float mine = me.response;
+  // (MODE 1: only kept points need a position; the flags were written by the launch before this one)
+  const int mykey = MODE == 0 ? (j < n ? (ord[j] & 0x7FFFFFFF) : -2) : 1;
+  const bool active = j < n && (MODE == 0 || ord[j] < 0);
+  const int own = j0 / UF_TILE * UF_TILE;
+  if (tid < BK_POINTS) scount[tid] = 0;
+  __syncthreads();
+  int cnt = 0;
+  float* ts = tsc[wave];
+  int* tk = tkey[wave];
+  for (int t0 = wave * UF_TILE; t0 < n; t0 += (UR_THREADS / 64) * UF_TILE) {
+#pragma unroll
+    for (int k = 0; k < UF_TILE / 64; ++k) {
+      const int q = t0 + k * 64 + lane;
+      float v = -3.0e38f;
+      int key = -1;  // (matches no bucket and no kept flag)
+      if (q < n) {
+        v = K[q].response;
+        // (MODE 0: other workgroups set bit 31 of these words meanwhile - the bucket is in the bits below)
+        const int o = __hip_atomic_load(&ord[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        key = MODE == 0 ? (o & 0x7FFFFFFF) : (o < 0 ? 1 : 0);
+      }
+      ts[k * 64 + lane] = v;
+      tk[k * 64 + lane] = key;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (active) {
+      // (four scores and four keys per LDS read: one element per iteration is bound by the latency of its two reads)
+      if (t0 < own) {
+#pragma unroll 2
+        for (int q = 0; q < UF_TILE; q += 4) {
+          const float4 sv = *reinterpret_cast<const float4*>(&ts[q]);
+          const int4 kv = *reinterpret_cast<const int4*>(&tk[q]);
+          cnt += ((kv.x == mykey && sv.x >= mine) ? 1 : 0) + ((kv.y == mykey && sv.y >= mine) ? 1 : 0) +
+                 ((kv.z == mykey && sv.z >= mine) ? 1 : 0) + ((kv.w == mykey && sv.w >= mine) ? 1 : 0);
+        }
+      } else if (t0 > own) {
+#pragma unroll 2
+        for (int q = 0; q < UF_TILE; q += 4) {
+          const float4 sv = *reinterpret_cast<const float4*>(&ts[q]);
+          const int4 kv = *reinterpret_cast<const int4*>(&tk[q]);
+          cnt += ((kv.x == mykey && sv.x > mine) ? 1 : 0) + ((kv.y == mykey && sv.y > mine) ? 1 : 0) +
+                 ((kv.z == mykey && sv.z > mine) ? 1 : 0) + ((kv.w == mykey && sv.w > mine) ? 1 : 0);
+        }
+      } else {
+        for (int q = 0; q < UF_TILE; ++q) cnt += (tk[q] == mykey && (ts[q] > mine || (ts[q] == mine && t0 + q < j))) ? 1 : 0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (cnt) atomicAdd(&scount[lane], cnt);
+  __syncthreads();
+  if (wave != 0 || !active) return;
+  cnt = scount[lane];
+  if (MODE == 0) { if (cnt < B.cap) __hip_atomic_fetch_or(&ord[j], (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  else tmp[(long)frame * kp_cap + cnt] = me;
+}
+
+__global__ void __launch_bounds__(UF_THREADS) k_bk_finish(BriskKeyPoint* __restrict__ kp, BriskFrameCounters* __restrict__ counters,
+                                                          const int* __restrict__ order, const BriskKeyPoint* __restrict__ tmp, int kp_cap,
+                                                          int single, int max_keypoints) {
   __shared__ int wsum[UF_THREADS / 64];
   __shared__ int kept_s;
   const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = min(counters[frame].nkp, kp_cap);
-  BriskKeyPoint* K = kp + (long)frame * kp_cap;
-  BriskKeyPoint* T = tmp + (long)frame * kp_cap;
-  int* ord = order + (long)frame * kp_cap;  // ord[i]: bit 31 = kept, low bits = output position of keypoint i among the kept
-  if (n == 0) return;
-  const bool single = (nbu == 1 || nbv == 1);
-  if (single && n <= max_keypoints) return;  // :87-88: one bucket sorts and cuts only when there are too many points - else the vector stays as the detector left it
-  const int cap = single ? max_keypoints : max_keypoints / (nbu * nbv);
-  const unsigned step_u = 1u + (unsigned)(cols - 1) / (unsigned)nbu, step_v = 1u + (unsigned)(rows - 1) / (unsigned)nbv;
-  // pass 1: is keypoint j kept?  (rank among the points of its bucket - of all points with one bucket - below the cap)
-  for (int j0 = 0; j0 < n; j0 += UF_THREADS) {
-    const int j = j0 + tid;
-    float mine = 0.f;
-    int mybucket = -1;
-    if (j < n) {
-      mine = K[j].response;
-      mybucket = single ? 0 : (int)((unsigned)(int)K[j].x / step_u) * nbv + (int)((unsigned)(int)K[j].y / step_v);
-    }
-    int better = 0;
-    for (int t0 = 0; t0 < n; t0 += UF_THREADS) {
-      __syncthreads();
-      if (t0 + tid < n) {
-        tile[tid] = K[t0 + tid].response;
-        btile[tid] = single ? 0 : (int)((unsigned)(int)K[t0 + tid].x / step_u) * nbv + (int)((unsigned)(int)K[t0 + tid].y / step_v);
-      }
-      __syncthreads();
-      const int m = min(UF_THREADS, n - t0);
-      if (j < n)
-        for (int q = 0; q < m; ++q) {
-          const float s = tile[q];
-          better += (btile[q] == mybucket && (s > mine || (s == mine && t0 + q < j))) ? 1 : 0;
-        }
-    }
-    if (j < n) ord[j] = (better < cap) ? (int)0x80000000 : 0;
-  }
-  __threadfence();
+  if (n == 0 || (single && n <= max_keypoints)) return;
+  const int* ord = order + (long)frame * kp_cap;
+  int kept = 0;
+  for (int j = tid; j < n; j += UF_THREADS) kept += ord[j] < 0 ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+  if (lane == 0) wsum[wave] = kept;
   __syncthreads();
-  // pass 2: output position of a kept keypoint = kept keypoints with a better score
-  for (int j0 = 0; j0 < n; j0 += UF_THREADS) {
-    const int j = j0 + tid;
-    const float mine = (j < n) ? K[j].response : 0.f;
-    const bool kept = (j < n) && (__hip_atomic_load(&ord[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0);
-    int pos = 0;
-    for (int t0 = 0; t0 < n; t0 += UF_THREADS) {
-      __syncthreads();
-      if (t0 + tid < n) {
-        tile[tid] = K[t0 + tid].response;
-        btile[tid] = __hip_atomic_load(&ord[t0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0 ? 1 : 0;
-      }
-      __syncthreads();
-      const int m = min(UF_THREADS, n - t0);
-      if (kept)
-        for (int q = 0; q < m; ++q) {
-          const float s = tile[q];
-          pos += (btile[q] && (s > mine || (s == mine && t0 + q < j))) ? 1 : 0;
-        }
-    }
-    if (kept) T[pos] = K[j];
-    const unsigned long long bal = __ballot(kept);
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    if (tid == 0) {
-      int t = (j0 == 0) ? 0 : kept_s;
-      for (int q = 0; q < UF_THREADS / 64; ++q) t += wsum[q];
-      kept_s = t;
-    }
-    __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int q = 0; q < UF_THREADS / 64; ++q) t += wsum[q];
+    kept_s = t;
   }
-  __threadfence();
   __syncthreads();
   const int nkept = kept_s;
+  BriskKeyPoint* K = kp + (long)frame * kp_cap;
+  const BriskKeyPoint* T = tmp + (long)frame * kp_cap;
   for (int i = tid; i < nkept; i += UF_THREADS) K[i] = T[i];
   if (tid == 0) counters[frame].nkp = nkept;
 }
@@ -533,6 +576,15 @@ __global__ void __launch_bounds__(UF_THREADS) k_bucketing(BriskKeyPoint* __restr
 void brisk_launch_bucketing(BriskKeyPoint* kp, BriskFrameCounters* counters, int* order, BriskKeyPoint* tmp, int kp_cap, int rows,
                             int cols, int nbu, int nbv, int max_keypoints, int nframes, hipStream_t s) {
   if (nframes <= 0) return;
-  hipLaunchKernelGGL(k_bucketing, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, kp_cap, rows, cols, nbu, nbv,
-                     max_keypoints);
+  BkBuckets B;
+  B.nbu = nbu; B.nbv = nbv;
+  B.single = (nbu == 1 || nbv == 1) ? 1 : 0;
+  B.cap = B.single ? max_keypoints : max_keypoints / (nbu * nbv);
+  B.step_u = 1u + (unsigned)(cols - 1) / (unsigned)nbu;
+  B.step_v = 1u + (unsigned)(rows - 1) / (unsigned)nbv;
+  const dim3 grid((kp_cap + BK_POINTS - 1) / BK_POINTS, nframes);
+  hipLaunchKernelGGL(k_bk_keys, dim3((kp_cap + 255) / 256, nframes), dim3(256), 0, s, kp, counters, order, kp_cap, B, max_keypoints);
+  hipLaunchKernelGGL(k_bk_count<0>, grid, dim3(UR_THREADS), 0, s, kp, counters, order, tmp, kp_cap, B, max_keypoints);
+  hipLaunchKernelGGL(k_bk_count<1>, grid, dim3(UR_THREADS), 0, s, kp, counters, order, tmp, kp_cap, B, max_keypoints);
+  hipLaunchKernelGGL(k_bk_finish, dim3(nframes), dim3(UF_THREADS), 0, s, kp, counters, order, tmp, kp_cap, B.single, max_keypoints);
 }

@@ -77,6 +77,8 @@ struct brisk_hip_ctx {
   BriskKeyPoint* d_uni_tmp = nullptr;
   int* d_uni_order = nullptr;
   size_t uni_items = 0;
+  void* d_img16[3] = {nullptr, nullptr, nullptr};  // scratch of the 16-bit image functions (source, destination, row sums): grown, never shrunk
+  size_t img16_bytes[3] = {0, 0, 0};
   void* d_match = nullptr;  // workspace of brisk_hip_match_knn_device
   size_t match_bytes = 0;
   // Calls share one workspace but may be issued on different streams: every call that uses the workspace first makes
@@ -354,6 +356,7 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
   free_buffers(c);
   hipFree(c->d_stage);
   if (c->d_match) hipFree(c->d_match);
+  for (int i = 0; i < 3; ++i) if (c->d_img16[i]) hipFree(c->d_img16[i]);
   if (c->done_ev) hipEventDestroy(c->done_ev);
   for (int i = 0; i < 2; ++i) {
     if (c->d_hstage[i]) hipFree(c->d_hstage[i]);
@@ -1334,28 +1337,28 @@ static int image16_call(brisk_hip_ctx* ctx, int which, const uint16_t* src, int 
   }
   if (dst_stride < dw) return fail(ctx, BRISK_HIP_ERR_ARG, "destination stride too small");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  uint16_t* d_src = nullptr;
-  void* d_dst = nullptr;
-  float* d_tmp = nullptr;
   hipStream_t s = ctx->stream;
-  int rc = BRISK_HIP_OK;
-  auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == BRISK_HIP_OK) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); rc = BRISK_HIP_ERR_HIP; } };
-  chk(hipMalloc(&d_src, (size_t)w * h * 2), "hipMalloc");
-  chk(hipMalloc(&d_dst, (size_t)dw * dh * delem), "hipMalloc");
-  if (which == 2) chk(hipMalloc(&d_tmp, (size_t)w * h * 4), "hipMalloc");
-  if (rc == BRISK_HIP_OK) {
-    chk(hipMemcpy2DAsync(d_src, (size_t)w * 2, src, (size_t)src_stride * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, s), "hipMemcpy2DAsync");
-    if (which == 0) brisk_launch_halfsample16(d_src, w, w, h, (uint16_t*)d_dst, dw, s);
-    else if (which == 1) brisk_launch_twothirdsample16(d_src, w, w, h, (uint16_t*)d_dst, dw, s);
-    else brisk_launch_integral16(d_src, w, w, h, d_tmp, (float*)d_dst, dw, s);
-    chk(hipGetLastError(), "launch");
-    chk(hipMemcpy2DAsync(dst, (size_t)dst_stride * delem, d_dst, (size_t)dw * delem, (size_t)dw * delem, dh, hipMemcpyDeviceToHost, s), "hipMemcpy2DAsync");
-    chk(hipStreamSynchronize(s), "hipStreamSynchronize");
+  // scratch kept by the context (the functions may be called per frame): grown when a call needs more, never shrunk
+  const size_t need[3] = {(size_t)w * h * 2, (size_t)dw * dh * delem, which == 2 ? (size_t)w * h * 4 : 0};
+  for (int i = 0; i < 3; ++i) {
+    if (need[i] <= ctx->img16_bytes[i]) continue;
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (ctx->d_img16[i]) (void)hipFree(ctx->d_img16[i]);
+    ctx->d_img16[i] = nullptr; ctx->img16_bytes[i] = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_img16[i], need[i]));
+    ctx->img16_bytes[i] = need[i];
   }
-  if (d_src) (void)hipFree(d_src);
-  if (d_dst) (void)hipFree(d_dst);
-  if (d_tmp) (void)hipFree(d_tmp);
-  return rc;
+  uint16_t* d_src = static_cast<uint16_t*>(ctx->d_img16[0]);
+  void* d_dst = ctx->d_img16[1];
+  float* d_tmp = static_cast<float*>(ctx->d_img16[2]);
+  HIPCHK(ctx, hipMemcpy2DAsync(d_src, (size_t)w * 2, src, (size_t)src_stride * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, s));
+  if (which == 0) brisk_launch_halfsample16(d_src, w, w, h, (uint16_t*)d_dst, dw, s);
+  else if (which == 1) brisk_launch_twothirdsample16(d_src, w, w, h, (uint16_t*)d_dst, dw, s);
+  else brisk_launch_integral16(d_src, w, w, h, d_tmp, (float*)d_dst, dw, s);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpy2DAsync(dst, (size_t)dst_stride * delem, d_dst, (size_t)dw * delem, (size_t)dw * delem, dh, hipMemcpyDeviceToHost, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  return BRISK_HIP_OK;
 }
 int brisk_hip_halfsample16(brisk_hip_ctx* ctx, const uint16_t* src, int w, int h, int src_stride, uint16_t* dst, int dst_stride) {
   return image16_call(ctx, 0, src, w, h, src_stride, dst, dst_stride);

@@ -1559,7 +1559,8 @@ int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlaye
   out[0] = c.ncand; out[1] = c.nkp; out[2] = c.ndesc; out[3] = c.overflow;
   *nlayers = ctx->G.nlayers;
   for (int l = 0; l < ctx->G.nlayers; ++l) out[4 + l] = c.ntie[l];
-  for (int i = 0; i < 4; ++i) out[20 + i] = c.pad[i];
+  for (int i = 0; i < 3; ++i) out[20 + i] = c.pad[i];
+  out[23] = c.low_score;
   out[25] = c.nestimate;
   out[26] = c.orient_ticket; out[27] = c.desc_ticket;
   return BRISK_HIP_OK;

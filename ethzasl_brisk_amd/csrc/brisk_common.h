@@ -20,8 +20,9 @@
 #endif
 
 #define BRISK_MAX_LAYERS 16
-// AGAST thresholds below this run the ordered path (k_ordered_keypoints): a detection may then store a score <= 2,
-// which the reference's lazy cache treats as "not cached" (brisk-layer.cc:118-132)
+// Below this AGAST threshold a detection may store a score <= 2, which the reference's lazy cache treats as "not cached"
+// (brisk-layer.cc:118-132): a FRAME in which k_detect stores such a score runs the ordered path (k_ordered_keypoints); all
+// other frames - thresholds 10 ... 19 on ordinary images: all of them - stay on the fast path (BriskFrameCounters::low_score)
 #define BRISK_FAST_PATH_MIN_THRESHOLD 20
 #define BRISK_STRIDE_ALIGN 64
 
@@ -108,7 +109,8 @@ struct BriskFrameCounters {
   int orient_ticket, desc_ticket;   // k_describe (stage 0 / 1): next run of keypoints (in processing order) to be handed out
   int nestimate;                    // kept keypoints that came without an angle (k_describe stage 0 skips frames that have none)
   int tie_sorted;                   // k_tie_resolve: bit l = layer l's tie list has been rewritten in raster order (layers beyond the on-chip capacity)
-  int pad[4];
+  int low_score;                    // k_detect stored a detection score <= 2 (possible below threshold 20 only): the frame takes the ordered path
+  int pad[3];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)

@@ -587,6 +587,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       const int D = tt;
       // the score-state map is all zero between batches (k_smap_clear): only detections are written
       smap[base + (long)gyy * stride + gx] = (uint16_t)D;
+      if (D <= 2) counters[frame].low_score = 1;  // (thresholds below 20 only) the lazy cache would not treat this as cached: ordered path for the frame
       const int ci = atomicAdd(&counters[frame].ncand, 1);
       if (ci < cand_cap) {
         BriskCand cnd;
@@ -661,6 +662,7 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
   int frame, bx;
   if (!xcd_frame_block(nframes, bpf, &frame, &bx)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (counters[frame].low_score) return;  // (the frame runs the ordered path)
   const int n = min(counters[frame].ncand, cand_cap);
   const uint8_t* fimg = pyr + (long)frame * G.pyr_elems;
   const uint8_t* img0 = G.l0_ext ? G.l0_ext + (long)frame * G.l0_pitch : nullptr;  // layer 0 read in place
@@ -782,6 +784,7 @@ __global__ void __launch_bounds__(64) k_classify_refine(BriskGeom G, uint8_t* py
                                                          int cand_cap, int tie_cap, int nframes, int bpf) {
   int frame, bx;
   if (!xcd_frame_block(nframes, bpf, &frame, &bx)) return;
+  if (counters[frame].low_score) return;  // (the frame runs the ordered path)
   const int n = min(counters[frame].ncand, cand_cap);
   for (int mine = bx * blockDim.x + threadIdx.x; mine < n; mine += bpf * blockDim.x) {
     BriskCand* c = &cand[(long)frame * cand_cap + mine];
@@ -855,7 +858,7 @@ __global__ void __launch_bounds__(64) k_classify_refine_direct(BriskGeom G, uint
                                                                 BriskFrameCounters* counters, int* tie_idx, int cand_cap,
                                                                 int tie_cap) {
   const int frame = blockIdx.y;
-  if (counters[frame].nredo == 0) return;
+  if (counters[frame].nredo == 0 || counters[frame].low_score) return;
   const int n = min(counters[frame].ncand, cand_cap);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     BriskCand* c = &cand[(long)frame * cand_cap + i];
@@ -908,8 +911,9 @@ __global__ void __launch_bounds__(64) k_classify_refine_direct(BriskGeom G, uint
 #define OC_THREADS 256
 __global__ void __launch_bounds__(OC_THREADS) k_order_candidates(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
                                                                  unsigned* order_scratch, int* row_scratch, long row_scratch_stride,
-                                                                 int cand_cap) {
+                                                                 int cand_cap, int only_flagged) {
   const int frame = blockIdx.x, tid = threadIdx.x;
+  if (only_flagged && !counters[frame].low_score) return;  // (thresholds below 20: only the frames that need the ordered path)
   const int n = min(counters[frame].ncand, cand_cap);
   const BriskCand* C = cand + (long)frame * cand_cap;
   unsigned* order = order_scratch + (long)frame * cand_cap * 2;  // [0, n): candidate indices in key order
@@ -960,9 +964,10 @@ __global__ void __launch_bounds__(OC_THREADS) k_order_candidates(BriskGeom G, co
 __global__ void __launch_bounds__(64) k_ordered_keypoints(BriskGeom G, uint8_t* pyr, uint16_t* smap, const BriskCand* cand,
                                                            BriskFrameCounters* counters, const unsigned* order_scratch,
                                                            BriskKeyPoint* kp_out, int cand_cap, int kp_cap, const uint8_t* mask,
-                                                           long mask_pitch_frame, int mask_row_pitch, int no_scale_nms) {
+                                                           long mask_pitch_frame, int mask_row_pitch, int no_scale_nms, int only_flagged) {
   if (threadIdx.x != 0) return;
   const int frame = blockIdx.x;
+  if (only_flagged && !counters[frame].low_score) return;
   const int n = min(counters[frame].ncand, cand_cap);
   counters[frame].full_clear = 1;  // the cache is written wherever a score was asked for: the next batch clears the whole map
   if (counters[frame].overflow & 1) return;
@@ -1163,6 +1168,10 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   __syncthreads();
   const int frame = ticket_s / ngroups, l0 = (ticket_s % ngroups) * lpw, l1 = min(l0 + lpw, nl);
   if (frame >= nframes) return;
+  if (counters[frame].low_score) {  // the frame runs the ordered path: nothing to resolve, nobody waits for this ticket
+    if (!persist) return;
+    continue;
+  }
   const BriskCand* C = cand + (long)frame * cand_cap;
   // a frame whose candidate or tie list overflowed is reported as an error and its result discarded; its map holds
   // tie candidates that are in no list, which nobody would ever decide: do not wait for them
@@ -1534,6 +1543,7 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
   __shared__ __attribute__((aligned(16))) unsigned skey[FN_SMALL + 4];
   __shared__ unsigned sidx[FN_SMALL];
   const int frame = blockIdx.x, tid = threadIdx.x;
+  if (counters[frame].low_score) return;  // (the frame runs the ordered path, which writes its keypoints itself)
   const int n = min(counters[frame].ncand, cand_cap);
   const BriskCand* C = cand + (long)frame * cand_cap;
   unsigned* keys = keys_scratch + (long)frame * cand_cap * 2;  // [key][cand index] (k_finalize_large reads them)
@@ -1942,14 +1952,23 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                      B.cand_cap);
   if (ov && fork_at == 2) fork_integral();
   brisk_prof_mark(prof, BRISK_STG_CLASSIFY, s);
-  if (G.threshold < BRISK_FAST_PATH_MIN_THRESHOLD || G.no_scale_nms || G.lower_threshold != BRISK_LOWER_THRESHOLD) {  // ordered path: the sequential algorithm on its literal cache
+  // Ordered path (the sequential algorithm on its literal cache): always for the multi-layer no-scale-NMS branch and for
+  // ComputeScale's pyramid; below threshold 20 only for the frames in which k_detect stored a score <= 2
+  // (BriskFrameCounters::low_score) - the other frames of such a batch go through the fast-path kernels below, which skip
+  // the flagged ones.
+  const bool ordered_all = G.no_scale_nms || G.lower_threshold != BRISK_LOWER_THRESHOLD;
+  const bool ordered_some = !ordered_all && G.threshold < BRISK_FAST_PATH_MIN_THRESHOLD;
+  auto launch_ordered = [&](int only_flagged) {
     const long row_stride = (long)BRISK_MAX_LAYERS * B.tie_cap;
     hipLaunchKernelGGL(k_order_candidates, dim3(nframes), dim3(OC_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.tie_idx,
-                       row_stride, B.cand_cap);
+                       row_stride, B.cand_cap, only_flagged);
+    hipLaunchKernelGGL(k_ordered_keypoints, dim3(nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.keys, B.kp_out,
+                       B.cand_cap, B.kp_cap, mask, mask_frame_pitch, mask_row_pitch, G.no_scale_nms, only_flagged);
+  };
+  if (ordered_all) {
     brisk_prof_mark(prof, BRISK_STG_TIES, s);
     if (ov && fork_at != 1 && fork_at != 2) fork_integral();
-    hipLaunchKernelGGL(k_ordered_keypoints, dim3(nframes), dim3(64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.keys, B.kp_out,
-                       B.cand_cap, B.kp_cap, mask, mask_frame_pitch, mask_row_pitch, G.no_scale_nms);
+    launch_ordered(0);
     brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
     brisk_prof_mark(prof, BRISK_STG_POSTFILTER, s);
     return;
@@ -1998,6 +2017,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                      B.kp_cap, mask, mask_frame_pitch, mask_row_pitch);
   hipLaunchKernelGGL(k_finalize_large, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys,
                      reinterpret_cast<unsigned*>(B.tie_idx), (long)BRISK_MAX_LAYERS * B.tie_cap, B.kp_out, B.cand_cap, B.kp_cap);
+  if (ordered_some) launch_ordered(1);  // (after the fast-path kernels, which left the flagged frames' lists and scratch alone)
   brisk_prof_mark(prof, BRISK_STG_POSTFILTER, s);
 }
 

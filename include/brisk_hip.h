@@ -27,7 +27,7 @@ enum {
   BRISK_HIP_ERR_NO_DEVICE = 2,  /* no usable HIP device */
   BRISK_HIP_ERR_HIP = 3,        /* a HIP runtime call failed */
   BRISK_HIP_ERR_CAPACITY = 4,   /* more candidates / keypoints than the configured capacity */
-  BRISK_HIP_ERR_THRESHOLD = 5,  /* AGAST threshold outside [1, 255] (1..19 run the ordered path) */
+  BRISK_HIP_ERR_THRESHOLD = 5,  /* AGAST threshold outside [1, 255] (below 20 some frames run the ordered path) */
   BRISK_HIP_ERR_PATTERN = 6,    /* malformed pattern (reference: CHECK_EQ(noShortPairs_, 384), :286) */
   BRISK_HIP_ERR_UNSUPPORTED = 7 /* no defined result in the reference on this input (see brisk_hip_detect), or an unsupported size */
 };
@@ -71,7 +71,8 @@ int brisk_hip_pattern_tables(const brisk_hip_pattern* p, float* scale_list, int*
 /* ---- host-buffer calls: what the two host classes forward to --------------------------------- */
 /* BriskFeatureDetector::detectImpl (brisk-feature-detector.cc:77-85): clears/overwrites `out`.
  * img: h x w u8, row pitch `stride` bytes.  mask: optional h x w u8 (0 = drop keypoint), or NULL.
- * threshold: 1..255 (20..255 on the fast path; below 20 the sequential ordered path, bit-exact but slow).
+ * threshold: 1..255 (20..255 on the fast path; below 20 a frame in which a detection stores a score <= 2 - nearly every
+ * frame below 10, few at 10..19 - takes the sequential ordered path, bit-exact but slow: ~19 us per AGAST candidate).
  * suppress_scale_nonmaxima = 0 (brisk-scale-space.cc:131-170): with octaves == 0 the single-layer 2-D refinement; with
  * more layers the reference takes every layer's point coordinates from layer 0's list (`agastPoints.at(0)[n]`, :137) -
  * reproduced on the ordered path; where that indexing leaves layer 0's list or a score matrix (the usual case for

@@ -281,7 +281,8 @@ struct EmulPattern {
 extern "C" {
 
 // returns keypoint count; *out malloc'd (free with emul_free). stats[0]=#candidates, [1]=#ties, [2]=relaxation sweeps,
-// [3]=longest per-layer chain, [4]=score-block cache misses.  mode: bits 0-1 tie scheme (0 Gauss-Seidel sweeps, 1 Jacobi
+// [3]=longest per-layer chain, [4]=score-block cache misses, [5]=candidates that stored a score <= 2 (BriskFrameCounters::low_score
+// on the device: such a frame takes the ordered path).  mode: bits 0-1 tie scheme (0 Gauss-Seidel sweeps, 1 Jacobi
 // sweeps, 2 sorted in-order = the kernel's main path), bit 2 = use the lane-parallel score-block caches, bit 3 = the
 // ordered path of thresholds below 20 (k_order_candidates + k_ordered_keypoints), bit 4 = the ordered path's
 // suppressScaleNonmaxima = false branch (returns -1 where the reference has no defined result)
@@ -298,6 +299,9 @@ int emul_detect(const uint8_t* img, int w, int h, int threshold, int octaves, un
     int nt = 0;
     for (int l = 0; l < E.G.nlayers; ++l) nt += (int)E.ties[l].size();
     stats[1] = nt; stats[2] = E.relax_iters; stats[3] = E.max_chain; stats[4] = (int)brisk_cache_misses;
+    int low = 0;
+    for (const BriskCand& c : E.cand) low += (c.D <= 2) ? 1 : 0;
+    stats[5] = low;
   }
   return (int)E.kps.size();
 }

@@ -54,7 +54,7 @@ def detect(img, threshold, octaves, shuffle_seed=0, jacobi=0):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
     out = C.c_void_p()
-    stats = np.zeros(5, np.int32)
+    stats = np.zeros(6, np.int32)
     n = lib().emul_detect(_p(img), w, h, threshold, octaves, shuffle_seed, jacobi, C.byref(out), _p(stats))
     if n < 0:
         lib().emul_free(out)

@@ -231,6 +231,28 @@ def test_ordered_path_literal_cache_equals_oracle(thr):
             assert same_kps(ke, ko), (img.shape, thr, octaves, len(ke), len(ko))
 
 
+def test_fast_path_below_threshold_20_is_exact_unless_a_detection_stores_a_score_of_2_or_less():
+    """What separates thresholds below 20 from the fast path is ONE thing: a detection may store a score <= 2, which the
+    reference's lazy cache treats as "not cached" (brisk-layer.cc:118-132).  A frame without such a detection - thresholds
+    10 ... 19 on ordinary images - is bit-equal to the oracle on the fast path (the engine decides per frame on the device:
+    BriskFrameCounters::low_score); frames with one differ there and are exact on the ordered path."""
+    rng = np.random.default_rng(2)
+    lowc = (120 + rng.integers(0, 4, (100, 140))).astype(np.uint8)
+    seen_clean, seen_low = 0, 0
+    for img in (synth.gen(400, 240, 100, 30), synth.gen(400, 240, 103, 30), synth.gen(333, 201, 3, 40), lowc):
+        for thr in (3, 8, 10, 14, 19):
+            ko = O.detect(img, thr, 3)
+            kf, st = E.detect(img, thr, 3, 3, 4 | 2)   # fast path, as the kernels run it
+            if st[5] == 0:
+                seen_clean += 1
+                assert same_kps(kf, ko), (img.shape, thr)
+            else:
+                seen_low += 1
+                kord, _ = E.detect(img, thr, 3, 3, 8)  # ordered path
+                assert same_kps(kord, ko), (img.shape, thr)
+    assert seen_clean >= 6 and seen_low >= 4
+
+
 def banded(seed, h=240, w=320, band=48, cell=3):
     """texture only in a band at the top: every layer's AGAST points then lie in its first rows, which is what makes
     the `agastPoints.at(0)[n]` indexing of the suppressScaleNonmaxima=false branch stay inside the score matrices"""

@@ -1,12 +1,16 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/profile_round.sh <tag>
+# usage (on the GPU box): bash tools/profile_round.sh <tag> [--config <c> ...]
+#   --config 4 | 4_uniform | 4_uniform_single | 5 | 1 | dense30 | dense50: afterwards the same per BASELINE configuration
+#   (tools/profile_config.sh: entry of bench.py's config.other_configs, kernel statistics, FETCH / WRITE passes, traffic)
 # Collects what profiles/ holds for a round into gpurun_out/<tag>/:
 #   kernel_stats_b256.csv    rocprofv3 --kernel-trace --stats of the default bench command
 #   pmc_fetch_b64.csv / pmc_write_b64.csv   separate PMC passes (FETCH_SIZE, WRITE_SIZE) of a 64-frame run, engine kernels only
 #   traffic.json             tools/pmc_traffic.py on those two passes (per kernel and per group, tagged with the kernel revision)
 #   sq_counters.txt          SQ occupancy / stall / instruction counters per kernel (tools/pmc_sq.sh)
 #   bench.json               the bench line of an un-profiled default run
-tag=$1
+tag=$1; shift
+configs=""
+while [ $# -gt 0 ]; do case $1 in --config) configs="$configs $2"; shift 2;; *) shift;; esac; done
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -34,3 +38,4 @@ cd $GRAFT_REPO_ROOT && bash tools/pmc_sq.sh $tag/sq > /dev/null 2>&1
 cp $out/sq/summary_all.txt $out/sq_counters.txt
 rm -rf $out/ks $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/sq; bash $GRAFT_REPO_ROOT/tools/pmc_describe.sh $tag/describe > /dev/null 2>&1; cp $out/describe/summary_describe.txt $out/describe_tcp_counters.txt
 cat $out/bench.json | cut -c1-600
+if [ -n "$configs" ]; then bash $GRAFT_REPO_ROOT/tools/profile_config.sh $tag $configs | tail -3; fi

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "brisk_hip_reserve", "brisk_hip_detect_uniform", "brisk_hip_detect_describe_batch_host", "brisk_hip_stream_ceiling",
     "brisk_hip_kernel_revision", "brisk_hip_compute_scale", "brisk_hip_describe_same_image", "brisk_hip_detect_filtered",
     "brisk_hip_comm_unique_id", "brisk_hip_comm_create", "brisk_hip_comm_destroy", "brisk_hip_comm_rank", "brisk_hip_comm_world",
-    "brisk_hip_comm_gather_results", "brisk_hip_comm_wait", "brisk_hip_debug_filter_keypoints",
+    "brisk_hip_comm_gather_results", "brisk_hip_comm_wait", "brisk_hip_debug_filter_keypoints", "brisk_hip_debug_integral_bits",
 ]
 
 
@@ -96,6 +96,7 @@ def load_library():
     L.brisk_hip_batch_status.argtypes = [vp, C.c_int, ip]
     L.brisk_hip_debug_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, ip]
     L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
+    L.brisk_hip_debug_integral_bits.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_counters.argtypes = [vp, C.c_int, vp, ip]
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
@@ -197,9 +198,13 @@ class Context:
                 "ties": [int(v) for v in out[4:4 + nl.value]], "experiment": [int(v) for v in out[20:28]]}
 
     def debug_integral(self, frame, w, h):
+        """(h + 1) x (w + 1) u32: the integral image of the last describe, modulo 2 ** debug_integral_bits()"""
         out = np.zeros((h + 1, w + 1), np.uint32)
         self.check(self._L.brisk_hip_debug_integral(self._h, frame, _ptr(out)))
         return out
+
+    def debug_integral_bits(self, frame=0):
+        return self._L.brisk_hip_debug_integral_bits(self._h, frame)
 
     def set_uniformity(self, radius, max_keypoints=0x7FFFFFFF):
         """Optional uniformity enforcement after the detector (0 = off); see brisk_hip_set_uniformity."""

@@ -77,6 +77,10 @@ struct brisk_hip_ctx {
   BriskKeyPoint* d_uni_tmp = nullptr;
   int* d_uni_order = nullptr;
   size_t uni_items = 0;
+  // candidate density of the last detect + describe batch (k_batch_density writes it into pinned host memory; read without
+  // synchronisation by the next batch: integral_format)
+  long long* h_density = nullptr;
+  double density_mpx = 0.0;  // megapixels per frame of the batch the word belongs to
   void* d_img16[3] = {nullptr, nullptr, nullptr};  // scratch of the 16-bit image functions (source, destination, row sums): grown, never shrunk
   size_t img16_bytes[3] = {0, 0, 0};
   void* d_match = nullptr;  // workspace of brisk_hip_match_knn_device
@@ -251,6 +255,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
     c->D.istride = istride;
     c->B.istride = istride;
     c->D.iframe_elems = iframe;
+    c->D.ibits = 32;
     return BRISK_HIP_OK;
   }
   HIPCHK(c, hipDeviceSynchronize());
@@ -294,6 +299,7 @@ static int ensure_buffers(brisk_hip_ctx* c, int nframes, const BriskGeom& G) {
   c->D.istride = istride;
   c->B.istride = istride;
   c->D.iframe_elems = iframe;
+  c->D.ibits = 32;
   return BRISK_HIP_OK;
 }
 
@@ -307,6 +313,34 @@ static int ensure_stage(brisk_hip_ctx* c, size_t bytes) {
   HIPCHK(c, hipMalloc(&c->d_stage, bytes + 256));
   c->stage_bytes = bytes;
   return BRISK_HIP_OK;
+}
+
+// Element size of a call's integral image: 32 bits, or 24 (3-byte elements, values modulo 2^24; where the pattern's boxes
+// allow it: BriskPatternDev::int24_ok).  The integral image is written and fetched once per frame; a quarter fewer bytes
+// shorten the window in which k_integral_final runs beside the tie chain (0.70 -> 0.63 ms per 256 frames; bench line + 1.4 %),
+// but k_describe itself is 2 - 10 % slower on 3-byte elements (byte-unaligned gathers straddle more sectors, one v_alignbit
+// per column): sparse frames gain, dense frames and descriptor-only calls with many keypoints lose (threshold 30: - 11 %,
+// config 5: 0.27 vs 0.31 ms).  So: 32 bits in descriptor-only calls; in detect + describe batches 24 bits while the
+// PREVIOUS batch of the context had at most 3 000 AGAST candidates per megapixel (BASELINE configs 2 and 4: 1 100; threshold
+// 50: 12 000) - a stream's batches look alike, the count comes back through pinned memory without a synchronisation, and it
+// only steers speed.  (Both forms in ONE k_describe, chosen per frame on the device, cost more registers - 224 instead of
+// 195 - than the smaller image saves.)  Debug bit 18 forces 32, bit 24 forces 24 (stage parity tests of both forms);
+// BRISK_INTEGRAL_BITS=32 / 24 for A / B runs.
+static void integral_format(const brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, bool batch_with_detect, int* ibits, int* i24_max_cand) {
+  static const int env = getenv("BRISK_INTEGRAL_BITS") ? atoi(getenv("BRISK_INTEGRAL_BITS")) : 0;
+  *ibits = 32;
+  *i24_max_cand = -1;  // (per-frame choice inside k_integral_final: not used, see above)
+  if (!pat || !pat->dev.int24_ok) return;
+  if (env == 32 || (ctx->debug_flags & (1 << 18))) return;
+  if (env == 24 || (ctx->debug_flags & (1 << 24))) { *ibits = 24; return; }
+  if (!batch_with_detect) return;
+  double density = 0.0;  // candidates per megapixel of the last batch (none yet: sparse is the common case)
+  if (ctx->h_density && ctx->density_mpx > 0.0) {
+    const long long wv = __atomic_load_n(ctx->h_density, __ATOMIC_RELAXED);
+    const long long frames = wv >> 40, cands = wv & 0xFFFFFFFFFFll;
+    if (frames > 0) density = (double)cands / ((double)frames * ctx->density_mpx);
+  }
+  if (density <= 3000.0) *ibits = 24;
 }
 
 // host image -> device staging (rows at `pitch`): one linear copy when neither side has row padding (a pitched copy is
@@ -357,6 +391,7 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
   hipFree(c->d_stage);
   if (c->d_match) hipFree(c->d_match);
   for (int i = 0; i < 3; ++i) if (c->d_img16[i]) hipFree(c->d_img16[i]);
+  if (c->h_density) hipHostFree(c->h_density);
   if (c->done_ev) hipEventDestroy(c->done_ev);
   for (int i = 0; i < 2; ++i) {
     if (c->d_hstage[i]) hipFree(c->d_hstage[i]);
@@ -440,7 +475,11 @@ static int upload_pattern(brisk_hip_ctx* ctx, brisk_hip_pattern* p) {
   d.reg_tables = (H.nlong <= 896 && H.nshort <= 512 && H.npoints <= 128) ? 1 : 0;
   for (int i = 0; i < H.nlong; ++i)
     if (H.long_pairs[4 * i + 2] < -32768 || H.long_pairs[4 * i + 2] > 32767 || H.long_pairs[4 * i + 3] < -32768 || H.long_pairs[4 * i + 3] > 32767) d.reg_tables = 0;
-  for (float sg : H.sigma) d.has_bilinear |= (sg < 0.5f) ? 1 : 0;
+  float sigma_max = 0.f;
+  for (float sg : H.sigma) { d.has_bilinear |= (sg < 0.5f) ? 1 : 0; sigma_max = sg > sigma_max ? sg : sigma_max; }
+  // 24-bit integral image: a box spans at most 2 sigma + 3 pixels a side (sigma = the half side SmoothedIntensity works with),
+  // every region sum it takes must stay below 2^24: (2 sigma + 3)^2 * 255 < 2^24  <=>  sigma < 126.7
+  d.int24_ok = (!d.has_bilinear && sigma_max < 120.0f) ? 1 : 0;
   d.mult = (const float*)(b + o_mult); d.sigma = (const float*)(b + o_sigma); d.uv = (const double*)(b + o_uv);
   d.scaling = (const int*)(b + o_scl);
   d.tab = (const int*)(b + o_tab);
@@ -567,6 +606,10 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   if (A.do_describe && A.pat && A.pat->host.strings > ctx->desc_pitch) ctx->desc_pitch = brisk_align_up(A.pat->host.strings, 16);
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
+  {
+    int unused;
+    integral_format(ctx, A.pat, A.do_detect && A.do_describe, &ctx->D.ibits, &unused);
+  }
   const bool bucketing = A.do_detect && !(A.uni_radius > 0.0) && A.bk_u > 0;
   if ((A.do_detect && A.uni_radius > 0.0) || bucketing) {
     rc = ensure_filter_buffers(ctx, A.w, A.h, nframes, bucketing ? 0.0 : A.uni_radius);
@@ -601,6 +644,7 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
   Bi.kp_out += f0 * Bi.kp_cap;
   Bi.bandsum += f0 * nbands * Bi.istride;
   BriskDescribeBuffers Di = ctx->D;
+  Di.ibits = ctx->D.ibits; Di.i24_max_cand = -1;  // (chosen once per call: batch_begin)
   Di.integral += f0 * Di.iframe_elems;
   Di.dkp += f0 * Bi.kp_cap;
   Di.dscale += f0 * Bi.kp_cap;
@@ -668,6 +712,14 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
 }
 
 static int batch_end(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipStream_t s) {
+  if (A.do_detect && A.do_describe) {  // candidate density of this batch for the next one's choice of integral format
+    if (!ctx->h_density) {
+      HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_density, sizeof(long long), hipHostMallocMapped));
+      *ctx->h_density = 0;
+    }
+    ctx->density_mpx = (double)A.w * (double)A.h / 1e6;
+    brisk_launch_batch_density(ctx->B.counters, nframes, ctx->B.cand_cap, ctx->h_density, s);
+  }
   if (ctx->prof.on) ctx->prof.calls++;
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = nframes;
@@ -1099,6 +1151,7 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
   // descriptor rows of this call at the caller's pitch when the caller's rows are packed (a cv::Mat of K x strings bytes):
   // the download is then one linear copy
   BriskDescribeBuffers Dd = ctx->D;
+  integral_format(ctx, pat, false, &Dd.ibits, &Dd.i24_max_cand);
   if (desc_stride == pat->host.strings && pat->host.strings % 8 == 0 && pat->host.strings <= ctx->D.desc_pitch) Dd.desc_pitch = pat->host.strings;
   brisk_launch_describe(ctx->G, P, Bd, Dd, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, &ctx->prof, nullptr, n_in);
   if (ctx->prof.on) ctx->prof.calls++;
@@ -1541,9 +1594,29 @@ int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out) {
   if (frame < 0 || frame >= ctx->slots) return fail(ctx, BRISK_HIP_ERR_ARG, "bad index");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, wait_own_work(ctx));
-  HIPCHK(ctx, hipMemcpy2D(out, (size_t)(ctx->G.w + 1) * 4, ctx->D.integral + (size_t)frame * ctx->D.iframe_elems,
-                          (size_t)ctx->D.istride * 4, (size_t)(ctx->G.w + 1) * 4, ctx->G.h + 1, hipMemcpyDeviceToHost));
+  const uint32_t* src = ctx->D.integral + (size_t)frame * ctx->D.iframe_elems;
+  BriskFrameCounters fc;
+  HIPCHK(ctx, hipMemcpy(&fc, ctx->B.counters + frame, sizeof(fc), hipMemcpyDeviceToHost));
+  if (fc.i24) {  // 3-byte elements (values modulo 2^24), row pitch istride * 3 bytes: zero-extended
+    const int wi = ctx->G.w + 1, hi = ctx->G.h + 1;
+    std::vector<uint8_t> tmp((size_t)wi * 3 * hi);
+    HIPCHK(ctx, hipMemcpy2D(tmp.data(), (size_t)wi * 3, src, (size_t)ctx->D.istride * 3, (size_t)wi * 3, hi, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < (size_t)wi * hi; ++i) out[i] = (uint32_t)tmp[3 * i] | ((uint32_t)tmp[3 * i + 1] << 8) | ((uint32_t)tmp[3 * i + 2] << 16);
+    return BRISK_HIP_OK;
+  }
+  HIPCHK(ctx, hipMemcpy2D(out, (size_t)(ctx->G.w + 1) * 4, src, (size_t)ctx->D.istride * 4, (size_t)(ctx->G.w + 1) * 4, ctx->G.h + 1,
+                          hipMemcpyDeviceToHost));
   return BRISK_HIP_OK;
+}
+
+int brisk_hip_debug_integral_bits(brisk_hip_ctx* ctx, int frame) {
+  if (!ctx) return 0;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (frame < 0 || frame >= ctx->slots || !ctx->B.counters) return 0;
+  if (hipSetDevice(ctx->device) != hipSuccess || wait_own_work(ctx) != hipSuccess) return 0;
+  BriskFrameCounters fc;
+  if (hipMemcpy(&fc, ctx->B.counters + frame, sizeof(fc), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return fc.i24 ? 24 : 32;
 }
 
 // per-frame work counts of the last batch: out[0] = candidates, out[1] = keypoints, out[2] = described keypoints,
@@ -1559,7 +1632,8 @@ int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlaye
   out[0] = c.ncand; out[1] = c.nkp; out[2] = c.ndesc; out[3] = c.overflow;
   *nlayers = ctx->G.nlayers;
   for (int l = 0; l < ctx->G.nlayers; ++l) out[4 + l] = c.ntie[l];
-  for (int i = 0; i < 3; ++i) out[20 + i] = c.pad[i];
+  for (int i = 0; i < 2; ++i) out[20 + i] = c.pad[i];
+  out[22] = c.i24;
   out[23] = c.low_score;
   out[25] = c.nestimate;
   out[26] = c.orient_ticket; out[27] = c.desc_ticket;

@@ -110,7 +110,8 @@ struct BriskFrameCounters {
   int nestimate;                    // kept keypoints that came without an angle (k_describe stage 0 skips frames that have none)
   int tie_sorted;                   // k_tie_resolve: bit l = layer l's tie list has been rewritten in raster order (layers beyond the on-chip capacity)
   int low_score;                    // k_detect stored a detection score <= 2 (possible below threshold 20 only): the frame takes the ordered path
-  int pad[3];
+  int i24;                          // k_integral_final wrote this frame's integral image in 3-byte elements (k_describe reads it accordingly)
+  int pad[2];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)
@@ -119,6 +120,7 @@ struct BriskPatternDev {
   int rotation_invariant, scale_invariant, basicscale;
   int reg_tables;         // at most 896 long pairs with 16-bit weights, at most 512 short pairs, at most 128 points: k_describe keeps the pair tables in registers
   int has_bilinear;       // some (scale, point) has sigma < 0.5: SmoothedIntensity's bilinear branch (:391-408) is reachable
+  int int24_ok;           // every box of the pattern covers fewer than 2^24 / 255 pixels: the 24-bit integral image suffices
   const float* mult;      // [64][npoints]  multiplier m so that x = (float)((double)m * U)
   const float* sigma;     // [64][npoints]  box half side
   const int* scaling;     // [64][npoints][2] {scaling, scaling2} of the box (functions of sigma only, :412-413)

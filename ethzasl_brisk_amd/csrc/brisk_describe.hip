@@ -299,23 +299,16 @@ struct DsLane {  // a lane's sample of one round
   int slot;      // keypoint-in-run * npoints + point
 };
 typedef BriskBoxPrep DsPrep;  // address / weight stage of a sample (brisk_device_describe.h)
-// DS_NO_IMAGE (default): the two displaced corner pixels of the reference quirk (brisk-descriptor-extractor.cc:453) come out
+// The two displaced corner pixels of the reference quirk (brisk-descriptor-extractor.cc:453) come out
 // of the integral image as well - pixel (u, v) = I[v+1][u+1] - I[v+1][u] - I[v][u+1] + I[v][u], exact in wrap-around
 // arithmetic: the bottom row pair's first row is loaded three columns wide and row y_bottom - 1 adds one 8-byte gather per
 // side - instead of two byte gathers from the frame, which then is no part of the kernel's working set (2.1 MB per 1080p
 // frame, a fifth of the compulsory misses).  Only a box that ends in the image's last column still reads the frame (the
 // reference's linear address is the first pixel of the next row): a rare, separate pair of loads.
-#ifndef DS_NO_IMAGE
-#define DS_NO_IMAGE 1
-#endif
 typedef uint32_t __attribute__((ext_vector_type(3))) ds_u32x3;
 struct DsRaw {
-#if DS_NO_IMAGE
   ds_u32x2 p00, p02, p10, p12, p30, p32, ql, qr;
   ds_u32x3 p20, p22;
-#else
-  ds_u32x2 p00, p02, p10, p12, p20, p22, p30, p32;
-#endif
   unsigned br, bl;
 };
 // SmoothedIntensity split into address / load / combine stages: the arithmetic is brisk_box_prep / brisk_box_acc /
@@ -326,18 +319,22 @@ __device__ __forceinline__ DsPrep ds_prep(float xf, float yf, float sigma_half, 
 // The 4 x 4 integral samples as eight gathers through a buffer descriptor of the frame's integral image: four 32-bit
 // offsets per lane (the corners), the second row of each pair through the scalar offset; plus what the two displaced
 // bottom corners of the reference quirk need (above).
+// I24: the integral image in 3-byte elements (values modulo 2^24): the same ten gathers at byte offsets 3 x - the
+// hardware takes 8- and 12-byte gathers at any byte alignment at the rate of aligned ones (tools/microbench_unaligned.hip:
+// 255 vs 259 G gathers/s out of L2) -, 8 bytes hold the 6 of two adjacent columns, 12 bytes the 9 of three.
+template <bool I24>
 __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, __amdgpu_buffer_rsrc_t rs_img, int stride, int cols,
                                         __amdgpu_buffer_rsrc_t rs_int, int istride) {
-  const int rowb = istride * 4;
+  constexpr int ES = I24 ? 3 : 4;
+  const int rowb = istride * ES;
   const int o_t = p.y_top * rowb, o_b = p.y_bottom * rowb;
-  const int o_tl = o_t + p.x_left * 4, o_tr = o_t + p.x_right * 4, o_bl = o_b + p.x_left * 4, o_br = o_b + p.x_right * 4;
-#if DS_NO_IMAGE
+  const int o_tl = o_t + p.x_left * ES, o_tr = o_t + p.x_right * ES, o_bl = o_b + p.x_left * ES, o_br = o_b + p.x_right * ES;
   r.p00 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, 0, 0);
   r.p02 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, 0, 0);
   r.p10 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, rowb, 0);
   r.p12 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, rowb, 0);
-  r.ql = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl - rowb + 4, 0, 0);   // row y_bottom - 1, columns x_left + 1, + 2
-  r.qr = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br - rowb + 4, 0, 0);   // row y_bottom - 1, columns x_right + 1, + 2
+  r.ql = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl - rowb + ES, 0, 0);   // row y_bottom - 1, columns x_left + 1, + 2
+  r.qr = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br - rowb + ES, 0, 0);   // row y_bottom - 1, columns x_right + 1, + 2
   r.p20 = __builtin_amdgcn_raw_buffer_load_b96(rs_int, o_bl, 0, 0);
   r.p22 = __builtin_amdgcn_raw_buffer_load_b96(rs_int, o_br, 0, 0);
   r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl, rowb, 0);
@@ -350,34 +347,32 @@ __device__ __forceinline__ void ds_load(DsRaw& r, const DsPrep& p, __amdgpu_buff
     r.bl = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xl + (xl >= cols ? wr : 0), 0, 0);
     r.br |= 0x100u; r.bl |= 0x100u;  // (marks "from the frame")
   }
-#else
-  int qy = max(p.y_bottom - 1, 0);
-  int xr = p.x_right + 1, xl = p.x_left + 1;
-  const int o_q = qy * stride;
-  const int wrap = stride - cols;  // x >= cols: first pixels of the next row
-  // (the image bytes first, then row by row: 1 % faster than bytes last, 4 % faster than left clusters before right ones)
-  r.br = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xr + (xr >= cols ? wrap : 0), 0, 0);
-  r.bl = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xl + (xl >= cols ? wrap : 0), 0, 0);
-  r.p00 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, 0, 0);
-  r.p02 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, 0, 0);
-  r.p10 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tl, rowb, 0);
-  r.p12 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_tr, rowb, 0);
-  r.p20 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl, 0, 0);
-  r.p22 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, 0, 0);
-  r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_bl, rowb, 0);
-  r.p32 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, o_br, rowb, 0);
-#endif
 }
+// two / three adjacent 24-bit columns out of the 8 / 12 bytes that start at the first one.  Only the low 24 bits of the
+// results mean anything: every use is a four-corner difference that brisk_box_acc masks to 24 bits, so the byte above is
+// left as it comes (one v_alignbit per column instead of shifts and masks).
+__device__ __forceinline__ void ds_unpack2(ds_u32x2 v, uint32_t& a, uint32_t& b) {
+  a = v.x;
+  b = __builtin_amdgcn_alignbit(v.y, v.x, 24);
+}
+template <bool I24>
 __device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
-#if DS_NO_IMAGE
-  unsigned qbr = r.p22.z - r.p22.y - r.qr.y + r.qr.x;  // pixel (x_right + 1, y_bottom - 1)
-  unsigned qbl = r.p20.z - r.p20.y - r.ql.y + r.ql.x;  // pixel (x_left + 1, y_bottom - 1)
+  uint32_t i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i2x, i22, i23, i2y, i30, i31, i32, i33, ql0, ql1, qr0, qr1;
+  if (I24) {
+    ds_unpack2(r.p00, i00, i01); ds_unpack2(r.p02, i02, i03); ds_unpack2(r.p10, i10, i11); ds_unpack2(r.p12, i12, i13);
+    ds_unpack2(ds_u32x2{r.p20.x, r.p20.y}, i20, i21); i2x = __builtin_amdgcn_alignbit(r.p20.z, r.p20.y, 16);
+    ds_unpack2(ds_u32x2{r.p22.x, r.p22.y}, i22, i23); i2y = __builtin_amdgcn_alignbit(r.p22.z, r.p22.y, 16);
+    ds_unpack2(r.p30, i30, i31); ds_unpack2(r.p32, i32, i33); ds_unpack2(r.ql, ql0, ql1); ds_unpack2(r.qr, qr0, qr1);
+  } else {
+    i00 = r.p00.x; i01 = r.p00.y; i02 = r.p02.x; i03 = r.p02.y; i10 = r.p10.x; i11 = r.p10.y; i12 = r.p12.x; i13 = r.p12.y;
+    i20 = r.p20.x; i21 = r.p20.y; i2x = r.p20.z; i22 = r.p22.x; i23 = r.p22.y; i2y = r.p22.z;
+    i30 = r.p30.x; i31 = r.p30.y; i32 = r.p32.x; i33 = r.p32.y; ql0 = r.ql.x; ql1 = r.ql.y; qr0 = r.qr.x; qr1 = r.qr.y;
+  }
+  constexpr uint32_t mask = I24 ? 0xFFFFFFu : 0xFFFFFFFFu;
+  unsigned qbr = (i2y - i23 - qr1 + qr0) & mask;  // pixel (x_right + 1, y_bottom - 1)
+  unsigned qbl = (i2x - i21 - ql1 + ql0) & mask;  // pixel (x_left + 1, y_bottom - 1)
   if (r.br & 0x100u) { qbr = r.br & 0xFFu; qbl = r.bl & 0xFFu; }
-#else
-  const unsigned qbr = r.br, qbl = r.bl;
-#endif
-  const uint32_t acc = brisk_box_acc(p, r.p00.x, r.p00.y, r.p02.x, r.p02.y, r.p10.x, r.p10.y, r.p12.x, r.p12.y, r.p20.x, r.p20.y, r.p22.x,
-                                     r.p22.y, r.p30.x, r.p30.y, r.p32.x, r.p32.y, qbr, qbl);
+  const uint32_t acc = brisk_box_acc(p, i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i22, i23, i30, i31, i32, i33, qbr, qbl, mask);
   if (__any(p.shift < 0)) return brisk_box_divide(p, acc);  // (a pattern with degenerate boxes: the plain division is compiled in but skipped)
   return brisk_div_by_magic((int)acc, p.magic, p.shift);
 }
@@ -400,7 +395,7 @@ struct DsTicket {  // wave-uniform
 // two-launch split doubles the compulsory misses - measured, and in tools/cache_sim.py), the keypoints an XCD has in
 // flight are one contiguous stretch of the spatial processing order, tickets are taken two runs ahead and the next
 // run's records are requested before the current run's gathers.
-template <int RUN, bool GENERIC, bool REGTAB>
+template <int RUN, bool GENERIC, bool REGTAB, bool I24>
 __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPatternDev P, const uint8_t* __restrict__ pyr,
                                                             const uint32_t* __restrict__ integral, int istride,
                                                             long iframe_elems, BriskFrameCounters* counters,
@@ -504,9 +499,9 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
         const DsPrep pr = ds_prep(xf, yf, sigma, Lc.tab.z, Lc.tab.w);
         DsRaw raw;
         __builtin_amdgcn_s_setprio(1);  // a wave that has its gathers to issue goes first (1 % of the kernel)
-        if (valid) ds_load(raw, pr, F.rs_img, stride, cols, F.rs_int, istride);
+        if (valid) ds_load<I24>(raw, pr, F.rs_img, stride, cols, F.rs_int, istride);
         __builtin_amdgcn_s_setprio(0);
-        value = ds_combine(pr, raw);
+        value = ds_combine<I24>(pr, raw);
       }
       if (valid) vals[Lc.slot] = value;
       Lc = Ln;
@@ -709,7 +704,8 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
                            long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov, int n_in_max) {
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
   if (!ov && !((G.debug_flags & (1 << 19)) && (G.debug_flags & (1 << 27))))  // (bits 19 + 27: brisk_capi.hip, timing experiments)
-    brisk_launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s);
+    brisk_launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s, Dd.ibits, B.counters,
+                          Dd.i24_max_cand);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap, Dd.dp_work, Dd.dp_work_stride);
@@ -755,8 +751,10 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
     size_t lds = describe_lds_bytes(P, run_max, regtab);
     const size_t lds_limit = 160 * 1024 / (size_t)(bpc + 1) + 512;  // bpc + 1 workgroups of this size do not fit a CU
     if (lds < lds_limit && !(G.debug_flags & (1 << 28))) lds = lds_limit;  // bit 28: no padding (other kernels share the CUs)
-    ds_kernel_t fn = regtab ? k_describe<DS_MAXRUN, false, true> : k_describe<DS_MAXRUN, false, false>;
-    if (P.has_bilinear) fn = k_describe<1, true, false>;
+    const bool i24 = Dd.ibits == 24;  // (decided by the caller from BriskPatternDev::int24_ok: never with the bilinear branch)
+    ds_kernel_t fn = regtab ? (i24 ? k_describe<DS_MAXRUN, false, true, true> : k_describe<DS_MAXRUN, false, true, false>)
+                            : (i24 ? k_describe<DS_MAXRUN, false, false, true> : k_describe<DS_MAXRUN, false, false, false>);
+    if (P.has_bilinear) fn = k_describe<1, true, false, false>;
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fn, dim3(ncu * bpc), dim3(DS_WAVES * 64), lds, s, G, P, B.pyr, Dd.integral, Dd.istride, Dd.iframe_elems,
                        B.counters, Dd.dkp, Dd.drec, Dd.desc, B.kp_cap, Dd.desc_pitch, nframes, run_fixed);

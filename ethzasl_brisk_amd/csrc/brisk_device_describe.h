@@ -231,18 +231,21 @@ BRISK_HD BriskBoxPrep brisk_box_prep(float xf, float yf, float sigma_half, int t
 // i[r][c]: integral samples at rows {y_top, y_top + 1, y_bottom, y_bottom + 1} x columns {x_left, x_left + 1, x_right,
 // x_right + 1}; br / bl: image pixels (x_right + 1, y_bottom - 1) / (x_left + 1, y_bottom - 1) (used when p.quirk).
 // Returns the weighted sum before the division by scaling2.
+// mask: 0xFFFFFFFF for the 32-bit integral image; 0xFFFFFF when the samples are integral values modulo 2^24 (every region
+// sum of the box - at most (2 sigma + 3)^2 pixels - is below 2^24, so the difference modulo 2^24 IS the region sum).
 BRISK_HD uint32_t brisk_box_acc(const BriskBoxPrep& p, uint32_t i00, uint32_t i01, uint32_t i02, uint32_t i03, uint32_t i10,
                                 uint32_t i11, uint32_t i12, uint32_t i13, uint32_t i20, uint32_t i21, uint32_t i22, uint32_t i23,
-                                uint32_t i30, uint32_t i31, uint32_t i32, uint32_t i33, unsigned qbr, unsigned qbl) {
-  const unsigned tl = i11 - i01 - i10 + i00;  // pixel (x_left, y_top)
-  const unsigned tr = i13 - i03 - i12 + i02;  // pixel (x_right, y_top)
-  const unsigned br = p.quirk ? qbr : (i33 - i23 - i32 + i22);
-  const unsigned bl = p.quirk ? qbl : (i31 - i21 - i30 + i20);
-  const uint32_t top = i12 - i11 - i02 + i01;
-  const uint32_t bottom = i32 - i31 - i22 + i21;
-  const uint32_t left = i21 - i20 - i11 + i10;
-  const uint32_t right = i23 - i22 - i13 + i12;
-  const uint32_t middle = i22 - i21 - i12 + i11;
+                                uint32_t i30, uint32_t i31, uint32_t i32, uint32_t i33, unsigned qbr, unsigned qbl,
+                                uint32_t mask = 0xFFFFFFFFu) {
+  const unsigned tl = (i11 - i01 - i10 + i00) & mask;  // pixel (x_left, y_top)
+  const unsigned tr = (i13 - i03 - i12 + i02) & mask;  // pixel (x_right, y_top)
+  const unsigned br = p.quirk ? qbr : ((i33 - i23 - i32 + i22) & mask);
+  const unsigned bl = p.quirk ? qbl : ((i31 - i21 - i30 + i20) & mask);
+  const uint32_t top = (i12 - i11 - i02 + i01) & mask;
+  const uint32_t bottom = (i32 - i31 - i22 + i21) & mask;
+  const uint32_t left = (i21 - i20 - i11 + i10) & mask;
+  const uint32_t right = (i23 - i22 - i13 + i12) & mask;
+  const uint32_t middle = (i22 - i21 - i12 + i11) & mask;
   return p.A * tl + p.B * tr + p.C * br + p.D * bl + p.r_y_1_i * top + p.r_y1_i * bottom + p.r_x_1_i * left + p.r_x1_i * right +
          (unsigned)p.scaling * middle;
 }

@@ -33,8 +33,13 @@ struct BriskDetectBuffers {
 };
 
 struct BriskDescribeBuffers {
-  uint32_t* integral;  // [slots][iframe_elems]
+  uint32_t* integral;  // [slots][iframe_elems] (frame pitch in 4-byte units whatever the element size)
   int istride;         // integral row stride (elements)
+  int ibits;           // element size of the integral image of this call: 32, or 24 = "3-byte elements allowed" (values modulo 2^24,
+                       // row pitch istride * 3 bytes: a quarter less to write and to fetch; BriskPatternDev::int24_ok) - taken
+                       // per frame by k_integral_final for the frames with at most i24_max_cand AGAST candidates (sparse frames
+                       // gain from the smaller image, dense ones lose more in k_describe; < 0: every frame)
+  int i24_max_cand;
   long iframe_elems;
   BriskKeyPoint* dkp;  // [slots][kp_cap] filtered keypoints (angle filled in)
   int* dscale;         // [slots][kp_cap]
@@ -91,7 +96,10 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
                               long frame_pitch, int row_pitch, hipStream_t s);
 // integral image of layer 0 from the band sums the pyramid kernel left (brisk_kernels.hip)
 void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
-                           long iframe_elems, int band_h, int nframes, hipStream_t s);
+                           long iframe_elems, int band_h, int nframes, hipStream_t s, int ibits = 32,
+                           BriskFrameCounters* counters = nullptr, int i24_max_cand = -1);
+// sum of the batch's candidate counts -> *host_word (pinned, mapped): candidates in bits 0-39, frames in bits 40-63
+void brisk_launch_batch_density(const BriskFrameCounters* counters, int nframes, int cand_cap, long long* host_word, hipStream_t s);
 // kp_in: [slots][kp_cap]; n_in: per-frame counts at byte stride n_in_stride
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,

@@ -1725,13 +1725,30 @@ __device__ __forceinline__ void ii_unpack(uint2 raw, int stride, int w, int c0, 
 
 // NCH = number of 2048-column chunks (template: the running sums and the prefetched row live in registers, and the
 // kernel has to stay at <= 64 VGPRs so that four 512-thread workgroups share a CU)
-template <int NCH>
+// B24: the integral image modulo 2^24 in 3-byte elements (row pitch istride * 3 bytes) - a thread's four columns are 12
+// bytes, one dwordx3 store; what k_describe needs of it are box sums below 2^24 (BriskPatternDev::int24_ok)
+typedef uint32_t __attribute__((ext_vector_type(3))) ii_u32x3;
+__device__ __forceinline__ void ii_store4(bool b24, uint32_t* out, long row, int istride, int c0, unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+  if (b24) {
+    ii_u32x3 v;
+    v.x = (a0 & 0xFFFFFFu) | (a1 << 24);
+    v.y = ((a1 >> 8) & 0xFFFFu) | (a2 << 16);
+    v.z = ((a2 >> 16) & 0xFFu) | (a3 << 8);
+    *reinterpret_cast<ii_u32x3*>(reinterpret_cast<uint8_t*>(out) + (row * istride + c0) * 3) = v;
+  } else {
+    *reinterpret_cast<uint4*>(out + row * istride + c0) = make_uint4(a0, a1, a2, a3);
+  }
+}
+template <int NCH, bool B24>
 __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, const uint8_t* __restrict__ pyr,
                                                                const uint32_t* __restrict__ bandsum,
                                                                uint32_t* __restrict__ integral, int istride, long iframe_elems,
-                                                               int nbands, int band_h) {
+                                                               int nbands, int band_h, BriskFrameCounters* counters, int i24_max_cand) {
   __shared__ unsigned wave_tot[2][II_THREADS / 64];
   const int frame = blockIdx.y, band = blockIdx.x;
+  // 3-byte elements for this frame?  (B24: allowed for the call; then every frame, or the frames with few candidates)
+  const bool b24 = B24 && (i24_max_cand < 0 || counters[frame].ncand <= i24_max_cand);
+  if (counters && band == 0 && threadIdx.x == 0) counters[frame].i24 = b24 ? 1 : 0;
   const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
   const uint8_t* img = brisk_layer_img(G, pyr, frame, 0);
   uint32_t* out = integral + (long)frame * iframe_elems;
@@ -1763,7 +1780,7 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
       buf ^= 1;
       carry += tot;
       acc[ch][0] = o + s0; acc[ch][1] = o + s1; acc[ch][2] = o + s2; acc[ch][3] = o + s3;
-      if (band == 0 && c0 <= w) *reinterpret_cast<uint4*>(out + c0) = make_uint4(0, 0, 0, 0);  // integral row 0
+      if (band == 0 && c0 <= w) ii_store4(b24, out, 0, istride, c0, 0, 0, 0, 0);  // integral row 0
     }
   }
   // II_ROWS rows per step: their row scans share ONE workgroup barrier (the loop is a chain of barriers); the pixels of
@@ -1812,8 +1829,7 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
         const unsigned o = wo + incl[k] - s[k][3] + carry[k];
         carry[k] += tot;
         acc[ch][0] += o + s[k][0]; acc[ch][1] += o + s[k][1]; acc[ch][2] += o + s[k][2]; acc[ch][3] += o + s[k][3];
-        if (c0 <= w && y + k < y1)
-          *reinterpret_cast<uint4*>(out + (long)(y + k + 1) * istride + c0) = make_uint4(acc[ch][0], acc[ch][1], acc[ch][2], acc[ch][3]);
+        if (c0 <= w && y + k < y1) ii_store4(b24, out, (long)(y + k + 1), istride, c0, acc[ch][0], acc[ch][1], acc[ch][2], acc[ch][3]);
       }
       buf ^= 1;
     }
@@ -1825,14 +1841,43 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
 }
 
 void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
-                            long iframe_elems, int band_h, int nframes, hipStream_t s) {
+                            long iframe_elems, int band_h, int nframes, hipStream_t s, int ibits, BriskFrameCounters* counters,
+                            int i24_max_cand) {
   const int nbands = (G.L[0].h + band_h - 1) / band_h;
   const int nchunks = (G.L[0].w + 1 + II_CHUNK - 1) / II_CHUNK;
   const dim3 grid(nbands, nframes), block(II_THREADS);
   static const int pad_lds = env_knob("BRISK_II_LDS", 0);  // tuning experiments: dynamic LDS bytes = fewer workgroups per CU
-  if (nchunks <= 1) hipLaunchKernelGGL(k_integral_final<1>, grid, block, pad_lds, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
-  else if (nchunks == 2) hipLaunchKernelGGL(k_integral_final<2>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
-  else hipLaunchKernelGGL(k_integral_final<II_MAXCHUNKS>, grid, block, 0, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, band_h);
+  const bool b24 = ibits == 24 && counters;  // (the per-frame flag lives in the counters)
+#define II_LAUNCH(NCH, LDS)                                                                                                                  \
+  if (b24) hipLaunchKernelGGL((k_integral_final<NCH, true>), grid, block, LDS, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, \
+                              band_h, counters, i24_max_cand);                                                                              \
+  else hipLaunchKernelGGL((k_integral_final<NCH, false>), grid, block, LDS, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands,    \
+                          band_h, counters, i24_max_cand);
+  if (nchunks <= 1) { II_LAUNCH(1, pad_lds) }
+  else if (nchunks == 2) { II_LAUNCH(2, 0) }
+  else { II_LAUNCH(II_MAXCHUNKS, 0) }
+#undef II_LAUNCH
+}
+
+// AGAST candidates of a batch, summed into host-visible (pinned, mapped) memory: what the NEXT batch of the context goes
+// by when it chooses the element size of its integral image (brisk_capi.hip: integral_format) - read there without any
+// synchronisation, so possibly a batch or two old; it steers speed only, never a result.
+__global__ void __launch_bounds__(256) k_batch_density(const BriskFrameCounters* __restrict__ counters, int nframes, int cand_cap,
+                                                       long long* __restrict__ host_word) {
+  __shared__ long long part[4];
+  long long sum = 0;
+  for (int f = threadIdx.x; f < nframes; f += 256) sum += min(counters[f].ncand, cand_cap);
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long total = part[0] + part[1] + part[2] + part[3];
+    // candidates in the low 40 bits, frames above: one 8-byte store
+    __hip_atomic_store(host_word, (total & 0xFFFFFFFFFFll) | ((long long)nframes << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void brisk_launch_batch_density(const BriskFrameCounters* counters, int nframes, int cand_cap, long long* host_word, hipStream_t s) {
+  hipLaunchKernelGGL(k_batch_density, dim3(1), dim3(256), 0, s, counters, nframes, cand_cap, host_word);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1942,7 +1987,8 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     (void)hipEventRecord(ov->fork, s);
     (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
     brisk_prof_mark_side(prof, 0, ov->side);
-    brisk_launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, B.band_h, nframes, ov->side);
+    brisk_launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, B.band_h, nframes, ov->side,
+                          ov->Dd->ibits, B.counters, ov->Dd->i24_max_cand);
     brisk_prof_mark_side(prof, 1, ov->side);
     (void)hipEventRecord(ov->join, ov->side);
   };

@@ -283,8 +283,12 @@ const char* brisk_hip_kernel_revision(void);
 int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, uint8_t* out, int* w, int* h);
 /* test knobs: bit0 = route every AGAST candidate through the direct-evaluation safety-net kernel */
 int brisk_hip_debug_set_flags(brisk_hip_ctx* ctx, int flags);
-/* integral image of frame slot `frame` after the last describe: (h+1) x (w+1) u32, tightly packed */
+/* integral image of frame slot `frame` after the last describe: (h+1) x (w+1) u32, tightly packed.  The engine keeps it
+ * modulo 2^24 in 3-byte elements where the pattern's boxes are small enough for that (every built-in pattern; the values
+ * come back zero-extended) and as u32 otherwise - brisk_hip_debug_integral_bits tells which (24 / 32); debug flag bit 18
+ * forces the 32-bit form. */
 int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out);
+int brisk_hip_debug_integral_bits(brisk_hip_ctx* ctx, int frame);
 /* number of describe calls that reused the image a detect call had left on the device (brisk_hip_describe_same_image, or
  * brisk_hip_describe under BRISK_HIP_IMAGE_CACHE=1) and skipped the upload and the layer-0 pass */
 int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx);

@@ -201,36 +201,54 @@ def test_pattern_tables_on_device_match_oracle(B):
         assert np.array_equal(a, X.scale_list()) and np.array_equal(b.astype(np.uint32), X.size_list())
 
 
-def test_integral_kernel(B, ctx, golden_ast):
-    img = golden_ast[0]["image"][:333, :517].copy()          # odd sizes
-    B.BriskDescriptorExtractor().compute(img, np.zeros(0, B.KEYPOINT))
-    k = np.zeros(1, B.KEYPOINT)
-    k["x"], k["y"], k["size"], k["angle"] = 200, 150, 12, -1
-    B.BriskDescriptorExtractor().compute(img, k)
-    got = ctx.debug_integral(0, 517, 333)
-    assert np.array_equal(got.astype(np.int64), O.integral(img).astype(np.int64) & 0xFFFFFFFF)
+def _integral_equals(ctx, got, want_u64):
+    """the engine keeps the integral image modulo 2^24 (3-byte elements) or as u32 (debug flag bit 18 forces that form)"""
+    bits = ctx.debug_integral_bits()
+    assert bits in (24, 32)
+    return np.array_equal(got.astype(np.uint64), want_u64 & ((1 << bits) - 1))
 
 
-def test_integral_kernel_wide_and_tall(B, ctx):
-    """More than one 2048-column chunk and more than one 64-row band (4K-style row length)."""
-    rng = np.random.default_rng(11)
-    for shape in ((150, 3840), (131, 2049), (65, 2047), (64, 4100)):
-        img = rng.integers(0, 256, shape, dtype=np.uint8)
+@pytest.mark.parametrize("force32", [False, True])
+def test_integral_kernel(B, ctx, golden_ast, force32):
+    ctx.debug_set_flags((1 << 18) if force32 else (1 << 24))   # (a descriptor-only call takes the 32-bit form by itself)
+    try:
+        img = golden_ast[0]["image"][:333, :517].copy()          # odd sizes
+        B.BriskDescriptorExtractor().compute(img, np.zeros(0, B.KEYPOINT))
         k = np.zeros(1, B.KEYPOINT)
-        k["x"], k["y"], k["size"], k["angle"] = shape[1] // 2, shape[0] // 2, 12, -1
+        k["x"], k["y"], k["size"], k["angle"] = 200, 150, 12, -1
         B.BriskDescriptorExtractor().compute(img, k)
-        got = ctx.debug_integral(0, shape[1], shape[0])
-        assert np.array_equal(got.astype(np.int64), O.integral(img).astype(np.int64) & 0xFFFFFFFF), shape
-    # the widest image the engine takes (four column chunks), tall and bright enough for the 32-bit sums to wrap
-    # around like the reference's int arithmetic does
-    img = rng.integers(200, 256, (2400, 8191), dtype=np.uint8)
-    k = np.zeros(1, B.KEYPOINT)
-    k["x"], k["y"], k["size"], k["angle"] = 4000, 1000, 12, -1
-    B.BriskDescriptorExtractor().compute(img, k)
-    got = ctx.debug_integral(0, 8191, 2400)
-    want = np.zeros((2401, 8192), np.uint64)
-    want[1:, 1:] = img.astype(np.uint64).cumsum(0).cumsum(1)
-    assert want.max() > 2 ** 32 and np.array_equal(got.astype(np.uint64), want & 0xFFFFFFFF)
+        assert ctx.debug_integral_bits() == (32 if force32 else 24)
+        got = ctx.debug_integral(0, 517, 333)
+        assert _integral_equals(ctx, got, O.integral(img).astype(np.int64).astype(np.uint64) & 0xFFFFFFFF)
+    finally:
+        ctx.debug_set_flags(0)
+
+
+@pytest.mark.parametrize("force32", [False, True])
+def test_integral_kernel_wide_and_tall(B, ctx, force32):
+    """More than one 2048-column chunk and more than one 64-row band (4K-style row length); both element sizes."""
+    ctx.debug_set_flags((1 << 18) if force32 else (1 << 24))
+    try:
+        rng = np.random.default_rng(11)
+        for shape in ((150, 3840), (131, 2049), (65, 2047), (64, 4100)):
+            img = rng.integers(0, 256, shape, dtype=np.uint8)
+            k = np.zeros(1, B.KEYPOINT)
+            k["x"], k["y"], k["size"], k["angle"] = shape[1] // 2, shape[0] // 2, 12, -1
+            B.BriskDescriptorExtractor().compute(img, k)
+            got = ctx.debug_integral(0, shape[1], shape[0])
+            assert _integral_equals(ctx, got, O.integral(img).astype(np.int64).astype(np.uint64) & 0xFFFFFFFF), shape
+        # the widest image the engine takes (four column chunks), tall and bright enough for the 32-bit sums to wrap
+        # around like the reference's int arithmetic does
+        img = rng.integers(200, 256, (2400, 8191), dtype=np.uint8)
+        k = np.zeros(1, B.KEYPOINT)
+        k["x"], k["y"], k["size"], k["angle"] = 4000, 1000, 12, -1
+        B.BriskDescriptorExtractor().compute(img, k)
+        got = ctx.debug_integral(0, 8191, 2400)
+        want = np.zeros((2401, 8192), np.uint64)
+        want[1:, 1:] = img.astype(np.uint64).cumsum(0).cumsum(1)
+        assert want.max() > 2 ** 32 and _integral_equals(ctx, got, want)
+    finally:
+        ctx.debug_set_flags(0)
 
 
 def test_batch_path_device_resident(B, ctx):

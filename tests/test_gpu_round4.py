@@ -71,6 +71,59 @@ def test_provided_keypoints_around_the_preparation_thresholds(B, n):
     ctx.close()
 
 
+@pytest.mark.parametrize("force32", [False, True])
+def test_descriptors_on_the_24_bit_and_the_32_bit_integral_image(B, force32):
+    """k_describe reads the integral image modulo 2^24 from 3-byte elements (gathers at byte offsets 3 x: any alignment) where
+    the pattern's boxes allow it, and from u32 elements otherwise (debug bit 18 forces that form): keypoints of every scale
+    index incl. the largest boxes (scale 63), widths whose 3-byte rows end at every alignment, both patterns."""
+    ctx = B.Context(0, max_candidates=65536, max_keypoints=32768)
+    ctx.debug_set_flags((1 << 18) if force32 else (1 << 24))   # (a descriptor-only call takes the 32-bit form by itself)
+    rng = np.random.default_rng(24)
+    for (w, h), version in (((1920, 1080), 2), ((1001, 587), 2), ((1283, 722), 1), ((641, 481), 2)):
+        img = synth.gen(w, h, w + h, max(8, w * h // 7000))
+        n = 6000
+        kp = np.zeros(n, B.KEYPOINT)
+        kp["size"] = np.exp(rng.uniform(np.log(8.64), np.log(260.0), n)).astype(np.float32)
+        kp["x"] = rng.uniform(0, w, n).astype(np.float32)
+        kp["y"] = rng.uniform(0, h, n).astype(np.float32)
+        kp["angle"] = np.where(rng.uniform(size=n) < 0.2, rng.uniform(0, 360, n), -1).astype(np.float32)
+        ext = B.BriskDescriptorExtractor(version=version, context=ctx)
+        k2, d2 = ext.compute(img, kp)
+        assert ctx.debug_integral_bits() == (32 if force32 else 24)
+        ko2, do = O.Extractor(version=version).compute(img, kp)
+        assert len(ko2) > 300 and same_kps(k2, ko2), (w, h, version, explain(k2, ko2))
+        assert np.array_equal(d2, do), (w, h, version)
+    ctx.close()
+
+
+def test_integral_format_follows_the_candidate_density_of_the_previous_batch(B):
+    """detect + describe batches keep the integral image in 3-byte elements while the context's previous batch was sparse
+    (at most 3 000 AGAST candidates per megapixel) and as u32 after a dense one; either way every slot equals the oracle."""
+    import torch
+    imgs = [synth.frame_1080p(820 + i) for i in range(4)]
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    X = O.Extractor()
+    want = {}
+    seen = []
+    for thr in (80, 80, 30, 30, 30, 80, 80):
+        ctx.detect_describe_batch(ext, d.data_ptr(), 4, 1920, 1080, 1920 * 1080, 1920, thr, 4, stream)
+        torch.cuda.synchronize()
+        assert ctx.batch_status(4) == 0
+        seen.append(ctx.debug_integral_bits(0))
+        if thr not in want:
+            ko = O.detect(imgs[1], thr, 4)
+            want[thr] = (ko,) + X.compute(imgs[1], ko)
+        kd, _ = ctx.batch_download(1, described=False)
+        kg, dg = ctx.batch_download(1, described=True)
+        assert same_kps(kd, want[thr][0]) and same_kps(kg, want[thr][1]) and np.array_equal(dg, want[thr][2]), (thr, seen)
+    # sparse, sparse, first dense batch still on the sparse format, then u32, and back after a sparse batch has been seen
+    assert seen == [24, 24, 24, 32, 32, 32, 24], seen
+    ctx.close()
+
+
 def test_uniformity_hashed_bins_dense_clusters(B):
     """k_uf_rank / k_uf_decide: 6 000 synthetic points in tight clusters (hundreds of points within reach of each other:
     long chains of decisions inside one wave), scores with many ties, several radii incl. the smallest (cells of 15 per

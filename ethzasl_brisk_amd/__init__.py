@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "brisk_hip_pattern_destroy", "brisk_hip_pattern_descriptor_size", "brisk_hip_pattern_points",
     "brisk_hip_pattern_tables", "brisk_hip_detect", "brisk_hip_describe", "brisk_hip_detect_describe_batch",
     "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
-    "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_debug_counters", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
+    "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_debug_counters", "brisk_hip_debug_counters_raw", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
     "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags", "brisk_hip_debug_image_reuse", "brisk_hip_set_bucketing", "brisk_hip_halfsample16", "brisk_hip_twothirdsample16",
     "brisk_hip_integral_image16",
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
@@ -98,6 +98,7 @@ def load_library():
     L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
     L.brisk_hip_debug_integral_bits.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_counters.argtypes = [vp, C.c_int, vp, ip]
+    L.brisk_hip_debug_counters_raw.argtypes = [vp, C.c_int, vp, C.c_int]
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_image_reuse.argtypes = [vp]
@@ -196,6 +197,14 @@ class Context:
         self.check(self._L.brisk_hip_debug_counters(self._h, frame, _ptr(out), C.byref(nl)))
         return {"candidates": int(out[0]), "keypoints": int(out[1]), "described": int(out[2]), "flags": int(out[3]),
                 "ties": [int(v) for v in out[4:4 + nl.value]], "experiment": [int(v) for v in out[20:28]]}
+
+    def debug_counters_raw(self, frame):
+        """the frame's counter record as int32 words (instrumented build variants append fields)"""
+        out = np.zeros(1024, np.int32)
+        n = self._L.brisk_hip_debug_counters_raw(self._h, frame, _ptr(out), out.nbytes)
+        if n < 0:
+            raise BriskHipError(-1, "brisk_hip_debug_counters_raw failed")
+        return out[:n // 4]
 
     def debug_integral(self, frame, w, h):
         """(h + 1) x (w + 1) u32: the integral image of the last describe, modulo 2 ** debug_integral_bits()"""
@@ -337,7 +346,7 @@ class BriskFeatureDetector:
             m = np.ascontiguousarray(mask, np.uint8)
             if m.shape != img.shape:
                 raise ValueError("mask must have the image's shape")
-        out = np.zeros(capacity, KEYPOINT)
+        out = np.empty(capacity, KEYPOINT)   # (records [0, n) are written by the call)
         n = C.c_int()
         c = self._ctx
         # the object's post-filter settings travel with the call (the context's own settings are neither used nor changed)

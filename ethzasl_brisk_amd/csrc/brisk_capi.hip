@@ -80,6 +80,11 @@ struct brisk_hip_ctx {
   // candidate density of the last detect + describe batch (k_batch_density writes it into pinned host memory; read without
   // synchronisation by the next batch: integral_format)
   long long* h_density = nullptr;
+  // results of a one-frame host-buffer call land here (pinned) behind the kernels: one wait per call (download_single)
+  uint8_t* h_res = nullptr;
+  int* d_pub_done = nullptr;  // k_publish_single: workgroups that have written their share
+  unsigned pub_seq = 0;       // sequence word of the last call (the host polls for it)
+  int spec_nkp = 1024;        // keypoints the next detect call is expected to return (sizes the publishing kernel's grid)
   double density_mpx = 0.0;  // megapixels per frame of the batch the word belongs to
   void* d_img16[3] = {nullptr, nullptr, nullptr};  // scratch of the 16-bit image functions (source, destination, row sums): grown, never shrunk
   size_t img16_bytes[3] = {0, 0, 0};
@@ -392,6 +397,8 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
   if (c->d_match) hipFree(c->d_match);
   for (int i = 0; i < 3; ++i) if (c->d_img16[i]) hipFree(c->d_img16[i]);
   if (c->h_density) hipHostFree(c->h_density);
+  if (c->h_res) hipHostFree(c->h_res);
+  if (c->d_pub_done) hipFree(c->d_pub_done);
   if (c->done_ev) hipEventDestroy(c->done_ev);
   for (int i = 0; i < 2; ++i) {
     if (c->d_hstage[i]) hipFree(c->d_hstage[i]);
@@ -971,6 +978,69 @@ static int download_locked(brisk_hip_ctx* ctx, int frame, int which, brisk_hip_k
   return BRISK_HIP_OK;
 }
 
+// Results of a ONE-frame host-buffer call (frame slot 0).  download_locked costs three blocking copies - the count, then
+// the keypoints, then the descriptor rows: 20 us each, a third of such a call on a 640 x 480 frame.  Here a small kernel
+// behind the call's kernels (k_publish_single) writes the counter record and the rows it announces straight into pinned
+// host memory and a sequence word behind them; the host polls that word (it changes a microsecond after the last store;
+// waking up from a stream wait takes ten) and copies out.  Results that do not fit the pinned buffer take download_locked.
+#define BRISK_SINGLE_BYTES (1u << 20)
+static int download_single(brisk_hip_ctx* ctx, int which, brisk_hip_keypoint* kps, int cap, int* n, uint8_t* desc,
+                           int desc_stride, int strings, int dev_pitch, int expect) {
+  const bool want_desc = desc && which;
+  if (!ctx->h_res) {
+    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_res, BRISK_SINGLE_BYTES, hipHostMallocCoherent));
+    memset(ctx->h_res, 0, 64);
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_pub_done, 64));
+    HIPCHK(ctx, hipMemset(ctx->d_pub_done, 0, 64));
+    HIPCHK(ctx, hipDeviceSynchronize());
+  }
+  const unsigned o_cnt = 64, o_kp = (unsigned)((o_cnt + sizeof(BriskFrameCounters) + 255) & ~(size_t)255);
+  const size_t row = sizeof(BriskKeyPoint) + (want_desc ? (size_t)dev_pitch : 0);
+  long max_kp = kps ? (long)((BRISK_SINGLE_BYTES - o_kp - 256) / row) : 0;
+  if (max_kp > cap) max_kp = cap;
+  if (max_kp > ctx->B.kp_cap) max_kp = ctx->B.kp_cap;
+  const unsigned o_desc = (unsigned)((o_kp + (size_t)max_kp * sizeof(BriskKeyPoint) + 63) & ~(size_t)63);
+  ctx->pub_seq = (ctx->pub_seq + 1) & 0x7FFFFFFFu;
+  if (!ctx->pub_seq) ctx->pub_seq = 1;
+  const unsigned seq = ctx->pub_seq;
+  brisk_launch_publish_single(ctx->B.counters, which ? ctx->D.dkp : ctx->B.kp_out, want_desc ? ctx->D.desc : nullptr, which, (int)max_kp,
+                              dev_pitch, expect < max_kp ? expect : (int)max_kp, ctx->h_res, o_cnt, o_kp, o_desc, ctx->d_pub_done, seq, ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(ctx->h_res);
+  unsigned v = 0;
+  for (unsigned spin = 1;; ++spin) {
+    v = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+    if ((v & 0x7FFFFFFFu) == seq) break;
+    if ((spin & 65535) == 0) {  // (about once per millisecond) a kernel that failed never writes the word
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) {
+        v = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+        if ((v & 0x7FFFFFFFu) == seq) break;
+        return fail(ctx, BRISK_HIP_ERR_HIP, "the result kernel finished without publishing");
+      }
+      if (q != hipErrorNotReady) HIPCHK(ctx, q);
+    }
+    __builtin_ia32_pause();
+  }
+  if (v & 0x80000000u) return download_locked(ctx, 0, which, kps, cap, n, desc, desc_stride, strings, dev_pitch);  // more than the pinned buffer holds
+  BriskFrameCounters c;
+  memcpy(&c, ctx->h_res + o_cnt, sizeof(c));
+  int rc = overflow_to_rc(ctx, c.overflow);
+  if (rc) return rc;
+  const int cnt = which ? c.ndesc : c.nkp;
+  if (n) *n = cnt;
+  if (!which) ctx->spec_nkp = cnt + cnt / 4 + 64;
+  if (!kps || cnt == 0) return BRISK_HIP_OK;
+  if (cnt > cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, want_desc ? "output descriptor buffer too small" : "output keypoint buffer too small");
+  memcpy(kps, ctx->h_res + o_kp, (size_t)cnt * sizeof(BriskKeyPoint));
+  if (want_desc) {
+    const uint8_t* src = ctx->h_res + o_desc;
+    if (dev_pitch == desc_stride && strings == desc_stride) memcpy(desc, src, (size_t)cnt * strings);
+    else for (int i = 0; i < cnt; ++i) memcpy(desc + (size_t)i * desc_stride, src + (size_t)i * dev_pitch, strings);
+  }
+  return BRISK_HIP_OK;
+}
+
 int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which, brisk_hip_keypoint* kps, int cap, int* n,
                              uint8_t* desc, int desc_stride) {
   if (!ctx) return BRISK_HIP_ERR_ARG;
@@ -1016,7 +1086,7 @@ static int detect_host(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int
   ctx->img_cache.ptr = img; ctx->img_cache.w = w; ctx->img_cache.h = h; ctx->img_cache.stride = stride;
   ctx->img_cache.hash = image_hash_reuse_enabled() ? image_sample_hash(img, w, h, stride) : 0;  // (while the GPU works)
   ctx->img_cache.l0_ext = ctx->last_l0_ext;
-  return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
+  return download_single(ctx, 0, out, cap, n, nullptr, 0, 0, 0, ctx->spec_nkp < cap ? ctx->spec_nkp : cap);
 }
 
 int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
@@ -1073,7 +1143,7 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
     rc = run_batch(ctx, nullptr, ctx->d_stage, 1, w, h, (long)img_bytes, pitch, threshold, octaves, nullptr, 0, 0, ctx->stream,
                    true, false, 0.0, 0x7FFFFFFF, !suppress_scale_nonmaxima, 0);
     if (rc) return rc;
-    return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
+    return download_single(ctx, 0, out, cap, n, nullptr, 0, 0, 0, ctx->spec_nkp < cap ? ctx->spec_nkp : cap);
   }
   make_geometry(w, h, threshold, octaves, &ctx->G, &ctx->T);
   ctx->G.debug_flags = ctx->debug_flags;
@@ -1091,7 +1161,7 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
   ctx->last_nframes = 1;
   ctx->last_has_desc = false;
   if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
-  return download_locked(ctx, 0, 0, out, cap, n, nullptr, 0, 0);
+  return download_single(ctx, 0, out, cap, n, nullptr, 0, 0, 0, ctx->spec_nkp < cap ? ctx->spec_nkp : cap);
 }
 
 static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
@@ -1160,7 +1230,7 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
   ctx->last_has_desc = true;
   ctx->last_desc_pitch = Dd.desc_pitch;
   if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
-  return download_locked(ctx, 0, 1, kps, n_in, n, desc, desc_stride, pat->host.strings, Dd.desc_pitch);
+  return download_single(ctx, 1, kps, n_in, n, desc, desc_stride, pat->host.strings, Dd.desc_pitch, n_in);
 }
 
 int brisk_hip_describe(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
@@ -1638,6 +1708,16 @@ int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlaye
   out[25] = c.nestimate;
   out[26] = c.orient_ticket; out[27] = c.desc_ticket;
   return BRISK_HIP_OK;
+}
+
+// experiments: the raw counter record of a frame (build variants append fields); returns its size
+int brisk_hip_debug_counters_raw(brisk_hip_ctx* ctx, int frame, void* out, int bytes) {
+  if (!ctx || !out) return -1;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (frame < 0 || frame >= ctx->slots || !ctx->B.counters || bytes < (int)sizeof(BriskFrameCounters)) return -1;
+  if (hipSetDevice(ctx->device) != hipSuccess || wait_own_work(ctx) != hipSuccess) return -1;
+  if (hipMemcpy(out, ctx->B.counters + frame, sizeof(BriskFrameCounters), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)sizeof(BriskFrameCounters);
 }
 
 }  // extern "C"

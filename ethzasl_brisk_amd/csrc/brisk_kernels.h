@@ -99,6 +99,9 @@ void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_
                            long iframe_elems, int band_h, int nframes, hipStream_t s, int ibits = 32,
                            BriskFrameCounters* counters = nullptr, int i24_max_cand = -1);
 // sum of the batch's candidate counts -> *host_word (pinned, mapped): candidates in bits 0-39, frames in bits 40-63
+void brisk_launch_publish_single(const BriskFrameCounters* counters, const BriskKeyPoint* kps, const uint8_t* desc, int which, int max_kp,
+                                 int dev_pitch, int expect, uint8_t* host, unsigned o_cnt, unsigned o_kp, unsigned o_desc, int* done,
+                                 unsigned seq, hipStream_t s);
 void brisk_launch_batch_density(const BriskFrameCounters* counters, int nframes, int cand_cap, long long* host_word, hipStream_t s);
 // kp_in: [slots][kp_cap]; n_in: per-frame counts at byte stride n_in_stride
 void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const BriskDetectBuffers& B,

@@ -1033,6 +1033,11 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 #else
 #define TR_T(i)
 #endif
+#ifdef TR_TIMELINE
+#define TR_STAMP(c_, l_, k_) if (c_) counters[frame].tl[(l_) * 8 + (k_)] = (int)wall_clock64();
+#else
+#define TR_STAMP(c_, l_, k_)
+#endif
 
 // Raster order of a layer's ties beyond the on-chip capacity, in O(n) (ranking by counting smaller keys took n^2 / 1024
 // steps per thread: 24 s for the 970 k ties of an all-tie 3645 x 2524 frame, 0.4 s now): ties counted per image row (LDS
@@ -1191,6 +1196,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
   for (int l = l0; l < l1; ++l) {
   int* const my_prog = &counters[frame].tie_prog[l];
   const int n = min(counters[frame].ntie[l], tie_cap);
+  TR_STAMP(tid == 0, l, 0)
   __syncthreads();  // (the previous layer's use of the on-chip arrays is over)
   if (n == 0 || skip_frame) {
     if (tid == 0) __hip_atomic_fetch_max(my_prog, TR_PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1296,6 +1302,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     // decision, which is exchanged through LDS (tstat); the window itself and the 5x5 score block of a wave's
     // NEXT tie are prefetched into registers while the current one is decided.
     int j = (wave < dwaves) ? wave : nc;
+    TR_STAMP(tid == 0, l, 1)
 #ifdef TR_TIMING
     int tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = (long long)wall_clock64();
@@ -1446,8 +1453,10 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
 #ifdef TR_TIMING
       tacc[6] += 1;
 #endif
+      TR_STAMP(tid == 0 && j == 0, l, 2)
       j += dwaves;
     }
+    TR_STAMP(tid == 0, l, 3)
     // ---- writer wave: decisions -> score-state map, candidate status, touches on the layer above; a tie counts as
     // done for the layer above once these are performed; the progress is the row of the first tie that is not done.
     // The deciding waves never wait for a memory write this way (an agent-scope atomic takes microseconds).
@@ -1512,7 +1521,9 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     // the touches are agent-scope atomics and the readers use L1-bypassing loads: completion of the atomics (vmcnt) +
     // the workgroup barrier is all the ordering the next chunk and the progress word need
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_STAMP(lane == 0 && wave == dwaves, l, 4)
     __syncthreads();
+    TR_STAMP(tid == 0, l, 5)
     if (tid == 0 && !last) {
       const int c1 = c0 + nc;
       const int row = (c1 < n) ? (int)((C[__hip_atomic_load(&list[c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)].key >> 13) & 0x1FFF) : TR_PROG_DONE;
@@ -1878,6 +1889,55 @@ __global__ void __launch_bounds__(256) k_batch_density(const BriskFrameCounters*
 }
 void brisk_launch_batch_density(const BriskFrameCounters* counters, int nframes, int cand_cap, long long* host_word, hipStream_t s) {
   hipLaunchKernelGGL(k_batch_density, dim3(1), dim3(256), 0, s, counters, nframes, cand_cap, host_word);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_publish_single: the results of a ONE-frame host-buffer call (frame slot 0) written straight into pinned host memory
+// by the device - counter record, the keypoints and descriptor rows the counters announce - and a sequence word behind
+// them that the host polls.  Replaces three blocking copies (count, keypoints, descriptor rows: 20 us each) by one small
+// kernel; the host sees the word a microsecond after the last store instead of waking up from a stream wait.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_publish_single(const BriskFrameCounters* __restrict__ counters, const BriskKeyPoint* __restrict__ kps,
+                                                        const uint8_t* __restrict__ desc, int which, int max_kp, int dev_pitch,
+                                                        uint8_t* host, unsigned o_cnt, unsigned o_kp, unsigned o_desc, int* done, unsigned seq) {
+  const int tid = threadIdx.x, gt = blockIdx.x * blockDim.x + tid, gn = gridDim.x * blockDim.x;
+  const int cnt = (counters[0].overflow & 7) ? 0 : (which ? counters[0].ndesc : counters[0].nkp);
+  const bool fits = cnt <= max_kp;
+  const int n = fits ? cnt : 0;
+  if (blockIdx.x == 0)
+    for (int i = tid; i < (int)(sizeof(BriskFrameCounters) / 4); i += blockDim.x)
+      reinterpret_cast<int*>(host + o_cnt)[i] = reinterpret_cast<const int*>(counters)[i];
+  {
+    const int* src = reinterpret_cast<const int*>(kps);
+    int* dst = reinterpret_cast<int*>(host + o_kp);
+    const int nd = n * (int)(sizeof(BriskKeyPoint) / 4);
+    for (int i = gt; i < nd; i += gn) dst[i] = src[i];
+  }
+  if (desc) {
+    const uint2* src = reinterpret_cast<const uint2*>(desc);
+    uint2* dst = reinterpret_cast<uint2*>(host + o_desc);
+    const long nd = (long)n * dev_pitch / 8;
+    for (long i = gt; i < nd; i += gn) dst[i] = src[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (int)gridDim.x - 1) {  // every workgroup's stores are out
+      __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(reinterpret_cast<unsigned*>(host), seq | (fits ? 0u : 0x80000000u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+void brisk_launch_publish_single(const BriskFrameCounters* counters, const BriskKeyPoint* kps, const uint8_t* desc, int which, int max_kp,
+                                 int dev_pitch, int expect, uint8_t* host, unsigned o_cnt, unsigned o_kp, unsigned o_desc, int* done,
+                                 unsigned seq, hipStream_t s) {
+  const long bytes = (long)expect * ((long)sizeof(BriskKeyPoint) + (desc ? dev_pitch : 0));
+  int grid = (int)((bytes + 16383) / 16384);
+  grid = grid < 1 ? 1 : (grid > 32 ? 32 : grid);
+  hipLaunchKernelGGL(k_publish_single, dim3(grid), dim3(256), 0, s, counters, kps, desc, which, max_kp, dev_pitch, host, o_cnt, o_kp, o_desc,
+                     done, seq);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -299,6 +299,9 @@ int brisk_hip_debug_filter_keypoints(brisk_hip_ctx* ctx, const brisk_hip_keypoin
 /* per-frame work counts of the last batch (tools only): out[0] candidates, out[1] keypoints, out[2] described
  * keypoints, out[3] overflow flags, out[4 + l] tie candidates of layer l, out[20 .. 27] experiment words; out holds 28 ints. */
 int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlayers);
+/* the raw counter record of a frame (tools only; instrumented build variants append fields): returns its size in bytes,
+ * -1 on error; `bytes` = size of out */
+int brisk_hip_debug_counters_raw(brisk_hip_ctx* ctx, int frame, void* out, int bytes);
 
 #ifdef __cplusplus
 }

@@ -704,12 +704,21 @@ BRISK_HD unsigned brisk_classify(const BriskLayerView& L, int x, int y, int cent
     const int nx = x + brisk_probe_dx(k), ny = y + brisk_probe_dy(k);
     int s = 0;
     if (!brisk_border3(L, nx, ny)) {
-      const int D = BRISK_SM_D(L.smap[(long)ny * L.stride + nx]);
-      if (D > 2) {
-        s = D;
+      if (DIRECT == 0) {
+        // The block value is D for a detection (D > 2) and K' otherwise (k_score_blocks), and the probe's value only
+        // matters where it reaches the centre: a detection's D below the centre changes nothing, whether it is kept or
+        // zeroed.  No map read, then - the eight of them, one after the other behind early exits, were 40 % of
+        // k_classify_refine's time (0.10 of 0.24 ms per 256 frames).
+        const int V = brisk_V<DIRECT>(L, nx, ny);
+        s = (V >= centre) ? V : 0;
       } else {
-        const int K = brisk_V<DIRECT>(L, nx, ny);  // == K' for a non-detection
-        s = (K >= centre) ? K : 0;
+        const int D = BRISK_SM_D(L.smap[(long)ny * L.stride + nx]);
+        if (D > 2) {
+          s = D;
+        } else {
+          const int K = brisk_V<DIRECT>(L, nx, ny);  // == K' for a non-detection
+          s = (K >= centre) ? K : 0;
+        }
       }
     }
     if (centre < s) {

@@ -2082,7 +2082,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   // blocks per frame: few for large batches (every block then walks several rounds of its frame's candidates on one
   // XCD), many for small ones (a single frame must spread over the chip)
   static const int sb_knob = env_knob("BRISK_SB_BLOCKS", 0), cr_knob = env_knob("BRISK_CR_BLOCKS", 0);
-  const int sb_blocks = sb_knob ? sb_knob : (nframes >= 64 ? 32 : 256), cr_blocks = cr_knob ? cr_knob : (nframes >= 64 ? 16 : 64);
+  const int sb_blocks = sb_knob ? sb_knob : (nframes >= 64 ? 32 : 256), cr_blocks = cr_knob ? cr_knob : (nframes >= 64 ? 24 : 64);
   {
     const int sb_bpf = grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, sb_blocks), cr_bpf = grid_for(B.cand_cap, 64, cr_blocks);
     hipLaunchKernelGGL(k_score_blocks, dim3(xcd_grid(nframes, sb_bpf)), dim3(SB_WAVES * 64), 0, s, G, B.pyr, B.smap, B.cand,

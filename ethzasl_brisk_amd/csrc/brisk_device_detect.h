@@ -419,7 +419,9 @@ struct BriskQuadric {
   int A, B, C, D, E, F;
 };
 BRISK_HD float brisk_quadric_at(const BriskQuadric& q, float x, float y) {
-  return (float)((q.A * x * x + q.B * y * y + q.C * x + q.D * y + q.E * x * y + q.F) / 18.0);
+  // (/ 18.0 in double, rounded to float, in the reference: the float division gives the same float for every float
+  // dividend - tools/verify_float_division.c; the dividend is a float expression there as well)
+  return (q.A * x * x + q.B * y * y + q.C * x + q.D * y + q.E * x * y + q.F) / 18.0f;
 }
 BRISK_HD float brisk_clamp_unit(float v) { return v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v); }
 
@@ -440,7 +442,7 @@ BRISK_HD_OUTLINE float brisk_subpixel2d(const int s_0_0, const int s_0_1, const 
   if (det == 0) {
     delta_x = 0.0f;
     delta_y = 0.0f;
-    return (float)((float)q.F / 18.0);
+    return (float)q.F / 18.0f;
   }
   if (!(det > 0 && q.A < 0)) {  // no maximum inside: the best of the four corners, first one wins a draw
     int best = q.C + q.D + q.E;
@@ -451,7 +453,7 @@ BRISK_HD_OUTLINE float brisk_subpixel2d(const int s_0_0, const int s_0_1, const 
       const int v = sx[k] * q.C + sy[k] * q.D + sx[k] * sy[k] * q.E;
       if (v > best) { best = v; delta_x = (float)sx[k]; delta_y = (float)sy[k]; }
     }
-    return (float)((float)(best + q.A + q.B + q.F) / 18.0);
+    return (float)(best + q.A + q.B + q.F) / 18.0f;
   }
   delta_x = (float)(2 * q.B * q.C - q.D * q.E) / (float)(-det);
   delta_y = (float)(2 * q.A * q.D - q.C * q.E) / (float)(-det);
@@ -546,8 +548,9 @@ BRISK_HD float brisk_scale_fit(const BriskScaleFit& f, const float s_below, cons
   else if (r > f.hi) r = f.clamp_hi;
   const int c = f.c[0] * v[0] + f.c[1] * v[1] + f.c[2] * v[2];
   max = (float)c + (float)a * r * r + (float)b * r;
-  if (f.float_division) max = max / (float)(int)f.denom;
-  else max = (float)(max / f.denom);
+  // (Refine1D_2 divides in float, the other two by 3072.0 / 2048.0 in double and round to float: the same float, a power of
+  // two exactly and 3072 by tools/verify_float_division.c)
+  max = max / (float)(int)f.denom;
   return r;
 }
 // Refine1D (:1101-1143), Refine1D_1 (:1145-1186), Refine1D_2 (:1188-1228)
@@ -577,13 +580,15 @@ BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above,
                                      BriskTouch* t) {
   const int threshold = thr + BRISK_DROP_THRESHOLD;
   ismax = false;
+  // (the reference divides by 6.0 and 4.0 in double and rounds the quotient to float; for a float dividend that equals the
+  // float division - every finite float checked, tools/verify_float_division.c - which costs a third of the double one here)
   float x_1, x1, y_1, y1;
   if (above) {
     if (!odd) {
-      x_1 = (float)((float)(4 * (x_layer)-1 - 2) / 6.0);
-      x1 = (float)((float)(4 * (x_layer)-1 + 2) / 6.0);
-      y_1 = (float)((float)(4 * (y_layer)-1 - 2) / 6.0);
-      y1 = (float)((float)(4 * (y_layer)-1 + 2) / 6.0);
+      x_1 = (float)(4 * (x_layer)-1 - 2) / 6.0f;
+      x1 = (float)(4 * (x_layer)-1 + 2) / 6.0f;
+      y_1 = (float)(4 * (y_layer)-1 - 2) / 6.0f;
+      y1 = (float)(4 * (y_layer)-1 + 2) / 6.0f;
     } else {
       x_1 = (float)(6 * (x_layer)-1 - 3) / 8.0f;
       x1 = (float)(6 * (x_layer)-1 + 3) / 8.0f;
@@ -592,15 +597,15 @@ BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above,
     }
   } else {
     if (!odd) {
-      x_1 = (float)((float)(8 * (x_layer) + 1 - 4) / 6.0);
-      x1 = (float)((float)(8 * (x_layer) + 1 + 4) / 6.0);
-      y_1 = (float)((float)(8 * (y_layer) + 1 - 4) / 6.0);
-      y1 = (float)((float)(8 * (y_layer) + 1 + 4) / 6.0);
+      x_1 = (float)(8 * (x_layer) + 1 - 4) / 6.0f;
+      x1 = (float)(8 * (x_layer) + 1 + 4) / 6.0f;
+      y_1 = (float)(8 * (y_layer) + 1 - 4) / 6.0f;
+      y1 = (float)(8 * (y_layer) + 1 + 4) / 6.0f;
     } else {
-      x_1 = (float)((float)(6 * (x_layer) + 1 - 3) / 4.0);
-      x1 = (float)((float)(6 * (x_layer) + 1 + 3) / 4.0);
-      y_1 = (float)((float)(6 * (y_layer) + 1 - 3) / 4.0);
-      y1 = (float)((float)(6 * (y_layer) + 1 + 3) / 4.0);
+      x_1 = (float)(6 * (x_layer) + 1 - 3) / 4.0f;
+      x1 = (float)(6 * (x_layer) + 1 + 3) / 4.0f;
+      y_1 = (float)(6 * (y_layer) + 1 - 3) / 4.0f;
+      y1 = (float)(6 * (y_layer) + 1 + 3) / 4.0f;
     }
   }
   if (t->on) {
@@ -894,8 +899,8 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
   const bool upwards = rel_scale > 1.0;
   const double wa = upwards ? (intra ? 4.0 : 1.5) : (cls == 0 ? -0.5 : intra ? -2.0 : -0.75);
   const double wb = upwards ? (intra ? -3.0 : -1.0) : (intra ? 3.0 : 1.0);
-  const double wc = intra ? 1.0 : ((upwards || cls == 0) ? 0.5 : 0.25);
-  const float w_own = (float)((wa + wb * rel_scale) / wc);
+  const double inv_wc = intra ? 1.0 : ((upwards || cls == 0) ? 2.0 : 4.0);  // (divisors 1, 0.5, 0.25: exact either way)
+  const float w_own = (float)((wa + wb * rel_scale) * inv_wc);
   const float w_nb = (float)(1.0 - w_own);
   const float nb_dx = upwards ? up_dx : dn_dx, nb_dy = upwards ? up_dy : dn_dy;
   // (octave 0: scale 1, offset 0 - the reference leaves them out where it interpolates downwards, the same value)

@@ -996,7 +996,9 @@ static int download_single(brisk_hip_ctx* ctx, int which, brisk_hip_keypoint* kp
   }
   const unsigned o_cnt = 64, o_kp = (unsigned)((o_cnt + sizeof(BriskFrameCounters) + 255) & ~(size_t)255);
   const size_t row = sizeof(BriskKeyPoint) + (want_desc ? (size_t)dev_pitch : 0);
-  long max_kp = kps ? (long)((BRISK_SINGLE_BYTES - o_kp - 256) / row) : 0;
+  // (debug bit 25: a 16 KB limit, so that tests reach the staged-copy path with a few hundred keypoints)
+  const size_t limit = (ctx->debug_flags & (1 << 25)) ? (size_t)o_kp + 256 + 16384 : (size_t)BRISK_SINGLE_BYTES;
+  long max_kp = kps ? (long)((limit - o_kp - 256) / row) : 0;
   if (max_kp > cap) max_kp = cap;
   if (max_kp > ctx->B.kp_cap) max_kp = ctx->B.kp_cap;
   const unsigned o_desc = (unsigned)((o_kp + (size_t)max_kp * sizeof(BriskKeyPoint) + 63) & ~(size_t)63);

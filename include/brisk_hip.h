@@ -281,7 +281,8 @@ const char* brisk_hip_kernel_revision(void);
 /* which: 0 pyramid image, 1 score-state map low byte (D), after the last detect on frame slot 0.
  * Copies layer `layer` (w x h, tightly packed u8) to the host buffer. */
 int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, uint8_t* out, int* w, int* h);
-/* test knobs: bit0 = route every AGAST candidate through the direct-evaluation safety-net kernel */
+/* test knobs: bit0 = route every AGAST candidate through the direct-evaluation safety-net kernel; bit 25 = the pinned
+ * result buffer of the one-frame host calls holds 16 KB only (results beyond it take the staged copies) */
 int brisk_hip_debug_set_flags(brisk_hip_ctx* ctx, int flags);
 /* integral image of frame slot `frame` after the last describe: (h+1) x (w+1) u32, tightly packed.  The engine keeps it
  * modulo 2^24 in 3-byte elements where the pattern's boxes are small enough for that (every built-in pattern; the values

@@ -214,3 +214,30 @@ def test_config3_512_frames_through_the_c_abi_gather_on_one_rank(B):
         assert all(cnts[f] == cnts[f % nd] for f in range(n))
     ctx._L.brisk_hip_comm_destroy(g.comm)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_one_frame_results_beyond_the_pinned_buffer(B):
+    """The results of a one-frame host call are published into pinned memory by a kernel (download_single); what does not
+    fit takes the staged copies.  Debug bit 25 shrinks the buffer to 16 KB: both paths must return the same bytes."""
+    import synth
+    img = synth.frame_1080p(3)
+    ctx = B.Context(0)
+    det = B.BriskFeatureDetector(80, 4, context=ctx)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    k0 = det.detect(img)
+    k0d, d0 = ext.compute(img, k0)
+    assert len(k0) > 16384 // 28 and len(k0d) > 16384 // 76   # (more than the small buffer holds)
+    ctx.debug_set_flags(1 << 25)
+    try:
+        k1 = det.detect(img)
+        k1d, d1 = ext.compute(img, k1)
+        # a few keypoints: fits the small buffer too (the publishing path with the flag set)
+        k2d, d2 = ext.compute(img, k0[:100])
+    finally:
+        ctx.debug_set_flags(0)
+    k3d, d3 = ext.compute(img, k0[:100])
+    assert k0.tobytes() == k1.tobytes()
+    assert k0d.tobytes() == k1d.tobytes() and np.array_equal(d0, d1)
+    assert k2d.tobytes() == k3d.tobytes() and np.array_equal(d2, d3)
+    ctx.close()

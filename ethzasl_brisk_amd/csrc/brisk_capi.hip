@@ -1021,6 +1021,7 @@ static int download_single(brisk_hip_ctx* ctx, int which, brisk_hip_keypoint* kp
         return fail(ctx, BRISK_HIP_ERR_HIP, "the result kernel finished without publishing");
       }
       if (q != hipErrorNotReady) HIPCHK(ctx, q);
+      (void)hipGetLastError();  // ("not ready" is no error of this call: do not leave it for a later hipGetLastError())
     }
     __builtin_ia32_pause();
   }

@@ -112,6 +112,9 @@ struct BriskFrameCounters {
   int low_score;                    // k_detect stored a detection score <= 2 (possible below threshold 20 only): the frame takes the ordered path
   int i24;                          // k_integral_final wrote this frame's integral image in 3-byte elements (k_describe reads it accordingly)
   int pad[2];
+#ifdef TR_TIMING  // experiments (build variant): per-phase time of k_tie_resolve's decision loop (tools/tie_phases.py)
+  int tphase[8];
+#endif
 #ifdef TR_TIMELINE  // experiments (build variant): wall-clock stamps of k_tie_resolve per layer (tools/tie_timeline.py)
   int tl[BRISK_MAX_LAYERS * 8];
 #endif

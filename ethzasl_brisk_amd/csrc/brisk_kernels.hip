@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 #define TR_PROG_DONE 0x7FFFFFFF
 #define TR_DONE_BIT 4
 #define TR_BM_WORDS 512  // 16384 cells of 8x8 pixels (or 16x16, ... for larger layers)
-#ifdef TR_TIMING  // experiments: per-phase time of the decision loop (10 ns units) summed into counters[frame].pad[]
+#ifdef TR_TIMING  // experiments: per-phase time of the decision loop (10 ns units) summed into counters[frame].tphase[]
 #define TR_T(i) { const long long now_ = (long long)wall_clock64(); tacc[i] += (int)(now_ - tlast); tlast = now_; }
 #else
 #define TR_T(i)
@@ -1511,7 +1511,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t
     }
 #ifdef TR_TIMING
     if (lane == 0 && wave < dwaves)
-      for (int i = 0; i < 8; ++i) atomicAdd(&counters[frame].pad[i], tacc[i]);
+      for (int i = 0; i < 8; ++i) atomicAdd(&counters[frame].tphase[i], tacc[i]);
 #endif
 #undef TR_TRY_PREFETCH
 #undef TR_POLL

@@ -6,7 +6,7 @@ import sys
 flags = sys.argv[1] if len(sys.argv) > 1 else "0"
 for batch in [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "16,24,32,48,64,128,256").split(",")]:
     inner = max(1, 2048 // batch)
-    out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-host-fed", "--steps", "3", "--warmup", "1", "--batch", str(batch),
+    out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-host-fed", "--no-other-configs", "--steps", "3", "--warmup", "1", "--batch", str(batch),
                           "--inner", str(inner), "--debug-flags", flags], capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])

@@ -30,7 +30,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 ms, _ = ctx.profile_read()
 c = ctx.debug_counters(0)
-e = c["experiment"]
+e = [int(v) for v in ctx.debug_counters_raw(0)[48:56]]   # BriskFrameCounters::tphase (TR_TIMING build)
 names = ["resolve -> decision", "layer-below need + poll", "next prefetch issue", "window -> LDS + search",
          "spin on earlier ties", "static replay", None, "wait for the layer below + window read"]
 print("thr %d, %d frames: k_tie_resolve %.3f ms; frame 0 ties %s" % (thr, n, ms.get("k_tie_resolve", 0), c["ties"]))

@@ -391,19 +391,23 @@ BRISK_HD int brisk_Vt(const BriskLayerView& L, int x, int y, BriskTouch* t) {
 
 // GetAgastScore(float, float, 1) (brisk-layer.cc:147-161): bilinear blend of 4 integer scores,
 // all four always evaluated (and touched), result truncated to u8.
+// (the blend itself, shared with the block form of GetScoreMaxAbove below: rx1 / ry1 = fractional parts of the position)
+BRISK_HD int brisk_bilinear_u8(const float rx1, const float ry1, const int s00, const int s10, const int s01, const int s11) {
+  const float rx = 1.0f - rx1;
+  const float ry = 1.0f - ry1;
+  return (int)(uint8_t)(rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11);
+}
 template <int DIRECT>
 BRISK_HD int brisk_Vf(const BriskLayerView& L, float xf, float yf, BriskTouch* t) {
   const int x = (int)xf;
   const float rx1 = xf - (float)x;
-  const float rx = 1.0f - rx1;
   const int y = (int)yf;
   const float ry1 = yf - (float)y;
-  const float ry = 1.0f - ry1;
   const int s00 = brisk_Vt<DIRECT>(L, x, y, t);
   const int s10 = brisk_Vt<DIRECT>(L, x + 1, y, t);
   const int s01 = brisk_Vt<DIRECT>(L, x, y + 1, t);
   const int s11 = brisk_Vt<DIRECT>(L, x + 1, y + 1, t);
-  return (int)(uint8_t)(rx * ry * s00 + rx1 * ry * s10 + rx * ry1 * s01 + rx1 * ry1 * s11);
+  return brisk_bilinear_u8(rx1, ry1, s00, s10, s01, s11);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -685,6 +689,137 @@ BRISK_HD float brisk_score_max_other(const BriskLayerView& Lo, const bool above,
 }
 
 // ---------------------------------------------------------------------------------------------
+// GetScoreMaxAbove on the candidate's 4 x 4 score block of the layer above (k_classify_refine: DIRECT == 0).  The same
+// function as brisk_score_max_other<0>(above = true), restated for what is known there: the window is less than a pixel
+// wide (4/6 or 6/8 of one), so its sample grid has two or three lines each way - border lines at the fractional window
+// ends, at most one integer line between them -, every sample's taps lie in block rows / columns 1 ... 3 and the 3 x 3
+// patch around the maximum inside the block.  The generic routine walks that grid with a bounds-checked, touch-recording
+// block lookup per tap (about 130 instructions per bilinear sample); here a block row is a register, a tap is a bit-field
+// extract, and a sample's touches are a 2 x 2 bit pattern masked with the pixels that are off the layer's 3-pixel border.
+// Same scan order and abort rule (a sample above centre + drop threshold ends the scan, except on the last grid row; the
+// touches of the samples before it stay), same first-wins maximum, same float expressions.  An assumption that does not
+// hold raises the miss flag (the candidate is then redone by k_classify_refine_direct); tests/emul checks the two forms
+// against each other on random blocks.
+// ---------------------------------------------------------------------------------------------
+BRISK_HD uint32_t brisk_blk_row(const BriskScoreBlock& b, int r) { return r < 2 ? (r == 0 ? b.w0 : b.w1) : (r == 2 ? b.w2 : b.w3); }
+BRISK_HD float brisk_score_max_above_blk(const BriskLayerView& Lo, const bool odd, const int x_layer, const int y_layer,
+                                         const int thr, bool& ismax, float& dx, float& dy, BriskTouch* t) {
+  const int threshold = thr + BRISK_DROP_THRESHOLD;
+  ismax = false;
+  float x_1, x1, y_1, y1;
+  if (!odd) {
+    x_1 = (float)(4 * (x_layer)-1 - 2) / 6.0f;
+    x1 = (float)(4 * (x_layer)-1 + 2) / 6.0f;
+    y_1 = (float)(4 * (y_layer)-1 - 2) / 6.0f;
+    y1 = (float)(4 * (y_layer)-1 + 2) / 6.0f;
+  } else {
+    x_1 = (float)(6 * (x_layer)-1 - 3) / 8.0f;
+    x1 = (float)(6 * (x_layer)-1 + 3) / 8.0f;
+    y_1 = (float)(6 * (y_layer)-1 - 3) / 8.0f;
+    y1 = (float)(6 * (y_layer)-1 + 3) / 8.0f;
+  }
+  const int ax = (int)x_1 - 1, ay = (int)y_1 - 1;  // block / footprint anchor
+  if (t->on) {
+    t->x0 = ax;
+    t->y0 = ay;
+  }
+  const int xs = (int)(x_1 + 1), xe = (int)x1, ys = (int)(y_1 + 1), ye = (int)y1;
+  const int nix = brisk_max(xe - xs + 1, 0), niy = brisk_max(ye - ys + 1, 0);
+  if (Lo.blk.cw != 4 || Lo.blk.ch != 4 || Lo.blk.x0 != ax || Lo.blk.y0 != ay || xs != ax + 2 || ys != ay + 2 || nix > 1 || niy > 1 ||
+      xe < ax + 1 || ye < ay + 1) {
+    Lo.miss = 1;
+    return 0;
+  }
+  // pixels of the block that a touch records (off the layer's 3-pixel border), as a 4 x 4 bit mask
+  unsigned okm = 0;
+  if (t->on) {
+    unsigned colm = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) colm |= (ax + b >= 3 && ax + b < Lo.w - 3) ? (1u << b) : 0u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) okm |= (ay + b >= 3 && ay + b < Lo.h - 3) ? (colm << (4 * b)) : 0u;
+  }
+  const uint32_t W1 = Lo.blk.w1, W2 = Lo.blk.w2, W3 = Lo.blk.w3;
+  unsigned touched = 0;
+  bool aborted = false, first = true;
+  int max_x = xs, max_y = ys;
+  float max = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const bool rlast = (r == niy + 1), rex = (r <= niy + 1), rborder = (r == 0 || rlast);
+    const float yf = (r == 0) ? y_1 : (rlast ? y1 : (float)ys);
+    const int ylab = (r == 0) ? ys : (rlast ? ye : ys);
+    const int iy = (int)yf - ay;  // 1 or 2
+    const uint32_t wa = (iy == 1) ? W1 : W2, wb = (iy == 1) ? W2 : W3;
+    const float ry1 = yf - (float)(int)yf;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bool jlast = (j == nix + 1), jex = (j <= nix + 1), jborder = (j == 0 || jlast);
+      const float xf = (j == 0) ? x_1 : (jlast ? x1 : (float)xs);
+      const int xlab = (j == 0) ? xs : (jlast ? xe : xs);
+      const int ix = (int)xf - ax;  // 1 or 2
+      float v;
+      unsigned tb;
+      if (rborder || jborder) {
+        const int sh = 8 * ix;
+        const int s00 = (int)((wa >> sh) & 0xFFu), s10 = (int)((wa >> (sh + 8)) & 0xFFu);
+        const int s01 = (int)((wb >> sh) & 0xFFu), s11 = (int)((wb >> (sh + 8)) & 0xFFu);
+        v = (float)brisk_bilinear_u8(xf - (float)(int)xf, ry1, s00, s10, s01, s11);
+        tb = 0x33u << (4 * iy + ix);
+      } else {  // the one inner sample (xs, ys) = block position (2, 2)
+        v = (float)(int)((W2 >> 16) & 0xFFu);
+        tb = 1u << 10;
+      }
+      if (rex && jex && !aborted) {
+        touched |= tb & okm;
+        if (!rlast && v > threshold) {
+          aborted = true;
+        } else if (first) {
+          max = v;
+          first = false;
+        } else if (v > max) {
+          max = v;
+          max_x = xlab;
+          if (r != 0) max_y = ylab;
+        }
+      }
+    }
+  }
+  if (aborted) {
+    t->mask |= touched;
+    return 0;
+  }
+  // 3 x 3 patch around the maximum: block columns ox ... ox + 2, rows oy ... oy + 2 (ox, oy in {0, 1})
+  const int ox = max_x - 1 - ax, oy = max_y - 1 - ay;
+  const int psh = 8 * ox;
+  const uint32_t p0 = brisk_blk_row(Lo.blk, oy) >> psh, p1 = brisk_blk_row(Lo.blk, oy + 1) >> psh, p2 = brisk_blk_row(Lo.blk, oy + 2) >> psh;
+  touched |= (0x777u << (4 * oy + ox)) & okm;
+  t->mask |= touched;
+  float dx_1, dy_1;
+  // s_x_y: column x, row y
+  const float refined_max = brisk_subpixel2d((int)(p0 & 0xFFu), (int)(p1 & 0xFFu), (int)(p2 & 0xFFu), (int)((p0 >> 8) & 0xFFu),
+                                             (int)((p1 >> 8) & 0xFFu), (int)((p2 >> 8) & 0xFFu), (int)((p0 >> 16) & 0xFFu),
+                                             (int)((p1 >> 16) & 0xFFu), (int)((p2 >> 16) & 0xFFu), dx_1, dy_1);
+  const float real_x = (float)max_x + dx_1;
+  const float real_y = (float)max_y + dy_1;
+  bool returnrefined = true;
+  if (!odd) {
+    dx = (real_x * 6.0f + 1.0f) / 4.0f - (float)x_layer;
+    dy = (real_y * 6.0f + 1.0f) / 4.0f - (float)y_layer;
+  } else {
+    dx = (float)((real_x * 8.0 + 1.0) / 6.0 - (float)x_layer);
+    dy = (float)((real_y * 8.0 + 1.0) / 6.0 - (float)y_layer);
+  }
+  if (dx > 1.0f) { dx = 1.0f; returnrefined = false; }
+  if (dx < -1.0f) { dx = -1.0f; returnrefined = false; }
+  if (dy > 1.0f) { dy = 1.0f; returnrefined = false; }
+  if (dy < -1.0f) { dy = -1.0f; returnrefined = false; }
+  ismax = true;
+  if (returnrefined) return refined_max > max ? refined_max : max;
+  return max;
+}
+
+// ---------------------------------------------------------------------------------------------
 // IsMax2D steps 1-2 (brisk-scale-space.cc:430-498): history-free classification.
 // Probe order W, E, N, S, SW, SE, NE, NW with early exit.
 // ---------------------------------------------------------------------------------------------
@@ -857,7 +992,8 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
   bool ismax = true;
   float up_dx = 0, up_dy = 0;
   touch->on = true;
-  const float up_peak = brisk_score_max_other<DIRECT>(Labove, true, intra, x_layer, y_layer, own_score, ismax, up_dx, up_dy, touch);
+  const float up_peak = (DIRECT == 0) ? brisk_score_max_above_blk(Labove, intra, x_layer, y_layer, own_score, ismax, up_dx, up_dy, touch)
+                                      : brisk_score_max_other<DIRECT>(Labove, true, intra, x_layer, y_layer, own_score, ismax, up_dx, up_dy, touch);
   if (!ismax) return false;
 
   float dn_peak, dn_dx, dn_dy;

@@ -457,6 +457,54 @@ int emul_state_split_mismatches(unsigned seed, int n) {
   return bad;
 }
 
+// The block form of GetScoreMaxAbove (brisk_score_max_above_blk, what k_classify_refine runs) against the generic
+// brisk_score_max_other<0>(above = true) on random 4 x 4 score blocks: candidates anywhere on random layers (incl. next to
+// the borders, where touches are not recorded and the block holds zeros), both layer parities, centre scores around the
+// block's values so that the abort rule fires at every grid position.  Everything the caller sees is compared: the value,
+// ismax, the offsets (bit patterns), the touch record and the miss flag.  Returns mismatches.
+int emul_score_max_above_blk_mismatches(unsigned seed, int n, int* stats /* 4: maxima, aborted scans, misses, touch masks that differ from 0 */) {
+  auto rnd = [&seed]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+  int bad = 0;
+  for (int it = 0; it < n; ++it) {
+    const bool odd = rnd() & 1;
+    // the layer above: w x h; the candidate (x, y) on the layer below it, anywhere the detector can place one
+    BriskLayerView La;
+    memset(&La, 0, sizeof(La));
+    La.w = 8 + (int)(rnd() % 60);
+    La.h = 8 + (int)(rnd() % 60);
+    La.stride = La.w;
+    // own layer is 1.5 (even -> odd above) or 4/3 (odd -> even above) times as large; keep the window inside [0, w)
+    const int ow = odd ? (La.w * 4) / 3 : (La.w * 3) / 2, oh = odd ? (La.h * 4) / 3 : (La.h * 3) / 2;
+    const int x = 3 + (int)(rnd() % (unsigned)brisk_max(ow - 6, 1)), y = 3 + (int)(rnd() % (unsigned)brisk_max(oh - 6, 1));
+    int ax, ay;
+    brisk_block_anchor(true, odd, x, y, &ax, &ay);
+    uint8_t vals[16];
+    const unsigned mode = rnd() % 4;
+    const int base = (int)(rnd() % 200);
+    for (int q = 0; q < 16; ++q) {
+      const int px = ax + (q & 3), py = ay + (q >> 2);
+      int v = mode == 0 ? (int)(rnd() % 256) : mode == 1 ? base + (int)(rnd() % 12) : mode == 2 ? ((rnd() % 3) ? base : base + (int)(rnd() % 40)) : (int)(rnd() % 8);
+      if (px < 3 || py < 3 || px >= La.w - 3 || py >= La.h - 3) v = 0;  // (k_score_blocks: 0 on the border)
+      vals[q] = (uint8_t)brisk_min(v, 255);
+    }
+    BriskLayerView A = La, B = La;
+    brisk_block_from_bytes(&A.blk, vals, 16, ax, ay, 4, 4);
+    brisk_block_from_bytes(&B.blk, vals, 16, ax, ay, 4, 4);
+    const int thr = mode == 1 || mode == 2 ? base - 8 + (int)(rnd() % 20) : (int)(rnd() % 256);
+    BriskTouch ta, tb;
+    ta.on = tb.on = true; ta.mask = tb.mask = 0; ta.x0 = tb.x0 = 0; ta.y0 = tb.y0 = 0;
+    bool ia = true, ib = true;
+    float dxa = 0, dya = 0, dxb = 0, dyb = 0;
+    const float ra = brisk_score_max_other<0>(A, true, odd, x, y, thr, ia, dxa, dya, &ta);
+    const float rb = brisk_score_max_above_blk(B, odd, x, y, thr, ib, dxb, dyb, &tb);
+    const bool same = ia == ib && memcmp(&ra, &rb, 4) == 0 && (!ia || (memcmp(&dxa, &dxb, 4) == 0 && memcmp(&dya, &dyb, 4) == 0)) &&
+                      ta.mask == tb.mask && ta.x0 == tb.x0 && ta.y0 == tb.y0 && A.miss == B.miss;
+    if (!same) ++bad;
+    if (stats) { stats[0] += ia ? 1 : 0; stats[1] += ia ? 0 : 1; stats[2] += A.miss ? 1 : 0; stats[3] += ta.mask ? 1 : 0; }
+  }
+  return bad;
+}
+
 // brisk_block_anchor uses integer quotients where brisk_score_max_other (and the reference, brisk-scale-space.cc:786-801,
 // 946-962) truncates float quotients: identical for every coordinate the engine admits
 int emul_block_anchor_mismatches(void) {

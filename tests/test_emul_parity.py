@@ -6,6 +6,7 @@ history-free refinement, order-faithful tie replay, factorised pattern tables, b
 the oracle, so that GPU minutes are only spent on GPU-specific behaviour.  The emulation is test
 infrastructure, never loaded by the product.
 """
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -186,6 +187,16 @@ def test_tie_pipeline_row_bound_covers_every_touch_footprint():
         img = np.ascontiguousarray(img)
         h, w = img.shape
         assert L.emul_tie_rows_needed_violations(img.ctypes.data, w, h, thr, octv) == 0
+
+
+def test_block_form_of_score_max_above_equals_the_generic_one():
+    """k_classify_refine's GetScoreMaxAbove on the 4 x 4 block (brisk_score_max_above_blk) vs brisk_score_max_other<0>."""
+    L = E.lib()
+    L.emul_score_max_above_blk_mismatches.argtypes = [C.c_uint, C.c_int, C.c_void_p]
+    stats = np.zeros(4, np.int32)
+    assert L.emul_score_max_above_blk_mismatches(5, 3000000, stats.ctypes.data_as(C.c_void_p)) == 0
+    # the cases cover both outcomes and recorded touches; the block always covers the accesses
+    assert stats[0] > 500000 and stats[1] > 500000 and stats[2] == 0 and stats[3] > 1000000, stats
 
 
 def test_block_anchor_integer_quotients_equal_the_float_ones():

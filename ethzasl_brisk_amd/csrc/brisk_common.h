@@ -115,6 +115,9 @@ struct BriskFrameCounters {
 #ifdef TR_TIMING  // experiments (build variant): per-phase time of k_tie_resolve's decision loop (tools/tie_phases.py)
   int tphase[8];
 #endif
+#ifdef CR_TIMING  // experiments (build variant): per-phase lane time of k_classify_refine (tools/classify_phases.py)
+  int cphase[8];
+#endif
 #ifdef TR_TIMELINE  // experiments (build variant): wall-clock stamps of k_tie_resolve per layer (tools/tie_timeline.py)
   int tl[BRISK_MAX_LAYERS * 8];
 #endif

@@ -375,7 +375,16 @@ struct BriskTouch {
   int x0, y0;
   unsigned mask;
   bool on;
+#ifdef CR_TIMING  // experiments (build variant): the refinement's phases on the 100 MHz clock, per lane (tools/classify_phases.py)
+  long long tlast;
+  int tacc[6];
+#endif
 };
+#if defined(CR_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define BRISK_CR_T(t_, i_) { const long long now_ = (long long)wall_clock64(); (t_)->tacc[i_] += (int)(now_ - (t_)->tlast); (t_)->tlast = now_; }
+#else
+#define BRISK_CR_T(t_, i_)
+#endif
 
 BRISK_HD void brisk_touch(BriskTouch* t, const BriskLayerView& L, int x, int y) {
   if (!t->on || brisk_border3(L, x, y)) return;
@@ -819,6 +828,123 @@ BRISK_HD float brisk_score_max_above_blk(const BriskLayerView& Lo, const bool od
   return max;
 }
 
+// GetScoreMaxBelow on the candidate's 4 x 4 score block of the layer below, in the same way (tools/classify_phases.py: the
+// generic walk of this window was the longest phase of k_classify_refine, 8 us of a wave's 19).  The window is 8/6 or 6/4
+// of a pixel wide: border lines at its ends and one or two integer lines between them, i.e. a grid of 3 or 4 lines each way
+// whose taps are the block's 16 pixels; no touches are recorded below.  Additionally to the scan rules above: an inner
+// sample that EQUALS the running maximum moves the maximum's position if its 3 x 3 neighbourhood, weighted [1 2 1; 2 0 2;
+// 1 2 1], outweighs that of the present position (:987-1010) - the four possible neighbourhood sums are formed up front.
+BRISK_HD int brisk_blk_px(const BriskScoreBlock& b, int bx, int by) { return (int)((brisk_blk_row(b, by) >> (8 * bx)) & 0xFFu); }
+BRISK_HD int brisk_blk_ring_sum(const BriskScoreBlock& b, int bx, int by) {  // (bx, by) in {1, 2}^2
+  const uint32_t ra = brisk_blk_row(b, by - 1) >> (8 * (bx - 1)), rb = brisk_blk_row(b, by) >> (8 * (bx - 1)), rc = brisk_blk_row(b, by + 1) >> (8 * (bx - 1));
+  const int corners = (int)(ra & 0xFFu) + (int)((ra >> 16) & 0xFFu) + (int)(rc & 0xFFu) + (int)((rc >> 16) & 0xFFu);
+  const int edges = (int)((ra >> 8) & 0xFFu) + (int)((rc >> 8) & 0xFFu) + (int)(rb & 0xFFu) + (int)((rb >> 16) & 0xFFu);
+  return 2 * edges + corners;
+}
+BRISK_HD float brisk_score_max_below_blk(const BriskLayerView& Lo, const bool odd, const int x_layer, const int y_layer,
+                                         const int thr, bool& ismax, float& dx, float& dy) {
+  const int threshold = thr + BRISK_DROP_THRESHOLD;
+  ismax = false;
+  float x_1, x1, y_1, y1;
+  if (!odd) {
+    x_1 = (float)(8 * (x_layer) + 1 - 4) / 6.0f;
+    x1 = (float)(8 * (x_layer) + 1 + 4) / 6.0f;
+    y_1 = (float)(8 * (y_layer) + 1 - 4) / 6.0f;
+    y1 = (float)(8 * (y_layer) + 1 + 4) / 6.0f;
+  } else {
+    x_1 = (float)(6 * (x_layer) + 1 - 3) / 4.0f;
+    x1 = (float)(6 * (x_layer) + 1 + 3) / 4.0f;
+    y_1 = (float)(6 * (y_layer) + 1 - 3) / 4.0f;
+    y1 = (float)(6 * (y_layer) + 1 + 3) / 4.0f;
+  }
+  const int ax = (int)x_1, ay = (int)y_1;  // block anchor
+  const int xs = (int)(x_1 + 1), xe = (int)x1, ys = (int)(y_1 + 1), ye = (int)y1;
+  const int nix = brisk_max(xe - xs + 1, 0), niy = brisk_max(ye - ys + 1, 0);
+  if (Lo.blk.cw != 4 || Lo.blk.ch != 4 || Lo.blk.x0 != ax || Lo.blk.y0 != ay || xs != ax + 1 || ys != ay + 1 || nix < 1 || nix > 2 ||
+      niy < 1 || niy > 2) {
+    Lo.miss = 1;
+    return 0;
+  }
+  const uint32_t W0 = Lo.blk.w0, W1 = Lo.blk.w1, W2 = Lo.blk.w2, W3 = Lo.blk.w3;
+  // neighbourhood sums of the four inner positions (tie rule), [by - 1][bx - 1]
+  const int rs11 = brisk_blk_ring_sum(Lo.blk, 1, 1), rs21 = brisk_blk_ring_sum(Lo.blk, 2, 1);
+  const int rs12 = brisk_blk_ring_sum(Lo.blk, 1, 2), rs22 = brisk_blk_ring_sum(Lo.blk, 2, 2);
+  bool aborted = false, first = true;
+  int max_x = xs, max_y = ys;
+  float max = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool rlast = (r == niy + 1), rex = (r <= niy + 1), rborder = (r == 0 || rlast);
+    const float yf = (r == 0) ? y_1 : (rlast ? y1 : (float)(ys + r - 1));
+    const int ylab = (r == 0) ? ys : (rlast ? ye : ys + r - 1);
+    const int iy = (int)yf - ay;  // 0 ... 2
+    const uint32_t wa = (iy == 0) ? W0 : ((iy == 1) ? W1 : W2), wb = (iy == 0) ? W1 : ((iy == 1) ? W2 : W3);
+    const float ry1 = yf - (float)(int)yf;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool jlast = (j == nix + 1), jex = (j <= nix + 1), jborder = (j == 0 || jlast);
+      const float xf = (j == 0) ? x_1 : (jlast ? x1 : (float)(xs + j - 1));
+      const int xlab = (j == 0) ? xs : (jlast ? xe : xs + j - 1);
+      const int ix = brisk_min((int)xf - ax, 2);  // 0 ... 2 (a line beyond the grid is never used: keep its shifts defined)
+      const int sh = 8 * ix;
+      const bool border = rborder || jborder;
+      float v;
+      if (border) {
+        const int s00 = (int)((wa >> sh) & 0xFFu), s10 = (int)((wa >> (sh + 8)) & 0xFFu);
+        const int s01 = (int)((wb >> sh) & 0xFFu), s11 = (int)((wb >> (sh + 8)) & 0xFFu);
+        v = (float)brisk_bilinear_u8(xf - (float)(int)xf, ry1, s00, s10, s01, s11);
+      } else {
+        v = (float)(int)((wa >> sh) & 0xFFu);  // plain read at (xlab, ylab) = block position (ix, iy)
+      }
+      if (rex && jex && !aborted) {
+        if (!rlast && v > threshold) {
+          aborted = true;
+        } else if (first) {
+          max = v;
+          first = false;
+        } else {
+          if (!border && v == max) {  // tie rule (inner samples only)
+            const int bx = xlab - ax, by = ylab - ay, mx = max_x - ax, my = max_y - ay;
+            const int t1 = (by == 1) ? (bx == 1 ? rs11 : rs21) : (bx == 1 ? rs12 : rs22);
+            const int t2 = (my == 1) ? (mx == 1 ? rs11 : rs21) : (mx == 1 ? rs12 : rs22);
+            if (t1 > t2) { max_x = xlab; max_y = ylab; }
+          }
+          if (v > max) {
+            max = v;
+            max_x = xlab;
+            if (r != 0) max_y = ylab;
+          }
+        }
+      }
+    }
+  }
+  if (aborted) return 0;
+  const int ox = max_x - 1 - ax, oy = max_y - 1 - ay;  // patch origin in the block: {0, 1}
+  const int psh = 8 * ox;
+  const uint32_t p0 = brisk_blk_row(Lo.blk, oy) >> psh, p1 = brisk_blk_row(Lo.blk, oy + 1) >> psh, p2 = brisk_blk_row(Lo.blk, oy + 2) >> psh;
+  float dx_1, dy_1;
+  const float refined_max = brisk_subpixel2d((int)(p0 & 0xFFu), (int)(p1 & 0xFFu), (int)(p2 & 0xFFu), (int)((p0 >> 8) & 0xFFu),
+                                             (int)((p1 >> 8) & 0xFFu), (int)((p2 >> 8) & 0xFFu), (int)((p0 >> 16) & 0xFFu),
+                                             (int)((p1 >> 16) & 0xFFu), (int)((p2 >> 16) & 0xFFu), dx_1, dy_1);
+  const float real_x = (float)max_x + dx_1;
+  const float real_y = (float)max_y + dy_1;
+  bool returnrefined = true;
+  if (!odd) {
+    dx = (float)((real_x * 6.0 + 1.0) / 8.0 - (float)x_layer);
+    dy = (float)((real_y * 6.0 + 1.0) / 8.0 - (float)y_layer);
+  } else {
+    dx = (float)((real_x * 4.0 - 1.0) / 6.0 - (float)x_layer);
+    dy = (float)((real_y * 4.0 - 1.0) / 6.0 - (float)y_layer);
+  }
+  if (dx > 1.0f) { dx = 1.0f; returnrefined = false; }
+  if (dx < -1.0f) { dx = -1.0f; returnrefined = false; }
+  if (dy > 1.0f) { dy = 1.0f; returnrefined = false; }
+  if (dy < -1.0f) { dy = -1.0f; returnrefined = false; }
+  ismax = true;
+  if (returnrefined) return refined_max > max ? refined_max : max;
+  return max;
+}
+
 // ---------------------------------------------------------------------------------------------
 // IsMax2D steps 1-2 (brisk-scale-space.cc:430-498): history-free classification.
 // Probe order W, E, N, S, SW, SE, NE, NW with early exit.
@@ -965,7 +1091,8 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
     float dx, dy;
     // (:227: the threshold argument is the float overload GetAgastScore(point_x, point_y, 1))
     const int centre = (DIRECT == 2) ? brisk_Vf<DIRECT>(tl, fx, fy, &none) : brisk_V<DIRECT>(tl, x_layer, y_layer);
-    brisk_score_max_other<DIRECT>(Lbelow, false, (layer & 1) != 0, x_layer, y_layer, centre, ismax, dx, dy, &none);
+    if (DIRECT == 0) brisk_score_max_below_blk(Lbelow, (layer & 1) != 0, x_layer, y_layer, centre, ismax, dx, dy);
+    else brisk_score_max_other<DIRECT>(Lbelow, false, (layer & 1) != 0, x_layer, y_layer, centre, ismax, dx, dy, &none);
     if (!ismax) return false;
     *e5 = true;
     float delta_x, delta_y;
@@ -994,13 +1121,22 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
   touch->on = true;
   const float up_peak = (DIRECT == 0) ? brisk_score_max_above_blk(Labove, intra, x_layer, y_layer, own_score, ismax, up_dx, up_dy, touch)
                                       : brisk_score_max_other<DIRECT>(Labove, true, intra, x_layer, y_layer, own_score, ismax, up_dx, up_dy, touch);
+  BRISK_CR_T(touch, 1)
   if (!ismax) return false;
 
   float dn_peak, dn_dx, dn_dy;
   if (cls == 0) {  // (:558-592) the layer below octave 0 does not exist: 5_8 scores of the 3 x 3 block around the point
     int q[9];
+    if (DIRECT == 0 && tl.blk58.cw && tl.blk58.x0 == x_layer - 1 && tl.blk58.y0 == y_layer - 1) {
+      // (the block IS this 3 x 3 neighbourhood, row-major in its bytes: no bounds-checked lookups)
+      const uint32_t u0 = tl.blk58.w0, u1 = tl.blk58.w1, u2 = tl.blk58.w2;
+      q[0] = (int)(u0 & 0xFFu); q[1] = (int)((u0 >> 8) & 0xFFu); q[2] = (int)((u0 >> 16) & 0xFFu); q[3] = (int)(u0 >> 24);
+      q[4] = (int)(u1 & 0xFFu); q[5] = (int)((u1 >> 8) & 0xFFu); q[6] = (int)((u1 >> 16) & 0xFFu); q[7] = (int)(u1 >> 24);
+      q[8] = (int)(u2 & 0xFFu);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) q[i] = brisk_V58<DIRECT>(tl, x_layer + i % 3 - 1, y_layer + i / 3 - 1);
+      for (int i = 0; i < 9; ++i) q[i] = brisk_V58<DIRECT>(tl, x_layer + i % 3 - 1, y_layer + i / 3 - 1);
+    }
     int best = q[0];
 #pragma unroll
     for (int i = 1; i < 9; ++i) best = brisk_max(best, q[i]);
@@ -1008,13 +1144,16 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
     brisk_subpixel2d(q[0], q[3], q[6], q[1], q[4], q[7], q[2], q[5], q[8], dn_dx, dn_dy);
     dn_peak = (float)best;
   } else {
-    dn_peak = brisk_score_max_other<DIRECT>(Lbelow, false, intra, x_layer, y_layer, own_score, ismax, dn_dx, dn_dy, &none);
+    dn_peak = (DIRECT == 0) ? brisk_score_max_below_blk(Lbelow, intra, x_layer, y_layer, own_score, ismax, dn_dx, dn_dy)
+                            : brisk_score_max_other<DIRECT>(Lbelow, false, intra, x_layer, y_layer, own_score, ismax, dn_dx, dn_dy, &none);
     if (!ismax) return false;
   }
+  BRISK_CR_T(touch, 2)
   *e5 = true;
   float own_dx, own_dy;
   int patch_centre;
   const float own_peak = brisk_patch_subpixel<DIRECT>(tl, x_layer, y_layer, &none, own_dx, own_dy, &patch_centre);
+  BRISK_CR_T(touch, 3)
 
   // maximum along the scale axis?  (kMaxThreshold_ = 1, kMinDrop_ = 15; ints against floats, as the reference compares them)
   const int near_margin = patch_centre - BRISK_MAX_THRESHOLD, far_margin = patch_centre - BRISK_MIN_DROP;
@@ -1044,6 +1183,7 @@ BRISK_HD bool brisk_refine(const BriskGeom& G, const BriskLayerView& Lbelow, con
   kp->y = (w_own * own_dy + w_nb * nb_dy + (float)y_layer) * lscale + loffset;
   kp->size = BRISK_BASIC_SIZE * (rel_scale * lscale);
   kp->response = response;
+  BRISK_CR_T(touch, 4)
   return true;
 }
 

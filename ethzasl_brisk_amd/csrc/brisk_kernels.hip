@@ -787,6 +787,9 @@ __global__ void __launch_bounds__(64) k_classify_refine(BriskGeom G, uint8_t* py
   if (counters[frame].low_score) return;  // (the frame runs the ordered path)
   const int n = min(counters[frame].ncand, cand_cap);
   for (int mine = bx * blockDim.x + threadIdx.x; mine < n; mine += bpf * blockDim.x) {
+#ifdef CR_TIMING
+    const long long cr_t0 = (long long)wall_clock64();
+#endif
     BriskCand* c = &cand[(long)frame * cand_cap + mine];
     const int x = c->x, y = c->y, l = c->layer, D = c->D;
     const bool has_above = !G.single_layer && (l + 1 < G.nlayers);
@@ -822,14 +825,27 @@ __global__ void __launch_bounds__(64) k_classify_refine(BriskGeom G, uint8_t* py
     kp.x = kp.y = kp.size = kp.response = 0.f;
     BriskTouch touch;
     touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
+#ifdef CR_TIMING
+    touch.tlast = cr_t0;
+    for (int i = 0; i < 6; ++i) touch.tacc[i] = 0;
+#endif
     bool e5 = false;
     const unsigned status = brisk_classify<false>(Lo, x, y, D, &nprobed);
+    BRISK_CR_T(&touch, 0)
     if (status != BRISK_ST_REJ && brisk_refine<false>(G, Lb, Lo, La, l, x, y, &kp, &e5, &touch)) flags |= 1;
+#ifdef CR_TIMING
+    { const long long now_ = (long long)wall_clock64(); atomicAdd(&counters[frame].cphase[7], (int)(now_ - touch.tlast)); touch.tlast = now_; }  // (lanes that ended early: waiting for the others)
+#endif
     if ((Lo.miss | La.miss | Lb.miss) || (G.debug_flags & 1)) {  // leave the candidate to k_classify_refine_direct
       c->status = 0xFF;
       atomicAdd(&counters[frame].nredo, 1);
       continue;
     }
+    // the tie list's slot first: the only memory operation of the record whose result is needed - requested in front of the
+    // stores and touches below, which it would otherwise queue behind (memory operations return in order; the write-out
+    // was the longest phase of the kernel, tools/classify_phases.py)
+    int tie_j = 0;
+    if (status == BRISK_ST_TIE) tie_j = atomicAdd(&counters[frame].ntie[l], 1);
     unsigned bits = ((unsigned)nprobed << 8) | (status << 12);
     if (e5) { flags |= 2; bits |= BRISK_SM_E5; }
     if (flags & 1) { c->kx = kp.x; c->ky = kp.y; c->ksize = kp.size; c->kresp = kp.response; }
@@ -840,12 +856,16 @@ __global__ void __launch_bounds__(64) k_classify_refine(BriskGeom G, uint8_t* py
       for (int bb = 0; bb < 16; ++bb)
         if (touch.mask & (1u << bb)) smap_or(La.smap, (long)(touch.y0 + (bb >> 2)) * La.stride + touch.x0 + (bb & 3), BRISK_SM_TOUCH);
     }
+    smap_or(Lo.smap, (long)y * Lo.stride + x, bits);
     if (status == BRISK_ST_TIE) {
-      const int j = atomicAdd(&counters[frame].ntie[l], 1);
-      if (j < tie_cap) tie_idx[((long)frame * BRISK_MAX_LAYERS + l) * tie_cap + j] = mine;
+      if (tie_j < tie_cap) tie_idx[((long)frame * BRISK_MAX_LAYERS + l) * tie_cap + tie_j] = mine;
       else atomicOr(&counters[frame].overflow, 2);
     }
-    smap_or(Lo.smap, (long)y * Lo.stride + x, bits);
+#ifdef CR_TIMING
+    BRISK_CR_T(&touch, 5)
+    for (int i = 0; i < 6; ++i) atomicAdd(&counters[frame].cphase[i], touch.tacc[i]);
+    atomicAdd(&counters[frame].cphase[6], 1);
+#endif
   }
 }
 

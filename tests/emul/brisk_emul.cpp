@@ -505,6 +505,50 @@ int emul_score_max_above_blk_mismatches(unsigned seed, int n, int* stats /* 4: m
   return bad;
 }
 
+// The same for GetScoreMaxBelow (brisk_score_max_below_blk vs brisk_score_max_other<0>(above = false)): 4 x 4 blocks of
+// the layer below with many equal values (the tie rule of :987-1010 moves the maximum between equal inner samples).
+int emul_score_max_below_blk_mismatches(unsigned seed, int n, int* stats /* 4: maxima, aborted scans, misses, unused */) {
+  auto rnd = [&seed]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+  int bad = 0;
+  for (int it = 0; it < n; ++it) {
+    const bool odd = rnd() & 1;
+    BriskLayerView Lb;
+    memset(&Lb, 0, sizeof(Lb));
+    Lb.w = 12 + (int)(rnd() % 80);
+    Lb.h = 12 + (int)(rnd() % 80);
+    Lb.stride = Lb.w;
+    // own layer: 3/4 (even: below is the intra-octave) or 2/3 (odd: below is the octave) of the layer below
+    const int ow = odd ? (Lb.w * 2) / 3 : (Lb.w * 3) / 4, oh = odd ? (Lb.h * 2) / 3 : (Lb.h * 3) / 4;
+    const int x = 3 + (int)(rnd() % (unsigned)brisk_max(ow - 6, 1)), y = 3 + (int)(rnd() % (unsigned)brisk_max(oh - 6, 1));
+    int ax, ay;
+    brisk_block_anchor(false, odd, x, y, &ax, &ay);
+    uint8_t vals[16];
+    const unsigned mode = rnd() % 5;
+    const int base = (int)(rnd() % 200);
+    for (int q = 0; q < 16; ++q) {
+      const int px = ax + (q & 3), py = ay + (q >> 2);
+      int v = mode == 0 ? (int)(rnd() % 256) : mode == 1 ? base + (int)(rnd() % 12) : mode == 2 ? ((rnd() % 3) ? base : base + (int)(rnd() % 40))
+              : mode == 3 ? base + (int)(rnd() % 3) : (int)(rnd() % 8);
+      if (px < 3 || py < 3 || px >= Lb.w - 3 || py >= Lb.h - 3) v = 0;
+      vals[q] = (uint8_t)brisk_min(v, 255);
+    }
+    BriskLayerView A = Lb, B = Lb;
+    brisk_block_from_bytes(&A.blk, vals, 16, ax, ay, 4, 4);
+    brisk_block_from_bytes(&B.blk, vals, 16, ax, ay, 4, 4);
+    const int thr = mode >= 1 && mode <= 3 ? base - 8 + (int)(rnd() % 20) : (int)(rnd() % 256);
+    BriskTouch none;
+    none.on = false; none.mask = 0; none.x0 = 0; none.y0 = 0;
+    bool ia = true, ib = true;
+    float dxa = 0, dya = 0, dxb = 0, dyb = 0;
+    const float ra = brisk_score_max_other<0>(A, false, odd, x, y, thr, ia, dxa, dya, &none);
+    const float rb = brisk_score_max_below_blk(B, odd, x, y, thr, ib, dxb, dyb);
+    const bool same = ia == ib && memcmp(&ra, &rb, 4) == 0 && (!ia || (memcmp(&dxa, &dxb, 4) == 0 && memcmp(&dya, &dyb, 4) == 0)) && A.miss == B.miss;
+    if (!same) ++bad;
+    if (stats) { stats[0] += ia ? 1 : 0; stats[1] += ia ? 0 : 1; stats[2] += A.miss ? 1 : 0; }
+  }
+  return bad;
+}
+
 // brisk_block_anchor uses integer quotients where brisk_score_max_other (and the reference, brisk-scale-space.cc:786-801,
 // 946-962) truncates float quotients: identical for every coordinate the engine admits
 int emul_block_anchor_mismatches(void) {

@@ -199,6 +199,15 @@ def test_block_form_of_score_max_above_equals_the_generic_one():
     assert stats[0] > 500000 and stats[1] > 500000 and stats[2] == 0 and stats[3] > 1000000, stats
 
 
+def test_block_form_of_score_max_below_equals_the_generic_one():
+    """the same for GetScoreMaxBelow (incl. its tie rule between equal inner samples)"""
+    L = E.lib()
+    L.emul_score_max_below_blk_mismatches.argtypes = [C.c_uint, C.c_int, C.c_void_p]
+    stats = np.zeros(4, np.int32)
+    assert L.emul_score_max_below_blk_mismatches(7, 3000000, stats.ctypes.data_as(C.c_void_p)) == 0
+    assert stats[0] > 500000 and stats[1] > 500000 and stats[2] == 0, stats
+
+
 def test_block_anchor_integer_quotients_equal_the_float_ones():
     assert E.lib().emul_block_anchor_mismatches() == 0
 

@@ -115,6 +115,9 @@ struct BriskFrameCounters {
 #ifdef TR_TIMING  // experiments (build variant): per-phase time of k_tie_resolve's decision loop (tools/tie_phases.py)
   int tphase[8];
 #endif
+#ifdef SB_TIMING  // experiments (build variant): per-phase wave time of k_score_blocks (tools/score_block_phases.py)
+  int sphase[8];
+#endif
 #ifdef CR_TIMING  // experiments (build variant): per-phase lane time of k_classify_refine (tools/classify_phases.py)
   int cphase[8];
 #endif

@@ -240,6 +240,59 @@ static inline uint32_t brisk_pk_mul(uint32_t a, uint32_t b) { return brisk_pk_pa
 static inline uint32_t brisk_pk_shr(uint32_t a, uint32_t s) { return brisk_pk_pack((int)((a & 0xFFFFu) >> (s & 0xFFFFu)), (int)((a >> 16) >> (s >> 16))); }
 #endif
 
+// a against b with its 16-bit halves exchanged: (min(a.lo, b.hi), min(a.hi, b.lo)) - on the device the exchange is the
+// instruction's operand-half selector (VOP3P op_sel), i.e. free
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t brisk_pk_min_sw(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t brisk_pk_max_sw(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#else
+static inline uint32_t brisk_pk_min_sw(uint32_t a, uint32_t b) { return brisk_pk_min(a, (b >> 16) | (b << 16)); }
+static inline uint32_t brisk_pk_max_sw(uint32_t a, uint32_t b) { return brisk_pk_max(a, (b >> 16) | (b << 16)); }
+#endif
+
+// brisk_oast9_16_M_from_d on packed lanes: P[i] = (d[i], d[i + 8]) as signed 16-bit halves, i = 0 ... 7.  The minimum over
+// the nine consecutive ring differences starting at i (and, in the other half, at i + 8) by doubling - windows of 2, 4, 8,
+// then the ninth element - where an index beyond 7 is the same register with its halves exchanged: 32 packed operations per
+// polarity for all 16 arcs instead of 48 three-input ones, and the maximum over the arcs on packed lanes too.
+// (ring pixels i and i + 8 minus the centre in both halves: one packed lane pair of brisk_oast9_16_M_from_pk)
+BRISK_HD uint32_t brisk_pk_ring_pair(uint32_t px_i, uint32_t px_i8, uint32_t centre_both) { return brisk_pk_sub(px_i | (px_i8 << 16), centre_both); }
+BRISK_HD int brisk_oast9_16_M_from_pk(const uint32_t* P) {
+  uint32_t lo2[8], hi2[8], lo4[8], hi4[8], lo8[8], hi8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    lo2[i] = (i < 7) ? brisk_pk_min(P[i], P[i + 1]) : brisk_pk_min_sw(P[7], P[0]);
+    hi2[i] = (i < 7) ? brisk_pk_max(P[i], P[i + 1]) : brisk_pk_max_sw(P[7], P[0]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    lo4[i] = (i < 6) ? brisk_pk_min(lo2[i], lo2[i + 2]) : brisk_pk_min_sw(lo2[i], lo2[i - 6]);
+    hi4[i] = (i < 6) ? brisk_pk_max(hi2[i], hi2[i + 2]) : brisk_pk_max_sw(hi2[i], hi2[i - 6]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    lo8[i] = (i < 4) ? brisk_pk_min(lo4[i], lo4[i + 4]) : brisk_pk_min_sw(lo4[i], lo4[i - 4]);
+    hi8[i] = (i < 4) ? brisk_pk_max(hi4[i], hi4[i + 4]) : brisk_pk_max_sw(hi4[i], hi4[i - 4]);
+  }
+  uint32_t bb = 0, bd = 0;  // running maximum of the arcs' minima / minimum of their maxima, both halves
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t lo9 = brisk_pk_min_sw(lo8[i], P[i]), hi9 = brisk_pk_max_sw(hi8[i], P[i]);  // (element i + 8)
+    bb = (i == 0) ? lo9 : brisk_pk_max(bb, lo9);
+    bd = (i == 0) ? hi9 : brisk_pk_min(bd, hi9);
+  }
+  const int best_bright = brisk_max((int)(int16_t)(bb & 0xFFFFu), (int)(int16_t)(bb >> 16));
+  const int best_dark = brisk_min((int)(int16_t)(bd & 0xFFFFu), (int)(int16_t)(bd >> 16));
+  return brisk_max(best_bright, -best_dark);
+}
+
 // c, n, s, w, e: centre and compass pixels (ring radius 3) of two pixels, one per 16-bit lane (values 0..255).
 // Returns bit 15 of the lane (0x8000) set for a pixel that passes the pre-gate, the lane zero otherwise.
 BRISK_HD uint32_t brisk_pregate_pair(uint32_t c, uint32_t n, uint32_t s, uint32_t w, uint32_t e, const BriskPregate& g) {

@@ -578,12 +578,14 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
     const int b2 = brisk_b2_fast(tc, kthr);  // == (tc * thr) / 100 without quarter-rate integer multiplies
     const int c = v[3][3];
     if (mx - c <= b2 && c - mn <= b2) continue;  // no ring pixel can differ by more than b2
-    int d[16];  // ring order of brisk_oast9_16_M (agast/include/agast/oast9-16.h:99-116)
-    d[0] = v[3][0] - c;  d[1] = v[2][0] - c;  d[2] = v[1][1] - c;  d[3] = v[0][2] - c;
-    d[4] = v[0][3] - c;  d[5] = v[0][4] - c;  d[6] = v[1][5] - c;  d[7] = v[2][6] - c;
-    d[8] = v[3][6] - c;  d[9] = v[4][6] - c;  d[10] = v[5][5] - c; d[11] = v[6][4] - c;
-    d[12] = v[6][3] - c; d[13] = v[6][2] - c; d[14] = v[5][1] - c; d[15] = v[4][0] - c;
-    if (brisk_oast9_16_M_from_d(d) > b2) {
+    // ring order of brisk_oast9_16_M (agast/include/agast/oast9-16.h:99-116), pixels i and i + 8 in one packed lane pair
+    const uint32_t cc = (uint32_t)c * 0x10001u;
+    uint32_t P[8];
+    P[0] = brisk_pk_ring_pair(v[3][0], v[3][6], cc); P[1] = brisk_pk_ring_pair(v[2][0], v[4][6], cc);
+    P[2] = brisk_pk_ring_pair(v[1][1], v[5][5], cc); P[3] = brisk_pk_ring_pair(v[0][2], v[6][4], cc);
+    P[4] = brisk_pk_ring_pair(v[0][3], v[6][3], cc); P[5] = brisk_pk_ring_pair(v[0][4], v[6][2], cc);
+    P[6] = brisk_pk_ring_pair(v[1][5], v[5][1], cc); P[7] = brisk_pk_ring_pair(v[2][6], v[4][0], cc);
+    if (brisk_oast9_16_M_from_pk(P) > b2) {
       const int D = tt;
       // the score-state map is all zero between batches (k_smap_clear): only detections are written
       smap[base + (long)gyy * stride + gx] = (uint16_t)D;
@@ -673,6 +675,13 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
   __shared__ __attribute__((aligned(16))) uint8_t patch[SB_WAVES][SB_PER_WAVE][3][SB_PROWS][16];
   if (threadIdx.x < BRISK_MAX_LAYERS) lgeo[threadIdx.x] = make_int4(G.L[threadIdx.x].w, G.L[threadIdx.x].h, G.L[threadIdx.x].stride, G.L[threadIdx.x].off);
   __syncthreads();
+#ifdef SB_TIMING
+  int sb_acc[4] = {0, 0, 0, 0};
+  long long sb_last = (long long)wall_clock64();
+#define SB_T(i) { const long long now_ = (long long)wall_clock64(); sb_acc[i] += (int)(now_ - sb_last); sb_last = now_; }
+#else
+#define SB_T(i)
+#endif
   for (int base = (bx * SB_WAVES + wave) * SB_PER_WAVE; base < n; base += bpf * SB_WAVES * SB_PER_WAVE) {
     // -- round trip 1: the candidate headers (x, y, layer) of the wave's SB_PER_WAVE candidates
     uint2 hdr[SB_PER_WAVE];
@@ -700,19 +709,22 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
       brisk_block_anchor(false, (l & 1) != 0, x, y, &bx, &by);
       // patch origins (top-left pixel each patch must contain) on the three layers
       const int ox0 = x - 5, oy0 = y - 5, ox1 = ax - 3, oy1 = ay - 3, ox2 = bx - 3, oy2 = by - 3;
-      // (a) patch loads: slot s = which * 44 + row * 4 + dword
+      // (a) patch loads: load round t fetches patch t (own / above / below), lane = row * 4 + dword (44 of the 64 lanes).
+      // The patch's layer, origin and base address are the same in every lane - scalars -; a lane only clamps its row and
+      // column (with the slots dealt 64 at a time across the patches, which patch a lane loads differed between lanes: a
+      // layer-geometry read from LDS, a pointer select and 64-bit address arithmetic per slot, a third of the kernel's
+      // vector instructions - tools/score_block_phases.py, ISA between the clock reads)
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        const int s_ = min(lane + 64 * t, SB_PSLOTS - 1);
-        const int which = s_ / (SB_PROWS * 4), r = (s_ % (SB_PROWS * 4)) >> 2, d = s_ & 3;
-        const int pl = (which == 0) ? l : (which == 1) ? (has_above ? l + 1 : l) : (has_below ? l - 1 : l);
-        const int4 pg = lgeo[pl];
-        const int pox = (which == 0) ? ox0 : (which == 1) ? ox1 : ox2;
-        const int poy = (which == 0) ? oy0 : (which == 1) ? oy1 : oy2;
-        const int gx = min(max((pox & ~3) + 4 * d, 0), pg.z - 4);
-        const int gy = min(max(poy + r, 0), pg.y - 1);
-        const uint8_t* limg = (pl == 0 && img0) ? img0 : fimg + pg.w;  // (layer geometry from LDS: pl differs between lanes)
-        pv[k][t] = *reinterpret_cast<const unsigned*>(limg + (long)gy * pg.z + gx);
+        const int r = min(lane >> 2, SB_PROWS - 1), d = lane & 3;
+        const int pl = (t == 0) ? l : (t == 1) ? (has_above ? l + 1 : l) : (has_below ? l - 1 : l);
+        const int pw = G.L[pl].stride, ph = G.L[pl].h;
+        const int pox = (t == 0) ? ox0 : (t == 1) ? ox1 : ox2;
+        const int poy = (t == 0) ? oy0 : (t == 1) ? oy1 : oy2;
+        const int gx = min(max((pox & ~3) + 4 * d, 0), pw - 4);
+        const int gy = min(max(poy + r, 0), ph - 1);
+        const uint8_t* limg = (pl == 0 && img0) ? img0 : fimg + G.L[pl].off;
+        pv[k][t] = *reinterpret_cast<const unsigned*>(limg + (gy * pw + gx));
       }
       // (b) the lane's pixel
       int ll = l, px = 0, py = 0, which = 0;
@@ -739,38 +751,54 @@ __global__ void __launch_bounds__(SB_WAVES * 64) k_score_blocks(BriskGeom G, con
       const int poy = (which == 0) ? oy0 : (which == 1) ? oy1 : oy2;
       cofs[k] = which * (SB_PROWS * 16) + (py - poy) * 16 + (px - (pox & ~3));
     }
+    SB_T(0)
     // -- patches to LDS (the wave's own region: wave-level ordering only)
 #pragma unroll
     for (int k = 0; k < SB_PER_WAVE; ++k)
 #pragma unroll
       for (int t = 0; t < 3; ++t)
-        if (lane + 64 * t < SB_PSLOTS) *reinterpret_cast<unsigned*>(&patch[wave][k][0][0][0] + (lane + 64 * t) * 4) = pv[k][t];
+        if (lane < SB_PROWS * 4) *reinterpret_cast<unsigned*>(&patch[wave][k][t][0][0] + lane * 4) = pv[k][t];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    SB_T(1)
     // -- evaluation: ring bytes from LDS, closed-form segment tests on registers
 #pragma unroll
     for (int k = 0; k < SB_PER_WAVE; ++k) {
       const uint8_t* pc = &patch[wave][k][0][0][0] + (ok[k] ? cofs[k] : 5 * 16 + 8);
       const int c = pc[0];
-      int d[16];
+      // every lane reads the 9_16 ring at fixed offsets (the lanes of the 5_8 block too: their ring lies inside the own-layer
+      // patch, the result is not used) - a per-lane choice between the two rings cost a select and an add per read
+      // ring differences (d[i], d[i + 8]) as signed 16-bit halves: the 16 arcs on packed lanes (brisk_oast9_16_M_from_pk)
+      uint32_t P[8];
+      const uint32_t cc = (uint32_t)c * 0x10001u;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int o16 = sb_dx16(j) + sb_dy16(j) * 16, o8 = sb_dx8(j & 7) + sb_dy8(j & 7) * 16;
-        d[j] = (int)pc[is8[k] ? o8 : o16] - c;
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t a = pc[sb_dx16(i) + sb_dy16(i) * 16], b = pc[sb_dx16(i + 8) + sb_dy16(i + 8) * 16];
+        P[i] = brisk_pk_ring_pair(a, b, cc);
       }
-      int v = brisk_Kp_from_M(brisk_oast9_16_M_from_d(d));
+      int v = brisk_Kp_from_M(brisk_oast9_16_M_from_pk(P));
       const int D = BRISK_SM_D(smv[k]);
       if (D > 2) v = D;
       if (__any(is8[k])) {  // (wave-uniform per candidate: only layer-0 candidates carry the 5_8 block)
-        const int v8 = brisk_Kp_from_M(brisk_agast5_8_M_from_d(d));
+        int d8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d8[j] = (int)pc[sb_dx8(j) + sb_dy8(j) * 16] - c;
+        const int v8 = brisk_Kp_from_M(brisk_agast5_8_M_from_d(d8));
         if (is8[k]) v = v8;
       }
       if (!ok[k]) v = 0;
       if (base + k < n) blocks[((long)frame * cand_cap + base + k) * 64 + lane] = (uint8_t)v;
     }
     __builtin_amdgcn_wave_barrier();  // the patches are overwritten by the wave's next candidates
+    SB_T(2)
+#ifdef SB_TIMING
+    sb_acc[3] += 1;
+#endif
   }
+#ifdef SB_TIMING
+  if (lane == 0) for (int i = 0; i < 4; ++i) atomicAdd(const_cast<int*>(&counters[frame].sphase[i]), sb_acc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

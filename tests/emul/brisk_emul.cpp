@@ -549,6 +549,26 @@ int emul_score_max_below_blk_mismatches(unsigned seed, int n, int* stats /* 4: m
   return bad;
 }
 
+// The packed form of the OAST 9_16 score (brisk_oast9_16_M_from_pk, k_score_blocks) against brisk_oast9_16_M_from_d on
+// random ring differences in [-255, 255] (plateaus and runs included).  Returns mismatches.
+int emul_oast_pk_mismatches(unsigned seed, int n) {
+  auto rnd = [&seed]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+  int bad = 0;
+  for (int it = 0; it < n; ++it) {
+    int d[16];
+    const unsigned mode = rnd() % 4;
+    const int c = (int)(rnd() % 256);
+    for (int j = 0; j < 16; ++j) {
+      const int v = mode == 0 ? (int)(rnd() % 256) : mode == 1 ? ((rnd() % 4) ? 200 : (int)(rnd() % 256)) : mode == 2 ? ((rnd() % 4) ? 10 : (int)(rnd() % 256)) : (j < (int)(rnd() % 17) ? 255 : 0);
+      d[j] = v - c;
+    }
+    uint32_t P[8];
+    for (int i = 0; i < 8; ++i) P[i] = ((uint32_t)d[i] & 0xFFFFu) | ((uint32_t)d[i + 8] << 16);
+    if (brisk_oast9_16_M_from_d(d) != brisk_oast9_16_M_from_pk(P)) ++bad;
+  }
+  return bad;
+}
+
 // brisk_block_anchor uses integer quotients where brisk_score_max_other (and the reference, brisk-scale-space.cc:786-801,
 // 946-962) truncates float quotients: identical for every coordinate the engine admits
 int emul_block_anchor_mismatches(void) {

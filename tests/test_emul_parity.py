@@ -208,6 +208,13 @@ def test_block_form_of_score_max_below_equals_the_generic_one():
     assert stats[0] > 500000 and stats[1] > 500000 and stats[2] == 0, stats
 
 
+def test_packed_oast_score_equals_the_scalar_one():
+    """k_score_blocks evaluates the 9-of-16 arcs on packed 16-bit lanes (brisk_oast9_16_M_from_pk)"""
+    L = E.lib()
+    L.emul_oast_pk_mismatches.argtypes = [C.c_uint, C.c_int]
+    assert L.emul_oast_pk_mismatches(3, 2000000) == 0
+
+
 def test_block_anchor_integer_quotients_equal_the_float_ones():
     assert E.lib().emul_block_anchor_mismatches() == 0
 

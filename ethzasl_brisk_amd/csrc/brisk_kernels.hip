@@ -1608,18 +1608,32 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
   unsigned* keys = keys_scratch + (long)frame * cand_cap * 2;  // [key][cand index] (k_finalize_large reads them)
   if (tid == 0) nvalid = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += FN_THREADS) {
-    const BriskCand& c = C[i];
-    bool valid = (c.status == BRISK_ST_PASS) && (c.flags & 1);
-    if (valid && mask) {  // RemoveInvalidKeyPoints (brisk-feature-detector.cc:49-66)
-      const uint8_t* m = mask + (long)frame * mask_pitch_frame;
-      valid = m[(long)(int)(c.ky + 0.5f) * mask_row_pitch + (int)(c.kx + 0.5f)] != 0;
+  // four candidates per thread and round: their status words and keys are requested together (one memory round trip per
+  // round instead of two per candidate - the kernel runs beside the integral kernel, which keeps the memory system busy)
+  constexpr int FN_U = 4;
+  for (int i0 = tid; i0 < n; i0 += FN_U * FN_THREADS) {
+    unsigned sw[FN_U], ck[FN_U];
+#pragma unroll
+    for (int u = 0; u < FN_U; ++u) {
+      const int i = min(i0 + u * FN_THREADS, n - 1);
+      sw[u] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const uint8_t*>(&C[i]) + 4);  // layer, D, status, flags
+      ck[u] = C[i].key;
     }
-    if (valid) {
-      const int j = atomicAdd(&nvalid, 1);
-      keys[2 * j] = c.key;
-      keys[2 * j + 1] = (unsigned)i;
-      if (j < FN_SMALL) { skey[j] = c.key; sidx[j] = (unsigned)i; }
+#pragma unroll
+    for (int u = 0; u < FN_U; ++u) {
+      const int i = i0 + u * FN_THREADS;
+      bool valid = i < n && ((sw[u] >> 16) & 0xFFu) == BRISK_ST_PASS && ((sw[u] >> 24) & 1u);
+      if (valid && mask) {  // RemoveInvalidKeyPoints (brisk-feature-detector.cc:49-66)
+        const BriskCand& c = C[i];
+        const uint8_t* m = mask + (long)frame * mask_pitch_frame;
+        valid = m[(long)(int)(c.ky + 0.5f) * mask_row_pitch + (int)(c.kx + 0.5f)] != 0;
+      }
+      if (valid) {
+        const int j = atomicAdd(&nvalid, 1);
+        keys[2 * j] = ck[u];
+        keys[2 * j + 1] = (unsigned)i;
+        if (j < FN_SMALL) { skey[j] = ck[u]; sidx[j] = (unsigned)i; }
+      }
     }
   }
   __threadfence_block();
@@ -1631,19 +1645,33 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
   }
   if (tid < 4) skey[nv + tid] = 0xFFFFFFFFu;  // the count below reads four keys at a time
   __syncthreads();
-  for (int j = tid; j < nv; j += FN_THREADS) {
-    const unsigned myk = skey[j];
-    int rank = 0;
+  // two keys per thread and pass over the key list (the list is read once for both; their candidate records are requested
+  // before the counting starts)
+  for (int j0 = tid; j0 < nv; j0 += 2 * FN_THREADS) {
+    const int j1 = j0 + FN_THREADS;
+    const bool has1 = j1 < nv;
+    const unsigned k0 = skey[j0], k1 = has1 ? skey[j1] : 0u;
+    const BriskCand& c0 = C[sidx[j0]];
+    const BriskCand& c1 = C[sidx[has1 ? j1 : j0]];
+    const float4 r0 = *reinterpret_cast<const float4*>(&c0.kx), r1 = *reinterpret_cast<const float4*>(&c1.kx);
+    const int l0 = c0.layer, l1 = c1.layer;
+    int rank0 = 0, rank1 = 0;
     for (int q = 0; q < nv; q += 4) {
       const uint4 kk = *reinterpret_cast<const uint4*>(&skey[q]);
-      rank += (kk.x < myk ? 1 : 0) + (kk.y < myk ? 1 : 0) + (kk.z < myk ? 1 : 0) + (kk.w < myk ? 1 : 0);
+      rank0 += (kk.x < k0 ? 1 : 0) + (kk.y < k0 ? 1 : 0) + (kk.z < k0 ? 1 : 0) + (kk.w < k0 ? 1 : 0);
+      rank1 += (kk.x < k1 ? 1 : 0) + (kk.y < k1 ? 1 : 0) + (kk.z < k1 ? 1 : 0) + (kk.w < k1 ? 1 : 0);
     }
-    if (rank < kp_cap) {
-      const BriskCand& c = C[sidx[j]];
+    if (rank0 < kp_cap) {
       BriskKeyPoint kp;
-      kp.x = c.kx; kp.y = c.ky; kp.size = c.ksize; kp.angle = -1.0f; kp.response = c.kresp;
-      kp.octave = G.single_layer ? 0 : c.layer; kp.class_id = -1;
-      kp_out[(long)frame * kp_cap + rank] = kp;
+      kp.x = r0.x; kp.y = r0.y; kp.size = r0.z; kp.angle = -1.0f; kp.response = r0.w;
+      kp.octave = G.single_layer ? 0 : l0; kp.class_id = -1;
+      kp_out[(long)frame * kp_cap + rank0] = kp;
+    }
+    if (has1 && rank1 < kp_cap) {
+      BriskKeyPoint kp;
+      kp.x = r1.x; kp.y = r1.y; kp.size = r1.z; kp.angle = -1.0f; kp.response = r1.w;
+      kp.octave = G.single_layer ? 0 : l1; kp.class_id = -1;
+      kp_out[(long)frame * kp_cap + rank1] = kp;
     }
   }
   if (tid == 0) {

@@ -170,20 +170,25 @@ __global__ void __launch_bounds__(DP_THREADS) k_dp_count(BriskGeom G, BriskPatte
   __shared__ int wtot[DP_THREADS / 64];
   const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
-  if (n <= DP_SMALL_N || (int)blockIdx.x * DP_THREADS >= n) return;
+  if (n <= DP_SMALL_N) return;
   int* wk = work + (long)frame * work_stride;
-  const DpItem it = dp_item(G, P, kp_in + (long)frame * kp_cap, blockIdx.x * DP_THREADS + tid, n);
-  const unsigned long long bal = __ballot(it.keep);
-  if (lane == 0) wtot[wave] = __popcll(bal);
-  const unsigned long long bal_e = __ballot(it.keep && it.kp.angle == -1.0f);
-  if (lane == 0 && bal_e) atomicAdd(&wk[0], __popcll(bal_e));
-  if (it.keep) atomicAdd(&wk[DP_W_HIST + dp_bucket(T, it.kp.x, it.kp.y)], 1);
-  __syncthreads();
-  if (tid == 0) {
-    int t = 0;
+  // (the grid holds a few workgroups per frame, not one per 1024 keypoints of the CAPACITY - 4096 workgroups that exit at
+  // once cost 46 us per launch in a 256-frame batch -: a workgroup takes block after block)
+  for (int blk = blockIdx.x; blk * DP_THREADS < n; blk += gridDim.x) {
+    const DpItem it = dp_item(G, P, kp_in + (long)frame * kp_cap, blk * DP_THREADS + tid, n);
+    const unsigned long long bal = __ballot(it.keep);
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    const unsigned long long bal_e = __ballot(it.keep && it.kp.angle == -1.0f);
+    if (lane == 0 && bal_e) atomicAdd(&wk[0], __popcll(bal_e));
+    if (it.keep) atomicAdd(&wk[DP_W_HIST + dp_bucket(T, it.kp.x, it.kp.y)], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
 #pragma unroll
-    for (int k = 0; k < DP_THREADS / 64; ++k) t += wtot[k];
-    wk[DP_W_BLK + blockIdx.x] = t;
+      for (int k = 0; k < DP_THREADS / 64; ++k) t += wtot[k];
+      wk[DP_W_BLK + blk] = t;
+    }
+    __syncthreads();  // (wtot is rewritten by the next block)
   }
 }
 
@@ -232,20 +237,24 @@ __global__ void __launch_bounds__(DP_THREADS) k_dp_scatter(BriskGeom G, BriskPat
   __shared__ int wtot[DP_THREADS / 64];
   const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
-  if (n <= DP_SMALL_N || (int)blockIdx.x * DP_THREADS >= n) return;
+  if (n <= DP_SMALL_N) return;
   int* wk = work + (long)frame * work_stride;
-  const DpItem it = dp_item(G, P, kp_in + (long)frame * kp_cap, blockIdx.x * DP_THREADS + tid, n);
-  const unsigned long long bal = __ballot(it.keep);
-  if (lane == 0) wtot[wave] = __popcll(bal);
-  __syncthreads();
-  if (!it.keep) return;
-  int j = wk[DP_W_BLK + blockIdx.x] + __popcll(bal & ((1ull << lane) - 1ull));
+  for (int blk = blockIdx.x; blk * DP_THREADS < n; blk += gridDim.x) {
+    const DpItem it = dp_item(G, P, kp_in + (long)frame * kp_cap, blk * DP_THREADS + tid, n);
+    const unsigned long long bal = __ballot(it.keep);
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    if (it.keep) {
+      int j = wk[DP_W_BLK + blk] + __popcll(bal & ((1ull << lane) - 1ull));
 #pragma unroll
-  for (int k = 0; k < DP_THREADS / 64; ++k) j += (k < wave) ? wtot[k] : 0;
-  dkp[(long)frame * kp_cap + j] = it.kp;
-  const int pos = atomicAdd(&wk[DP_W_HIST + dp_bucket(T, it.kp.x, it.kp.y)], 1);
-  drec[(long)frame * kp_cap + pos] = make_uint4(__float_as_uint(it.kp.x), __float_as_uint(it.kp.y), __float_as_uint(it.kp.angle),
-                                                (unsigned)it.sc | ((unsigned)j << 8));
+      for (int k = 0; k < DP_THREADS / 64; ++k) j += (k < wave) ? wtot[k] : 0;
+      dkp[(long)frame * kp_cap + j] = it.kp;
+      const int pos = atomicAdd(&wk[DP_W_HIST + dp_bucket(T, it.kp.x, it.kp.y)], 1);
+      drec[(long)frame * kp_cap + pos] = make_uint4(__float_as_uint(it.kp.x), __float_as_uint(it.kp.y), __float_as_uint(it.kp.angle),
+                                                    (unsigned)it.sc | ((unsigned)j << 8));
+    }
+    __syncthreads();  // (wtot is rewritten by the next block)
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -717,7 +726,9 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
     while ((((T.w - 1) >> T.shift) + 1) * (((T.h - 1) >> T.shift) + 1) > DP_MAXBUCKETS) ++T.shift;
     T.tiles_x = ((T.w - 1) >> T.shift) + 1;
     const int nbuckets = T.tiles_x * (((T.h - 1) >> T.shift) + 1);
-    const dim3 grid((B.kp_cap + DP_THREADS - 1) / DP_THREADS, nframes);
+    // workgroups per frame: what the capacity needs at most, but no more than fill the chip twice over (they loop)
+    const int dp_blocks = min((B.kp_cap + DP_THREADS - 1) / DP_THREADS, max(1, 512 / nframes));
+    const dim3 grid(dp_blocks, nframes);
     hipLaunchKernelGGL(k_dp_count, grid, dim3(DP_THREADS), 0, s, G, P, T, kp_in, n_in, n_in_stride, B.kp_cap, Dd.dp_work, Dd.dp_work_stride);
     hipLaunchKernelGGL(k_dp_scan, dim3(nframes), dim3(DP_THREADS), 0, s, n_in, n_in_stride, B.kp_cap, nbuckets, B.counters, Dd.dp_work,
                        Dd.dp_work_stride);

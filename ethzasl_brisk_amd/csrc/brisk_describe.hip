@@ -64,7 +64,13 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
     for (int q = tid; q < DP_W_BLK; q += DP_THREADS) wk[q] = 0;
     return;
   }
+  // the kept keypoints' records (what k_describe reads) by compacted index, and the border per scale index, on chip: the
+  // processing order below writes a record straight from here (it used to go order -> memory -> keypoint -> scale ->
+  // record: three dependent round trips beside the integral kernel, which keeps the memory system busy)
+  __shared__ uint4 srec[DP_SMALL_N];
+  __shared__ int sborder[BRISK_SCALES];
   if (tid == 0) { base = 0; nest = 0; }
+  if (tid < BRISK_SCALES) sborder[tid] = P.size_list[tid];
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
     const int i = i0 + tid;
@@ -74,7 +80,8 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
     if (i < n) {
       kp = K[i];
       sc = brisk_scale_index(P, kp.size);
-      keep = brisk_inside_border(P, sc, kp.x, kp.y, G.L[0].w, G.L[0].h);
+      const int border = sborder[sc];  // == brisk_inside_border(P, sc, ...)
+      keep = !((kp.x < (float)border) || (kp.x >= (float)(G.L[0].w - border)) || (kp.y < (float)border) || (kp.y >= (float)(G.L[0].h - border)));
     }
     // stable compaction: position = kept keypoints before this one (ballots inside the wave, wave totals through LDS)
     const unsigned long long bal = __ballot(keep);
@@ -93,8 +100,8 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
     if (keep) {
       const int j = base + wbase + before;
       dkp[(long)frame * kp_cap + j] = kp;
-      dscale[(long)frame * kp_cap + j] = sc;
       if (j < DP_MAXSORT) pkey[j] = dp_order_key((int)kp.x, (int)kp.y, sc, j, (G.debug_flags >> 4) & 0xF);
+      srec[j] = make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), __float_as_uint(kp.angle), (unsigned)sc | ((unsigned)j << 8));
     }
     __syncthreads();
     if (tid == 0) base += total;
@@ -103,35 +110,20 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
   if (tid == 0) { counters[frame].ndesc = base; counters[frame].nestimate = nest; counters[frame].desc_ticket = 0; counters[frame].orient_ticket = 0; }
   // Processing order for k_describe: keypoints sorted by 64-row band, then x, so that keypoints sampled at the
   // same time touch the same part of the integral image (the output order stays (layer, y, x)).
+  // (m <= DP_SMALL_N here: the keys carry j in their low bits, all different)
   const int m = base;
-  int* perm = dperm + (long)frame * kp_cap;
-  if (m <= DP_MAXSORT) {
-    if (tid < 4) pkey[m + tid] = 0xFFFFFFFFu;  // the count below reads four keys at a time
-    __syncthreads();
-    for (int j = tid; j < m; j += DP_THREADS) {
-      const unsigned kj = pkey[j];
-      int r = 0;
-      if (m <= 2048) {  // the keys carry j: all different
-        for (int q = 0; q < m; q += 4) {
-          const uint4 kk = *reinterpret_cast<const uint4*>(&pkey[q]);
-          r += (kk.x < kj ? 1 : 0) + (kk.y < kj ? 1 : 0) + (kk.z < kj ? 1 : 0) + (kk.w < kj ? 1 : 0);
-        }
-      } else {
-        for (int q = 0; q < m; ++q) r += (pkey[q] < kj || (pkey[q] == kj && q < j)) ? 1 : 0;
-      }
-      perm[r] = j;
-    }
-  } else {
-    for (int j = tid; j < m; j += DP_THREADS) perm[j] = j;
-  }
+  if (tid < 4) pkey[m + tid] = 0xFFFFFFFFu;  // the count below reads four keys at a time
+  __syncthreads();
   // the keypoints again, in processing order, as one 16-byte record each: k_describe reads them with a single
   // (prefetchable) load instead of the dependent chain order -> keypoint -> scale
-  __syncthreads();
-  for (int r = tid; r < m; r += DP_THREADS) {
-    const int j = perm[r];
-    const BriskKeyPoint& q = dkp[(long)frame * kp_cap + j];
-    drec[(long)frame * kp_cap + r] = make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.angle),
-                                                 (unsigned)dscale[(long)frame * kp_cap + j] | ((unsigned)j << 8));
+  for (int j = tid; j < m; j += DP_THREADS) {
+    const unsigned kj = pkey[j];
+    int r = 0;
+    for (int q = 0; q < m; q += 4) {
+      const uint4 kk = *reinterpret_cast<const uint4*>(&pkey[q]);
+      r += (kk.x < kj ? 1 : 0) + (kk.y < kj ? 1 : 0) + (kk.z < kj ? 1 : 0) + (kk.w < kj ? 1 : 0);
+    }
+    drec[(long)frame * kp_cap + r] = srec[j];
   }
 }
 

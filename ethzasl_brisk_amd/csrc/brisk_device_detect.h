@@ -1546,6 +1546,74 @@ BRISK_HD int brisk_state_at(const BriskLayerView& L, const bool float_patch, con
 // ---------------------------------------------------------------------------------------------
 #define BRISK_SS_FINAL 0x80000000u
 BRISK_HD int brisk_clz(unsigned v) { return __builtin_clz(v); }  // v != 0
+// Which of a pixel's 24 neighbours can act on it at all depends only on where the pixel lies relative to the candidate
+// (raster-earlier than the candidate or the candidate itself once its own probes are done) - in the tie kernel a constant
+// of the lane: bit i of `actmask` = neighbour i may act, bit i of `nselfmask` = neighbour i is not the candidate itself.
+BRISK_HD void brisk_state_masks(int sx, int sy /* pixel - candidate */, bool own, unsigned* actmask, unsigned* nselfmask) {
+  unsigned am = 0, ns = 0;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    const int oy = i / 5 - 2, ox = i % 5 - 2;
+    if (ox == 0 && oy == 0) continue;
+    const int rx = sx + ox, ry = sy + oy;  // neighbour - candidate
+    const bool self = (rx == 0) && (ry == 0);
+    const bool earlier = (ry < 0) || (ry == 0 && rx <= 0);
+    if (earlier && !(self && !own)) am |= 1u << i;
+    if (!self) ns |= 1u << i;
+  }
+  *actmask = am;
+  *nselfmask = ns;
+}
+BRISK_HD unsigned brisk_state_static_m(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int px,
+                                       int py, int cx, int cy, const unsigned actmask, const unsigned nselfmask,
+                                       const uint16_t* sm_local, int lx0, int ly0, int lw, const uint8_t* kp5, unsigned* dynmask) {
+  *dynmask = 0;
+  if (brisk_border3(L, px, py)) return BRISK_SS_FINAL;
+  const uint16_t* wp = sm_local + (py - ly0) * lw + (px - lx0);
+  const unsigned smp = wp[0];
+  const int D = BRISK_SM_D(smp);
+  if (D > 2) return BRISK_SS_FINAL | (unsigned)D;
+  const int Kp = (int)kp5[(py - cy + 2) * 5 + (px - cx + 2)];
+  if (Kp == 0) return BRISK_SS_FINAL;
+  bool cached = (smp & BRISK_SM_TOUCH) != 0, any = cached;
+  int t_last = cached ? 1 : 0;
+  int last_static = 0;  // index + 1 of the last static event
+  unsigned dyn = 0;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    const int oy = i / 5 - 2, ox = i % 5 - 2;
+    if (ox == 0 && oy == 0) continue;
+    const int ddx = -ox, ddy = -oy;  // p - q
+    const unsigned smq = wp[oy * lw + ox];
+    const int Dq = BRISK_SM_D(smq);
+    const bool act = ((actmask >> i) & 1u) && (Dq != 0);
+    const bool near = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1;
+    if (near) {
+      const bool pr = act && (brisk_probe_index(ddx, ddy) < (int)BRISK_SM_NPROBED(smq));
+      any = any || pr;
+      t_last = pr ? Dq : t_last;
+      last_static = pr ? i + 1 : last_static;
+      cached = cached || (pr && Dq <= Kp);
+    }
+    bool touched = false;
+    if (!float_patch) {
+      touched = near && (smq & BRISK_SM_E5);
+    } else {
+      if (pass_touch2x2 && ddx >= 0 && ddx <= 1 && ddy >= 0 && ddy <= 1) touched = true;
+      if ((smq & BRISK_SM_E5) && ddx >= -1 && ddx <= 2 && ddy >= -1 && ddy <= 2) touched = true;
+    }
+    const bool open = act && ((nselfmask >> i) & 1u) && touched;
+    const unsigned stq = BRISK_SM_STATUS(smq);
+    const bool tc = open && (stq == BRISK_ST_PASS);
+    any = any || tc;
+    t_last = tc ? 1 : t_last;
+    last_static = tc ? i + 1 : last_static;
+    cached = cached || tc;
+    dyn |= (open && stq == BRISK_ST_TIE) ? (1u << i) : 0u;
+  }
+  *dynmask = dyn;
+  return (unsigned)Kp | ((unsigned)t_last << 8) | ((unsigned)last_static << 16) | (cached ? 1u << 22 : 0u) | (any ? 1u << 23 : 0u);
+}
 BRISK_HD unsigned brisk_state_static(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int px,
                                      int py, int cx, int cy, bool own, const uint16_t* sm_local, int lx0, int ly0, int lw,
                                      const uint8_t* kp5, unsigned* dynmask) {
@@ -1635,6 +1703,21 @@ BRISK_HD unsigned brisk_tie_slot_static(const BriskLayerView& L, const bool floa
   *dynmask = 0;
   if (!probe && px == cx && py == cy) return BRISK_SS_FINAL;  // (the centre: the caller substitutes it)
   return brisk_state_static(L, float_patch, pass_touch2x2, px, py, cx, cy, !probe, sm_local, lx0, ly0, lw, kp5, dynmask);
+}
+// the static step of slot 0..32 with the lane's masks (brisk_state_masks of the slot's offset: computed once per lane)
+BRISK_HD void brisk_tie_slot_offset(int slot, int* sx, int* sy, bool* own) {
+  const bool probe = slot < 8;
+  const int q = probe ? 0 : slot - 8;
+  *sx = probe ? brisk_probe_dx(slot) : (q % 5) - 2;
+  *sy = probe ? brisk_probe_dy(slot) : (q / 5) - 2;
+  *own = !probe;
+}
+BRISK_HD unsigned brisk_tie_slot_static_m(const BriskLayerView& L, const bool float_patch, const bool pass_touch2x2, int cx, int cy,
+                                          int slot, int sx, int sy, unsigned actmask, unsigned nselfmask, const uint16_t* sm_local,
+                                          int lx0, int ly0, int lw, const uint8_t* kp5, unsigned* dynmask) {
+  *dynmask = 0;
+  if (slot >= 8 && sx == 0 && sy == 0) return BRISK_SS_FINAL;  // (the centre: the caller substitutes it)
+  return brisk_state_static_m(L, float_patch, pass_touch2x2, cx + sx, cy + sy, cx, cy, actmask, nselfmask, sm_local, lx0, ly0, lw, kp5, dynmask);
 }
 BRISK_HD int brisk_tie_slot_resolve(const BriskLayerView& L, unsigned packed, unsigned dynmask, int cx, int cy, int centre,
                                     int slot, const uint16_t* sm_local, int lx0, int ly0, int lw, const uint8_t* kp5) {

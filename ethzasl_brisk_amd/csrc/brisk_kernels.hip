@@ -1094,496 +1094,30 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 // holds at most its width) and written back over the layer's list, which is then in raster order.  pool: 12288 words of
 // LDS (4096 words of row counters + 8192 row offsets).  Not inlined: a cold path, and the tie kernel must stay at 104
 // VGPRs at most (k_tie_resolve).
-__device__ __noinline__ void tie_sort_large(const BriskCand* C, int* list, int n, int h, unsigned* gkey, unsigned* gci, unsigned* pool,
-                                            unsigned* wsum) {
-  const int tid = threadIdx.x, nthreads = blockDim.x, wave = tid >> 6, lane = tid & 63;
-  unsigned* cnt32 = pool;            // [4096]
-  unsigned* rowstart = pool + 4096;  // [8192]
-  int* wlist = list;
-  #pragma unroll 1
-  for (int i = tid; i < 4096; i += nthreads) cnt32[i] = 0;
-  __syncthreads();
-  #pragma unroll 1
-  for (int j = tid; j < n; j += nthreads) {
-    const unsigned y = (C[list[j]].key >> 13) & 0x1FFFu;
-    atomicAdd(&cnt32[y >> 1], (y & 1) ? 0x10000u : 1u);
-  }
-  __syncthreads();
-  {  // exclusive prefix over the 8192 rows: a contiguous stretch of rows per thread, wave scan, wave totals
-    const int rpt = (8192 + nthreads - 1) / nthreads;
-    const int r0 = min(tid * rpt, 8192), r1 = min(r0 + rpt, 8192);
-    unsigned local = 0;
-    #pragma unroll 1
-    for (int r = r0; r < r1; ++r) local += (cnt32[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
-    const unsigned incl = (unsigned)wave_inclusive_scan((int)local);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned base = incl - local;
-    #pragma unroll 1
-    for (int q = 0; q < wave; ++q) base += wsum[q];
-    #pragma unroll 1
-    for (int r = r0; r < r1; ++r) {
-      rowstart[r] = base;
-      base += (cnt32[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
-    }
-  }
-  __syncthreads();
-  #pragma unroll 1
-  for (int i = tid; i < 4096; i += nthreads) cnt32[i] = 0;
-  __syncthreads();
-  #pragma unroll 1
-  for (int j = tid; j < n; j += nthreads) {
-    const int ci = list[j];
-    const unsigned key = C[ci].key;
-    const unsigned y = (key >> 13) & 0x1FFFu;
-    const unsigned old = atomicAdd(&cnt32[y >> 1], (y & 1) ? 0x10000u : 1u);
-    const unsigned pos = rowstart[y] + ((old >> (16 * (y & 1))) & 0xFFFFu);
-    gkey[pos] = key;
-    gci[pos] = (unsigned)ci;
-  }
-  // (the buckets are read by other waves of this workgroup: stores acknowledged, then the barrier; L1-bypassing loads)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  #pragma unroll 1
-  for (int y = wave; y < h; y += (nthreads >> 6)) {
-    const int b0 = (int)rowstart[y], nb = (int)((cnt32[y >> 1] >> (16 * (y & 1))) & 0xFFFFu);
-    #pragma unroll 1
-    for (int e0 = 0; e0 < nb; e0 += 64) {
-      const bool mine = e0 + lane < nb;
-      const unsigned myk = mine ? __hip_atomic_load(&gkey[b0 + e0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      const int ci = mine ? (int)__hip_atomic_load(&gci[b0 + e0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      int r = 0;
-      #pragma unroll 1
-      for (int i0 = 0; i0 < nb; i0 += 64) {  // 64 keys of the bucket per load, handed round by lane broadcasts
-        const unsigned kk = (i0 + lane < nb) ? __hip_atomic_load(&gkey[b0 + i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-#pragma unroll 8
-        for (int t = 0; t < 64; ++t) r += ((unsigned)__builtin_amdgcn_readlane((int)kk, t) < myk) ? 1 : 0;
-      }
-      // (read by the workgroup of the layer above, possibly on another XCD: through memory, like the score-state map)
-      if (mine) __hip_atomic_store(&wlist[b0 + r], ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
+// (tie_sort_large: in brisk_tie_kernel.inc, one copy per kernel - a function with two callers is a real call whose
+// register needs add to both kernels: 94 -> 108 VGPRs)
 
-// (at most 104 VGPRs: beside this kernel's 16 waves a CU must still have room for one 512-thread workgroup of the
-// integral kernel - 2 waves x 40 allocated VGPRs per SIMD -, or the two stop overlapping: 0.74 -> 0.84 ms for the window.
-// tie_sort_large is called, not inlined, at a point where little is live: 95 VGPRs.)
-__global__ void __launch_bounds__(TR_THREADS) k_tie_resolve(BriskGeom G, uint8_t* pyr, uint16_t* smap, BriskCand* cand,
-                                                             BriskFrameCounters* counters, const int* tie_idx,
-                                                             const uint8_t* blocks, unsigned* gscratch, int cand_cap,
-                                                             int tie_cap, int nframes, int lpw, int persist) {
-  __shared__ uint8_t kp5s[TR_WAVES][32];
-  __shared__ uint16_t win[TR_WAVES][TR_WIN * TR_WIN + 1];  // per-wave window of the tie being decided
-  // the four TR_CHUNK-sized arrays as ONE block of LDS: the raster sort of a layer beyond the on-chip capacity
-  // (tie_sort_large) uses all of it for its row tables (4096 words of row counters + 8192 row offsets) before any of
-  // them holds live data
-  constexpr int TR_SK = TR_CHUNK > TR_THREADS ? TR_CHUNK : TR_THREADS;
-  struct TiePool {
-    unsigned skey[TR_SK];
-    int sorder[TR_CHUNK];      // candidate index of the tie with raster rank r
-    unsigned sxyd[TR_CHUNK];   // its key (layer, y, x)
-    int vals_ci[TR_CHUNK];     // candidate index of the tie (unsorted order)
-    unsigned pad[(TR_SK + 3 * TR_CHUNK) < 12288 ? 12288 - (TR_SK + 3 * TR_CHUNK) : 1];
-  };
-  __shared__ TiePool tp;
-  __shared__ unsigned wsum[TR_WAVES];
-  unsigned (&skey)[TR_SK] = tp.skey;
-  int (&sorder)[TR_CHUNK] = tp.sorder;
-  unsigned (&sxyd)[TR_CHUNK] = tp.sxyd;
-  unsigned* const pool = reinterpret_cast<unsigned*>(&tp);
-  __shared__ int vals[TR_WAVES][40];
-  int (&vals_ci)[TR_CHUNK] = tp.vals_ci;
-  __shared__ uint16_t sfpm[TR_CHUNK];   // e3 footprint mask of the tie with raster rank r
-  __shared__ unsigned below_bm[TR_BM_WORDS];  // cells of this layer that a tie of the layer below can touch
-  __shared__ int ticket_s, abort_s, seen_s;
-  int* const tstat = reinterpret_cast<int*>(skey);               // after the sort: decision of rank r (0 = pending)
-  unsigned* const sfpxy = reinterpret_cast<unsigned*>(vals_ci);  // after the sort: footprint anchor of rank r
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nthreads = blockDim.x, dwaves = (nthreads >> 6) - 1;  // deciding waves; the last wave writes the decisions to memory
-  const int nl = G.nlayers;
-  const int ngroups = (nl + lpw - 1) / lpw;  // tickets per frame, `lpw` consecutive layers each
-  // persist: the grid is one workgroup per CU and a workgroup draws ticket after ticket (frames whose layers differ a lot
-  // in ties - 4K: 23 ... 1026 per layer - then balance by themselves; a ticket still only waits for tickets drawn before it)
-  for (;;) {
-  __syncthreads();  // (the previous ticket's use of the on-chip arrays and of ticket_s is over)
-  if (tid == 0) {
-    abort_s = 0;
-    if (nframes >= 8) {  // one ticket counter per XCD residue: frames g * 8 + xcd, layer groups in ascending order
-      const int xcd = blockIdx.x & 7;
-      const int t = atomicAdd(&counters[xcd].tie_ticket, 1);
-      ticket_s = ((t / ngroups) * 8 + xcd) * ngroups + t % ngroups;
-    } else {
-      ticket_s = atomicAdd(&counters[0].tie_ticket, 1);
-    }
-  }
-  __syncthreads();
-  const int frame = ticket_s / ngroups, l0 = (ticket_s % ngroups) * lpw, l1 = min(l0 + lpw, nl);
-  if (frame >= nframes) return;
-  if (counters[frame].low_score) {  // the frame runs the ordered path: nothing to resolve, nobody waits for this ticket
-    if (!persist) return;
-    continue;
-  }
-  const BriskCand* C = cand + (long)frame * cand_cap;
-  // a frame whose candidate or tie list overflowed is reported as an error and its result discarded; its map holds
-  // tie candidates that are in no list, which nobody would ever decide: do not wait for them
-  const bool skip_frame = (counters[frame].overflow & 3) != 0;
-  // Safety net of the waits below (a wait that cannot end must not hang the GPU): a wait may legitimately last as long
-  // as all raster-earlier work of the frame - a frame of 150 k ties that all depend on each other decides one tie per
-  // 4 us, and the layer above waits at its front for most of that -, so the bound is 0.5 s + 20 us per tie of the frame
-  // on the 100 MHz wall clock, not a spin count.
-  long long wait_budget = 50000000ll;
-  for (int q = 0; q < nl; ++q) {
-    const long long nq = min(counters[frame].ntie[q], tie_cap);
-    wait_budget += nq * 2000ll;
-    // (a layer beyond the on-chip capacity is first put into raster order through global scratch: O(n), at most a
-    // row's width of steps per tie)
-    if (nq > TR_CHUNK) wait_budget += nq * 2000ll;
-  }
-  for (int l = l0; l < l1; ++l) {
-  int* const my_prog = &counters[frame].tie_prog[l];
-  const int n = min(counters[frame].ntie[l], tie_cap);
-  TR_STAMP(tid == 0, l, 0)
-  __syncthreads();  // (the previous layer's use of the on-chip arrays is over)
-  if (n == 0 || skip_frame) {
-    if (tid == 0) __hip_atomic_fetch_max(my_prog, TR_PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    continue;
-  }
-  if (n > TR_CHUNK) {
-    // raster order in O(n) through global scratch (this layer's share: the ties of all layers together are at most the
-    // candidates), before the per-layer state below is built: the tie kernel must stay at 104 VGPRs
-    int off = 0;
-    for (int q = 0; q < l; ++q) off += min(counters[frame].ntie[q], tie_cap);
-    unsigned* gk = gscratch + (long)frame * cand_cap * 2 + off;
-    tie_sort_large(C, const_cast<int*>(tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap), n, G.L[l].h, gk, gk + cand_cap, pool, wsum);
-    // the list was rewritten in place: the workgroup of the layer above reads it (for its bitmap) only after this flag
-    if (tid == 0) __hip_atomic_fetch_or(&counters[frame].tie_sorted, 1 << l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (tid == 0) seen_s = 0;
-  const BriskLayerView L = make_view(G, pyr, smap, frame, l);
-  const bool last = (l == nl - 1);
-  const bool float_patch = last || G.single_layer;
-  const bool touch2x2 = last && !G.single_layer;
-  const int* list = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l) * tie_cap;
-  // the layer below is either this workgroup's previous layer (complete) or another workgroup's (in progress)
-  const bool below_elsewhere = (l == l0) && (l > 0);
-  const int* below_prog = below_elsewhere ? &counters[frame].tie_prog[l - 1] : nullptr;
-  const bool below_is_octave = ((l - 1) & 1) == 0;
-  int seen = below_elsewhere ? 0 : TR_PROG_DONE;  // last observed progress of the layer below (wave-uniform, monotone)
-  // Most ties do not depend on the layer below at all: only a tie of the layer below that passes touches this layer,
-  // and only inside its 4x4 footprint.  A coarse bitmap of this layer's cells within reach of such a footprint (the
-  // tie's 5x5 block is 2 pixels wide on each side) tells which ties have to wait for the layer below.
-  int bm_shift = 3;
-  while (((L.w >> bm_shift) + 1) * ((L.h >> bm_shift) + 1) > TR_BM_WORDS * 32) ++bm_shift;
-  const int bm_w = (L.w >> bm_shift) + 1;
-  if (below_elsewhere) {
-    for (int i = tid; i < TR_BM_WORDS; i += nthreads) below_bm[i] = 0;
-    __syncthreads();
-    const int nb = min(counters[frame].ntie[l - 1], tie_cap);
-    const int* listb = tie_idx + ((long)frame * BRISK_MAX_LAYERS + l - 1) * tie_cap;
-    if (nb > TR_CHUNK) {  // that list is rewritten in raster order by its workgroup (tie_sort_large): not before it is done
-      long long t0 = 0;
-      for (int spin = 0; !(__hip_atomic_load(&counters[frame].tie_sorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1 << (l - 1))); ++spin) {
-        if (__hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        __builtin_amdgcn_s_sleep(8);
-        if ((spin & 255) == 255) {
-          const long long now = (long long)wall_clock64();
-          if (!t0) t0 = now;
-          else if (now - t0 > wait_budget) { __hip_atomic_store(&abort_s, 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
-        }
-      }
-    }
-    for (int j = tid; j < nb; j += nthreads) {
-      const BriskCand* c = &C[__hip_atomic_load(&listb[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
-      if (!c->fp_mask) continue;
-      const int x0 = max((int)c->fp_x0 - 2, 0) >> bm_shift, x1 = min((int)c->fp_x0 + 5, L.w - 1) >> bm_shift;
-      const int y0 = max((int)c->fp_y0 - 2, 0) >> bm_shift, y1 = min((int)c->fp_y0 + 5, L.h - 1) >> bm_shift;
-      for (int y = y0; y <= y1; ++y)
-        for (int x = x0; x <= x1; ++x) atomicOr(&below_bm[(y * bm_w + x) >> 5], 1u << ((y * bm_w + x) & 31));
-    }
-    // (the barriers of the sort below order the bitmap before its first use)
-  }
-
-  // ---- raster order of the layer's ties
-  const bool on_chip = n <= TR_CHUNK;
-  if (on_chip) {
-    for (int j = tid; j < n; j += nthreads) {
-      const int ci = list[j];
-      vals_ci[j] = ci;
-      skey[j] = C[ci].key;
-    }
-    __syncthreads();
-    for (int j = tid; j < n; j += nthreads) {
-      const unsigned k = skey[j];
-      int r = 0;
-      for (int q = 0; q < n; ++q) r += (skey[q] < k) ? 1 : 0;
-      sorder[r] = vals_ci[j];
-      sxyd[r] = k;
-    }
-    __syncthreads();
-  }
-  // (a layer beyond the on-chip capacity was put into raster order at the top of the layer loop: tie_sort_large)
-
-  uint16_t* wl = win[wave];
-  for (int c0 = 0; c0 < n; c0 += TR_CHUNK) {
-    const int nc = min(TR_CHUNK, n - c0);
-    if (!on_chip) {
-      __syncthreads();
-      for (int r = tid; r < nc; r += nthreads) {
-        const int ci = __hip_atomic_load(&list[c0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (rewritten above: not from L1)
-        sorder[r] = ci;
-        sxyd[r] = C[ci].key;
-      }
-      __syncthreads();
-    }
-    // everything the decision loop needs besides the smap window goes on chip: footprints by rank, decisions
-    for (int r = tid; r < nc; r += nthreads) {
-      const BriskCand* c = &C[sorder[r]];
-      sfpxy[r] = (unsigned)(uint16_t)c->fp_x0 | ((unsigned)(uint16_t)c->fp_y0 << 16);
-      sfpm[r] = c->fp_mask;
-      tstat[r] = 0;
-    }
-    __syncthreads();
-    // Round-robin over the raster-sorted ties: neighbouring ties (which depend on each other) run on different
-    // waves back to back.  The only thing a tie needs from raster-earlier ties of its 9x9 window is their
-    // decision, which is exchanged through LDS (tstat); the window itself and the 5x5 score block of a wave's
-    // NEXT tie are prefetched into registers while the current one is decided.
-    int j = (wave < dwaves) ? wave : nc;
-    TR_STAMP(tid == 0, l, 1)
-#ifdef TR_TIMING
-    int tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = (long long)wall_clock64();
-#endif
-    unsigned pw0 = 0, pw1 = 0, pkb = 0;
-    bool pvalid = false;
-#define TR_PREFETCH(jj)                                                                                          \
-  {                                                                                                              \
-    const unsigned k_ = sxyd[jj];                                                                                \
-    const int cx_ = k_ & 0x1FFF, cy_ = (k_ >> 13) & 0x1FFF;                                                      \
-    const int e1_ = min(lane + 64, TR_WIN * TR_WIN - 1);                                                         \
-    const int qx0_ = cx_ + lane % TR_WIN - 4, qy0_ = cy_ + lane / TR_WIN - 4;                                    \
-    const int qx1_ = cx_ + e1_ % TR_WIN - 4, qy1_ = cy_ + e1_ / TR_WIN - 4;                                      \
-    pw0 = smap_load_fresh(L.smap, (long)min(max(qy0_, 0), L.h - 1) * L.stride + min(max(qx0_, 0), L.w - 1));     \
-    pw1 = smap_load_fresh(L.smap, (long)min(max(qy1_, 0), L.h - 1) * L.stride + min(max(qx1_, 0), L.w - 1));     \
-    if (qx0_ < 0 || qy0_ < 0 || qx0_ >= L.w || qy0_ >= L.h) pw0 = 0;                                            \
-    if (qx1_ < 0 || qy1_ < 0 || qx1_ >= L.w || qy1_ >= L.h) pw1 = 0;                                            \
-  }
-#define TR_PREFETCH_BLOCK(jj) pkb = blocks[((long)frame * cand_cap + sorder[jj]) * 64 + min(lane, 24)];
-    // the window may only be read once the layer below is past the rows that can touch it
-#define TR_NEED(key_, need_)                                                                                     \
-  {                                                                                                              \
-    const int x_ = (int)((key_) & 0x1FFF), y_ = (int)(((key_) >> 13) & 0x1FFF);                                  \
-    const int cell_ = (y_ >> bm_shift) * bm_w + (x_ >> bm_shift);                                                \
-    need_ = (below_elsewhere && ((below_bm[cell_ >> 5] >> (cell_ & 31)) & 1u)) ? brisk_tie_rows_needed(y_, below_is_octave) : 0; \
-  }
-#define TR_POLL(need_)                                                                                           \
-  if (seen < need_) {                                                                                            \
-    seen = max(seen, __hip_atomic_load(&seen_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));                \
-    if (seen < need_) {                                                                                          \
-      seen = __hip_atomic_load(below_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                          \
-      if (lane == 0) __hip_atomic_fetch_max(&seen_s, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      \
-    }                                                                                                            \
-  }
-#define TR_TRY_PREFETCH(jj)                                                                                      \
-  {                                                                                                              \
-    int need_;                                                                                                   \
-    TR_NEED(sxyd[jj], need_)                                                                                     \
-    TR_POLL(need_)                                                                                               \
-    TR_T(1)                                                                                                      \
-    pvalid = seen >= need_;                                                                                      \
-    if (pvalid) TR_PREFETCH(jj)                                                                                  \
-    TR_PREFETCH_BLOCK(jj)                                                                                        \
-  }
-    if (j < nc) TR_TRY_PREFETCH(j)
-    while (j < nc) {
-      unsigned v0 = pw0;
-      unsigned v1 = pw1;
-      const unsigned kb = pkb;
-      const bool valid = pvalid;
-      const unsigned key = sxyd[j];
-      const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
-      {
-        const int jn = min(j + dwaves, nc - 1);  // (the last prefetch of a wave is redundant, never out of range)
-        TR_TRY_PREFETCH(jn)
-      }
-      TR_T(2)
-      if (!valid) {  // pipeline front: wait for the layer below, then read the window
-        int need;
-        TR_NEED(key, need)
-        long long t0 = 0;
-        for (int spin = 0; seen < need; ++spin) {
-          TR_POLL(need)
-          if (seen >= need || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-          __builtin_amdgcn_s_sleep(8);
-          if ((spin & 255) == 255) {
-            const long long now = (long long)wall_clock64();
-            if (!t0) t0 = now;
-            else if (now - t0 > wait_budget) break;
-          }
-        }
-        if (seen < need) __hip_atomic_store(&abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (the layer below: never observed)
-        const unsigned s0 = pw0, s1 = pw1;  // keep the next tie's prefetch
-        TR_PREFETCH(j)
-        v0 = pw0; v1 = pw1;
-        pw0 = s0; pw1 = s1;
-      }
-      TR_T(7)
-      // the window as it was read (ties that were pending then show status TIE) and the score block go to LDS
-      wl[lane] = (uint16_t)v0;
-      if (lane + 64 < TR_WIN * TR_WIN) wl[lane + 64] = (uint16_t)v1;
-      if (lane < 25) kp5s[wave][lane] = (uint8_t)kb;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int centre = BRISK_SM_D(wl[4 * TR_WIN + 4]);
-      // lanes 0-7: the 8 probe values, lanes 32-56: the 5x5 raw block (vals[8..32])
-      const int slot = (lane < 8) ? lane : (lane >= 32 && lane < 57) ? lane - 24 : -1;
-      // raster-earlier ties of the window (entries 0..39 of the 81) that were pending: where their decisions will appear
-      int lo = -1;
-      {
-        const int dy = lane / TR_WIN - 4, dx = lane % TR_WIN - 4;
-        if (lane < 40 && BRISK_SM_D(v0) && BRISK_SM_STATUS(v0) == BRISK_ST_TIE) {
-          const unsigned k2 = ((unsigned)l << 26) | ((unsigned)(cy + dy) << 13) | (unsigned)(cx + dx);
-          int hi = j;
-          lo = 0;
-          while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sxyd[mid] < k2) lo = mid + 1; else hi = mid;
-          }
-          // (a pending raster-earlier tie of the window is always in this chunk: earlier chunks are complete and the
-          // window was read after they were)
-          if (!(lo < j && sxyd[lo] == k2)) {
-            __hip_atomic_store(&abort_s, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
-            lo = -1;
-          }
-        }
-      }
-      TR_T(3)
-      // everything of the cache replay that does not depend on those decisions, before waiting for them
-      unsigned spk = BRISK_SS_FINAL, sdyn = 0;
-      if (slot >= 0) spk = brisk_tie_slot_static(L, float_patch, touch2x2, cx, cy, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave], &sdyn);
-      TR_T(5)
-      if (lo >= 0) {
-        int st = 0;
-        long long t0 = 0;
-        for (int spin = 0;; ++spin) {
-          st = __hip_atomic_load(&tstat[lo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 3;
-          if (st || __hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-          __builtin_amdgcn_s_sleep(1);
-          if ((spin & 4095) == 4095) {  // (the other wave may itself be waiting for the layer below)
-            const long long now = (long long)wall_clock64();
-            if (!t0) t0 = now;
-            else if (now - t0 > wait_budget) break;
-          }
-        }
-        if (!st && !__hip_atomic_load(&abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __hip_atomic_store(&abort_s, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (never observed)
-        if (st) wl[lane] = (uint16_t)((v0 & ~0x3000u) | ((unsigned)st << 12));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      TR_T(4)
-      // the open events with the decisions in
-      if (slot >= 0)
-        vals[wave][slot] = brisk_tie_slot_resolve(L, spk, sdyn, cx, cy, centre, slot, wl, cx - 4, cy - 4, TR_WIN, kp5s[wave]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // the eight neighbours of the tie list on eight lanes (a serial walk on one lane costs ~70 dependent LDS reads)
-      const bool nb_ok = (lane >= 8) || brisk_tie_neighbour_ok(centre, &vals[wave][0], &vals[wave][8], lane);
-      const bool pass = __all(nb_ok);
-      const int dec = pass ? (int)BRISK_ST_PASS : (int)BRISK_ST_FAIL;
-      // the decision goes to LDS only (other waves spin on it); the writer wave takes it to memory
-      if (lane == 0) __hip_atomic_store(&tstat[j], dec, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __builtin_amdgcn_wave_barrier();
-      TR_T(0)
-#ifdef TR_TIMING
-      tacc[6] += 1;
-#endif
-      TR_STAMP(tid == 0 && j == 0, l, 2)
-      j += dwaves;
-    }
-    TR_STAMP(tid == 0, l, 3)
-    // ---- writer wave: decisions -> score-state map, candidate status, touches on the layer above; a tie counts as
-    // done for the layer above once these are performed; the progress is the row of the first tie that is not done.
-    // The deciding waves never wait for a memory write this way (an agent-scope atomic takes microseconds).
-    if (wave == dwaves) {
-      int w = 0, row_pub = -1;
-      long long t0 = 0;
-      for (int idle = 0; w < nc;) {
-        const int i = w + lane;
-        const int st = (i < nc) ? __hip_atomic_load(&tstat[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-        const bool todo = (st & 3) && !(st & TR_DONE_BIT);
-        if (todo) {
-          const unsigned key = sxyd[i];
-          const int cx = key & 0x1FFF, cy = (key >> 13) & 0x1FFF;
-          const bool pass = (st & 3) == (int)BRISK_ST_PASS;
-          if (pass) smap_xor(L.smap, (long)cy * L.stride + cx, 0x3000u);  // TIE (10b) -> PASS (01b)
-          else smap_or(L.smap, (long)cy * L.stride + cx, 0x1000u);       // TIE (10b) -> FAIL (11b)
-          cand[(long)frame * cand_cap + sorder[i]].status = (uint8_t)(st & 3);
-          const unsigned fpm = (pass && !last) ? (unsigned)sfpm[i] : 0u;
-          if (fpm) {
-            const int fx = (int16_t)(sfpxy[i] & 0xFFFFu), fy = (int16_t)(sfpxy[i] >> 16);
-            const BriskLayerView La = make_view(G, pyr, smap, frame, l + 1);
-            for (int b = 0; b < 16; ++b)
-              if (fpm & (1u << b)) smap_or(La.smap, (long)(fy + (b >> 2)) * La.stride + fx + (b & 3), BRISK_SM_TOUCH);
-          }
-        }
-        if (__any(todo)) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (todo) __hip_atomic_fetch_or(&tstat[i], TR_DONE_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        const unsigned long long decided = __ballot((i < nc) && (st & 3));
-        const int lead = (~decided == 0ull) ? 64 : __builtin_ctzll(~decided);
-        if (lead) {
-          w += lead;
-          idle = 0;
-          if (lane == 0 && !last && w < nc) {
-            const int row = (int)((sxyd[w] >> 13) & 0x1FFF);
-            if (row > row_pub) __hip_atomic_fetch_max(my_prog, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (w < nc) row_pub = max(row_pub, (int)((sxyd[w] >> 13) & 0x1FFF));
-        } else {
-          if ((++idle & 4095) == 0) {  // (the deciding waves may be waiting for the layer below)
-            const long long now = (long long)wall_clock64();
-            if (idle == 4096) t0 = now;
-            else if (now - t0 > wait_budget) {  // (never observed)
-              __hip_atomic_store(&abort_s, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              break;
-            }
-          }
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-    }
-#ifdef TR_TIMING
-    if (lane == 0 && wave < dwaves)
-      for (int i = 0; i < 8; ++i) atomicAdd(&counters[frame].tphase[i], tacc[i]);
-#endif
-#undef TR_TRY_PREFETCH
-#undef TR_POLL
-#undef TR_NEED
-#undef TR_PREFETCH_BLOCK
-#undef TR_PREFETCH
-    // the touches are agent-scope atomics and the readers use L1-bypassing loads: completion of the atomics (vmcnt) +
-    // the workgroup barrier is all the ordering the next chunk and the progress word need
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TR_STAMP(lane == 0 && wave == dwaves, l, 4)
-    __syncthreads();
-    TR_STAMP(tid == 0, l, 5)
-    if (tid == 0 && !last) {
-      const int c1 = c0 + nc;
-      const int row = (c1 < n) ? (int)((C[__hip_atomic_load(&list[c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)].key >> 13) & 0x1FFF) : TR_PROG_DONE;
-      __hip_atomic_fetch_max(my_prog, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  }  // layers of this ticket
-  __syncthreads();
-  if (tid == 0 && abort_s) atomicOr(&counters[frame].overflow, 8 | (abort_s << 8));  // a wait ran into its bound: reported as an error (bits 8-10: which wait)
-  if (!persist) return;
-  }  // tickets of this workgroup
-}
+// k_tie_resolve (batches of 32 frames and more) must stay at 96 VGPRs at most: beside its 16 waves a CU must still have
+// room for one 512-thread workgroup of the integral kernel - 2 waves x 56 allocated VGPRs per SIMD in the 24-bit form (51
+// used) -, or the two stop overlapping (seen twice: 0.74 -> 0.84 ms for the window in round 3; 72.4 -> 70.2 k frames/s in
+// round 4 when a variant of this kernel reached 99).  tie_sort_large is called, not inlined, at a point where little is
+// live: 94 VGPRs.
+// k_tie_resolve_small (fewer than 32 frames: nothing competes for the CUs) runs the static step of the cache replay with
+// the lane's precomputed act / not-self masks (brisk_state_masks; TR_KERNEL_MASKS): 13 % fewer instructions per tie, 98
+// VGPRs; one 640 x 480 frame: detect 294 -> 281 us, 1080p 415 -> 386 us.
+#define TR_KERNEL_NAME k_tie_resolve
+#define TR_SORT_NAME tie_sort_large
+#define TR_KERNEL_MASKS 0
+#include "brisk_tie_kernel.inc"
+#undef TR_KERNEL_NAME
+#undef TR_KERNEL_MASKS
+#undef TR_SORT_NAME
+#define TR_KERNEL_NAME k_tie_resolve_small
+#define TR_SORT_NAME tie_sort_large_small
+#define TR_KERNEL_MASKS 1
+#include "brisk_tie_kernel.inc"
+#undef TR_KERNEL_NAME
+#undef TR_KERNEL_MASKS
 
 // ------------------------------------------------------------------------------------------------
 // k_finalize: keypoints of a frame in (layer, y, x) order.  One workgroup per frame; ranks by
@@ -2191,8 +1725,12 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     // of a large batch: the batch gets 1 % faster, the tie kernel itself 40 % slower - not taken.)
     static const int waves_knob = env_knob("BRISK_TR_WAVES", 0);
     const int tr_waves = waves_knob ? min(max(waves_knob, 2), TR_WAVES) : TR_WAVES;
-    hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                       B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist);
+    if (nframes < 32)
+      hipLaunchKernelGGL(k_tie_resolve_small, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
+                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist);
+    else
+      hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
+                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist);
   }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,

@@ -451,6 +451,12 @@ int emul_state_split_mismatches(unsigned seed, int n) {
         const unsigned pk = brisk_tie_slot_static(L, float_patch, touch2x2, cx, cy, slot, wpre, cx - 4, cy - 4, 9, kp5, &dyn);
         const int got = brisk_tie_slot_resolve(L, pk, dyn, cx, cy, centre, slot, wfin, cx - 4, cy - 4, 9, kp5);
         if (ref != got) ++bad;
+        // the kernel's form: the slot's act / not-self masks precomputed (brisk_state_masks)
+        int sx, sy; bool own; unsigned am, ns, dyn2 = 0;
+        brisk_tie_slot_offset(slot, &sx, &sy, &own);
+        brisk_state_masks(sx, sy, own, &am, &ns);
+        const unsigned pk2 = brisk_tie_slot_static_m(L, float_patch, touch2x2, cx, cy, slot, sx, sy, am, ns, wpre, cx - 4, cy - 4, 9, kp5, &dyn2);
+        if (pk2 != pk || dyn2 != dyn) ++bad;
       }
     }
   }

@@ -1715,16 +1715,23 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     // (pyramids of more than 8 layers - 4K frames with 6 octaves: 23 ... 1026 ties per layer - in groups that leave a
     // quarter of the CUs to the integral kernel beside them: 64 frames x 12 layers 1.03 -> 0.89 ms)
     const int per_wg = G.nlayers > 8 ? 192 : 256;
-    const int lpw = lpw_knob ? min(lpw_knob, G.nlayers)
-                             : (nframes * G.nlayers <= 512 ? 1 : min((nframes * G.nlayers + per_wg - 1) / per_wg, G.nlayers));
+    // (the fewest layers per workgroup whose ticket count still fits: 192 frames x 8 layers by six gave 384 workgroups on
+    // 256 CUs - 0.67 ms; one workgroup per frame: 0.40)
+    int lpw_auto = G.nlayers;
+    for (int c = 1; c <= G.nlayers; ++c)
+      if (nframes * ((G.nlayers + c - 1) / c) <= per_wg) { lpw_auto = c; break; }
+    const int lpw = lpw_knob ? min(lpw_knob, G.nlayers) : (nframes * G.nlayers <= 512 ? 1 : lpw_auto);
     int tr_grid = (nframes >= 8 ? (nframes + 7) / 8 * 8 : nframes) * ((G.nlayers + lpw - 1) / lpw);
     static const int persist_knob = env_knob("BRISK_TR_PERSIST", -1), pgrid_knob = env_knob("BRISK_TR_PGRID", 256);
     const int persist = persist_knob >= 0 ? persist_knob : (tr_grid > pgrid_knob ? 1 : 0);
     if (persist && tr_grid > pgrid_knob) tr_grid = pgrid_knob;
-    // waves per workgroup: 16 (15 deciding).  (12 leave room for a third integral workgroup per CU on the side stream
-    // of a large batch: the batch gets 1 % faster, the tie kernel itself 40 % slower - not taken.)
+    // waves per workgroup: 16 (15 deciding).  Where a workgroup owns a whole frame of a large batch (one workgroup per CU,
+    // the integral kernel beside it): 12 - a second 512-thread workgroup of the integral kernel then fits on the CU (3 x 96
+    // + 4 x 56 VGPRs per SIMD), the tie kernel itself gets slower and the batch 0.9 % faster (72.95 -> 73.6 k frames/s; 14:
+    // 72.7, 10: 72.5, 8: 70.9).  Not for the ticketed forms: 64 4K frames 15.2 -> 14.7 k frames/s with 12 (there the tie
+    // kernel is what the window waits for).
     static const int waves_knob = env_knob("BRISK_TR_WAVES", 0);
-    const int tr_waves = waves_knob ? min(max(waves_knob, 2), TR_WAVES) : TR_WAVES;
+    const int tr_waves = waves_knob ? min(max(waves_knob, 2), TR_WAVES) : ((!persist && lpw >= G.nlayers && nframes >= 192) ? 12 : TR_WAVES);
     if (nframes < 32)
       hipLaunchKernelGGL(k_tie_resolve_small, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
                          B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist);

@@ -54,7 +54,8 @@ def _run_batch_and_compare(B, frames_distinct, n, thr, octaves, w, h, every_slot
 
 @pytest.mark.parametrize("n", [96, 128, 200, 255, 65])
 def test_1080p_batches_between_65_and_255_frames(B, n):
-    """lpw (layers per tie workgroup) = 3, 4, 7, 8 and 2 at BASELINE config-2 content; eight distinct frames, every
+    """lpw (layers per tie workgroup) = 4, 4, 8, 8 and 3 at BASELINE config-2 content (round 4's rule: the fewest layers per
+    workgroup whose ticket count fits 256; 12-wave workgroups from 192 frames on); eight distinct frames, every
     slot of the batch - the last one included - bit-equal to the oracle."""
     distinct = [synth.frame_1080p(300 + s) for s in range(8)]
     total = _run_batch_and_compare(B, distinct, n, 80, 4, 1920, 1080)

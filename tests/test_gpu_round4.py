@@ -241,3 +241,14 @@ def test_one_frame_results_beyond_the_pinned_buffer(B):
     assert k0d.tobytes() == k1d.tobytes() and np.array_equal(d0, d1)
     assert k2d.tobytes() == k3d.tobytes() and np.array_equal(d2, d3)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8, 31, 32])
+def test_1080p_batches_around_the_small_tie_kernel_threshold(B, n):
+    """batches below 32 frames run k_tie_resolve_small (precomputed act / not-self masks in the static step of the cache
+    replay; per-XCD tickets from 8 frames on), 32 and more the plain form: every slot against the oracle, twice (dirty
+    workspace)"""
+    distinct = [synth.frame_1080p(500 + s) for s in range(4)]
+    total = _run_batch_and_compare(B, distinct, n, 80, 4, 1920, 1080)
+    assert total > 3000

@@ -3,7 +3,8 @@
 
 A "step" is one pass of the hot path (pyramid -> AGAST detect -> NMS/refine -> describe) over one batch of synthetic
 1080p frames that already sit in HBM (BASELINE config 2: Appendix-C recipe, 4 octaves, threshold 80, ~1k keypoints per
-frame).  The batch of a step is `--batch x --inner` frames (default 256 x 32 = 8192 per GPU): the engine takes it in
+frame).  The batch of a step is `--batch x --inner` frames (default 512 x 16 = 8192 per GPU; 256-frame chunks until the
+end of round 4: 2 % slower, `tools/sweep_batch.py`): the engine takes it in
 chunks of `--batch` frames through one workspace, so that a step is ~0.1-0.2 s of GPU work and the timed region
 lasts seconds (clocks settled), while the per-chunk time stays comparable between rounds (`config.ms_per_chunk`).
 
@@ -251,8 +252,8 @@ def parse_args(argv):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per engine call (chunk) per GPU")
-    ap.add_argument("--inner", type=int, default=32, help="chunks per step: a step is batch x inner frames per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frames per engine call (chunk) per GPU")
+    ap.add_argument("--inner", type=int, default=16, help="chunks per step: a step is batch x inner frames per GPU")
     ap.add_argument("--frames", type=int, default=0,
                     help="BASELINE config 3: this many frames in total per step, split over the ranks by "
                          "sharding.shard_frames (strong scaling); 0 = weak scaling with --batch x --inner per GPU")

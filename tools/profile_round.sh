@@ -3,7 +3,8 @@
 #   --config 4 | 4_uniform | 4_uniform_single | 5 | 1 | dense30 | dense50: afterwards the same per BASELINE configuration
 #   (tools/profile_config.sh: entry of bench.py's config.other_configs, kernel statistics, FETCH / WRITE passes, traffic)
 # Collects what profiles/ holds for a round into gpurun_out/<tag>/:
-#   kernel_stats_b256.csv    rocprofv3 --kernel-trace --stats of the default bench command
+#   kernel_stats_b512.csv    rocprofv3 --kernel-trace --stats of the default bench command (512 frames per launch)
+#   kernel_stats_b256.csv    the same at --batch 256
 #   pmc_fetch_b64.csv / pmc_write_b64.csv   separate PMC passes (FETCH_SIZE, WRITE_SIZE) of a 64-frame run, engine kernels only
 #   traffic.json             tools/pmc_traffic.py on those two passes (per kernel and per group, tagged with the kernel revision)
 #   sq_counters.txt          SQ occupancy / stall / instruction counters per kernel (tools/pmc_sq.sh)
@@ -15,7 +16,12 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/bench.py > $out/bench.json 2> $out/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --no-other-configs --steps 2 --warmup 1 --inner 8 > $out/ks.log 2>&1
+# the default command (512 frames per launch: what the bench line is quoted on) ...
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks5 -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --no-other-configs --steps 2 --warmup 1 --inner 4 > $out/ks5.log 2>&1
+cp $(find $out/ks5 -name "*kernel_stats.csv" | head -1) $out/kernel_stats_b512.csv
+rm -rf $out/ks5
+# ... and 256 frames per launch (the unit of DESIGN.md's kernel tables and of the earlier rounds' files)
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks -o r --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --no-other-configs --batch 256 --steps 2 --warmup 1 --inner 8 > $out/ks.log 2>&1
 cp $(find $out/ks -name "*kernel_stats.csv" | head -1) $out/kernel_stats_b256.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c -d $out/pmc_$c -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-fed --no-other-configs --batch 64 --inner 2 --steps 2 --warmup 1 > $out/pmc_$c.log 2>&1

@@ -252,3 +252,13 @@ def test_1080p_batches_around_the_small_tie_kernel_threshold(B, n):
     distinct = [synth.frame_1080p(500 + s) for s in range(4)]
     total = _run_batch_and_compare(B, distinct, n, 80, 4, 1920, 1080)
     assert total > 3000
+
+
+@pytest.mark.gpu
+def test_bench_default_launch_shape_512_frames(B):
+    """the bench's default chunk since the end of round 4: 512 1080p frames in one call (two rounds of one 12-wave tie
+    workgroup per frame, more than DS_MAXQ frames per k_describe launch): every slot against the oracle, on a fresh and
+    on a dirty workspace"""
+    distinct = [synth.frame_1080p(700 + s) for s in range(4)]
+    total = _run_batch_and_compare(B, distinct, 512, 80, 4, 1920, 1080)
+    assert total > 3000

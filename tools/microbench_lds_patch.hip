@@ -1,0 +1,585 @@
+// microbench_lds_patch.hip - LDS patch staging for the descriptor's sampling pattern, measured before k_describe is
+// touched (round-4 review item 1; brisk/src/brisk-descriptor-extractor.cc:370-530, 618-662).
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/mblds tools/microbench_lds_patch.hip \
+//         ethzasl_brisk_amd/csrc/brisk_pattern.cpp
+//   python3 tools/gen_lds_patch_input.py /tmp/lds_in.bin && /tmp/mblds /tmp/lds_in.bin
+//
+// Workload: the keypoints of BASELINE config 2 (4 distinct 1080p frames, the oracle's positions, scale indices and
+// rotations) on 256 frame slots, dealt like k_describe deals them (frame f -> queue f % 8 = XCD, spatial processing
+// order).  Every variant computes the SAME 132 SmoothedIntensity values per keypoint with the engine's own arithmetic
+// (brisk_box_prep / brisk_box_acc / brisk_div_by_magic) - the checksums must agree - plus `filler` dependent integer
+// operations per keypoint for the long pairs / bits the real kernel runs beside the sampling.
+//   gather_u32 / gather_i24   the shipped formulation: runs of 2 keypoints, 3 rounds per pass, ten buffer gathers per
+//                             sample from the global integral image (32-bit / 3-byte elements)
+//   lds_*                     one keypoint per wave: its patch of the integral image staged in LDS with coalesced row
+//                             loads, then 4 rounds (64 + 2 samples per pass) of ten ds_read2 per sample
+//     lds_u16_from_i24 / _u32   low 16 bits of the integral rows (every region sum of a box with interior <= 256 px is
+//                               below 2^16: scale indices <= 28, patch side <= 101 px), 2 bytes per element
+//     lds_u32_from_u32          the rows as they are (review variant ii)
+//     lds_u16_from_pix / lds_u32_from_pix   u8 pixels -> local integral by DPP row scans (review variant i)
+// Classes by patch side 2 * sizeList_[scale] + 1: <= 67, <= 101, <= 151, <= 201, all.
+// Output: one JSON row per (variant, class): samples/ns chip-wide, us per keypoint and CU, checksum.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../ethzasl_brisk_amd/csrc/brisk_common.h"
+#include "../ethzasl_brisk_amd/csrc/brisk_device_describe.h"
+#include "../ethzasl_brisk_amd/csrc/brisk_pattern.h"
+
+#define CHECK(x)                                                                   \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__);  \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+#define GETREG_XCC_ID (20 | (3 << 11))
+typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+typedef uint32_t __attribute__((ext_vector_type(3))) u32x3;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) u32x2a4;
+
+struct MbArgs {
+  const uint32_t* integ32;  // [NF] (h + 1) x (w + 1) u32
+  const uint8_t* integ24;   // [NF] the same in 3-byte elements
+  const uint8_t* pix;       // [NF] h x w u8
+  long f32_elems, f24_bytes, pix_bytes;
+  int iw, ih, w, h;
+  const int4* tab4;
+  const double2* uv2;
+  const int* size_list;
+  int np;
+  const uint4* kps;     // {x bits, y bits, scale, theta}
+  const uint4* tasks;   // [8][max_tasks] {frame slot, kp0, kp1 or -1, 0}
+  const int* ntasks;    // [8]
+  int max_tasks;
+  int* tickets;         // [8], 32 ints apart
+  unsigned long long* checksum;
+  int filler;
+};
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct Raw {
+  u32x2 p00, p02, p10, p12, p30, p32, ql, qr;
+  u32x3 p20, p22;
+};
+template <bool I24>
+__device__ __forceinline__ void gather_load(Raw& r, const BriskBoxPrep& p, __amdgpu_buffer_rsrc_t rs, int istride) {
+  constexpr int ES = I24 ? 3 : 4;
+  const int rowb = istride * ES;
+  const int o_t = p.y_top * rowb, o_b = p.y_bottom * rowb;
+  const int o_tl = o_t + p.x_left * ES, o_tr = o_t + p.x_right * ES, o_bl = o_b + p.x_left * ES, o_br = o_b + p.x_right * ES;
+  r.p00 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_tl, 0, 0);
+  r.p02 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_tr, 0, 0);
+  r.p10 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_tl, rowb, 0);
+  r.p12 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_tr, rowb, 0);
+  r.ql = __builtin_amdgcn_raw_buffer_load_b64(rs, o_bl - rowb + ES, 0, 0);
+  r.qr = __builtin_amdgcn_raw_buffer_load_b64(rs, o_br - rowb + ES, 0, 0);
+  r.p20 = __builtin_amdgcn_raw_buffer_load_b96(rs, o_bl, 0, 0);
+  r.p22 = __builtin_amdgcn_raw_buffer_load_b96(rs, o_br, 0, 0);
+  r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_bl, rowb, 0);
+  r.p32 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_br, rowb, 0);
+}
+__device__ __forceinline__ void unpack2(u32x2 v, uint32_t& a, uint32_t& b) {
+  a = v.x;
+  b = __builtin_amdgcn_alignbit(v.y, v.x, 24);
+}
+template <bool I24>
+__device__ __forceinline__ int gather_combine(const BriskBoxPrep& p, const Raw& r) {
+  uint32_t i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i2x, i22, i23, i2y, i30, i31, i32, i33, ql0, ql1, qr0, qr1;
+  if (I24) {
+    unpack2(r.p00, i00, i01); unpack2(r.p02, i02, i03); unpack2(r.p10, i10, i11); unpack2(r.p12, i12, i13);
+    unpack2(u32x2{r.p20.x, r.p20.y}, i20, i21); i2x = __builtin_amdgcn_alignbit(r.p20.z, r.p20.y, 16);
+    unpack2(u32x2{r.p22.x, r.p22.y}, i22, i23); i2y = __builtin_amdgcn_alignbit(r.p22.z, r.p22.y, 16);
+    unpack2(r.p30, i30, i31); unpack2(r.p32, i32, i33); unpack2(r.ql, ql0, ql1); unpack2(r.qr, qr0, qr1);
+  } else {
+    i00 = r.p00.x; i01 = r.p00.y; i02 = r.p02.x; i03 = r.p02.y; i10 = r.p10.x; i11 = r.p10.y; i12 = r.p12.x; i13 = r.p12.y;
+    i20 = r.p20.x; i21 = r.p20.y; i2x = r.p20.z; i22 = r.p22.x; i23 = r.p22.y; i2y = r.p22.z;
+    i30 = r.p30.x; i31 = r.p30.y; i32 = r.p32.x; i33 = r.p32.y; ql0 = r.ql.x; ql1 = r.ql.y; qr0 = r.qr.x; qr1 = r.qr.y;
+  }
+  constexpr uint32_t mask = I24 ? 0xFFFFFFu : 0xFFFFFFFFu;
+  const unsigned qbr = (i2y - i23 - qr1 + qr0) & mask;
+  const unsigned qbl = (i2x - i21 - ql1 + ql0) & mask;
+  const uint32_t acc = brisk_box_acc(p, i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i22, i23, i30, i31, i32, i33, qbr, qbl, mask);
+  return brisk_div_by_magic((int)acc, p.magic, p.shift);
+}
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- the shipped formulation -----------------------------------------------------------------------------------
+template <bool I24>
+__global__ void __launch_bounds__(128) k_gather(MbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* vals = reinterpret_cast<int*>(lds + wave * 1024);
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 7);
+  const int np = A.np;
+  long long sum = 0;
+  for (int gi = 0; gi < 8; ++gi) {
+    const int g = (xcc + gi) & 7;
+    const int nt = A.ntasks[g];
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&A.tickets[g * 32], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nt) break;
+      const uint4 task = A.tasks[(long)g * A.max_tasks + t];
+      const int cnt = (int)task.z >= 0 ? 2 : 1, total = cnt * np;
+      const uint4 rec0 = A.kps[task.y], rec1 = A.kps[cnt == 2 ? task.z : task.y];
+      const __amdgpu_buffer_rsrc_t rs =
+          I24 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.integ24 + (long)task.x * A.f24_bytes), 0, (int)A.f24_bytes, 0x00020000)
+              : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A.integ32 + (long)task.x * A.f32_elems), 0, (int)(A.f32_elems * 4), 0x00020000);
+      int ksum = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int s0 = 0; s0 < total; s0 += 64) {
+          const int s = s0 + lane;
+          const bool valid = s < total;
+          const int sc = min(s, total - 1);
+          const int kq = sc >= np ? 1 : 0, pt = sc - kq * np;
+          const uint4 rec = kq ? rec1 : rec0;
+          const int theta = pass ? (int)rec.w : 0;
+          const int4 tab = A.tab4[(int)rec.z * np + pt];
+          const double2 uv = A.uv2[theta * np + pt];
+          const double mm = (double)__int_as_float(tab.x);
+          const float xf = (float)(mm * uv.x) + __uint_as_float(rec.x), yf = (float)(mm * uv.y) + __uint_as_float(rec.y);
+          const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
+          Raw raw;
+          if (valid) gather_load<I24>(raw, pr, rs, A.iw);
+          const int value = gather_combine<I24>(pr, raw);
+          if (valid) { vals[sc] = value; ksum += value; }
+        }
+        wave_sync();
+      }
+      int f = vals[lane] + ksum;
+      for (int k = 0; k < A.filler * cnt; ++k) f = f * 1664525 + 1013904223;
+      if (f == 0x12345678) ksum += 1;
+      sum += ksum;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
+  if (lane == 0) atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
+}
+
+// ---- LDS patch variants ------------------------------------------------------------------------------------------
+// patch geometry of a keypoint with border b (sizeList_[scale]): integral columns x0 .. x0 + pw - 1, rows y0 .. y0 + ph - 1
+// with x0 = int(kx) - b, y0 = int(ky) - b; every sample needs columns >= x0 + 1 and <= x0 + 2 b + 2 (the three-wide
+// bottom reads included), rows >= y0 + 1 and <= y0 + 2 b + 1; pw is padded to a multiple of 4 beyond 2 b + 6 (the aligned
+// dword pairs of the 16-bit form reach 3 elements past an even column)
+__host__ __device__ inline int patch_pw(int b) { return (2 * b + 8 + 3) & ~3; }
+__host__ __device__ inline int patch_ph(int b) { return 2 * b + 3; }
+
+// SRC 0 = u32 integral, 1 = 3-byte integral, 2 = pixels
+template <int SRC, bool U16>
+__device__ __forceinline__ void stage_patch(const MbArgs& A, int frame, unsigned char* patch, int x0, int y0, int pw, int ph, int lane) {
+  const int pitchB = pw * (U16 ? 2 : 4);
+  if (SRC == 2) {
+    // pixels -> local integral (origin at the patch corner: every four-corner difference equals the global one).
+    // lane l owns pixel columns 2 l - 1, 2 l (relative) = integral columns 2 l, 2 l + 1 of the NEXT row
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.pix + (long)frame * A.pix_bytes), 0, (int)A.pix_bytes, 0x00020000);
+    const bool act = 2 * lane < pw;
+    uint32_t c0 = 0, c1 = 0;
+    if (act) {
+      if (U16) *reinterpret_cast<uint32_t*>(patch + lane * 4) = 0;
+      else *reinterpret_cast<u32x2*>(patch + lane * 8) = u32x2{0, 0};
+    }
+    const int colb = x0 + 2 * lane - 1;
+    for (int r = 0; r + 1 < ph; r += 2) {
+      // two pixel rows per scan: row sums stay below 2^15, so two of them share a register
+      const int o0 = (y0 + r) * A.w + colb;
+      uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+      if (act) {
+        if (lane) { a0 = __builtin_amdgcn_raw_buffer_load_b8(rs, o0, 0, 0); a1 = __builtin_amdgcn_raw_buffer_load_b8(rs, o0 + A.w, 0, 0); }
+        b0 = __builtin_amdgcn_raw_buffer_load_b8(rs, o0 + 1, 0, 0);
+        b1 = __builtin_amdgcn_raw_buffer_load_b8(rs, o0 + 1 + A.w, 0, 0);
+      }
+      int v = (int)((a0 + b0) | ((a1 + b1) << 16));
+      v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+      const uint32_t S0 = (uint32_t)v & 0xFFFFu, S1 = (uint32_t)v >> 16;
+      c0 += S0 - b0; c1 += S0;
+      if (act) {
+        if (U16) *reinterpret_cast<uint32_t*>(patch + (r + 1) * pitchB + lane * 4) = (c0 & 0xFFFFu) | (c1 << 16);
+        else *reinterpret_cast<u32x2*>(patch + (r + 1) * pitchB + lane * 8) = u32x2{c0, c1};
+      }
+      c0 += S1 - b1; c1 += S1;
+      if (act && r + 2 < ph) {
+        if (U16) *reinterpret_cast<uint32_t*>(patch + (r + 2) * pitchB + lane * 4) = (c0 & 0xFFFFu) | (c1 << 16);
+        else *reinterpret_cast<u32x2*>(patch + (r + 2) * pitchB + lane * 8) = u32x2{c0, c1};
+      }
+    }
+    return;
+  }
+  // integral rows copied: a lane moves 4 elements, 64 / (pw / 4) rows per instruction, 8 instructions in flight
+  const int nl = pw >> 2;
+  const int rpi = 64 / nl;  // (pw <= 256)
+  const int lr = lane / nl, lc = lane - lr * nl;
+  const bool lact = lr < rpi;
+  const __amdgpu_buffer_rsrc_t rs =
+      SRC == 1 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.integ24 + (long)frame * A.f24_bytes), 0, (int)A.f24_bytes, 0x00020000)
+               : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A.integ32 + (long)frame * A.f32_elems), 0, (int)(A.f32_elems * 4), 0x00020000);
+  constexpr int ES = SRC == 1 ? 3 : 4;
+  constexpr int NB = 8;
+  const int gbase = ((y0 + lr) * A.iw + x0 + 4 * lc) * ES;
+  const int gstep = rpi * A.iw * ES;
+  const int lbase = lr * pitchB + lc * (U16 ? 8 : 16);
+  const int lstep = rpi * pitchB;
+  for (int r0 = 0, blk = 0; r0 < ph; r0 += rpi * NB, blk += NB) {
+    u32x4 d[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int r = r0 + k * rpi + lr;
+      d[k] = u32x4{0, 0, 0, 0};
+      if (lact && r < ph) {
+        const int go = gbase + (blk + k) * gstep;
+        if (SRC == 1) { const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, go, 0, 0); d[k] = u32x4{t.x, t.y, t.z, 0}; }
+        else d[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, go, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int r = r0 + k * rpi + lr;
+      if (lact && r < ph) {
+        unsigned char* dst = patch + lbase + (blk + k) * lstep;
+        if (U16) {
+          u32x2 o;
+          if (SRC == 1) { o.x = __builtin_amdgcn_perm(d[k].y, d[k].x, 0x04030100u); o.y = __builtin_amdgcn_perm(d[k].z, d[k].y, 0x06050302u); }
+          else { o.x = __builtin_amdgcn_perm(d[k].y, d[k].x, 0x05040100u); o.y = __builtin_amdgcn_perm(d[k].w, d[k].z, 0x05040100u); }
+          *reinterpret_cast<u32x2*>(dst) = o;
+        } else {
+          u32x4 o = d[k];
+          if (SRC == 1) {
+            o.x = d[k].x; o.y = __builtin_amdgcn_alignbit(d[k].y, d[k].x, 24); o.z = __builtin_amdgcn_alignbit(d[k].z, d[k].y, 16); o.w = d[k].z >> 8;
+          }
+          *reinterpret_cast<u32x4*>(dst) = o;
+        }
+      }
+    }
+  }
+}
+
+template <bool U16, uint32_t MASK>
+__device__ __forceinline__ int lds_sample(const unsigned char* patch, int pitchB, int x0, int y0, const BriskBoxPrep& p) {
+  const int cxl = p.x_left - x0, cxr = p.x_right - x0, ryt = p.y_top - y0, ryb = p.y_bottom - y0;
+  uint32_t i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i2x, i22, i23, i2y, i30, i31, i32, i33, ql0, ql1, qr0, qr1;
+  if (U16) {
+    const int shl = (cxl & 1) * 16, shr = (cxr & 1) * 16;
+    const unsigned char* aL = patch + (cxl >> 1) * 4 + ryt * pitchB;
+    const unsigned char* aR = patch + (cxr >> 1) * 4 + ryt * pitchB;
+    const int db = (ryb - ryt) * pitchB;
+    const u32x2 L0 = *reinterpret_cast<const u32x2a4*>(aL), R0 = *reinterpret_cast<const u32x2a4*>(aR);
+    const u32x2 L1 = *reinterpret_cast<const u32x2a4*>(aL + pitchB), R1 = *reinterpret_cast<const u32x2a4*>(aR + pitchB);
+    const u32x2 Lq = *reinterpret_cast<const u32x2a4*>(aL + db - pitchB), Rq = *reinterpret_cast<const u32x2a4*>(aR + db - pitchB);
+    const u32x2 L2 = *reinterpret_cast<const u32x2a4*>(aL + db), R2 = *reinterpret_cast<const u32x2a4*>(aR + db);
+    const u32x2 L3 = *reinterpret_cast<const u32x2a4*>(aL + db + pitchB), R3 = *reinterpret_cast<const u32x2a4*>(aR + db + pitchB);
+    // elements x, x + 1 of a row = the 32 bits at bit offset (x & 1) * 16 of its two dwords; only the low 16 bits of
+    // each operand matter (brisk_box_acc masks every difference)
+    i00 = __builtin_amdgcn_alignbit(L0.y, L0.x, shl); i01 = i00 >> 16;
+    i02 = __builtin_amdgcn_alignbit(R0.y, R0.x, shr); i03 = i02 >> 16;
+    i10 = __builtin_amdgcn_alignbit(L1.y, L1.x, shl); i11 = i10 >> 16;
+    i12 = __builtin_amdgcn_alignbit(R1.y, R1.x, shr); i13 = i12 >> 16;
+    i20 = __builtin_amdgcn_alignbit(L2.y, L2.x, shl); i21 = i20 >> 16; i2x = L2.y >> shl;
+    i22 = __builtin_amdgcn_alignbit(R2.y, R2.x, shr); i23 = i22 >> 16; i2y = R2.y >> shr;
+    i30 = __builtin_amdgcn_alignbit(L3.y, L3.x, shl); i31 = i30 >> 16;
+    i32 = __builtin_amdgcn_alignbit(R3.y, R3.x, shr); i33 = i32 >> 16;
+    ql0 = __builtin_amdgcn_alignbit(Lq.y, Lq.x, shl) >> 16; ql1 = Lq.y >> shl;
+    qr0 = __builtin_amdgcn_alignbit(Rq.y, Rq.x, shr) >> 16; qr1 = Rq.y >> shr;
+  } else {
+    const unsigned char* aL = patch + cxl * 4 + ryt * pitchB;
+    const unsigned char* aR = patch + cxr * 4 + ryt * pitchB;
+    const int db = (ryb - ryt) * pitchB;
+    const u32x2 L0 = *reinterpret_cast<const u32x2a4*>(aL), R0 = *reinterpret_cast<const u32x2a4*>(aR);
+    const u32x2 L1 = *reinterpret_cast<const u32x2a4*>(aL + pitchB), R1 = *reinterpret_cast<const u32x2a4*>(aR + pitchB);
+    const u32x2 Lq = *reinterpret_cast<const u32x2a4*>(aL + db - pitchB + 4), Rq = *reinterpret_cast<const u32x2a4*>(aR + db - pitchB + 4);
+    const u32x2 L2 = *reinterpret_cast<const u32x2a4*>(aL + db), R2 = *reinterpret_cast<const u32x2a4*>(aR + db);
+    const uint32_t L2z = *reinterpret_cast<const uint32_t*>(aL + db + 8), R2z = *reinterpret_cast<const uint32_t*>(aR + db + 8);
+    const u32x2 L3 = *reinterpret_cast<const u32x2a4*>(aL + db + pitchB), R3 = *reinterpret_cast<const u32x2a4*>(aR + db + pitchB);
+    i00 = L0.x; i01 = L0.y; i02 = R0.x; i03 = R0.y; i10 = L1.x; i11 = L1.y; i12 = R1.x; i13 = R1.y;
+    i20 = L2.x; i21 = L2.y; i2x = L2z; i22 = R2.x; i23 = R2.y; i2y = R2z;
+    i30 = L3.x; i31 = L3.y; i32 = R3.x; i33 = R3.y; ql0 = Lq.x; ql1 = Lq.y; qr0 = Rq.x; qr1 = Rq.y;
+  }
+  const unsigned qbr = (i2y - i23 - qr1 + qr0) & MASK;
+  const unsigned qbl = (i2x - i21 - ql1 + ql0) & MASK;
+  const uint32_t acc = brisk_box_acc(p, i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i22, i23, i30, i31, i32, i33, qbr, qbl, MASK);
+  return brisk_div_by_magic((int)acc, p.magic, p.shift);
+}
+
+template <int SRC, bool U16>
+__global__ void __launch_bounds__(64) k_lds(MbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  int* vals = reinterpret_cast<int*>(lds);  // 66 (<= 128) values
+  unsigned char* patch = lds + 512;
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 7);
+  const int np = A.np;
+  constexpr uint32_t MASK = U16 ? 0xFFFFu : (SRC == 1 ? 0xFFFFFFu : 0xFFFFFFFFu);
+  long long sum = 0;
+  for (int gi = 0; gi < 8; ++gi) {
+    const int g = (xcc + gi) & 7;
+    const int nt = A.ntasks[g];
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&A.tickets[g * 32], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nt) break;
+      const uint4 task = A.tasks[(long)g * A.max_tasks + t];
+      const uint4 rec = A.kps[task.y];
+      const float kx = __uint_as_float(rec.x), ky = __uint_as_float(rec.y);
+      const int b = A.size_list[rec.z];
+      const int x0 = (int)kx - b, y0 = (int)ky - b, pw = patch_pw(b), ph = patch_ph(b);
+      const int pitchB = pw * (U16 ? 2 : 4);
+      stage_patch<SRC, U16>(A, (int)task.x, patch, x0, y0, pw, ph, lane);
+      wave_sync();
+      int ksum = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int s0 = 0; s0 < np; s0 += 64) {
+          const int s = s0 + lane;
+          const bool valid = s < np;
+          const int pt = min(s, np - 1);
+          const int theta = pass ? (int)rec.w : 0;
+          const int4 tab = A.tab4[(int)rec.z * np + pt];
+          const double2 uv = A.uv2[theta * np + pt];
+          const double mm = (double)__int_as_float(tab.x);
+          const float xf = (float)(mm * uv.x) + kx, yf = (float)(mm * uv.y) + ky;
+          const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
+          if (valid) {
+            const int value = lds_sample<U16, MASK>(patch, pitchB, x0, y0, pr);
+            vals[pt] = value;
+            ksum += value;
+          }
+        }
+        wave_sync();
+      }
+      int f = vals[lane] + ksum;
+      for (int k = 0; k < A.filler; ++k) f = f * 1664525 + 1013904223;
+      if (f == 0x12345678) ksum += 1;
+      sum += ksum;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
+  if (lane == 0) atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
+}
+
+// ---- host --------------------------------------------------------------------------------------------------------
+struct KpRec { float x, y; int s, t; };
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s <input.bin> [filler=300] [only=<variant substring>]\n", argv[0]); return 2; }
+  const int filler = argc > 2 ? atoi(argv[2]) : 300;
+  const char* only = argc > 3 ? argv[3] : "";
+  FILE* fi = fopen(argv[1], "rb");
+  if (!fi) { perror(argv[1]); return 1; }
+  int hdr[3];
+  if (fread(hdr, 4, 3, fi) != 3) return 1;
+  const int nd = hdr[0], w = hdr[1], h = hdr[2];
+  std::vector<std::vector<KpRec>> kp(nd);
+  for (int f = 0; f < nd; ++f) {
+    int n;
+    if (fread(&n, 4, 1, fi) != 1) return 1;
+    kp[f].resize(n);
+    if (fread(kp[f].data(), sizeof(KpRec), n, fi) != (size_t)n) return 1;
+  }
+  std::vector<std::vector<uint8_t>> img(nd, std::vector<uint8_t>((size_t)w * h));
+  for (int f = 0; f < nd; ++f)
+    if (fread(img[f].data(), 1, (size_t)w * h, fi) != (size_t)w * h) return 1;
+  fclose(fi);
+
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int ncu = prop.multiProcessorCount;
+  const int NF = 256;
+  const int iw = w + 1, ih = h + 1;
+  const long f32_elems = (long)iw * ih, f24_bytes = ((f32_elems * 3 + 15) & ~15L) + 16, pix_bytes = (long)w * h;
+  uint32_t* d_i32; uint8_t* d_i24; uint8_t* d_pix;
+  CHECK(hipMalloc(&d_i32, NF * f32_elems * 4));
+  CHECK(hipMalloc(&d_i24, NF * f24_bytes));
+  CHECK(hipMalloc(&d_pix, NF * pix_bytes + 64));
+  {
+    std::vector<uint32_t> I(f32_elems);
+    std::vector<uint8_t> I3(f24_bytes);
+    for (int f = 0; f < nd; ++f) {
+      std::fill(I.begin(), I.end(), 0u);
+      for (int y = 0; y < h; ++y) {
+        uint32_t run = 0;
+        for (int x = 0; x < w; ++x) {
+          run += img[f][(size_t)y * w + x];
+          I[(size_t)(y + 1) * iw + x + 1] = I[(size_t)y * iw + x + 1] + run;
+        }
+      }
+      for (long i = 0; i < f32_elems; ++i) { I3[3 * i] = I[i] & 0xFF; I3[3 * i + 1] = (I[i] >> 8) & 0xFF; I3[3 * i + 2] = (I[i] >> 16) & 0xFF; }
+      for (int s = f; s < NF; s += nd) {
+        CHECK(hipMemcpy(d_i32 + s * f32_elems, I.data(), f32_elems * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d_i24 + s * f24_bytes, I3.data(), f24_bytes, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d_pix + s * pix_bytes, img[f].data(), pix_bytes, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  BriskPatternHost H;
+  std::string err;
+  if (!brisk_pattern_build_default(2, 1.0f, &H, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+  const int np = H.npoints;
+  std::vector<int> tab(64 * np * 4);
+  for (int i = 0; i < 64 * np; ++i) {
+    memcpy(&tab[4 * i], &H.mult[i], 4);
+    memcpy(&tab[4 * i + 1], &H.sigma[i], 4);
+    brisk_pack_tab(H.scaling[2 * i], H.scaling[2 * i + 1], &tab[4 * i + 2], &tab[4 * i + 3]);
+  }
+  int4* d_tab; double2* d_uv; int* d_size;
+  CHECK(hipMalloc(&d_tab, tab.size() * 4));
+  CHECK(hipMemcpy(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMalloc(&d_uv, H.uv.size() * 8));
+  CHECK(hipMemcpy(d_uv, H.uv.data(), H.uv.size() * 8, hipMemcpyHostToDevice));
+  CHECK(hipMalloc(&d_size, 64 * 4));
+  CHECK(hipMemcpy(d_size, H.size_list.data(), 64 * 4, hipMemcpyHostToDevice));
+  // keypoint records, all distinct frames concatenated
+  std::vector<uint4> recs;
+  std::vector<int> base(nd);
+  for (int f = 0; f < nd; ++f) {
+    base[f] = (int)recs.size();
+    for (const KpRec& k : kp[f]) {
+      uint4 r;
+      memcpy(&r.x, &k.x, 4); memcpy(&r.y, &k.y, 4); r.z = (unsigned)k.s; r.w = (unsigned)k.t;
+      recs.push_back(r);
+    }
+  }
+  uint4* d_kps;
+  CHECK(hipMalloc(&d_kps, recs.size() * 16));
+  CHECK(hipMemcpy(d_kps, recs.data(), recs.size() * 16, hipMemcpyHostToDevice));
+  const int max_tasks = NF / 8 * 2048;
+  uint4* d_tasks; int* d_ntasks; int* d_tickets; unsigned long long* d_sum;
+  CHECK(hipMalloc(&d_tasks, (size_t)8 * max_tasks * 16));
+  CHECK(hipMalloc(&d_ntasks, 8 * 4));
+  CHECK(hipMalloc(&d_tickets, 8 * 32 * 4));
+  CHECK(hipMalloc(&d_sum, 8));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+
+  MbArgs A;
+  A.integ32 = d_i32; A.integ24 = d_i24; A.pix = d_pix; A.f32_elems = f32_elems; A.f24_bytes = f24_bytes; A.pix_bytes = pix_bytes;
+  A.iw = iw; A.ih = ih; A.w = w; A.h = h; A.tab4 = d_tab; A.uv2 = d_uv; A.size_list = d_size; A.np = np; A.kps = d_kps;
+  A.tasks = d_tasks; A.ntasks = d_ntasks; A.max_tasks = max_tasks; A.tickets = d_tickets; A.checksum = d_sum; A.filler = filler;
+
+  struct Cls { const char* name; int lo, hi; };  // patch side range (lo, hi]
+  const Cls classes[] = {{"side<=67", 0, 67}, {"67<side<=101", 67, 101}, {"side<=101", 0, 101}, {"101<side<=151", 101, 151},
+                         {"151<side<=201", 151, 201}, {"side>201", 201, 100000}, {"all", 0, 100000}};
+  struct Var { const char* name; int kind; int src; bool u16; int max_side; };
+  const Var vars[] = {{"gather_i24", 0, 1, false, 100000},    {"gather_u32", 0, 0, false, 100000},   {"lds_u16_from_i24", 1, 1, true, 101},
+                      {"lds_u16_from_u32", 1, 0, true, 101}, {"lds_u32_from_u32", 1, 0, false, 201}, {"lds_u32_from_i24", 1, 1, false, 201},
+                      {"lds_u16_from_pix", 1, 2, true, 101}, {"lds_u32_from_pix", 1, 2, false, 101}};
+  printf("{\"device\": \"%s\", \"cus\": %d, \"frames\": %d, \"filler\": %d, \"rows\": [\n", prop.gcnArchName, ncu, NF, filler);
+  bool first = true;
+  for (const Cls& C : classes) {
+    for (const Var& V : vars) {
+      if (only[0] && !strstr(V.name, only)) continue;
+      if (C.hi > V.max_side) continue;
+      // tasks of this class: queue g = frames g, g + 8, ... (last first, as the engine), keypoints in processing order;
+      // the gather variants take them in runs of two
+      std::vector<std::vector<uint4>> tq(8);
+      long nkp = 0;
+      int bmax = 0;
+      for (int g = 0; g < 8; ++g)
+        for (int s = NF - 8 + g; s >= 0; s -= 8) {
+          const int f = s % nd;
+          std::vector<int> sel;
+          for (int i = 0; i < (int)kp[f].size(); ++i) {
+            const int b = H.size_list[kp[f][i].s], side = 2 * b + 1;
+            if (side <= C.lo || side > C.hi) continue;
+            if ((int)kp[f][i].x + b + 2 > w) continue;  // (the displaced-corner wrap of the last column: not part of this benchmark)
+            sel.push_back(i);
+            bmax = std::max(bmax, b);
+          }
+          nkp += (long)sel.size();
+          if (V.kind == 0) {
+            for (size_t i = 0; i < sel.size(); i += 2)
+              tq[g].push_back(make_uint4((unsigned)s, (unsigned)(base[f] + sel[i]), i + 1 < sel.size() ? (unsigned)(base[f] + sel[i + 1]) : 0xFFFFFFFFu, 0));
+          } else {
+            for (int i : sel) tq[g].push_back(make_uint4((unsigned)s, (unsigned)(base[f] + i), 0xFFFFFFFFu, 0));
+          }
+        }
+      int nt[8];
+      for (int g = 0; g < 8; ++g) {
+        nt[g] = (int)tq[g].size();
+        if (nt[g] > max_tasks) { fprintf(stderr, "task overflow\n"); return 1; }
+        if (nt[g]) CHECK(hipMemcpy(d_tasks + (size_t)g * max_tasks, tq[g].data(), (size_t)nt[g] * 16, hipMemcpyHostToDevice));
+      }
+      CHECK(hipMemcpy(d_ntasks, nt, 32, hipMemcpyHostToDevice));
+      if (!nkp) continue;
+      std::vector<int> wpcs;
+      size_t lds = 0;
+      if (V.kind == 0) {
+        wpcs = {3};
+      } else {
+        lds = 512 + (size_t)patch_pw(bmax) * patch_ph(bmax) * (V.u16 ? 2 : 4);
+        if (lds > 160 * 1024) continue;
+        const int fit = (int)(160 * 1024 / lds);
+        wpcs.push_back(std::min(fit, 16));
+        if (fit > 8) wpcs.push_back(8);
+      }
+      for (int wpc : wpcs) {
+        double best_ms = 1e30;
+        unsigned long long sum = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+          CHECK(hipMemsetAsync(d_tickets, 0, 8 * 32 * 4, 0));
+          CHECK(hipMemsetAsync(d_sum, 0, 8, 0));
+          CHECK(hipEventRecord(e0, 0));
+          if (V.kind == 0) {
+            const size_t l = 160 * 1024 / 4 + 512;
+            auto fn = V.src == 1 ? k_gather<true> : k_gather<false>;
+            CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+            hipLaunchKernelGGL(fn, dim3(ncu * wpc), dim3(128), l, 0, A);
+          } else {
+            void (*fn)(MbArgs) = nullptr;
+            if (V.src == 1 && V.u16) fn = k_lds<1, true>;
+            if (V.src == 0 && V.u16) fn = k_lds<0, true>;
+            if (V.src == 0 && !V.u16) fn = k_lds<0, false>;
+            if (V.src == 1 && !V.u16) fn = k_lds<1, false>;
+            if (V.src == 2 && V.u16) fn = k_lds<2, true>;
+            if (V.src == 2 && !V.u16) fn = k_lds<2, false>;
+            CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fn, dim3(ncu * wpc), dim3(64), lds, 0, A);
+          }
+          CHECK(hipEventRecord(e1, 0));
+          CHECK(hipEventSynchronize(e1));
+          CHECK(hipGetLastError());
+          float ms;
+          CHECK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep) best_ms = std::min(best_ms, (double)ms);
+          CHECK(hipMemcpy(&sum, d_sum, 8, hipMemcpyDeviceToHost));
+        }
+        const double samples = (double)nkp * 2 * np;
+        printf("%s{\"class\": \"%s\", \"variant\": \"%s\", \"keypoints\": %ld, \"max_border\": %d, \"lds_bytes\": %zu, \"waves_per_cu\": %d, "
+               "\"ms\": %.4f, \"samples_per_ns_chip\": %.2f, \"us_per_keypoint_cu\": %.3f, \"checksum\": %llu}",
+               first ? "" : ",\n", C.name, V.name, nkp, bmax, lds, V.kind == 0 ? wpc * 2 : wpc, best_ms, samples / (best_ms * 1e6),
+               best_ms * 1e3 * ncu / (double)nkp, sum);
+        first = false;
+        fflush(stdout);
+      }
+    }
+  }
+  printf("\n]}\n");
+  return 0;
+}

@@ -66,6 +66,7 @@ struct MbArgs {
   int* tickets;         // [8], 32 ints apart
   unsigned long long* checksum;
   int filler;
+  unsigned long long* phase;  // [8] summed s_memtime ticks per phase of k_lds2 (lane 0 of every wave)
 };
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(128) k_gather(MbArgs A) {
         wave_sync();
       }
       int f = vals[lane] + ksum;
-      for (int k = 0; k < A.filler * cnt; ++k) f = f * 1664525 + 1013904223;
+      { int f1 = f ^ 5, f2 = f + 7, f3 = f * 3; for (int k = 0; k < A.filler * cnt / 12; ++k) { f += (f >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; } f ^= f1 ^ f2 ^ f3; }
       if (f == 0x12345678) ksum += 1;
       sum += ksum;
       __builtin_amdgcn_wave_barrier();
@@ -251,12 +252,9 @@ __device__ __forceinline__ void stage_patch(const MbArgs& A, int frame, unsigned
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const int r = r0 + k * rpi + lr;
-      d[k] = u32x4{0, 0, 0, 0};
-      if (lact && r < ph) {
-        const int go = gbase + (blk + k) * gstep;
-        if (SRC == 1) { const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, go, 0, 0); d[k] = u32x4{t.x, t.y, t.z, 0}; }
-        else d[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, go, 0, 0);
-      }
+      const int go = (lact && r < ph) ? gbase + (blk + k) * gstep : 0x7FFF0000;  // (no branch around a load, see k_lds3)
+      if (SRC == 1) { const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, go, 0, 0); d[k] = u32x4{t.x, t.y, t.z, 0}; }
+      else d[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, go, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
@@ -373,10 +371,257 @@ __global__ void __launch_bounds__(64) k_lds(MbArgs A) {
         wave_sync();
       }
       int f = vals[lane] + ksum;
-      for (int k = 0; k < A.filler; ++k) f = f * 1664525 + 1013904223;
+      { int f1 = f ^ 5, f2 = f + 7, f3 = f * 3; for (int k = 0; k < A.filler / 12; ++k) { f += (f >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; } f ^= f1 ^ f2 ^ f3; }
       if (f == 0x12345678) ksum += 1;
       sum += ksum;
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
+  if (lane == 0) atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
+}
+
+// ---- lds2: the 16-bit patch variant with its latencies taken out of the wave's dependency chain: tickets and keypoint
+// records one keypoint ahead, the table entries of both rounds and the unrotated offsets requested in front of the
+// staging loads, NB staging loads in flight; LEFT = false leaves the two 2-sample rounds out (what a formulation that
+// hands points 64 / 65 to a separate, fully occupied gather round would run: the checksum then differs)
+template <int SRC, int NB, bool LEFT>
+__global__ void __launch_bounds__(64) k_lds2(MbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  int* vals = reinterpret_cast<int*>(lds);
+  unsigned char* patch = lds + 512;
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 7);
+  const int np = A.np;
+  constexpr int ES = SRC == 1 ? 3 : 4;
+  long long sum = 0;
+  unsigned long long ph_t[5] = {0, 0, 0, 0, 0};
+  auto now = [&]() {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return t;
+  };
+  for (int gi = 0; gi < 8; ++gi) {
+    const int g = (xcc + gi) & 7;
+    const int nt = A.ntasks[g];
+    auto take = [&]() {
+      int t = nt;
+      if (lane == 0) t = atomicAdd(&A.tickets[g * 32], 1);
+      return t;
+    };
+    int t1 = take(), t2 = take();
+    int tc = __builtin_amdgcn_readfirstlane(t1);
+    uint4 task = make_uint4(0, 0, 0, 0), rec = make_uint4(0, 0, 0, 0);
+    if (tc < nt) { task = A.tasks[(long)g * A.max_tasks + tc]; rec = A.kps[task.y]; }
+    while (tc < nt) {
+      const unsigned long long T0 = now();
+      const int tn = __builtin_amdgcn_readfirstlane(t2);
+      t2 = take();
+      uint4 ntask = make_uint4(0, 0, 0, 0), nrec = make_uint4(0, 0, 0, 0);
+      if (tn < nt) { ntask = A.tasks[(long)g * A.max_tasks + tn]; nrec = A.kps[ntask.y]; }
+      const float kx = __uint_as_float(rec.x), ky = __uint_as_float(rec.y);
+      const int sc = (int)rec.z, theta = (int)rec.w;
+      const int b = A.size_list[sc];
+      const int x0 = (int)kx - b, y0 = (int)ky - b, pw = patch_pw(b), ph = patch_ph(b);
+      const int pitchB = pw * 2;
+      const int ptB = min(64 + lane, np - 1);
+      const int4 tabA = A.tab4[sc * np + lane], tabB = A.tab4[sc * np + ptB];
+      const double2 uvA0 = A.uv2[lane], uvB0 = A.uv2[ptB];
+      const unsigned long long T1 = now();
+      // staging
+      {
+        const int nl = pw >> 2, rpi = 64 / nl;
+        const int lr = lane / nl, lc = lane - lr * nl;
+        const bool lact = lr < rpi;
+        const __amdgpu_buffer_rsrc_t rs =
+            SRC == 1 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.integ24 + (long)task.x * A.f24_bytes), 0, (int)A.f24_bytes, 0x00020000)
+                     : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A.integ32 + (long)task.x * A.f32_elems), 0, (int)(A.f32_elems * 4), 0x00020000);
+        const int gbase = ((y0 + lr) * A.iw + x0 + 4 * lc) * ES, gstep = rpi * A.iw * ES;
+        const int lbase = lr * pitchB + lc * 8, lstep = rpi * pitchB;
+        for (int r0 = 0, blk = 0; r0 < ph; r0 += rpi * NB, blk += NB) {
+          u32x4 d[NB];
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            const int r = r0 + k * rpi + lr;
+            const int go = (lact && r < ph) ? gbase + (blk + k) * gstep : 0x7FFF0000;  // (no branch around a load, see k_lds3)
+            if (SRC == 1) { const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, go, 0, 0); d[k] = u32x4{t.x, t.y, t.z, 0}; }
+            else d[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, go, 0, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            const int r = r0 + k * rpi + lr;
+            if (lact && r < ph) {
+              u32x2 o;
+              if (SRC == 1) { o.x = __builtin_amdgcn_perm(d[k].y, d[k].x, 0x04030100u); o.y = __builtin_amdgcn_perm(d[k].z, d[k].y, 0x06050302u); }
+              else { o.x = __builtin_amdgcn_perm(d[k].y, d[k].x, 0x05040100u); o.y = __builtin_amdgcn_perm(d[k].w, d[k].z, 0x05040100u); }
+              *reinterpret_cast<u32x2*>(patch + lbase + (blk + k) * lstep) = o;
+            }
+          }
+        }
+      }
+      wave_sync();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long T2 = now();
+      int ksum = 0;
+      auto sample = [&](const int4& tab, const double2& uv, int pt, bool valid) {
+        const double mm = (double)__int_as_float(tab.x);
+        const float xf = (float)(mm * uv.x) + kx, yf = (float)(mm * uv.y) + ky;
+        const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
+        if (valid) {
+          const int value = lds_sample<true, 0xFFFFu>(patch, pitchB, x0, y0, pr);
+          vals[pt] = value;
+          ksum += value;
+        }
+      };
+      sample(tabA, uvA0, lane, true);
+      if (LEFT) sample(tabB, uvB0, ptB, 64 + lane < np);
+      wave_sync();
+      const unsigned long long T3 = now();
+      const double2 uvA1 = A.uv2[theta * np + lane], uvB1 = A.uv2[theta * np + ptB];  // (theta: known after the first pass)
+      int f = vals[lane] + ksum;
+      { int f1 = f ^ 5, f2 = f + 7, f3 = f * 3; for (int k = 0; k < A.filler / 24; ++k) { f += (f >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; } f ^= f1 ^ f2 ^ f3; }
+      const unsigned long long T4 = now();
+      sample(tabA, uvA1, lane, true);
+      if (LEFT) sample(tabB, uvB1, ptB, 64 + lane < np);
+      wave_sync();
+      const unsigned long long T5 = now();
+      f += vals[lane];
+      { int f1 = f ^ 5, f2 = f + 7, f3 = f * 3; for (int k = 0; k < A.filler / 24; ++k) { f += (f >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; } f ^= f1 ^ f2 ^ f3; }
+      if (f == 0x12345678) ksum += 1;
+      sum += ksum;
+      __builtin_amdgcn_wave_barrier();
+      tc = tn; task = ntask; rec = nrec;
+      const unsigned long long T6 = now();
+      ph_t[0] += T1 - T0; ph_t[1] += T2 - T1; ph_t[2] += T3 - T2; ph_t[3] += T5 - T4; ph_t[4] += (T4 - T3) + (T6 - T5);
+    }
+  }
+  const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
+  if (lane == 0) {
+    atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
+    for (int k = 0; k < 5; ++k) atomicAdd(&A.phase[k], ph_t[k]);
+  }
+}
+
+// ---- lds3: lds2 with the NEXT keypoint's patch rows prefetched into registers (up to 52 x 12 bytes per lane: a 7-wave
+// CU has the registers) while the current keypoint is sampled from LDS: issue order per keypoint = rotated offsets, next
+// table entries, next patch rows (the vector memory counter is in order: what pass 1 waits for is in front of the rows);
+// the unrotated offsets live in registers for the kernel's lifetime.  filler = independent chains (ILP as in the pair code).
+template <bool LEFT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lds3(MbArgs A, const uint4* __restrict__ r_tasks, const uint4* __restrict__ r_kps, const int* __restrict__ r_size,
+                                                                                          const int* __restrict__ r_ntasks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  int* vals = reinterpret_cast<int*>(lds);
+  int4* ltab = reinterpret_cast<int4*>(lds + 320);       // [2] table entries of points 64, 65 (this keypoint), [2] of the next
+  double2* luv = reinterpret_cast<double2*>(lds + 384);  // [2] unrotated, [2] rotated offsets of points 64, 65
+  unsigned char* patch = lds + 512;
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 7);
+  const int np = A.np;
+  constexpr int NBT = 52;
+  const int ptB = min(64 + lane, np - 1);
+  const double2 uvA0 = A.uv2[lane];
+  if (lane < 2) luv[lane] = A.uv2[ptB];
+  long long sum = 0;
+  struct Geo { int x0, y0, pitchB, ph, rpi, lr, lbase, lstep; bool lact; };
+  u32x3 d[NBT];
+  auto issue = [&](const uint4& task, const uint4& rec, Geo& G) {
+    const int b = r_size[(int)rec.z];
+    const int pw = patch_pw(b);
+    G.x0 = (int)__uint_as_float(rec.x) - b; G.y0 = (int)__uint_as_float(rec.y) - b; G.pitchB = pw * 2; G.ph = patch_ph(b);
+    const int nl = pw >> 2;
+    G.rpi = 64 / nl;
+    G.lr = lane / nl;
+    const int lc = lane - G.lr * nl;
+    G.lact = G.lr < G.rpi;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.integ24 + (long)task.x * A.f24_bytes), 0, (int)A.f24_bytes, 0x00020000);
+    const int gbase = ((G.y0 + G.lr) * A.iw + G.x0 + 4 * lc) * 3, gstep = __builtin_amdgcn_readfirstlane(G.rpi * A.iw * 3);
+    G.lbase = G.lr * G.pitchB + lc * 8; G.lstep = G.rpi * G.pitchB;
+#pragma unroll
+    for (int k = 0; k < NBT; ++k) {
+      // (no branch around a load: the compiler's wait-count insertion would wait for every load at the join;
+      // lanes beyond the patch read past the descriptor's end: zero, no memory access)
+      d[k] = __builtin_amdgcn_raw_buffer_load_b96(rs, (G.lact && k * G.rpi + G.lr < G.ph) ? gbase : 0x7FFF0000, k * gstep, 0);
+    }
+  };
+  auto commit = [&](const Geo& G) {
+#pragma unroll
+    for (int k = 0; k < NBT; ++k) {
+      u32x2 o;
+      o.x = __builtin_amdgcn_perm(d[k].y, d[k].x, 0x04030100u);
+      o.y = __builtin_amdgcn_perm(d[k].z, d[k].y, 0x06050302u);
+      const bool act = G.lact && k * G.rpi + G.lr < G.ph;
+      const int off = act ? 512 + G.lbase + k * G.lstep : 448;  // (448: a dump slot)
+      *reinterpret_cast<u32x2*>(lds + off) = o;
+    }
+  };
+  for (int gi = 0; gi < 8; ++gi) {
+    const int g = (xcc + gi) & 7;
+    const int nt = r_ntasks[g];
+    auto take = [&]() {
+      int t = nt;
+      if (lane == 0) t = atomicAdd(&A.tickets[g * 32], 1);
+      return t;
+    };
+    int t1 = take(), t2 = take();
+    int tc = __builtin_amdgcn_readfirstlane(t1);
+    uint4 task = make_uint4(0, 0, 0, 0), rec = make_uint4(0, 0, 0, 0);
+    int4 tabA = make_int4(0, 0, 0, 0);
+    int tsel = 0;
+    Geo G = {};
+    if (tc < nt) {
+      task = r_tasks[(long)g * A.max_tasks + tc]; rec = r_kps[task.y];
+      tabA = A.tab4[(int)rec.z * np + lane];
+      if (lane < 2) ltab[lane] = A.tab4[(int)rec.z * np + ptB];
+      issue(task, rec, G);
+    }
+    while (tc < nt) {
+      const int tn = __builtin_amdgcn_readfirstlane(t2);
+      t2 = take();
+      uint4 ntask = make_uint4(0, 0, 0, 0), nrec = make_uint4(0, 0, 0, 0);
+      if (tn < nt) { ntask = r_tasks[(long)g * A.max_tasks + tn]; nrec = r_kps[ntask.y]; }
+      const float kx = __uint_as_float(rec.x), ky = __uint_as_float(rec.y);
+      const int theta = (int)rec.w;
+      commit(G);
+      wave_sync();
+      const int x0 = G.x0, y0 = G.y0, pitchB = G.pitchB;
+      int ksum = 0;
+      auto sample = [&](const int4& tab, const double2& uv, int pt, bool valid) {
+        const double mm = (double)__int_as_float(tab.x);
+        const float xf = (float)(mm * uv.x) + kx, yf = (float)(mm * uv.y) + ky;
+        const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
+        if (valid) {
+          const int value = lds_sample<true, 0xFFFFu>(patch, pitchB, x0, y0, pr);
+          vals[pt] = value;
+          ksum += value;
+        }
+      };
+      sample(tabA, uvA0, lane, true);
+      if (LEFT) sample(ltab[tsel + (lane & 1)], luv[lane & 1], ptB, 64 + lane < np);
+      wave_sync();
+      int f0 = vals[lane] + ksum, f1 = f0 ^ 5, f2 = f0 + 7, f3 = f0 * 3;
+      for (int k = 0; k < A.filler / 24; ++k) { f0 += (f0 >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; }
+      const double2 uvA1 = A.uv2[theta * np + lane];  // (theta: known after the first pass)
+      if (lane < 2) luv[2 + lane] = A.uv2[theta * np + ptB];
+      int4 ntabA = tabA;
+      Geo NG = G;
+      const int4 ctabA = tabA;
+      // pass 1 of this keypoint reads the patch in LDS; the next keypoint's rows travel meanwhile
+      // (the registers d[] are free: committed above)
+      if (tn < nt) {
+        ntabA = A.tab4[(int)nrec.z * np + lane];
+        if (lane < 2) ltab[(tsel ^ 2) + lane] = A.tab4[(int)nrec.z * np + ptB];
+        issue(ntask, nrec, NG);
+      }
+      sample(ctabA, uvA1, lane, true);
+      wave_sync();
+      if (LEFT) sample(ltab[tsel + (lane & 1)], luv[2 + (lane & 1)], ptB, 64 + lane < np);
+      wave_sync();
+      f0 += vals[lane];
+      for (int k = 0; k < A.filler / 24; ++k) { f0 += (f0 >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; }
+      if ((f0 ^ f1 ^ f2 ^ f3) == 0x12345678) ksum += 1;
+      sum += ksum;
+      __builtin_amdgcn_wave_barrier();
+      tc = tn; task = ntask; rec = nrec; tabA = ntabA; tsel ^= 2; G = NG;
     }
   }
   const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
@@ -474,6 +719,8 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&d_ntasks, 8 * 4));
   CHECK(hipMalloc(&d_tickets, 8 * 32 * 4));
   CHECK(hipMalloc(&d_sum, 8));
+  unsigned long long* d_phase;
+  CHECK(hipMalloc(&d_phase, 64));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
@@ -481,7 +728,7 @@ int main(int argc, char** argv) {
   MbArgs A;
   A.integ32 = d_i32; A.integ24 = d_i24; A.pix = d_pix; A.f32_elems = f32_elems; A.f24_bytes = f24_bytes; A.pix_bytes = pix_bytes;
   A.iw = iw; A.ih = ih; A.w = w; A.h = h; A.tab4 = d_tab; A.uv2 = d_uv; A.size_list = d_size; A.np = np; A.kps = d_kps;
-  A.tasks = d_tasks; A.ntasks = d_ntasks; A.max_tasks = max_tasks; A.tickets = d_tickets; A.checksum = d_sum; A.filler = filler;
+  A.tasks = d_tasks; A.ntasks = d_ntasks; A.max_tasks = max_tasks; A.tickets = d_tickets; A.checksum = d_sum; A.filler = filler; A.phase = d_phase;
 
   struct Cls { const char* name; int lo, hi; };  // patch side range (lo, hi]
   const Cls classes[] = {{"side<=67", 0, 67}, {"67<side<=101", 67, 101}, {"side<=101", 0, 101}, {"101<side<=151", 101, 151},
@@ -489,7 +736,10 @@ int main(int argc, char** argv) {
   struct Var { const char* name; int kind; int src; bool u16; int max_side; };
   const Var vars[] = {{"gather_i24", 0, 1, false, 100000},    {"gather_u32", 0, 0, false, 100000},   {"lds_u16_from_i24", 1, 1, true, 101},
                       {"lds_u16_from_u32", 1, 0, true, 101}, {"lds_u32_from_u32", 1, 0, false, 201}, {"lds_u32_from_i24", 1, 1, false, 201},
-                      {"lds_u16_from_pix", 1, 2, true, 101}, {"lds_u32_from_pix", 1, 2, false, 101}};
+                      {"lds_u16_from_pix", 1, 2, true, 101}, {"lds_u32_from_pix", 1, 2, false, 101},
+                      {"lds2_i24_nb13", 2, 1, true, 101}, {"lds2_i24_nb26", 3, 1, true, 101}, {"lds2_u32_nb13", 4, 0, true, 101},
+                      {"lds2_i24_nb13_noleft", 5, 1, true, 101}, {"lds2_i24_nb26_noleft", 6, 1, true, 101},
+                      {"lds3_i24", 7, 1, true, 101}, {"lds3_i24_noleft", 8, 1, true, 101}};
   printf("{\"device\": \"%s\", \"cus\": %d, \"frames\": %d, \"filler\": %d, \"rows\": [\n", prop.gcnArchName, ncu, NF, filler);
   bool first = true;
   for (const Cls& C : classes) {
@@ -545,6 +795,7 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 3; ++rep) {
           CHECK(hipMemsetAsync(d_tickets, 0, 8 * 32 * 4, 0));
           CHECK(hipMemsetAsync(d_sum, 0, 8, 0));
+          CHECK(hipMemsetAsync(d_phase, 0, 64, 0));
           CHECK(hipEventRecord(e0, 0));
           if (V.kind == 0) {
             const size_t l = 160 * 1024 / 4 + 512;
@@ -559,8 +810,19 @@ int main(int argc, char** argv) {
             if (V.src == 1 && !V.u16) fn = k_lds<1, false>;
             if (V.src == 2 && V.u16) fn = k_lds<2, true>;
             if (V.src == 2 && !V.u16) fn = k_lds<2, false>;
-            CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fn, dim3(ncu * wpc), dim3(64), lds, 0, A);
+            if (V.kind == 2) fn = k_lds2<1, 13, true>;
+            if (V.kind == 3) fn = k_lds2<1, 26, true>;
+            if (V.kind == 4) fn = k_lds2<0, 13, true>;
+            if (V.kind == 5) fn = k_lds2<1, 13, false>;
+            if (V.kind == 6) fn = k_lds2<1, 26, false>;
+            if (V.kind >= 7) {
+              auto f3 = V.kind == 7 ? k_lds3<true> : k_lds3<false>;
+              CHECK(hipFuncSetAttribute((const void*)f3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+              hipLaunchKernelGGL(f3, dim3(ncu * wpc), dim3(64), lds, 0, A, A.tasks, A.kps, A.size_list, A.ntasks);
+            } else {
+              CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+              hipLaunchKernelGGL(fn, dim3(ncu * wpc), dim3(64), lds, 0, A);
+            }
           }
           CHECK(hipEventRecord(e1, 0));
           CHECK(hipEventSynchronize(e1));
@@ -571,10 +833,14 @@ int main(int argc, char** argv) {
           CHECK(hipMemcpy(&sum, d_sum, 8, hipMemcpyDeviceToHost));
         }
         const double samples = (double)nkp * 2 * np;
+        unsigned long long php[8];
+        CHECK(hipMemcpy(php, d_phase, 64, hipMemcpyDeviceToHost));
         printf("%s{\"class\": \"%s\", \"variant\": \"%s\", \"keypoints\": %ld, \"max_border\": %d, \"lds_bytes\": %zu, \"waves_per_cu\": %d, "
-               "\"ms\": %.4f, \"samples_per_ns_chip\": %.2f, \"us_per_keypoint_cu\": %.3f, \"checksum\": %llu}",
+               "\"ms\": %.4f, \"samples_per_ns_chip\": %.2f, \"us_per_keypoint_cu\": %.3f, \"checksum\": %llu, "
+               "\"wave_us_per_keypoint\": {\"ticket_params\": %.2f, \"staging\": %.2f, \"pass0\": %.2f, \"pass1\": %.2f, \"other\": %.2f}}",
                first ? "" : ",\n", C.name, V.name, nkp, bmax, lds, V.kind == 0 ? wpc * 2 : wpc, best_ms, samples / (best_ms * 1e6),
-               best_ms * 1e3 * ncu / (double)nkp, sum);
+               best_ms * 1e3 * ncu / (double)nkp, sum, php[0] * 0.01 / nkp, php[1] * 0.01 / nkp, php[2] * 0.01 / nkp, php[3] * 0.01 / nkp,
+               php[4] * 0.01 / nkp);
         first = false;
         fflush(stdout);
       }

@@ -385,6 +385,10 @@ struct DsFrame {  // wave-uniform: the frame a ticket belongs to
   const uint32_t* integ;
   __amdgpu_buffer_rsrc_t rs_img, rs_int;
 };
+struct DsSide {  // what a run's first pass requests for the runs behind it
+  int t;       // ticket (lane 0; every lane with static dealing)
+  uint4 rec;   // the next run's records (lane = keypoint of the run)
+};
 struct DsTicket {  // wave-uniform
   int frame, k0, cnt, total;
   bool ok;
@@ -416,11 +420,11 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int table_bytes = REGTAB ? 0 : ((lp_in_lds ? P.nlong * 16 : 0) + ((P.nshort * 4 + 15) & ~15));
   const int vals_bytes = (RUN * np * 4 + 15) & ~15;
-  const int per_wave = RUN * 16 + ((RUN * 4 + 15) & ~15) + vals_bytes + 2 * DS_MAXQ * 4;
+  const int per_wave = 2 * RUN * 16 + ((RUN * 4 + 15) & ~15) + vals_bytes + 2 * DS_MAXQ * 4;
   unsigned char* wbase = ds_lds + table_bytes + wave * per_wave;
-  uint4* krec = reinterpret_cast<uint4*>(wbase);            // [RUN]
-  int* kth = reinterpret_cast<int*>(wbase + RUN * 16);     // [RUN]
-  int* vals = reinterpret_cast<int*>(wbase + RUN * 16 + ((RUN * 4 + 15) & ~15));
+  uint4* krec2 = reinterpret_cast<uint4*>(wbase);          // [2][RUN]: the records of this run and of the next one
+  int* kth = reinterpret_cast<int*>(wbase + 2 * RUN * 16);  // [RUN]
+  int* vals = reinterpret_cast<int*>(wbase + 2 * RUN * 16 + ((RUN * 4 + 15) & ~15));
   int* cum = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(vals) + vals_bytes);  // [DS_MAXQ] runs up to and including entry j
   int* cnt_q = cum + DS_MAXQ;                                                              // [DS_MAXQ] keypoints of entry j
   unsigned lp_ij[DS_REG_LONG], lp_w[DS_REG_LONG], sp_ij[DS_REG_SHORT];  // i | j << 8, wdx (low half) | wdy << 16; i | j << 16
@@ -449,6 +453,15 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   }
 
   const int xcc = (int)(__builtin_amdgcn_s_getreg(DS_GETREG_XCC_ID) & 7);
+#ifdef DS_TIMING  // experiments: s_memtime ticks per phase of a run, summed per wave into counters[0].dphase[] (tools/describe_phases.py)
+  unsigned dt_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long dt_last = 0;
+#define DS_T0() do { dt_last = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#define DS_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dt_acc[i] += (unsigned)(t_ - dt_last); dt_last = t_; } while (0)
+#else
+#define DS_T0() do { } while (0)
+#define DS_T(i) do { } while (0)
+#endif
   const int stride = G.L[0].stride, cols = G.L[0].w;
   const int img_bytes = (G.L[0].h - 1) * stride + cols;
   const unsigned inv20 = (1u << 20) / (unsigned)np + 1u;  // s / np == (s * inv20) >> 20 for s < 2048
@@ -463,7 +476,7 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   };
   // parameters of sample s of the run (clamped to the run's last sample: surplus lanes repeat it and are masked at the
   // loads)
-  auto fetch = [&](int total, int s, bool rotated) {
+  auto fetch = [&](const uint4* krec, int total, int s, bool rotated) {
     DsLane L;
     const int sc = min(s, total - 1);
     const int kq = (int)(((unsigned)sc * inv20) >> 20);
@@ -481,12 +494,22 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
   // the next round are requested before the current round's gathers.  (Measured and dropped: all rounds of a pass in
   // flight together - parameters of every round, then every round's gathers, then the combines: 234 VGPRs, no faster;
   // dedicated sampler waves fed by helper waves through LDS: profiles/r03_describe_roles_experiment.txt.)
-  auto pass = [&](const DsFrame& F, int total, bool rotated) {
-    DsLane Lc = fetch(total, lane, rotated);
+  // (first: the first round's parameters if they were requested at the end of the previous run; by value - a reference
+  // or a captured variable keeps the record on the stack)
+  // side: the run's first pass also takes the ticket of the run after the next one and requests the next run's records,
+  // directly in front of its first burst of gathers (take_fn, nsrc, ncnt; returned).  The vector memory counter is in
+  // order: anywhere earlier, the first wait behind them - for the first round's parameters - would wait for the atomic's
+  // microseconds too; here they travel with the gathers, whose wait is a full one anyway.
+  auto pass = [&](const DsFrame& F, const uint4* krec, int total, bool rotated, bool use_first, DsLane first, bool side,
+                  auto&& take_fn, const uint4* nsrc, int ncnt) {
+    DsSide out;
+    out.t = 0; out.rec = make_uint4(0, 0, 0, 0);
+    DsLane Lc = first;
+    if (!use_first) Lc = fetch(krec, total, lane, rotated);
     for (int s0 = 0; s0 < total; s0 += 64) {
       const bool valid = s0 + lane < total;
       DsLane Ln = Lc;
-      if (s0 + 64 < total) Ln = fetch(total, s0 + 64 + lane, rotated);
+      if (s0 + 64 < total) Ln = fetch(krec, total, s0 + 64 + lane, rotated);
       const double mm = (double)__int_as_float(Lc.tab.x);
       const float sigma = __int_as_float(Lc.tab.y);
       const float xf = (float)(mm * Lc.uv.x) + Lc.kx, yf = (float)(mm * Lc.uv.y) + Lc.ky;
@@ -499,6 +522,10 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
       } else {
         const DsPrep pr = ds_prep(xf, yf, sigma, Lc.tab.z, Lc.tab.w);
         DsRaw raw;
+        if (side && s0 == 0) {
+          out.t = take_fn();
+          if (lane < ncnt) out.rec = nsrc[lane];
+        }
         __builtin_amdgcn_s_setprio(1);  // a wave that has its gathers to issue goes first (1 % of the kernel)
         if (valid) ds_load<I24>(raw, pr, F.rs_img, stride, cols, F.rs_int, istride);
         __builtin_amdgcn_s_setprio(0);
@@ -507,7 +534,12 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
       if (valid) vals[Lc.slot] = value;
       Lc = Ln;
     }
+    if (GENERIC && side) {  // (the generic sampler has no burst: here)
+      out.t = take_fn();
+      if (lane < ncnt) out.rec = nsrc[lane];
+    }
     wave_sync();
+    return out;
   };
   auto frame_of = [&](int frame) {
     DsFrame F;
@@ -577,39 +609,59 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
     };
     // Fewer than 8 frames (one queue for the whole chip; typically one frame per call, where latency matters): the runs
     // are dealt statically, wave w takes runs w, w + waves, ... - no atomics.  Otherwise lane 0 takes tickets from the
-    // group's counter (an agent-scope atomic takes microseconds: taken two runs ahead).
+    // group's counter.  An agent-scope atomic takes microseconds, so a ticket is taken two runs ahead and - round 5 - READ
+    // where the wave has just waited for its last gathers anyway: the vector memory counter is in order, whatever was
+    // issued before those gathers has arrived with them.  Until then the compiler had the wave wait for every ticket the
+    // moment it was taken (its atomic optimizer turns a one-lane atomic on a uniform address into mbcnt / readfirstlane
+    // code that needs the result at once; the pointer is made opaque below so that it keeps its hands off) and for the next
+    // run's records - requested two instructions earlier - at the top of every run (the LDS write of THIS run's records
+    // sat behind them: a full wait).  Now the top of a run waits for nothing: the records of the next run go to the second
+    // LDS buffer and the first sampling round of its orientation pass is requested at the END of this run, under the bit
+    // tests and the descriptor stores.
     const bool static_deal = ngroups == 1;
     int static_next = (int)(blockIdx.x * DS_WAVES + wave);
+    typedef __attribute__((address_space(1))) int* ds_gptr;  // (global address space: a flat atomic would count as an LDS access as well)
+    ds_gptr ticket_opaque = (ds_gptr)ticket;
+    asm volatile("" : "+v"(ticket_opaque));  // (not provably uniform any more: no atomic optimizer)
     auto take = [&]() {
       int t = total_runs;
       if (static_deal) {
         t = min(static_next, total_runs);
         static_next += (int)(gridDim.x * DS_WAVES);
       } else if (lane == 0) {
-        t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __hip_atomic_fetch_add(ticket_opaque, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       return t;
     };
     // groups of other XCDs - normally finished by their own waves - get a plain look first
     if (gi > 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= total_runs) continue;
-    int t1 = take();
-    int t2 = take();
+    const int t1 = take();
+    const int t2 = take();
     DsTicket cur = decode(__builtin_amdgcn_readfirstlane(t1));
+    DsTicket nxt = decode(__builtin_amdgcn_readfirstlane(t2));
+    int kb = 0;  // record buffer of the current run
     uint4 myrec = make_uint4(0, 0, 0, 0);
     if (lane < cur.cnt) myrec = (drec + (long)cur.frame * kp_cap)[cur.k0 + lane];
+    if (lane < cur.cnt) krec2[lane] = myrec;
+    bool have_first = false;  // (wave-uniform) `first` holds the first round of this run's orientation pass
+    DsLane first;
+    first.kx = 0.f; first.ky = 0.f; first.tab = make_int4(0, 0, 0, 0); first.ti = 0; first.uv = make_double2(0., 0.); first.slot = 0;
+    DS_T0();
     while (cur.ok) {
-      const DsTicket nxt = decode(__builtin_amdgcn_readfirstlane(t2));
-      t2 = take();
-      uint4 nrec = make_uint4(0, 0, 0, 0);
-      if (lane < nxt.cnt) nrec = (drec + (long)nxt.frame * kp_cap)[nxt.k0 + lane];  // in flight under this run's gathers
+      uint4* krec = krec2 + kb * RUN;
+      const uint4* nsrc = drec + (long)nxt.frame * kp_cap + nxt.k0;
       const DsFrame F = frame_of(cur.frame);
-      if (lane < cur.cnt) krec[lane] = myrec;
       const bool estimate = P.rotation_invariant && lane < cur.cnt && __uint_as_float(myrec.z) == -1.0f;
       int theta = 0;
-      if (__any(estimate)) {
+      DsSide side;
+      side.t = 0; side.rec = make_uint4(0, 0, 0, 0);
+      const bool two_passes = __any(estimate);
+      DS_T(0);
+      if (two_passes) {
         // orientation (:714-739): unrotated pattern, long pairs
         wave_sync();
-        pass(F, cur.total, false);
+        side = pass(F, krec, cur.total, false, have_first, first, true, take, nsrc, nxt.cnt);
+        DS_T(1);
         int md0 = 0, md1 = 0;
         for (int kq = 0; kq < cur.cnt; ++kq) {
           const int* v = vals + kq * np;
@@ -655,7 +707,21 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
       if (P.rotation_invariant && !estimate) theta = brisk_theta_from_angle(__uint_as_float(myrec.z), false);
       if (lane < cur.cnt) kth[lane] = theta;
       wave_sync();
-      pass(F, cur.total, true);
+      DS_T(2);
+      {
+        const DsSide s2 = pass(F, krec, cur.total, true, false, first, !two_passes, take, nsrc, nxt.cnt);
+        if (!two_passes) side = s2;
+      }
+      DS_T(3);
+      const int t3 = side.t;
+      const uint4 nrec = side.rec;
+      // The wave has just waited for the rotated pass's last gathers: the ticket taken at the top of the run and the next
+      // run's records have arrived with them.  Decode the ticket and put the records into the other buffer.
+      const DsTicket nn = decode(__builtin_amdgcn_readfirstlane(t3));
+      uint4* krec_n = krec2 + (kb ^ 1) * RUN;
+      if (lane < nxt.cnt) krec_n[lane] = nrec;
+      const bool est_n = P.rotation_invariant && lane < nxt.cnt && __uint_as_float(nrec.z) == -1.0f;
+      have_first = nxt.ok && __any(est_n);
       // bit p = values[i] > values[j], LSB first in little-endian u32 words (:538-564)
       for (int kq = 0; kq < cur.cnt; ++kq) {
         const int* v = vals + kq * np;
@@ -682,18 +748,34 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
         if (lane < nwords)
           *reinterpret_cast<unsigned long long*>(desc + ((long)cur.frame * kp_cap + k) * desc_pitch + lane * 8) = mine;
       }
-      __builtin_amdgcn_wave_barrier();  // vals[], krec[], kth[] are reused
+      // (behind the loop with the descriptor stores: in front of it the compiler drains the memory counter at the loop's
+      // entry; what hides this request is the top of the next run)
+      if (have_first) {
+        wave_sync();
+        first = fetch(krec_n, nxt.total, lane, false);
+      }
+      __builtin_amdgcn_wave_barrier();  // vals[], kth[] and this run's records are reused
       cur = nxt;
+      nxt = nn;
       myrec = nrec;
+      kb ^= 1;
+      DS_T(4);
+#ifdef DS_TIMING
+      dt_acc[5] += 1;
+#endif
     }
   }
+#ifdef DS_TIMING
+  if (lane == 0)
+    for (int k = 0; k < 6; ++k) atomicAdd(&counters[0].dphase[k], (int)(dt_acc[k] >> (k < 5 ? 4 : 0)));  // (16-tick units: 512 frames overflow an int otherwise)
+#endif
 }
 
 long brisk_dp_work_ints(int kp_cap) { return DP_W_BLK + (kp_cap + DP_THREADS - 1) / DP_THREADS + 16; }
 
 static size_t describe_lds_bytes(const BriskPatternDev& P, int run, bool regtab) {
   const size_t table = regtab ? 0 : (P.nlong <= DS_LP_LDS ? (size_t)P.nlong * 16 : 0) + (((size_t)P.nshort * 4 + 15) & ~(size_t)15);
-  const size_t per_wave = (size_t)run * 16 + (((size_t)run * 4 + 15) & ~(size_t)15) + (((size_t)run * P.npoints * 4 + 15) & ~(size_t)15) + 2 * DS_MAXQ * 4;
+  const size_t per_wave = 2 * (size_t)run * 16 + (((size_t)run * 4 + 15) & ~(size_t)15) + (((size_t)run * P.npoints * 4 + 15) & ~(size_t)15) + 2 * DS_MAXQ * 4;
   return table + DS_WAVES * per_wave;
 }
 

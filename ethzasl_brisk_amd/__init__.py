@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "brisk_hip_kernel_revision", "brisk_hip_compute_scale", "brisk_hip_describe_same_image", "brisk_hip_detect_filtered",
     "brisk_hip_comm_unique_id", "brisk_hip_comm_create", "brisk_hip_comm_destroy", "brisk_hip_comm_rank", "brisk_hip_comm_world",
     "brisk_hip_comm_gather_results", "brisk_hip_comm_wait", "brisk_hip_debug_filter_keypoints", "brisk_hip_debug_integral_bits",
+    "brisk_hip_set_integral_format", "brisk_hip_debug_forge_pattern_device",
 ]
 
 
@@ -101,6 +102,8 @@ def load_library():
     L.brisk_hip_debug_counters_raw.argtypes = [vp, C.c_int, vp, C.c_int]
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
+    L.brisk_hip_set_integral_format.argtypes = [vp, C.c_int]
+    L.brisk_hip_debug_forge_pattern_device.argtypes = [vp, C.c_int]
     L.brisk_hip_debug_image_reuse.argtypes = [vp]
     L.brisk_hip_set_bucketing.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     for f in (L.brisk_hip_halfsample16, L.brisk_hip_twothirdsample16, L.brisk_hip_integral_image16):
@@ -253,6 +256,10 @@ class Context:
     def debug_image_reuse(self):
         """describe calls that reused the device copy of the image a detect call had uploaded"""
         return self._L.brisk_hip_debug_image_reuse(self._h)
+
+    def set_integral_format(self, fmt):
+        """0 = automatic (from the previous batch's candidate density), 24 / 32 = that element size for every call"""
+        self.check(self._L.brisk_hip_set_integral_format(self._h, int(fmt)))
 
     def debug_set_flags(self, flags):
         self.check(self._L.brisk_hip_debug_set_flags(self._h, flags))

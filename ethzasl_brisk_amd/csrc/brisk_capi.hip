@@ -20,6 +20,7 @@ static_assert(sizeof(brisk_hip_keypoint) == 28 && sizeof(BriskKeyPoint) == 28, "
 
 struct brisk_hip_pattern {
   int device;  // device the tables live on (usable from every context of that device)
+  int true_device;  // (device can be forged by a test: brisk_hip_debug_forge_pattern_device)
   BriskPatternHost host;
   BriskPatternDev dev;  // device pointers
   void* blob;           // single device allocation backing dev.*
@@ -80,6 +81,7 @@ struct brisk_hip_ctx {
   // candidate density of the last detect + describe batch (k_batch_density writes it into pinned host memory; read without
   // synchronisation by the next batch: integral_format)
   long long* h_density = nullptr;
+  int integral_fmt = 0;  // brisk_hip_set_integral_format: 0 auto, 24, 32
   // results of a one-frame host-buffer call land here (pinned) behind the kernels: one wait per call (download_single)
   uint8_t* h_res = nullptr;
   int* d_pub_done = nullptr;  // k_publish_single: workgroups that have written their share
@@ -331,13 +333,14 @@ static int ensure_stage(brisk_hip_ctx* c, size_t bytes) {
 // only steers speed.  (Both forms in ONE k_describe, chosen per frame on the device, cost more registers - 224 instead of
 // 195 - than the smaller image saves.)  Debug bit 18 forces 32, bit 24 forces 24 (stage parity tests of both forms);
 // BRISK_INTEGRAL_BITS=32 / 24 for A / B runs.
-static void integral_format(const brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, bool batch_with_detect, int* ibits, int* i24_max_cand) {
+static void integral_format(const brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, bool batch_with_detect, int* ibits) {
   static const int env = getenv("BRISK_INTEGRAL_BITS") ? atoi(getenv("BRISK_INTEGRAL_BITS")) : 0;
   *ibits = 32;
-  *i24_max_cand = -1;  // (per-frame choice inside k_integral_final: not used, see above)
   if (!pat || !pat->dev.int24_ok) return;
   if (env == 32 || (ctx->debug_flags & (1 << 18))) return;
   if (env == 24 || (ctx->debug_flags & (1 << 24))) { *ibits = 24; return; }
+  if (ctx->integral_fmt == BRISK_HIP_INTEGRAL_U32) return;                     // brisk_hip_set_integral_format
+  if (ctx->integral_fmt == BRISK_HIP_INTEGRAL_U24) { *ibits = 24; return; }
   if (!batch_with_detect) return;
   double density = 0.0;  // candidates per megapixel of the last batch (none yet: sparse is the common case)
   if (ctx->h_density && ctx->density_mpx > 0.0) {
@@ -346,6 +349,17 @@ static void integral_format(const brisk_hip_ctx* ctx, const brisk_hip_pattern* p
     if (frames > 0) density = (double)cands / ((double)frames * ctx->density_mpx);
   }
   if (density <= 3000.0) *ibits = 24;
+}
+// a pattern's tables live on ONE device: a context of another device would dereference that device's memory from its
+// kernels (a fault, or silent peer reads on every sample) - the mistake a one-thread-per-GPU host makes first
+static int check_pattern_device(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat) {
+  if (pat && pat->device != ctx->device) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "pattern handle was created on device %d, the context runs on device %d: create one extractor per GPU",
+             pat->device, ctx->device);
+    return fail(ctx, BRISK_HIP_ERR_ARG, msg);
+  }
+  return BRISK_HIP_OK;
 }
 
 // host image -> device staging (rows at `pitch`): one linear copy when neither side has row padding (a pitched copy is
@@ -502,7 +516,7 @@ static int pattern_finish(brisk_hip_ctx* ctx, brisk_hip_pattern* p, bool ok, con
     delete p;
     return BRISK_HIP_ERR_PATTERN;
   }
-  p->device = ctx->device;
+  p->device = p->true_device = ctx->device;
   p->blob = nullptr;
   const int rc = upload_pattern(ctx, p);
   if (rc != BRISK_HIP_OK) {
@@ -568,6 +582,7 @@ struct BatchArgs {
   int bk_u = 0, bk_v = 0, bk_max = 0;  // KeyPointBucketing of this call (0 buckets = off)
   bool no_scale_nms = false;  // suppressScaleNonmaxima == false with octaves > 0
   int lower_threshold = BRISK_LOWER_THRESHOLD;  // 0: ComputeScale's pyramid (brisk-feature-detector.cc:90)
+  bool format_as_full_batch = false;  // timing experiments (debug bit 27): the descriptor half alone, on the integral format the whole batch would use
   bool inplace_ok = true;  // layer 0 may be read from the frame buffer (not for the host-fed path's recycled staging buffers)
 };
 
@@ -613,10 +628,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   if (A.do_describe && A.pat && A.pat->host.strings > ctx->desc_pitch) ctx->desc_pitch = brisk_align_up(A.pat->host.strings, 16);
   rc = ensure_buffers(ctx, nframes, ctx->G);
   if (rc) return rc;
-  {
-    int unused;
-    integral_format(ctx, A.pat, A.do_detect && A.do_describe, &ctx->D.ibits, &unused);
-  }
+  integral_format(ctx, A.pat, A.format_as_full_batch || (A.do_detect && A.do_describe), &ctx->D.ibits);
   const bool bucketing = A.do_detect && !(A.uni_radius > 0.0) && A.bk_u > 0;
   if ((A.do_detect && A.uni_radius > 0.0) || bucketing) {
     rc = ensure_filter_buffers(ctx, A.w, A.h, nframes, bucketing ? 0.0 : A.uni_radius);
@@ -651,7 +663,7 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
   Bi.kp_out += f0 * Bi.kp_cap;
   Bi.bandsum += f0 * nbands * Bi.istride;
   BriskDescribeBuffers Di = ctx->D;
-  Di.ibits = ctx->D.ibits; Di.i24_max_cand = -1;  // (chosen once per call: batch_begin)
+  Di.ibits = ctx->D.ibits;  // (chosen once per call: batch_begin)
   Di.integral += f0 * Di.iframe_elems;
   Di.dkp += f0 * Bi.kp_cap;
   Di.dscale += f0 * Bi.kp_cap;
@@ -744,12 +756,15 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
                      int lower_threshold = BRISK_LOWER_THRESHOLD, const int* bucketing = nullptr) {
   if (!d_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
+  if (int rcp = check_pattern_device(ctx, pat)) return rcp;
   // timing experiments only (debug bit 27): the descriptor half of a batch alone, on the keypoints the previous batch left
+  const bool full_batch = do_detect && do_describe;
   if (do_detect && do_describe && (ctx->debug_flags & (1 << 27)) && ctx->last_nframes >= nframes) do_detect = false;
   BatchArgs A{pat, w, h, threshold, octaves, frame_pitch, row_pitch, d_mask, mask_frame_pitch, mask_row_pitch, do_detect,
               do_describe, uni_radius < 0.0 ? ctx->uni_radius : uni_radius, uni_radius < 0.0 ? ctx->uni_max : uni_max};
   A.no_scale_nms = no_scale_nms;
   A.lower_threshold = lower_threshold;
+  A.format_as_full_batch = full_batch;
   // post-filters given per call (uni_radius >= 0 / bucketing != null) never read or write the context's settings
   if (bucketing) { A.bk_u = bucketing[0]; A.bk_v = bucketing[1]; A.bk_max = bucketing[2]; }
   else if (uni_radius < 0.0) { A.bk_u = ctx->bk_u; A.bk_v = ctx->bk_v; A.bk_max = ctx->bk_max; }
@@ -818,6 +833,7 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!h_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
+  if (int rcp = check_pattern_device(ctx, pat)) return rcp;
   BatchArgs A{pat, w, h, threshold, octaves, 0, 0, nullptr, 0, 0, true, true, ctx->uni_radius, ctx->uni_max};
   A.bk_u = ctx->bk_u; A.bk_v = ctx->bk_v; A.bk_max = ctx->bk_max;
   A.inplace_ok = false;  // the staging buffers are recycled slice after slice: the engine keeps its own layer-0 copy (the link, not the engine, bounds this path)
@@ -914,7 +930,9 @@ int brisk_hip_batch_results(brisk_hip_ctx* ctx, const int** d_detected, const in
   if (d_described_kps) *d_described_kps = (const brisk_hip_keypoint*)ctx->D.dkp;
   if (d_desc) *d_desc = ctx->D.desc;
   if (kp_cap) *kp_cap = ctx->B.kp_cap;
-  if (desc_pitch) *desc_pitch = ctx->D.desc_pitch;
+  // (a host describe call with packed destination rows wrote slot 0's rows at that pitch: what the rows HAVE, not what the
+  // workspace was allocated for)
+  if (desc_pitch) *desc_pitch = ctx->last_desc_pitch ? ctx->last_desc_pitch : ctx->D.desc_pitch;
   return BRISK_HIP_OK;
 }
 
@@ -1175,6 +1193,7 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
   if (w <= 0 || h <= 0 || w > 8191 || h > 8191 || stride < w) return fail(ctx, BRISK_HIP_ERR_ARG, "bad image description");
   if (*n > 0 && desc_stride < pat->host.strings) return fail(ctx, BRISK_HIP_ERR_ARG, "descriptor stride too small");
   if (*n > ctx->kp_cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "more keypoints than the configured capacity");
+  if (int rcp = check_pattern_device(ctx, pat)) return rcp;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int pitch = brisk_align_up(w, 64);
   const size_t img_bytes = (size_t)pitch * h;
@@ -1224,7 +1243,7 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
   // descriptor rows of this call at the caller's pitch when the caller's rows are packed (a cv::Mat of K x strings bytes):
   // the download is then one linear copy
   BriskDescribeBuffers Dd = ctx->D;
-  integral_format(ctx, pat, false, &Dd.ibits, &Dd.i24_max_cand);
+  integral_format(ctx, pat, false, &Dd.ibits);
   if (desc_stride == pat->host.strings && pat->host.strings % 8 == 0 && pat->host.strings <= ctx->D.desc_pitch) Dd.desc_pitch = pat->host.strings;
   brisk_launch_describe(ctx->G, P, Bd, Dd, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, &ctx->prof, nullptr, n_in);
   if (ctx->prof.on) ctx->prof.calls++;
@@ -1587,6 +1606,21 @@ int brisk_hip_stream_ceiling(brisk_hip_ctx* ctx, size_t bytes, double* copy_GBps
   if (copy_GBps) *copy_GBps = best[0];
   if (read_GBps) *read_GBps = best[1];
   HIPCHK(ctx, hipGetLastError());
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_set_integral_format(brisk_hip_ctx* ctx, int format) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (format != BRISK_HIP_INTEGRAL_AUTO && format != BRISK_HIP_INTEGRAL_U24 && format != BRISK_HIP_INTEGRAL_U32)
+    return fail(ctx, BRISK_HIP_ERR_ARG, "integral format must be BRISK_HIP_INTEGRAL_AUTO, _U24 or _U32");
+  ctx->integral_fmt = format;
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_debug_forge_pattern_device(brisk_hip_pattern* p, int device) {
+  if (!p) return BRISK_HIP_ERR_ARG;
+  p->device = device < 0 ? p->true_device : device;
   return BRISK_HIP_OK;
 }
 

@@ -787,8 +787,7 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
                            long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov, int n_in_max) {
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
   if (!ov && !((G.debug_flags & (1 << 19)) && (G.debug_flags & (1 << 27))))  // (bits 19 + 27: brisk_capi.hip, timing experiments)
-    brisk_launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s, Dd.ibits, B.counters,
-                          Dd.i24_max_cand);
+    brisk_launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s, Dd.ibits, B.counters);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
                      Dd.dscale, Dd.dperm, Dd.drec, B.kp_cap, Dd.dp_work, Dd.dp_work_stride);

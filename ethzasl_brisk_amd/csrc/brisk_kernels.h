@@ -35,11 +35,10 @@ struct BriskDetectBuffers {
 struct BriskDescribeBuffers {
   uint32_t* integral;  // [slots][iframe_elems] (frame pitch in 4-byte units whatever the element size)
   int istride;         // integral row stride (elements)
-  int ibits;           // element size of the integral image of this call: 32, or 24 = "3-byte elements allowed" (values modulo 2^24,
-                       // row pitch istride * 3 bytes: a quarter less to write and to fetch; BriskPatternDev::int24_ok) - taken
-                       // per frame by k_integral_final for the frames with at most i24_max_cand AGAST candidates (sparse frames
-                       // gain from the smaller image, dense ones lose more in k_describe; < 0: every frame)
-  int i24_max_cand;
+  int ibits;           // element size of the integral image of this call, every frame alike: 32, or 24 = 3-byte elements (values
+                       // modulo 2^24, row pitch istride * 3 bytes: a quarter less to write and to fetch; BriskPatternDev::int24_ok).
+                       // k_describe is instantiated for one of the two per launch: the choice is per CALL (brisk_capi.hip,
+                       // integral_format), never per frame
   long iframe_elems;
   BriskKeyPoint* dkp;  // [slots][kp_cap] filtered keypoints (angle filled in)
   int* dscale;         // [slots][kp_cap]
@@ -97,7 +96,7 @@ void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, i
 // integral image of layer 0 from the band sums the pyramid kernel left (brisk_kernels.hip)
 void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
                            long iframe_elems, int band_h, int nframes, hipStream_t s, int ibits = 32,
-                           BriskFrameCounters* counters = nullptr, int i24_max_cand = -1);
+                           BriskFrameCounters* counters = nullptr);
 // sum of the batch's candidate counts -> *host_word (pinned, mapped): candidates in bits 0-39, frames in bits 40-63
 void brisk_launch_publish_single(const BriskFrameCounters* counters, const BriskKeyPoint* kps, const uint8_t* desc, int which, int max_kp,
                                  int dev_pitch, int expect, uint8_t* host, unsigned o_cnt, unsigned o_kp, unsigned o_desc, int* done,

@@ -1364,11 +1364,12 @@ template <int NCH, bool B24>
 __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, const uint8_t* __restrict__ pyr,
                                                                const uint32_t* __restrict__ bandsum,
                                                                uint32_t* __restrict__ integral, int istride, long iframe_elems,
-                                                               int nbands, int band_h, BriskFrameCounters* counters, int i24_max_cand) {
+                                                               int nbands, int band_h, BriskFrameCounters* counters) {
   __shared__ unsigned wave_tot[2][II_THREADS / 64];
   const int frame = blockIdx.y, band = blockIdx.x;
-  // 3-byte elements for this frame?  (B24: allowed for the call; then every frame, or the frames with few candidates)
-  const bool b24 = B24 && (i24_max_cand < 0 || counters[frame].ncand <= i24_max_cand);
+  // B24: 3-byte elements, for every frame of the call (k_describe is instantiated for one form per launch); the flag in
+  // the counters is what the debug download reads
+  constexpr bool b24 = B24;
   if (counters && band == 0 && threadIdx.x == 0) counters[frame].i24 = b24 ? 1 : 0;
   const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
   const uint8_t* img = brisk_layer_img(G, pyr, frame, 0);
@@ -1462,8 +1463,7 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
 }
 
 void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_t* bandsum, uint32_t* integral, int istride,
-                            long iframe_elems, int band_h, int nframes, hipStream_t s, int ibits, BriskFrameCounters* counters,
-                            int i24_max_cand) {
+                            long iframe_elems, int band_h, int nframes, hipStream_t s, int ibits, BriskFrameCounters* counters) {
   const int nbands = (G.L[0].h + band_h - 1) / band_h;
   const int nchunks = (G.L[0].w + 1 + II_CHUNK - 1) / II_CHUNK;
   const dim3 grid(nbands, nframes), block(II_THREADS);
@@ -1471,9 +1471,9 @@ void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_
   const bool b24 = ibits == 24 && counters;  // (the per-frame flag lives in the counters)
 #define II_LAUNCH(NCH, LDS)                                                                                                                  \
   if (b24) hipLaunchKernelGGL((k_integral_final<NCH, true>), grid, block, LDS, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, \
-                              band_h, counters, i24_max_cand);                                                                              \
+                              band_h, counters);                                                                                            \
   else hipLaunchKernelGGL((k_integral_final<NCH, false>), grid, block, LDS, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands,    \
-                          band_h, counters, i24_max_cand);
+                          band_h, counters);
   if (nchunks <= 1) { II_LAUNCH(1, pad_lds) }
   else if (nchunks == 2) { II_LAUNCH(2, 0) }
   else { II_LAUNCH(II_MAXCHUNKS, 0) }
@@ -1658,7 +1658,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
     brisk_prof_mark_side(prof, 0, ov->side);
     brisk_launch_integral(G, B.pyr, B.bandsum, ov->Dd->integral, ov->Dd->istride, ov->Dd->iframe_elems, B.band_h, nframes, ov->side,
-                          ov->Dd->ibits, B.counters, ov->Dd->i24_max_cand);
+                          ov->Dd->ibits, B.counters);
     brisk_prof_mark_side(prof, 1, ov->side);
     (void)hipEventRecord(ov->join, ov->side);
   };

@@ -111,7 +111,7 @@ class BruteForceMatcher : public cv::DescriptorMatcher {
     BruteForceMatcher* matcher = new BruteForceMatcher(distance_);
     if (!emptyTrainData)
       for (size_t i = 0; i < trainDescCollection.size(); ++i) matcher->trainDescCollection.push_back(trainDescCollection[i].clone());
-    return matcher;
+    return cv::Ptr<cv::DescriptorMatcher>(matcher);  // (cv::Ptr's raw-pointer constructor is explicit in OpenCV 3)
   }
 
  protected:

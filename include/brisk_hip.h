@@ -82,7 +82,9 @@ int brisk_hip_detect(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int s
                      int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, brisk_hip_keypoint* out,
                      int cap, int* n);
 /* The same call with the uniformity post-filter (see brisk_hip_set_uniformity) given per call instead of as context
- * state: uniformity_radius 0 = off, else >= 1; at most max_keypoints keypoints are kept. */
+ * state: uniformity_radius 0 = off, else >= 1; at most max_keypoints keypoints are kept.  Nothing of the context's
+ * settings applies to this call: with radius 0 it returns the unfiltered detections even if brisk_hip_set_uniformity /
+ * brisk_hip_set_bucketing are set on the context (those are for the batch path and brisk_hip_detect). */
 int brisk_hip_detect_uniform(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
                              int suppress_scale_nonmaxima, const uint8_t* mask, int mask_stride, double uniformity_radius,
                              int max_keypoints, brisk_hip_keypoint* out, int cap, int* n);
@@ -136,6 +138,19 @@ int brisk_hip_describe_same_image(brisk_hip_ctx* ctx, const brisk_hip_pattern* p
 int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames,
                                     int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
                                     int octaves, void* stream);
+/* Element format of the integral image the descriptor kernels build and sample (IntegralImage8,
+ * brisk/include/brisk/internal/integral-image.h:56-161).  The result never depends on it - both forms are bit-equal to
+ * the reference wherever the 24-bit form is used at all - only the speed does:
+ *   BRISK_HIP_INTEGRAL_AUTO (default)  3-byte elements (values modulo 2^24) in detect + describe batches while the
+ *        context's PREVIOUS batch was sparse (at most 3 000 AGAST candidates per megapixel), u32 otherwise and for
+ *        descriptor-only calls: a stream's batches look alike, and the sparse ones gain from the smaller image.  The
+ *        choice of a call therefore depends on the call before it - a benchmark that wants one form says so:
+ *   BRISK_HIP_INTEGRAL_U24 / _U32      that form for every call of the context (U24 only where it is exact: patterns
+ *        whose boxes cover fewer than 2^24 / 255 pixels - every built-in one; other patterns use u32).
+ * (BRISK_INTEGRAL_BITS=24 / 32 in the environment and debug bits 18 / 24 do the same for A / B runs and tests and
+ * take precedence.)  brisk_hip_debug_integral_bits reports what the last call used. */
+enum { BRISK_HIP_INTEGRAL_AUTO = 0, BRISK_HIP_INTEGRAL_U24 = 24, BRISK_HIP_INTEGRAL_U32 = 32 };
+int brisk_hip_set_integral_format(brisk_hip_ctx* ctx, int format);
 /* Host-fed form of the batch (the PCIe-fed stream): h_frames is HOST memory (pinned with hipHostMalloc /
  * hipHostRegister for full speed; pageable memory works but copies synchronously).  The frames are moved in slices of 64
  * into two device staging buffers on a copy stream while the previous slice is computed on the context's stream; the
@@ -152,8 +167,10 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
 int brisk_hip_detect_batch(brisk_hip_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, long frame_pitch,
                            int row_pitch, int threshold, int octaves, void* stream);
 /* Device pointers of the last batch's results.  d_counts: per frame {detected, described} at
- * byte stride *count_stride (ints); keypoints [frame][kp_cap]; descriptors [frame][kp_cap][desc_pitch] (desc_pitch is 64 until a pattern
- * with longer descriptors was used on this context: read it after the call, not once). */
+ * byte stride *count_stride (ints); keypoints [frame][kp_cap]; descriptors [frame][kp_cap][desc_pitch].  desc_pitch is the
+ * pitch of the rows the LAST call wrote - read it after every call, not once: batches write 64-byte rows (more once a
+ * pattern with longer descriptors was used on the context), a host-buffer brisk_hip_describe whose destination rows are
+ * packed (desc_stride == descriptor size) writes slot 0's rows at that packed pitch (48 for the default pattern). */
 int brisk_hip_batch_results(brisk_hip_ctx* ctx, const int** d_detected, const int** d_described, int* count_stride,
                             const brisk_hip_keypoint** d_detected_kps, const brisk_hip_keypoint** d_described_kps,
                             const uint8_t** d_desc, int* kp_cap, int* desc_pitch);
@@ -290,6 +307,10 @@ int brisk_hip_debug_set_flags(brisk_hip_ctx* ctx, int flags);
  * forces the 32-bit form. */
 int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out);
 int brisk_hip_debug_integral_bits(brisk_hip_ctx* ctx, int frame);
+/* test knob: overwrites the device a pattern handle believes its tables live on (the engine refuses a pattern / context
+ * pair of different devices with BRISK_HIP_ERR_ARG; a one-GPU box can only test the refusal by forging the field).
+ * device < 0 restores the true one. */
+int brisk_hip_debug_forge_pattern_device(brisk_hip_pattern* p, int device);
 /* number of describe calls that reused the image a detect call had left on the device (brisk_hip_describe_same_image, or
  * brisk_hip_describe under BRISK_HIP_IMAGE_CACHE=1) and skipped the upload and the layer-0 pass */
 int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx);

@@ -1,0 +1,164 @@
+"""GPU tests added in round 5 (run with -m gpu): the pattern / context device guard, the explicit integral-format knob of
+the C ABI, the descriptor pitch brisk_hip_batch_results reports after a packed host describe call, and the restructured
+run loop of k_describe (tickets and next-run records read behind the run's last gathers) on batch sizes that leave waves
+with zero, one and many runs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+from test_gpu_parity import same_kps, explain  # noqa: F401
+from test_gpu_round3 import _run_batch_and_compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import ethzasl_brisk_amd as B
+    from ethzasl_brisk_amd import build
+    build.build()
+    B.load_library()
+    return B
+
+
+def test_pattern_of_another_device_is_refused(B):
+    """An extractor built for GPU A used with a context of GPU B would make B's kernels dereference A's tables: every entry
+    that takes a pattern refuses the pair (BRISK_HIP_ERR_ARG, a message that says what to do).  One GPU per box: the
+    handle's device field is forged (brisk_hip_debug_forge_pattern_device), restored, and the same calls succeed."""
+    import torch
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    img = synth.frame_vga(3)
+    kps = B.BriskFeatureDetector(70, 4, context=ctx).detect(img)
+    d = torch.from_numpy(np.stack([img, img])).cuda()
+    pinned = torch.from_numpy(np.stack([img, img])).pin_memory()
+    stream = torch.cuda.current_stream().cuda_stream
+    L = ctx._L
+    assert L.brisk_hip_debug_forge_pattern_device(ext._h, 5) == 0
+    for call in (lambda: ext.compute(img, kps),
+                 lambda: ctx.detect_describe_batch(ext, d.data_ptr(), 2, 640, 480, 640 * 480, 640, 70, 4, stream),
+                 lambda: ctx.detect_describe_batch_host(ext, pinned.data_ptr(), 2, 640, 480, 640 * 480, 640, 70, 4)):
+        with pytest.raises(B.BriskHipError) as e:
+            call()
+        assert e.value.code == 1 and "device 5" in str(e.value) and "device 0" in str(e.value), str(e.value)
+    assert L.brisk_hip_debug_forge_pattern_device(ext._h, -1) == 0
+    k2, desc = ext.compute(img, kps)
+    ko = O.detect(img, 70, 4)
+    ko2, do = O.Extractor().compute(img, ko)
+    assert same_kps(k2, ko2) and np.array_equal(desc, do)
+    ctx.detect_describe_batch(ext, d.data_ptr(), 2, 640, 480, 640 * 480, 640, 70, 4, stream)
+    torch.cuda.synchronize()
+    assert ctx.batch_status(2) == 0
+    kg, dg = ctx.batch_download(1, described=True)
+    assert same_kps(kg, ko2) and np.array_equal(dg, do)
+    ctx.close()
+
+
+def test_explicit_integral_format(B):
+    """brisk_hip_set_integral_format: U32 / U24 hold for every call whatever the previous batch looked like (AUTO follows
+    its candidate density: test_gpu_round4), descriptor-only host calls included; every result equals the oracle."""
+    import torch
+    imgs = [synth.frame_1080p(840 + i) for i in range(2)]
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    X = O.Extractor()
+    want = {}
+    for fmt, thrs in ((32, (80, 80)), (24, (30, 30, 80)), (0, (80, 80))):
+        ctx.set_integral_format(fmt)
+        for thr in thrs:
+            ctx.detect_describe_batch(ext, d.data_ptr(), 2, 1920, 1080, 1920 * 1080, 1920, thr, 4, stream)
+            torch.cuda.synchronize()
+            assert ctx.batch_status(2) == 0
+            bits = ctx.debug_integral_bits(0)
+            assert bits == (fmt if fmt else 24), (fmt, thr, bits)
+            if thr not in want:
+                ko = O.detect(imgs[1], thr, 4)
+                want[thr] = X.compute(imgs[1], ko)
+            kg, dg = ctx.batch_download(1, described=True)
+            assert same_kps(kg, want[thr][0]) and np.array_equal(dg, want[thr][1]), (fmt, thr)
+        # a descriptor-only host call: u32 unless 24 is asked for
+        ko = O.detect(imgs[0], 80, 4)
+        k2, desc = ext.compute(imgs[0], ko)
+        assert ctx.debug_integral_bits(0) == (24 if fmt == 24 else 32)
+        k2o, do = X.compute(imgs[0], ko)
+        assert same_kps(k2, k2o) and np.array_equal(desc, do)
+    with pytest.raises(B.BriskHipError):
+        ctx.set_integral_format(16)
+    ctx.close()
+
+
+def test_batch_results_pitch_after_a_packed_host_describe(B):
+    """brisk_hip_describe with packed destination rows writes slot 0's descriptor rows at that pitch (48): what
+    brisk_hip_batch_results reports must be THAT pitch (round-4 advisor finding: it reported the workspace's 64), so that
+    the device rows can go straight into brisk_hip_match_knn_device; after a batch it is the workspace pitch again."""
+    import torch
+    img = synth.frame_vga(11)
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    kps = B.BriskFeatureDetector(60, 4, context=ctx).detect(img)
+    k2, desc = ext.compute(img, kps)
+    assert desc.shape[1] == 48 and len(k2) > 200
+    vp = C.c_void_p
+    d_det, d_n, d_kd, d_kp, d_desc = vp(), vp(), vp(), vp(), vp()
+    cstride, cap, pitch = C.c_int(), C.c_int(), C.c_int()
+    ctx.check(ctx._L.brisk_hip_batch_results(ctx._h, C.byref(d_det), C.byref(d_n), C.byref(cstride), C.byref(d_kd), C.byref(d_kp),
+                                             C.byref(d_desc), C.byref(cap), C.byref(pitch)))
+    assert pitch.value == 48, pitch.value
+    # the device rows against the host copy of the same descriptors (shifted by one row: no trivial zero distances)
+    train = torch.from_numpy(np.roll(desc, 1, axis=0).copy()).cuda()
+    nq = len(k2)
+    out = torch.zeros((nq, 2, 4), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.check(ctx._L.brisk_hip_match_knn_device(ctx._h, d_desc.value, nq, pitch.value, train.data_ptr(), nq, 48, 48, 2,
+                                                out.data_ptr(), cnt.data_ptr(), stream))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(B.DMATCH).reshape(nq, 2)
+    want = O.match_knn(desc, [np.roll(desc, 1, axis=0).copy()], 2)
+    for q in range(nq):
+        assert [(m["trainIdx"], m["distance"]) for m in got[q]] == [(m["trainIdx"], m["distance"]) for m in want[q]], q
+    assert all(got[q][0]["trainIdx"] == (q + 1) % nq and got[q][0]["distance"] == 0 for q in range(nq))
+    # a batch afterwards: rows at the workspace pitch again
+    d = torch.from_numpy(img[None]).cuda()
+    ctx.detect_describe_batch(ext, d.data_ptr(), 1, 640, 480, 640 * 480, 640, 60, 4, stream)
+    torch.cuda.synchronize()
+    ctx.check(ctx._L.brisk_hip_batch_results(ctx._h, C.byref(d_det), C.byref(d_n), C.byref(cstride), C.byref(d_kd), C.byref(d_kp),
+                                             C.byref(d_desc), C.byref(cap), C.byref(pitch)))
+    assert pitch.value == 64
+    ctx.close()
+
+
+@pytest.mark.parametrize("nframes", [1, 2, 7, 9, 40])
+def test_describe_run_loop_small_and_odd_batches(B, nframes):
+    """k_describe's run loop reads a ticket two runs after it was taken and keeps two record buffers: batches in which most
+    waves get no run, exactly one, or an odd number (static dealing below 8 frames, ticket queues from 8 on; 9 and 40
+    frames leave queues of different lengths), every slot against the oracle."""
+    distinct = [synth.frame_vga(200 + s) for s in range(3)]
+    _run_batch_and_compare(B, distinct, nframes, 70, 4, 640, 480, every_slot=True)
+
+
+def test_describe_runs_of_eight_and_provided_angles(B):
+    """dense frames take runs of 8 keypoints per ticket (threshold 30), and keypoints that arrive WITH an angle skip the
+    orientation pass: the run's ticket / record requests then travel with the rotated pass's first burst instead."""
+    img = synth.frame_1080p(77)
+    ko = O.detect(img, 30, 4)
+    assert len(ko) > 20000
+    X = O.Extractor()
+    ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    for mode in range(3):
+        kin = ko.copy()
+        if mode == 1:
+            kin["angle"] = (np.arange(len(kin)) * 7.3 % 360).astype(np.float32)   # every keypoint brings its angle
+        if mode == 2:
+            kin["angle"][::3] = 123.5                                               # a third of them do
+        kg, dg = ext.compute(img, kin)
+        kw, dw = X.compute(img, kin)
+        assert same_kps(kg, kw), explain(kg, kw)
+        assert np.array_equal(dg, dw), mode
+    ctx.close()

@@ -483,6 +483,8 @@ def main():
         gather.finish()
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) / 4 * 1e3 * inner
+        gather.verify_counts()   # outside every timed region: no frame had more rows than the slabs carry
+        gather.close()
 
     total_frames = frames_per_step_total * nsteps
     fps = total_frames / dt
@@ -936,6 +938,17 @@ class ResultGather:
         if self.pg is not None:
             self.last = self.pg.finish()
 
+    def verify_counts(self):
+        """outside the timed regions, rank 0: the gathered counts are the frames' FULL counts - one above the slab size would
+        mean rows that were not sent (the slab size is fixed before the timed region from the warm-up batches)"""
+        if self.rank == 0 and self.last is not None:
+            m = int(self.last[0].max().item())
+            if m > self.kpad:
+                raise RuntimeError("result gather: a frame has %d described keypoints, the slabs carry %d rows" % (m, self.kpad))
+
+    def close(self):
+        pass
+
     def check_kpad(self, ctl):
         """outside the timed region: the slab size must cover every frame of the batch (rounded up to 128)"""
         self.finish()
@@ -999,6 +1012,17 @@ class CapiGather(ResultGather):
             self.ctx.check(self.ctx._L.brisk_hip_comm_wait(self.comm, None))
             sl = getattr(self, "cur", None)
             self.last = (sl["ac"], sl["gk"], sl["gd"]) if sl else None
+
+    def close(self):
+        if getattr(self, "comm", None) is not None and self.comm:
+            self.ctx._L.brisk_hip_comm_destroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 (interpreter shutdown)
+            pass
 
 
 if __name__ == "__main__":

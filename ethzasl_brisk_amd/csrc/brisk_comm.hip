@@ -9,8 +9,37 @@
 // instead of a second one.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+// The RCCL entry points are looked up at run time; their declarations come from the RCCL header where the ROCm install
+// has it and from the (NCCL 2.7+, stable) ABI subset below where it does not - the engine builds either way and answers
+// BRISK_HIP_ERR_UNSUPPORTED when no librccl can be opened (round-4 advisor finding: a missing header broke the whole
+// library's build, single-GPU users included).
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define BRISK_HAVE_RCCL_HEADER 1
+#endif
+#endif
+#ifndef BRISK_HAVE_RCCL_HEADER
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -40,10 +69,17 @@ RcclApi* rccl() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
+    // BRISK_HIP_RCCL_LIB: the library to open instead of the default names (a site's own RCCL build; the test suite's
+    // socket-based double, tests/cpp/fake_rccl.cc, which lets several ranks share the one GPU of a test box)
+    const char* own = getenv("BRISK_HIP_RCCL_LIB");
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* n : names) {
-      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-      if (api.lib) break;
+    if (own && own[0]) {
+      api.lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char* n : names) {
+        api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+      }
     }
     if (!api.lib) { api.err = std::string("librccl not found: ") + dlerror(); return; }
 #define BRISK_RCCL_SYM(field, name)                                             \

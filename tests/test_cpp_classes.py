@@ -64,6 +64,53 @@ def test_result_gather_through_the_c_abi_world_1():
     assert r.returncode == 0 and "gather OK" in r.stdout
 
 
+def build_fake_rccl():
+    """tests/cpp/fake_rccl.cc -> tests/cpp/libfake_rccl.so: the eight RCCL entry points brisk_comm.hip uses, over Unix sockets
+    and staged hipMemcpy (a test double: several ranks on the one GPU of a test box)"""
+    src = os.path.join(ROOT, "tests", "cpp", "fake_rccl.cc")
+    out = os.path.join(ROOT, "tests", "cpp", "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               "-o", out, src, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+def test_fake_rccl_builds_and_exports_the_rccl_subset():
+    import ctypes
+    lib = ctypes.CDLL(build_fake_rccl())
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv",
+                "ncclGetErrorString"):
+        assert hasattr(lib, sym), sym
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_result_gather_through_the_c_abi_with_peers(tmp_path, world):
+    """brisk_hip_comm_gather_results with PEERS: world 2 and 3, one fresh process per rank, all on the box's one GPU over the
+    socket double of RCCL (BRISK_HIP_RCCL_LIB; RCCL itself refuses two ranks on one device).  Executes what world 1 never
+    does - every ncclSend of a non-root rank, every ncclRecv into rank r's slab at d_counts + r * frames_max, d_kps + r *
+    nb_k, d_desc + r * nb_d - with shards of unequal size (11 frames over 2 / 3 ranks) and three batches in a row (both
+    send slabs reused); the root compares every peer's slab with its own recomputation of that peer's frames."""
+    b = build_binary("test_gather", hip_runtime=True)
+    env = dict(os.environ, BRISK_HIP_RCCL_LIB=build_fake_rccl())
+    idf = str(tmp_path / "unique_id.bin")
+    procs = [subprocess.Popen([b, "--rank", str(r), "--world", str(world), "--id-file", idf], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    print("\n".join(outs))
+    assert [p.returncode for p in procs] == [0] * world, outs
+    assert "gather OK: world %d" % world in outs[0]
+    for r in range(1, world):
+        assert "rank %d of %d done" % (r, world) in outs[r]
+
+
 OPENCV_STUB = os.path.join(ROOT, "tests", "cpp", "opencv_stub")
 
 

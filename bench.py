@@ -269,6 +269,9 @@ def parse_args(argv):
                          "C-ABI communicator (brisk_hip_comm_*: RCCL directly, what a C++ host uses)")
     ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="timing experiments only (results become wrong)")
     ap.add_argument("--pattern-version", type=int, default=2)
+    ap.add_argument("--integral-format", default="auto", choices=["auto", "24", "32"],
+                    help="brisk_hip_set_integral_format: element size of the integral image (auto = from the previous batch's candidate "
+                         "density: 24 bits on this sparse stream); reported in config.integral_format_bits")
     ap.add_argument("--min-region-s", type=float, default=2.0,
                     help="--frames mode: the step is repeated until the timed region is at least this long")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 1 / 4 / 5 and the dense regimes (config.other_configs)")
@@ -364,6 +367,7 @@ def main():
     del ring
 
     ctx = B.Context(local_rank)
+    ctx.set_integral_format({"auto": 0, "24": 24, "32": 32}[args.integral_format])
     ctx.set_streams(args.streams)
     ctx.debug_set_flags(args.debug_flags)
     ext = B.BriskDescriptorExtractor(version=args.pattern_version, context=ctx)
@@ -488,6 +492,7 @@ def main():
 
     total_frames = frames_per_step_total * nsteps
     fps = total_frames / dt
+    integral_bits = ctx.debug_integral_bits(0)   # what the timed region's batches used (every batch alike: same stream)
     groups = algorithmic_bytes(W, H, OCTAVES, int(round(mean_kp)))
     per_frame_bytes = sum(groups.values())
     traffic = load_traffic(ctx)
@@ -520,6 +525,7 @@ def main():
                    "gather_note": None if gather_ms is None else "result gather of one step run alone after the timed region (inside it the transfers overlap the next chunk's kernels)",
                    "stream_slices": args.streams, "frames_per_kernel_launch": fpl, "distinct_frames_per_gpu": nd,
                    "mean_keypoints_per_frame": round(mean_kp, 1),
+                   "integral_format_bits": integral_bits, "integral_format_setting": args.integral_format,
                    "parallelism": "frames sharded over %d rank(s)%s" % (world, ((", asynchronous RCCL gather of keypoints+descriptors to rank 0 after every chunk (overlaps the next chunk; %s)" % ("C-ABI communicator brisk_hip_comm_*" if args.gather == "capi" else "torch.distributed")) if (world > 1 and gather) else "") + gather_note),
                    "algorithmic_MB_per_frame": round(per_frame_bytes / 1e6, 3),
                    "pipeline_achieved_GBps": round(per_frame_bytes * fps / 1e9, 2),
@@ -530,12 +536,19 @@ def main():
                                  "region); kernel_groups: algorithmic bytes of SURVEY 8(d) per group x frames per launch / "
                                  "interval; hbm_bytes from the committed rocprofv3 PMC passes when they belong to this "
                                  "kernel revision, else null"},
-        "roofline": {"bound": "hbm", "kernel": dom_stage, "achieved": round(dom_gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # "bound": the roofline the fraction is PRICED against (the contract knows "hbm" and "mfma"; there is no MFMA work on
+        # this path); "bound_by": what the kernel's time actually follows
+        "roofline": {"bound": "hbm", "bound_by": "l1_gather" if dom_stage == "k_describe" else ("valu_issue" if dom_stage in ("k_detect", "k_classify_refine") else "hbm"),
+                     "kernel": dom_stage, "achieved": round(dom_gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(dom_gb / HBM_PEAK_GBS, 5), "traffic": dom_traffic,
+                     # the same fraction on the COUNTER-measured HBM bytes of that kernel (committed PMC passes of this kernel
+                     # revision; null when they belong to another revision)
+                     "hbm_frac": None if not dom_traffic or dom_ms <= 0 else round(dom_traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "algorithmic_bytes_per_launch": dom_alg, "avg_launch_ms": round(dom_ms, 4), "launches_timed": ncalls,
-                     "note": ("k_describe is bound by the L2 misses / L1 line fills of its gathers at the compulsory-miss level, "
-                              "not by HBM bandwidth, occupancy or instruction issue: DESIGN.md 5, profiles/r03_microbench_gather.json, "
-                              "profiles/r03_describe_tcp_counters.txt; " if dom_stage == "k_describe" else "")
+                     "note": ("k_describe is bound by the vector L1's line fills for its gathers (ten 128-byte lines moved per sample "
+                              "for 88 bytes used: 47 of the 64 bytes per clock and CU the L1 can take from L2), not by HBM bandwidth, "
+                              "occupancy or instruction issue: DESIGN.md 5, profiles/r05_describe_phases.txt, "
+                              "profiles/r05_microbench_lds_patch.json; " if dom_stage == "k_describe" else "")
                              + "every kernel group: config.kernel_groups"},
     }
     if rank == 0:
@@ -549,7 +562,7 @@ def main():
             out["config"]["pcie_fed"] = host_fed(ctx, ext, host, chunk, strings)
         if world == 1 and not args.no_other_configs:
             try:
-                out["config"]["other_configs"] = other_configs(local_rank, traffic_rev=ctx.kernel_revision())
+                out["config"]["other_configs"] = other_configs(local_rank)
             except Exception as e:  # reported, never fatal for the bench line
                 out["config"]["other_configs"] = "failed: %r" % (e,)
         if cpu is not None:
@@ -591,7 +604,7 @@ def config5_keypoints(n=100000, seed=7):
     return kp
 
 
-def other_configs(device, only="", seconds=0.4, traffic_rev=None):
+def other_configs(device, only="", seconds=0.4):
     try:
         return _other_configs(device, only, seconds)
     finally:

@@ -121,6 +121,9 @@ struct BriskFrameCounters {
 #ifdef CR_TIMING  // experiments (build variant): per-phase lane time of k_classify_refine (tools/classify_phases.py)
   int cphase[8];
 #endif
+#ifdef DT_TIMING  // experiments (build variant): per-phase wave time of k_detect (tools/detect_phases.py)
+  int tdet[8];
+#endif
 #ifdef DS_TIMING  // experiments (build variant): per-phase wave time of k_describe (tools/describe_phases.py)
   int dphase[8];
 #endif

@@ -443,6 +443,14 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
   __shared__ uint16_t queue[DT_H * DT_W];                              // tile-local pixel index py * 64 + px
   __shared__ int qcount;
   const int frame = blockIdx.y;
+#ifdef DT_TIMING  // experiments: s_memtime ticks per phase and wave, summed into counters[frame].tdet[] (tools/detect_phases.py)
+  unsigned long long dt_last = __builtin_amdgcn_s_memtime();
+  unsigned dt_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define DT_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dt_acc[i] += (unsigned)(t_ - dt_last); dt_last = t_; } while (0)
+#else
+#define DT_T(i) do { } while (0)
+#endif
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so blocks with equal blockIdx.x % 8
   // share an XCD (and its L2) within a frame.  Give each residue a contiguous eighth of the frame's tile list so
   // that the halo rows/columns shared by neighbouring tiles are fetched into one L2 instead of eight.
@@ -492,7 +500,9 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       if (rg < DT_RG && rg + DT_RG * k < DT_LH) *reinterpret_cast<unsigned*>(tp + DT_RG * k * DT_PITCH) = stg[k];
   }
   if (threadIdx.x == 0) qcount = 0;
+  DT_T(0);  // tile decode + staging (address arithmetic, global loads, LDS writes)
   __syncthreads();
+  DT_T(1);  // waiting for the workgroup's other waves at the barrier
 
   // ---- phase A: 4 columns x DT_R rows per thread.  Window rows 0..DT_R+5 = image rows gy-3 .. gy+DT_R+2, three
   // dwords each = image columns gx-4 .. gx+7.  Pairs of horizontally adjacent pixels as packed 16-bit lanes:
@@ -514,6 +524,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       CA[r] = __builtin_amdgcn_perm(0u, R[r][1], 0x0c010c00u);   // (col 0, col 1)
       CB[r] = __builtin_amdgcn_perm(0u, R[r][1], 0x0c030c02u);   // (col 2, col 3)
     }
+    DT_T(2);  // window: 30 LDS dword reads + the centre / N / S byte pairs
     // pass flags of the thread's 16 pixels: every pair's two sign bits (15 and 31) are shifted in from the top, so
     // pair k = 2 * rr + (j >> 1) ends at bits 16 - 2 DT_R + k (column j even) and 32 - 2 DT_R + k (column j odd)
     unsigned m = 0;
@@ -529,6 +540,7 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       m = (m >> 1) | gA;
       m = (m >> 1) | gB;
     }
+    DT_T(3);  // W / E byte pairs + the packed pre-gate on 16 pixels
     // compaction: wave prefix sum of the per-thread counts, one LDS atomic per wave
     const int cnt = __popc(m);
     const int incl = wave_inclusive_scan(cnt);
@@ -546,7 +558,9 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       }
     }
   }
+  DT_T(4);  // compaction of the survivors
   __syncthreads();
+  DT_T(5);  // barrier in front of phase B
 
   // ---- phase B: exact contrast + closed-form segment test on the survivors (one lane each)
   const int nq = qcount;
@@ -603,6 +617,13 @@ __global__ void __launch_bounds__(256) k_detect(BriskGeom G, BriskTileTable T, c
       }
     }
   }
+  DT_T(6);  // phase B: exact contrast + segment test on the survivors
+#ifdef DT_TIMING
+  if ((threadIdx.x & 63) == 0 && ((blockIdx.x >> 3) & 15) == 3) {  // (one tile in 16 reports: 2 M atomics per launch took ten times the kernel)
+    for (int k = 0; k < 7; ++k) atomicAdd(&counters[frame].tdet[k], (int)dt_acc[k]);
+    atomicAdd(&counters[frame].tdet[7], 1);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

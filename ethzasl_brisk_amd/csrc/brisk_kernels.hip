@@ -1668,7 +1668,10 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
                          const BriskOverlap* ov) {
   (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters) * (size_t)nframes, s);
   brisk_prof_mark(prof, BRISK_STG_PYRAMID, s);
-  launch_pyramid(G, B, nframes, frames, frame_pitch, row_pitch, s);
+  // timing probes only (tools/overlap_probe3.py; the batch's results are meaningless): 1 = the call ends behind k_detect,
+  // 2 = and skips the pyramid kernel (k_detect alone, on whatever pyramid the buffers hold)
+  const int probe_stop = env_knob("BRISK_DETECT_PROBE", 0);  // (read per call: the probe switches it on after its set-up batches)
+  if (probe_stop != 2) launch_pyramid(G, B, nframes, frames, frame_pitch, row_pitch, s);
   // The integral image only needs layer 0 and the band sums (pyramid kernel) and is HBM-bound; tie resolution
   // (one workgroup per frame, a chain of dependent decisions) and the final ordering are latency-bound and leave
   // most of the chip idle.  The integral kernel runs beside them on a second, low-priority stream (forked in front
@@ -1687,6 +1690,7 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   brisk_prof_mark(prof, BRISK_STG_DETECT, s);
   hipLaunchKernelGGL(k_detect, dim3((T.total_tiles + 7) / 8 * 8, nframes), dim3(256), 0, s, G, T, B.pyr, B.smap, B.cand, B.counters,
                      B.cand_cap);
+  if (probe_stop) return;
   if (ov && fork_at == 2) fork_integral();
   brisk_prof_mark(prof, BRISK_STG_CLASSIFY, s);
   // Ordered path (the sequential algorithm on its literal cache): always for the multi-layer no-scale-NMS branch and for

@@ -257,7 +257,7 @@ def test_describe_work_queues_beyond_2048_frames(B):
 
 
 def test_random_sizes_thresholds_octaves_fuzz():
-    """tools/soak4.py in a process of its own (it forks its oracle workers before HIP is initialised): 250 random cases -
+    """tools/soak.py callspace in a process of its own (it forks its oracle workers before HIP is initialised): 250 random cases -
     image sides 9 ... 1100, thresholds 1 ... 140 (ordered and fast path), 0 ... 6 octaves, five content kinds incl. all-tie
     block images, host calls and small device batches - each bit-equal to the oracle (keypoints before and after
     compute(), descriptors).  Cases the default workspace answers with BRISK_HIP_ERR_CAPACITY are repeated on a larger one."""
@@ -265,23 +265,23 @@ def test_random_sizes_thresholds_octaves_fuzz():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak4.py"), "250", "11"], capture_output=True, text=True, timeout=900)
-    tail = [ln for ln in r.stdout.splitlines() if ln.startswith(("soak4", "ERROR", "MISMATCH"))]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "callspace", "250", "11"], capture_output=True, text=True, timeout=900)
+    tail = [ln for ln in r.stdout.splitlines() if ln.startswith(("callspace", "ERROR", "MISMATCH"))]
     print("\n".join(tail[-20:]), r.stderr[-2000:])
-    assert r.returncode == 0 and tail and tail[-1].startswith("soak4: 250 cases") and " 0 bad" in tail[-1]
+    assert r.returncode == 0 and tail and tail[-1].startswith("callspace: 250 cases") and " 0 bad" in tail[-1]
 
 
-@pytest.mark.parametrize("tool,cases", [("soak5", 200), ("soak6", 200)])
+@pytest.mark.parametrize("tool,cases", [("options", 200), ("matcher", 200)])
 def test_option_and_matcher_fuzz(tool, cases):
-    """tools/soak5.py (options of the two classes: masks, suppressScaleNonmaxima = false incl. the inputs without a defined
+    """tools/soak.py options (options of the two classes: masks, suppressScaleNonmaxima = false incl. the inputs without a defined
     result, uniformity / bucketing parameters, invariance flags, both pattern versions at three pattern scales) and
-    tools/soak6.py (the matcher: set sizes incl. empty ones, 1 ... 6 train images, descriptor lengths 16 ... 224, masks,
+    tools/soak.py matcher (the matcher: set sizes incl. empty ones, 1 ... 6 train images, descriptor lengths 16 ... 224, masks,
     k, radii), each in a process of its own, every case equal to the oracle"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool + ".py"), str(cases), "13"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), tool, str(cases), "13"], capture_output=True, text=True, timeout=900)
     tail = [ln for ln in r.stdout.splitlines() if ln.startswith((tool, "ERROR", "MISMATCH"))]
     print("\n".join(tail[-20:]), r.stderr[-2000:])
     assert r.returncode == 0 and tail and tail[-1].startswith("%s: %d cases" % (tool, cases)) and " 0 bad" in tail[-1]

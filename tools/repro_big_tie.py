@@ -3,8 +3,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
-import soak7
-from soak4 import make_image
+import large as soak7
+from callspace import make_image
 import ethzasl_brisk_amd as B
 c = [soak7.big_case(i, 44) for i in range(20)]
 c = [x for x in c if x[0] == 3645][0]

@@ -3,7 +3,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
-import soak6
+import matcher as soak6
 import oracle_lib as O
 import ethzasl_brisk_amd as B
 for i, seed in ((1479, 1), (1449, 1), (1497, 1)):

@@ -3,11 +3,11 @@
 classes), thresholds (1 ... 140: fast and ordered path), octave counts (0 ... 6), content kinds and call shapes (single
 host call; device batch of 1 ... 5 frames, tight / in-place eligible / padded / unaligned layouts; host-fed batch), each
 compared bit-exactly with the oracle.
-usage: python3 tools/soak4.py [cases] [seed]"""
+usage: python3 tools/soak.py callspace [cases] [seed]"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -142,7 +142,7 @@ def main():
                         print("MISMATCH", c, "frame", f, "detected %d vs %d" % (len(a[0]) // KP.itemsize, len(b[0]) // KP.itemsize),
                               "described %d vs %d" % (len(a[1]) // KP.itemsize, len(b[1]) // KP.itemsize),
                               "kp equal", a[0] == b[0], a[1] == b[1], "desc equal", a[2] == b[2], flush=True)
-        print("soak4: %d cases (seed %d), %d bad, %d of them repeated on a larger workspace after BRISK_HIP_ERR_CAPACITY" % (n, seed, bad, skipped))
+        print("callspace: %d cases (seed %d), %d bad, %d of them repeated on a larger workspace after BRISK_HIP_ERR_CAPACITY" % (n, seed, bad, skipped))
         sys.exit(1 if bad else 0)
 
 

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""One-off soak (GPU box) of the paths tools/soak.py does not reach: descriptor-only calls with random keypoints (all
+"""One-off soak (GPU box) of the paths tools/soak.py frames does not reach: descriptor-only calls with random keypoints (all
 sizes up to the largest scale, packed against all four borders, provided angles, both patterns, invariance flags) on
 padded and unpadded widths; dense / tie-heavy detection at thresholds 20..30; a 4K six-octave frame; the host-buffer
 calls against the batch path.  Everything bit-exact against the oracle."""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -81,5 +81,5 @@ k2g, dg = ext.compute(img, kg)
 ok = same(kg, ko) and same(k2g, k2o) and np.array_equal(dg, do)
 print("4K six octaves: %d / %d keypoints  %s" % (len(ko), len(k2o), "ok" if ok else "MISMATCH"))
 bad += not ok
-print("soak2: %d mismatching cases" % bad)
+print("describe: %d mismatching cases" % bad)
 sys.exit(1 if bad else 0)

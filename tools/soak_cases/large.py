@@ -2,16 +2,16 @@
 """One-off fuzz (GPU box): (a) the 16-bit image functions on random shapes and contents (incl. saturated values and the
 widths the reference CHECKs against: both sides must refuse those), (b) a few large frames (2000 ... 4600 px wide, up to
 6 octaves) through detect + describe, (c) ComputeScale on random keypoint lists - against the oracle.
-usage: python3 tools/soak7.py [cases] [seed]"""
+usage: python3 tools/soak.py large [cases] [seed]"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "soak_cases"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from soak4 import make_image
+from callspace import make_image
 
 
 def img16(i, seed):
@@ -148,7 +148,7 @@ def main():
             except Exception as e:  # noqa
                 bad += 1
                 print("ERROR ComputeScale", c[:7], repr(e)[:300], flush=True)
-        print("soak7: %d 16-bit images (%d calls refused on both sides), %d large frames, %d ComputeScale lists (%d without a defined result), %d bad"
+        print("large: %d 16-bit images (%d calls refused on both sides), %d large frames, %d ComputeScale lists (%d without a defined result), %d bad"
               % (n, refused, nbig, n, undefined, bad))
         sys.exit(1 if bad else 0)
 

@@ -4,11 +4,11 @@ included), 1 ... 6 train images, descriptor lengths 16 ... 224 bytes (also lengt
 reference ignores the bytes beyond the last full 128-bit word), low-entropy descriptors (plenty of equal distances),
 masks of several kinds, k from 1 to beyond the train set, radii from 0 to beyond every distance - knnMatch and
 radiusMatch rows compared with the oracle (brute-force-matcher.cc:80-213).
-usage: python3 tools/soak6.py [cases] [seed]"""
+usage: python3 tools/soak.py matcher [cases] [seed]"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -93,7 +93,7 @@ def main():
                 wa, wb = want
                 print("MISMATCH", c, "knn rows differ: %d" % sum(x != y for x, y in zip(a, wa)), "(%d vs %d rows)" % (len(a), len(wa)),
                       "radius rows differ: %d" % sum(x != y for x, y in zip(b, wb)), "(%d vs %d rows)" % (len(b), len(wb)), flush=True)
-        print("soak6: %d cases (seed %d), %d bad" % (n, seed, bad))
+        print("matcher: %d cases (seed %d), %d bad" % (n, seed, bad))
         sys.exit(1 if bad else 0)
 
 

@@ -3,16 +3,16 @@
 uniformity enforcement / KeyPointBucketing with random parameters, extractor flags (rotation / scale invariance), both
 pattern versions, pattern scales, and keypoints that come back through the host between detect() and compute() -
 every case bit-equal to the oracle (or both sides agree that the reference has no defined result).
-usage: python3 tools/soak5.py [cases] [seed]"""
+usage: python3 tools/soak.py options [cases] [seed]"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "soak_cases"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from soak4 import make_image
+from callspace import make_image
 
 PATTERN_SCALES = (1.0, 0.7, 1.3, 1.0)
 
@@ -125,7 +125,7 @@ def main():
                 print("MISMATCH", c, "detected %d vs %d" % (len(want[0]) // KP.itemsize, len(have[0]) // KP.itemsize),
                       "described %d vs %d" % (len(want[1]) // KP.itemsize, len(have[1]) // KP.itemsize),
                       "kp equal", want[0] == have[0], want[1] == have[1], "desc equal", want[2] == have[2], flush=True)
-        print("soak5: %d cases (seed %d), %d bad, %d without a defined result in the reference (both sides agree)" % (n, seed, bad, undefined))
+        print("options: %d cases (seed %d), %d bad, %d without a defined result in the reference (both sides agree)" % (n, seed, bad, undefined))
         sys.exit(1 if bad else 0)
 
 

@@ -4,7 +4,7 @@ ComputeScale on random images / keypoint lists, bit-exact against the oracle (wh
 defined result: both sides must agree on that too)."""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -69,5 +69,5 @@ for it in range(16):
     bad += not ok
     print("compute_scale thr %2d octaves %d suppress %d, %3d provided: %s %s"
           % (thr, octaves, suppress, n, "undefined" if ko is None else "%d keypoints" % len(ko), "ok" if ok else "MISMATCH"))
-print("soak3: %d cases (%d undefined in the reference), %d mismatches" % (n_cases, n_undefined, bad))
+print("ordered: %d cases (%d undefined in the reference), %d mismatches" % (n_cases, n_undefined, bad))
 sys.exit(1 if bad else 0)

@@ -10,13 +10,14 @@
 #include "brisk_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-#define DP_MAXSORT 4096
+#define DP_MAXSORT 2048   // (= DP_SMALL_N: the one-workgroup kernel never sees more)
 #ifndef DP_THREADS
 #define DP_THREADS 1024
 #endif
 // Frames with more input keypoints than this take the multi-workgroup path (k_dp_count / k_dp_scan / k_dp_scatter): the
 // one-workgroup kernel below ranks its keys by counting (n^2 / 1024 steps per thread) and walks its inputs 1024 at a time.
 #define DP_SMALL_N 2048
+#define DP_SB DP_THREADS  // buckets of the one-workgroup kernel's processing order (pieces of 64-row bands)
 // work area of the multi-workgroup path, ints per frame: [0] keypoints without an angle, [DP_W_HIST ..] bucket histogram /
 // cursors (DP_MAXBUCKETS + 1), [DP_W_BLK ..] kept keypoints per block of 1024 inputs (then their exclusive prefix)
 #define DP_MAXBUCKETS 4096
@@ -116,14 +117,63 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
   __syncthreads();
   // the keypoints again, in processing order, as one 16-byte record each: k_describe reads them with a single
   // (prefetchable) load instead of the dependent chain order -> keypoint -> scale
-  for (int j = tid; j < m; j += DP_THREADS) {
-    const unsigned kj = pkey[j];
-    int r = 0;
-    for (int q = 0; q < m; q += 4) {
-      const uint4 kk = *reinterpret_cast<const uint4*>(&pkey[q]);
-      r += (kk.x < kj ? 1 : 0) + (kk.y < kj ? 1 : 0) + (kk.z < kj ? 1 : 0) + (kk.w < kj ? 1 : 0);
+  if (((G.debug_flags >> 4) & 0xF) != 0) {  // the experimental orders (debug bits 4-7): rank by counting all smaller keys
+    for (int j = tid; j < m; j += DP_THREADS) {
+      const unsigned kj = pkey[j];
+      int r = 0;
+      for (int q = 0; q < m; q += 4) {
+        const uint4 kk = *reinterpret_cast<const uint4*>(&pkey[q]);
+        r += (kk.x < kj ? 1 : 0) + (kk.y < kj ? 1 : 0) + (kk.z < kj ? 1 : 0) + (kk.w < kj ? 1 : 0);
+      }
+      drec[(long)frame * kp_cap + r] = srec[j];
     }
-    drec[(long)frame * kp_cap + r] = srec[j];
+    return;
+  }
+  // Rank = keys of smaller buckets + smaller keys of the own bucket; a bucket is a piece of a 64-row band (the key's
+  // order: band, x), a few keypoints, chained in LDS.  Round 5: counting ALL smaller keys per key (n^2 / 4 LDS reads) was
+  // half of the kernel's 44 us for a 1080p frame's 1 200 keypoints - on the critical path of every one-frame compute()
+  // and of the window beside the integral kernel in a batch.
+  {
+    __shared__ int bhead[DP_SB], bstart[DP_SB];
+    __shared__ int bnext[DP_SMALL_N];
+    const int nbands = ((G.L[0].h - 1) >> 6) + 1;
+    int xs = 6;
+    while (nbands * (((G.L[0].w - 1) >> xs) + 1) > DP_SB) ++xs;
+    const int nbx = ((G.L[0].w - 1) >> xs) + 1;
+    auto bucket_of = [&](unsigned key) { return (int)(key >> 24) * nbx + (int)(((key >> 11) & 0x1FFFu) >> xs); };
+    for (int b = tid; b < DP_SB; b += DP_THREADS) { bhead[b] = -1; bstart[b] = 0; }
+    __syncthreads();
+    for (int j = tid; j < m; j += DP_THREADS) {
+      const int b = bucket_of(pkey[j]);
+      atomicAdd(&bstart[b], 1);
+      bnext[j] = atomicExch(&bhead[b], j);
+    }
+    __syncthreads();
+    {  // exclusive prefix over the buckets (one per thread)
+      static_assert(DP_SB == DP_THREADS, "one bucket per thread");
+      const int v = bstart[tid];
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      __syncthreads();  // (wtot: the compaction's last use is over)
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();
+      int woff = 0;
+#pragma unroll
+      for (int k = 0; k < DP_THREADS / 64; ++k) woff += (k < wave) ? wtot[k] : 0;
+      bstart[tid] = woff + incl - v;
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += DP_THREADS) {
+      const unsigned kj = pkey[j];
+      const int b = bucket_of(kj);
+      int r = bstart[b];
+      for (int q = bhead[b]; q >= 0; q = bnext[q]) r += (pkey[q] < kj) ? 1 : 0;
+      drec[(long)frame * kp_cap + r] = srec[j];
+    }
   }
 }
 

@@ -1141,20 +1141,21 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 #undef TR_KERNEL_MASKS
 
 // ------------------------------------------------------------------------------------------------
-// k_finalize: keypoints of a frame in (layer, y, x) order.  One workgroup per frame; ranks by
-// counting smaller keys among the valid candidates (a few thousand at most).
+// k_finalize: keypoints of a frame in (layer, y, x) order.  One workgroup per frame; a key's rank is found through
+// row buckets on chip (up to FN_SMALL keypoints; denser frames: k_finalize_large).
 // ------------------------------------------------------------------------------------------------
 #ifndef FN_THREADS
 #define FN_THREADS 512
 #endif
 #define FN_BUCKETS 2048
-#define FN_SMALL 3072   // up to this many keypoints: rank by counting smaller keys (keys on chip)
+#define FN_SMALL 3072   // up to this many keypoints the keys stay on chip (k_finalize); more: k_finalize_large
+#define FN_SB 1024      // row buckets of k_finalize's on-chip ordering (a multiple of FN_THREADS)
 __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const BriskCand* cand, BriskFrameCounters* counters,
                                                           unsigned* keys_scratch, BriskKeyPoint* kp_out, int cand_cap,
                                                           int kp_cap, const uint8_t* mask, long mask_pitch_frame,
                                                           int mask_row_pitch) {
   __shared__ int nvalid;
-  __shared__ __attribute__((aligned(16))) unsigned skey[FN_SMALL + 4];
+  __shared__ unsigned skey[FN_SMALL];
   __shared__ unsigned sidx[FN_SMALL];
   const int frame = blockIdx.x, tid = threadIdx.x;
   if (counters[frame].low_score) return;  // (the frame runs the ordered path, which writes its keypoints itself)
@@ -1198,35 +1199,64 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
     if (tid == 0) counters[frame].nvalid_large = nv;
     return;
   }
-  if (tid < 4) skey[nv + tid] = 0xFFFFFFFFu;  // the count below reads four keys at a time
-  __syncthreads();
-  // two keys per thread and pass over the key list (the list is read once for both; their candidate records are requested
-  // before the counting starts)
-  for (int j0 = tid; j0 < nv; j0 += 2 * FN_THREADS) {
-    const int j1 = j0 + FN_THREADS;
-    const bool has1 = j1 < nv;
-    const unsigned k0 = skey[j0], k1 = has1 ? skey[j1] : 0u;
-    const BriskCand& c0 = C[sidx[j0]];
-    const BriskCand& c1 = C[sidx[has1 ? j1 : j0]];
-    const float4 r0 = *reinterpret_cast<const float4*>(&c0.kx), r1 = *reinterpret_cast<const float4*>(&c1.kx);
-    const int l0 = c0.layer, l1 = c1.layer;
-    int rank0 = 0, rank1 = 0;
-    for (int q = 0; q < nv; q += 4) {
-      const uint4 kk = *reinterpret_cast<const uint4*>(&skey[q]);
-      rank0 += (kk.x < k0 ? 1 : 0) + (kk.y < k0 ? 1 : 0) + (kk.z < k0 ? 1 : 0) + (kk.w < k0 ? 1 : 0);
-      rank1 += (kk.x < k1 ? 1 : 0) + (kk.y < k1 ? 1 : 0) + (kk.z < k1 ? 1 : 0) + (kk.w < k1 ? 1 : 0);
+  // Rank of a key = keys of smaller buckets + smaller keys of its own bucket.  A bucket is FN_ROWS_PER_BUCKET consecutive
+  // rows of the pyramid (layers stacked: the key is (layer, y, x)) - a handful of keypoints -, its members hang on a linked
+  // list in LDS.  Round 5: the kernel used to count ALL smaller keys per key, n^2 / 4 LDS reads - 25 of its 40 us for the
+  // 1 200 keypoints of a 1080p frame, on the critical path of every one-frame call and of the window beside the integral
+  // kernel in a batch.
+  {
+    __shared__ int rbase[BRISK_MAX_LAYERS + 1];
+    __shared__ int bhead[FN_SB];       // last member of the bucket (-1: empty)
+    __shared__ int bstart[FN_SB];      // keys in smaller buckets
+    __shared__ int bnext[FN_SMALL];    // next member of the same bucket
+    __shared__ int wsum[FN_THREADS / 64];
+    if (tid == 0) {
+      int acc = 0;
+      for (int l = 0; l < G.nlayers; ++l) { rbase[l] = acc; acc += G.L[l].h; }
+      rbase[G.nlayers] = acc;
     }
-    if (rank0 < kp_cap) {
-      BriskKeyPoint kp;
-      kp.x = r0.x; kp.y = r0.y; kp.size = r0.z; kp.angle = -1.0f; kp.response = r0.w;
-      kp.octave = G.single_layer ? 0 : l0; kp.class_id = -1;
-      kp_out[(long)frame * kp_cap + rank0] = kp;
+    for (int b = tid; b < FN_SB; b += FN_THREADS) { bhead[b] = -1; bstart[b] = 0; }
+    __syncthreads();
+    int shift = 0;
+    while ((rbase[G.nlayers] >> shift) >= FN_SB) ++shift;
+    auto bucket_of = [&](unsigned key) { return (rbase[key >> 26] + (int)((key >> 13) & 0x1FFF)) >> shift; };
+    for (int j = tid; j < nv; j += FN_THREADS) {
+      const int b = bucket_of(skey[j]);
+      atomicAdd(&bstart[b], 1);
+      bnext[j] = atomicExch(&bhead[b], j);
     }
-    if (has1 && rank1 < kp_cap) {
-      BriskKeyPoint kp;
-      kp.x = r1.x; kp.y = r1.y; kp.size = r1.z; kp.angle = -1.0f; kp.response = r1.w;
-      kp.octave = G.single_layer ? 0 : l1; kp.class_id = -1;
-      kp_out[(long)frame * kp_cap + rank1] = kp;
+    __syncthreads();
+    {  // exclusive prefix over the buckets: FN_SB / FN_THREADS consecutive buckets per thread
+      constexpr int PER = FN_SB / FN_THREADS;
+      int loc[PER], sum = 0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) { loc[q] = bstart[tid * PER + q]; sum += loc[q]; }
+      const int incl = wave_inclusive_scan(sum);
+      const int lane = tid & 63, wave = tid >> 6;
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int woff = 0;
+#pragma unroll
+      for (int q = 0; q < FN_THREADS / 64; ++q) woff += (q < wave) ? wsum[q] : 0;
+      int run = woff + incl - sum;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) { bstart[tid * PER + q] = run; run += loc[q]; }
+    }
+    __syncthreads();
+    for (int j = tid; j < nv; j += FN_THREADS) {
+      const unsigned k = skey[j];
+      const BriskCand& c = C[sidx[j]];
+      const float4 r = *reinterpret_cast<const float4*>(&c.kx);  // (requested before the list walk)
+      const int lyr = c.layer;
+      const int b = bucket_of(k);
+      int rank = bstart[b];
+      for (int q = bhead[b]; q >= 0; q = bnext[q]) rank += (skey[q] < k) ? 1 : 0;
+      if (rank < kp_cap) {
+        BriskKeyPoint kp;
+        kp.x = r.x; kp.y = r.y; kp.size = r.z; kp.angle = -1.0f; kp.response = r.w;
+        kp.octave = G.single_layer ? 0 : lyr; kp.class_id = -1;
+        kp_out[(long)frame * kp_cap + rank] = kp;
+      }
     }
   }
   if (tid == 0) {

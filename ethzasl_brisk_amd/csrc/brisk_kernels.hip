@@ -1411,21 +1411,28 @@ __device__ __forceinline__ void ii_store4(bool b24, uint32_t* out, long row, int
     *reinterpret_cast<uint4*>(out + row * istride + c0) = make_uint4(a0, a1, a2, a3);
   }
 }
-template <int NCH, bool B24>
+// SUB (calls of a few frames): a band is cut into `nsub` pieces of `sub_h` rows, one workgroup each - a band is a chain of
+// band_h / II_ROWS barrier steps, and a single 1080p frame has 12 or 17 of them for 256 CUs: 40 us of a one-frame call.
+// A piece's carry row = the bands above + the column sums of its band's rows above it, which it adds up itself.
+template <int NCH, bool B24, bool SUB>
 __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, const uint8_t* __restrict__ pyr,
                                                                const uint32_t* __restrict__ bandsum,
                                                                uint32_t* __restrict__ integral, int istride, long iframe_elems,
-                                                               int nbands, int band_h, BriskFrameCounters* counters) {
+                                                               int nbands, int band_h, BriskFrameCounters* counters, int nsub, int sub_h) {
   __shared__ unsigned wave_tot[2][II_THREADS / 64];
-  const int frame = blockIdx.y, band = blockIdx.x;
+  const int frame = blockIdx.y, band = SUB ? (int)blockIdx.x / nsub : (int)blockIdx.x;
+  const int sub = SUB ? (int)blockIdx.x - band * nsub : 0;
   // B24: 3-byte elements, for every frame of the call (k_describe is instantiated for one form per launch); the flag in
   // the counters is what the debug download reads
   constexpr bool b24 = B24;
-  if (counters && band == 0 && threadIdx.x == 0) counters[frame].i24 = b24 ? 1 : 0;
+  if (counters && blockIdx.x == 0 && threadIdx.x == 0) counters[frame].i24 = b24 ? 1 : 0;
   const int w = G.L[0].w, h = G.L[0].h, stride = G.L[0].stride;
   const uint8_t* img = brisk_layer_img(G, pyr, frame, 0);
   uint32_t* out = integral + (long)frame * iframe_elems;
-  const int y0 = band * band_h, y1 = min(h, y0 + band_h);
+  const int yb = band * band_h;                                       // first row of the band
+  const int y0 = SUB ? yb + sub * sub_h : yb;                          // rows of this workgroup
+  const int y1 = SUB ? min(min(h, yb + band_h), y0 + sub_h) : min(h, y0 + band_h);
+  if (SUB && y0 >= y1) return;
   int buf = 0;
   unsigned acc[NCH][4];  // running integral values of this thread's columns (row above the current one)
   // first pixel row of the band: in flight while the carry row is computed
@@ -1444,6 +1451,19 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
           const uint4 v = *reinterpret_cast<const uint4*>(bandsum + ((long)frame * nbands + b) * istride + c0);
           C.x += v.x; C.y += v.y; C.z += v.z; C.w += v.w;
         }
+      if (SUB && c0 <= w) {  // the band's rows above this piece (independent loads, six rows in flight)
+        for (int r0 = yb; r0 < y0; r0 += 6) {
+          uint2 rr[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) rr[k] = ii_fetch(img + (long)min(r0 + k, y0 - 1) * stride, stride, c0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            unsigned px[4];
+            ii_unpack(rr[k], stride, w, c0, px);
+            if (r0 + k < y0) { C.x += px[0]; C.y += px[1]; C.z += px[2]; C.w += px[3]; }
+          }
+        }
+      }
       if (c0 + 1 > w) C.y = 0;  // integral columns beyond w are padding (their band sums are not written)
       if (c0 + 2 > w) C.z = 0;
       if (c0 + 3 > w) C.w = 0;
@@ -1453,7 +1473,7 @@ __global__ void __launch_bounds__(II_THREADS) k_integral_final(BriskGeom G, cons
       buf ^= 1;
       carry += tot;
       acc[ch][0] = o + s0; acc[ch][1] = o + s1; acc[ch][2] = o + s2; acc[ch][3] = o + s3;
-      if (band == 0 && c0 <= w) ii_store4(b24, out, 0, istride, c0, 0, 0, 0, 0);  // integral row 0
+      if (band == 0 && sub == 0 && c0 <= w) ii_store4(b24, out, 0, istride, c0, 0, 0, 0, 0);  // integral row 0
     }
   }
   // II_ROWS rows per step: their row scans share ONE workgroup barrier (the loop is a chain of barriers); the pixels of
@@ -1517,18 +1537,26 @@ void brisk_launch_integral(const BriskGeom& G, const uint8_t* pyr, const uint32_
                             long iframe_elems, int band_h, int nframes, hipStream_t s, int ibits, BriskFrameCounters* counters) {
   const int nbands = (G.L[0].h + band_h - 1) / band_h;
   const int nchunks = (G.L[0].w + 1 + II_CHUNK - 1) / II_CHUNK;
-  const dim3 grid(nbands, nframes), block(II_THREADS);
+  // calls of up to 4 frames: bands in pieces of 5 or 6 barrier steps (a single frame's 12 / 17 bands leave the chip idle and
+  // are chains of 32 / 22 steps)
+  static const int sub_knob = env_knob("BRISK_II_SUB", -1);
+  const int sub_h = ((sub_knob > 0 ? sub_knob : (band_h >= 96 ? 18 : 15)) + II_ROWS - 1) / II_ROWS * II_ROWS;
+  const bool sub = sub_knob != 0 && nframes <= 4 && sub_h < band_h;
+  const int nsub = sub ? (band_h + sub_h - 1) / sub_h : 1;
+  const dim3 grid(nbands * nsub, nframes), block(II_THREADS);
   static const int pad_lds = env_knob("BRISK_II_LDS", 0);  // tuning experiments: dynamic LDS bytes = fewer workgroups per CU
   const bool b24 = ibits == 24 && counters;  // (the per-frame flag lives in the counters)
+#define II_LAUNCH1(NCH, LDS, B24_, SUB_)                                                                                                   \
+  hipLaunchKernelGGL((k_integral_final<NCH, B24_, SUB_>), grid, block, LDS, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands,   \
+                     band_h, counters, nsub, sub_h);
 #define II_LAUNCH(NCH, LDS)                                                                                                                  \
-  if (b24) hipLaunchKernelGGL((k_integral_final<NCH, true>), grid, block, LDS, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands, \
-                              band_h, counters);                                                                                            \
-  else hipLaunchKernelGGL((k_integral_final<NCH, false>), grid, block, LDS, s, G, pyr, bandsum, integral, istride, iframe_elems, nbands,    \
-                          band_h, counters);
+  if (b24) { if (sub) { II_LAUNCH1(NCH, LDS, true, true) } else { II_LAUNCH1(NCH, LDS, true, false) } }                                      \
+  else { if (sub) { II_LAUNCH1(NCH, LDS, false, true) } else { II_LAUNCH1(NCH, LDS, false, false) } }
   if (nchunks <= 1) { II_LAUNCH(1, pad_lds) }
   else if (nchunks == 2) { II_LAUNCH(2, 0) }
   else { II_LAUNCH(II_MAXCHUNKS, 0) }
 #undef II_LAUNCH
+#undef II_LAUNCH1
 }
 
 // AGAST candidates of a batch, summed into host-visible (pinned, mapped) memory: what the NEXT batch of the context goes

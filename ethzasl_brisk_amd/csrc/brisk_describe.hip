@@ -617,13 +617,13 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
       const int j = j0 + lane;
       const int nkp = j < m ? counters[g + (m - 1 - j) * ngroups].ndesc : 0;
       // keypoints per ticket of this frame (RUN is the kernel's maximum): sparse frames small runs - the stretch of
-      // keypoints an XCD has in flight must stay local (2 at BASELINE config 2's ~480 keypoints per megapixel) -, dense
+      // keypoints an XCD has in flight must stay local (3 at BASELINE config 2's ~480 keypoints per megapixel) -, dense
       // frames larger ones (fuller sampling rounds, fewer tickets: 30 k keypoints per frame 6.6 -> 5.8 ms per 64 frames),
       // and never fewer tickets than there are waves to take them (one frame per call: 1 keypoint per ticket)
       int runf = run_fixed;
       if (runf == 0) {
         const long density = (long)nkp * (1 << 20) / ((long)cols * G.L[0].h);  // keypoints per megapixel
-        runf = density < 1500 ? 2 : density < 6000 ? 4 : 8;
+        runf = density < 1500 ? 3 : density < 6000 ? 4 : 8;  // (3, not 2, since round 5: 198 of 256 sampling lanes instead of 132 of 192, 2.60 -> 2.56 ms per 512 frames)
         const int waves_serving = (int)(gridDim.x * DS_WAVES) / ngroups;
         runf = min(runf, max(1, nkp / max(waves_serving, 1)));
       }

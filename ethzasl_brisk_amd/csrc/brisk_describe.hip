@@ -70,8 +70,9 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
   // record: three dependent round trips beside the integral kernel, which keeps the memory system busy)
   __shared__ uint4 srec[DP_SMALL_N];
   __shared__ int sborder[BRISK_SCALES];
+  __shared__ float sthr[BRISK_SCALES];  // the 64 size thresholds of the scale index: one load instead of a chain of them per keypoint
   if (tid == 0) { base = 0; nest = 0; }
-  if (tid < BRISK_SCALES) sborder[tid] = P.size_list[tid];
+  if (tid < BRISK_SCALES) { sborder[tid] = P.size_list[tid]; sthr[tid] = P.size_thresh[tid]; }
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += DP_THREADS) {
     const int i = i0 + tid;
@@ -80,7 +81,11 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
     BriskKeyPoint kp;
     if (i < n) {
       kp = K[i];
-      sc = brisk_scale_index(P, kp.size);
+      if (!P.scale_invariant) sc = P.basicscale;  // (brisk_scale_index, on the thresholds in LDS)
+      else {
+#pragma unroll 8
+        for (int q = 1; q < BRISK_SCALES; ++q) sc += (kp.size >= sthr[q]) ? 1 : 0;
+      }
       const int border = sborder[sc];  // == brisk_inside_border(P, sc, ...)
       keep = !((kp.x < (float)border) || (kp.x >= (float)(G.L[0].w - border)) || (kp.y < (float)border) || (kp.y >= (float)(G.L[0].h - border)));
     }

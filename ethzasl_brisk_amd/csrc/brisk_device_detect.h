@@ -1372,13 +1372,69 @@ BRISK_HD bool brisk_provided_on_layer(const BriskGeom& G, int l, const BriskKeyP
   return !(*kx < 3 || *ky < 3 || *kx > G.L[l].w - 3 || *ky > G.L[l].h - 3);
 }
 
+// ---- the items of the ComputeScale walk (below).  The walk is sequential in the reference, but its three phases are
+// order-free among themselves (round 5; k_cs_* in brisk_kernels.hip run one lane per (layer, provided point)):
+//   touch    GetAgastScore(float, float, 0) of every admitted point (brisk-scale-space.cc:118-121): all accesses of the phase
+//            use threshold 0, so what a pixel holds afterwards does not depend on their order;
+//   score    GetAgastPoints on the provided list (brisk-layer.cc:106-116): a function of the image alone, written after the
+//            layer's touches;
+//   refine   everything GetKeypoints does per point (:172-287): threshold-1 accesses only, whose result is the cached value
+//            where that is > 2 and K' otherwise - history-free once the first two phases of ALL layers are complete, and the
+//            values they store are the ones any other access would store.
+BRISK_HD void brisk_cs_touch(const BriskGeom& G, uint8_t* pyr_frame, uint16_t* smap_frame, int l, float kx, float ky) {
+  const BriskLayerView L = brisk_view_of(G, pyr_frame, smap_frame, l);
+  // GetAgastScore(float, float, 0): the four integer accesses with threshold 0 (the blend itself is discarded)
+  const int x = (int)kx, y = (int)ky;
+  brisk_S_literal(L, x, y, 0); brisk_S_literal(L, x + 1, y, 0); brisk_S_literal(L, x, y + 1, 0); brisk_S_literal(L, x + 1, y + 1, 0);
+}
+// returns true where the reference reads beyond the image (undefined there)
+BRISK_HD bool brisk_cs_score(const BriskGeom& G, uint8_t* pyr_frame, uint16_t* smap_frame, int l, float kx, float ky) {
+  const BriskLayerView L = brisk_view_of(G, pyr_frame, smap_frame, l);
+  const long total = (long)L.w * L.h;
+  const int offs = (int)(kx + ky * (float)L.w);
+  if ((long)offs - 3 * L.w - 1 < 0 || (long)offs + 3 * L.w + 1 >= total) return true;  // the ring leaves the image
+  const int ox = offs % L.w, oy = offs / L.w;
+  const int thr = brisk_thrmap_at(L, ox, oy);
+  const int M = brisk_M_linear(L, offs);
+  L.smap[(long)oy * L.stride + ox] = (uint16_t)(uint8_t)brisk_max(thr, brisk_min(M - 1, 254));
+  return false;
+}
+// :172-209 (one layer) and :211-287: false = the point is rejected on this layer
+BRISK_HD bool brisk_cs_refine(const BriskGeom& G, uint8_t* pyr_frame, uint16_t* smap_frame, int i, const BriskKeyPoint& src, float kx,
+                              float ky, BriskKeyPoint* out) {
+  const bool has_above = !G.single_layer && (i + 1 < G.nlayers);
+  const bool has_below = !G.single_layer && (i > 0);
+  const BriskLayerView Lo = brisk_view_of(G, pyr_frame, smap_frame, i);
+  const BriskLayerView La = brisk_view_of(G, pyr_frame, smap_frame, has_above ? i + 1 : i);
+  const BriskLayerView Lb = brisk_view_of(G, pyr_frame, smap_frame, has_below ? i - 1 : i);
+  float fxy[2] = {kx, ky};
+  BriskTouch touch;
+  touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
+  bool e5 = false;
+  BriskKeyPoint kp = src;
+  if (!brisk_refine<2>(G, Lb, Lo, La, i, (int)fxy[0], (int)fxy[1], &kp, &e5, &touch, fxy)) return false;
+  kp.class_id = src.class_id;  // `agast::KeyPoint kp = keypoint;` keeps the provided class_id (:199, 244, 275)
+  *out = kp;
+  return true;
+}
+// :131-170 (suppressScaleNonmaxima == false, several layers): layer i at the coordinates of LAYER 0's entry (src0, px, py)
+BRISK_HD void brisk_cs_flat(const BriskGeom& G, uint8_t* pyr_frame, uint16_t* smap_frame, int i, const BriskKeyPoint& src0, float px,
+                            float py, BriskKeyPoint* out) {
+  const BriskLayerView Li = brisk_view_of(G, pyr_frame, smap_frame, i);
+  BriskKeyPoint kp = src0;
+  float dx, dy;
+  const float mx = brisk_patch_subpixel_f<2>(Li, px, py, dx, dy);
+  kp.x = px + dx; kp.y = py + dy;
+  kp.size = BRISK_BASIC_SIZE * G.L[i].scale;
+  kp.angle = -1.0f; kp.response = mx; kp.octave = 0;
+  *out = kp;
+}
+
 BRISK_HD bool brisk_compute_scale_walk(const BriskGeom& G, uint8_t* pyr_frame, uint16_t* smap_frame, const BriskKeyPoint* in,
                                        int n_in, bool suppress, uint32_t* det, int det_cap, BriskOrderedOut* out,
                                        bool* cap_exceeded) {
   BriskScaleList lists[BRISK_MAX_LAYERS];
   int det_n = 0;
-  BriskTouch none;
-  none.on = false; none.mask = 0; none.x0 = 0; none.y0 = 0;
   *cap_exceeded = false;
   for (int i = 0; i < G.nlayers; ++i) {  // :99-126
     const BriskLayerView L = brisk_view_of(G, pyr_frame, smap_frame, i);
@@ -1386,9 +1442,7 @@ BRISK_HD bool brisk_compute_scale_walk(const BriskGeom& G, uint8_t* pyr_frame, u
     for (int k = 0; k < n_in; ++k) {
       float kx, ky;
       if (!brisk_provided_on_layer(G, i, in[k], &kx, &ky)) continue;
-      // GetAgastScore(float, float, 0): the four integer accesses with threshold 0 (the blend itself is discarded)
-      const int x = (int)kx, y = (int)ky;
-      brisk_S_literal(L, x, y, 0); brisk_S_literal(L, x + 1, y, 0); brisk_S_literal(L, x, y + 1, 0); brisk_S_literal(L, x + 1, y + 1, 0);
+      brisk_cs_touch(G, pyr_frame, smap_frame, i, kx, ky);
       lists[i].count++;
     }
     if (lists[i].count == 0) {  // GetAgastPoints on an empty list: detect (lower threshold G.lower_threshold = 0), raster order
@@ -1406,16 +1460,10 @@ BRISK_HD bool brisk_compute_scale_walk(const BriskGeom& G, uint8_t* pyr_frame, u
         L.smap[(long)y * L.stride + x] = (uint16_t)brisk_thrmap_at(L, x, y);
       }
     } else {  // brisk-layer.cc:106-116 with the float coordinates
-      const long total = (long)L.w * L.h;
       for (int k = 0; k < n_in; ++k) {
         float kx, ky;
         if (!brisk_provided_on_layer(G, i, in[k], &kx, &ky)) continue;
-        const int offs = (int)(kx + ky * (float)L.w);
-        if ((long)offs - 3 * L.w - 1 < 0 || (long)offs + 3 * L.w + 1 >= total) return true;  // the ring leaves the image
-        const int ox = offs % L.w, oy = offs / L.w;
-        const int thr = brisk_thrmap_at(L, ox, oy);
-        const int M = brisk_M_linear(L, offs);
-        L.smap[(long)oy * L.stride + ox] = (uint16_t)(uint8_t)brisk_max(thr, brisk_min(M - 1, 254));
+        if (brisk_cs_score(G, pyr_frame, smap_frame, i, kx, ky)) return true;  // the ring leaves the image
       }
     }
   }
@@ -1433,40 +1481,25 @@ BRISK_HD bool brisk_compute_scale_walk(const BriskGeom& G, uint8_t* pyr_frame, u
   };
   if (!suppress && !G.single_layer) {  // :131-170, perform_2d_nonMax == false
     for (int i = 0; i < G.nlayers; ++i) {
-      const BriskLayerView Li = brisk_view_of(G, pyr_frame, smap_frame, i);
       if (lists[i].count > lists[0].count) return true;  // agastPoints.at(0)[n] throws std::out_of_range
       int cur0 = 0;
       for (int k = 0; k < lists[i].count; ++k) {
         float px, py;
-        BriskKeyPoint kp;
-        entry(0, k, &cur0, &px, &py, &kp);
-        float dx, dy;
-        const float mx = brisk_patch_subpixel_f<2>(Li, px, py, dx, dy);
-        kp.x = px + dx; kp.y = py + dy;
-        kp.size = BRISK_BASIC_SIZE * G.L[i].scale;
-        kp.angle = -1.0f; kp.response = mx; kp.octave = 0;
+        BriskKeyPoint src0, kp;
+        entry(0, k, &cur0, &px, &py, &src0);
+        brisk_cs_flat(G, pyr_frame, smap_frame, i, src0, px, py, &kp);
         brisk_ordered_emit(out, kp);
       }
     }
     return false;
   }
   for (int i = 0; i < G.nlayers; ++i) {  // :172-209 (one layer) and :211-287
-    const bool has_above = !G.single_layer && (i + 1 < G.nlayers);
-    const bool has_below = !G.single_layer && (i > 0);
-    const BriskLayerView Lo = brisk_view_of(G, pyr_frame, smap_frame, i);
-    const BriskLayerView La = brisk_view_of(G, pyr_frame, smap_frame, has_above ? i + 1 : i);
-    const BriskLayerView Lb = brisk_view_of(G, pyr_frame, smap_frame, has_below ? i - 1 : i);
     int cur = 0;
     for (int k = 0; k < lists[i].count; ++k) {
-      float fxy[2];
+      float kx, ky;
       BriskKeyPoint src, kp;
-      entry(i, k, &cur, &fxy[0], &fxy[1], &src);
-      BriskTouch touch;
-      touch.on = false; touch.mask = 0; touch.x0 = 0; touch.y0 = 0;
-      bool e5 = false;
-      kp = src;
-      if (!brisk_refine<2>(G, Lb, Lo, La, i, (int)fxy[0], (int)fxy[1], &kp, &e5, &touch, fxy)) continue;
-      kp.class_id = src.class_id;  // `agast::KeyPoint kp = keypoint;` keeps the provided class_id (:199, 244, 275)
+      entry(i, k, &cur, &kx, &ky, &src);
+      if (!brisk_cs_refine(G, pyr_frame, smap_frame, i, src, kx, ky, &kp)) continue;
       brisk_ordered_emit(out, kp);
     }
   }

@@ -1054,11 +1054,137 @@ __global__ void __launch_bounds__(64) k_ordered_keypoints(BriskGeom G, uint8_t* 
   if (out.n > kp_cap) atomicOr(&counters[frame].overflow, 4);
 }
 
-// ComputeScale (brisk-feature-detector.cc:87-92): provided keypoints, one lane (brisk_compute_scale_walk); one frame.
+// ComputeScale (brisk-feature-detector.cc:87-92): provided keypoints, one frame.
+// k_compute_scale is the reference's walk on one lane (brisk_compute_scale_walk: ~19 us per point and layer - 3 000 points
+// on a 1080p frame took 0.45 s).  Round 5: the walk's phases are order-free among themselves (brisk_cs_* in
+// brisk_device_detect.h), so they run one lane per (layer, provided point):
+//   k_cs_admit   a workgroup per layer: which points the layer admits (stable compaction -> adm[layer][j]), their four
+//                threshold-0 touches
+//   k_cs_scores  GetAgastPoints on the provided lists (the score at the reference's linear offset; flags the inputs on which
+//                the reference reads beyond the image)
+//   k_cs_refine  the per-point refinement of GetKeypoints -> tmp[layer][j] = keypoint, valid
+//   k_cs_emit    the valid ones in (layer, provided) order
+// A layer that admits no provided point DETECTS instead (brisk-layer.cc:99-105) and its raster-ordered list feeds the same
+// loop: that case - and a point count beyond the scratch buffers - stays on the one-lane walk (k_compute_scale runs when
+// counters[0].pad[0] is set; the touches k_cs_admit already made are the ones the walk makes first, and are idempotent).
+#define CS_THREADS 256
+__global__ void __launch_bounds__(CS_THREADS) k_cs_admit(BriskGeom G, uint8_t* pyr, uint16_t* smap, const BriskKeyPoint* in, int n_in,
+                                                          BriskFrameCounters* counters, int* adm) {
+  __shared__ int wtot[CS_THREADS / 64];
+  __shared__ int base;
+  const int l = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < n_in; k0 += CS_THREADS) {
+    const int k = k0 + tid;
+    float kx = 0.f, ky = 0.f;
+    const bool ok = k < n_in && brisk_provided_on_layer(G, l, in[k], &kx, &ky);
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < CS_THREADS / 64; ++q) { wbase += (q < wave) ? wtot[q] : 0; total += wtot[q]; }
+    if (ok) {
+      adm[(long)l * n_in + base + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+      brisk_cs_touch(G, pyr, smap, l, kx, ky);
+    }
+    __syncthreads();
+    if (tid == 0) base += total;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    counters[0].ntie[l] = base;  // (the tie lists are not used by this call: admitted points of layer l)
+    counters[0].full_clear = 1;   // the cache is written wherever a score was asked for: the next batch clears the whole map
+    if (base == 0) atomicOr(&counters[0].pad[0], 1);  // the layer detects instead: the one-lane walk takes the call
+  }
+}
+
+__global__ void __launch_bounds__(CS_THREADS) k_cs_scores(BriskGeom G, uint8_t* pyr, uint16_t* smap, const BriskKeyPoint* in, int n_in,
+                                                           BriskFrameCounters* counters, const int* adm) {
+  if (counters[0].pad[0]) return;
+  const int l = blockIdx.y, j = blockIdx.x * CS_THREADS + threadIdx.x;
+  if (j >= counters[0].ntie[l]) return;
+  float kx, ky;
+  (void)brisk_provided_on_layer(G, l, in[adm[(long)l * n_in + j]], &kx, &ky);
+  if (brisk_cs_score(G, pyr, smap, l, kx, ky)) atomicOr(&counters[0].overflow, 16);
+}
+
+__global__ void __launch_bounds__(64) k_cs_refine(BriskGeom G, uint8_t* pyr, uint16_t* smap, const BriskKeyPoint* in, int n_in, int suppress,
+                                                   BriskFrameCounters* counters, const int* adm, unsigned* tmp) {
+  if (counters[0].pad[0] || (counters[0].overflow & 16)) return;
+  const int l = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+  const int cnt = counters[0].ntie[l];
+  const bool flat = !suppress && !G.single_layer;  // :131-170: layer l at the coordinates of layer 0's j-th entry
+  if (flat && cnt > counters[0].ntie[0]) {          // agastPoints.at(0)[n] throws std::out_of_range
+    if (j == 0) atomicOr(&counters[0].overflow, 16);
+    return;
+  }
+  if (j >= cnt) return;
+  BriskKeyPoint kp;
+  bool valid = true;
+  float kx, ky;
+  if (flat) {
+    const BriskKeyPoint src0 = in[adm[j]];
+    (void)brisk_provided_on_layer(G, 0, src0, &kx, &ky);
+    brisk_cs_flat(G, pyr, smap, l, src0, kx, ky, &kp);
+  } else {
+    const BriskKeyPoint src = in[adm[(long)l * n_in + j]];
+    (void)brisk_provided_on_layer(G, l, src, &kx, &ky);
+    valid = brisk_cs_refine(G, pyr, smap, l, src, kx, ky, &kp);
+  }
+  unsigned* t = tmp + ((long)l * n_in + j) * 8;
+  t[7] = valid ? 1u : 0u;
+  if (valid) {
+    t[0] = __float_as_uint(kp.x); t[1] = __float_as_uint(kp.y); t[2] = __float_as_uint(kp.size); t[3] = __float_as_uint(kp.angle);
+    t[4] = __float_as_uint(kp.response); t[5] = (unsigned)kp.octave; t[6] = (unsigned)kp.class_id;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_cs_emit(BriskGeom G, BriskFrameCounters* counters, const unsigned* tmp, int n_in,
+                                                   BriskKeyPoint* kp_out, int kp_cap) {
+  if (counters[0].pad[0] || (counters[0].overflow & 16)) return;
+  __shared__ int wtot[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int l = 0; l < G.nlayers; ++l) {
+    const int cnt = counters[0].ntie[l];
+    for (int j0 = 0; j0 < cnt; j0 += 1024) {
+      const int j = j0 + tid;
+      const unsigned* t = tmp + ((long)l * n_in + j) * 8;
+      const bool ok = j < cnt && t[7] != 0;
+      const unsigned long long bal = __ballot(ok);
+      if (lane == 0) wtot[wave] = __popcll(bal);
+      __syncthreads();
+      int wbase = 0, total = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { wbase += (q < wave) ? wtot[q] : 0; total += wtot[q]; }
+      const int pos = base + wbase + __popcll(bal & ((1ull << lane) - 1ull));
+      if (ok && pos < kp_cap) {
+        BriskKeyPoint kp;
+        kp.x = __uint_as_float(t[0]); kp.y = __uint_as_float(t[1]); kp.size = __uint_as_float(t[2]); kp.angle = __uint_as_float(t[3]);
+        kp.response = __uint_as_float(t[4]); kp.octave = (int)t[5]; kp.class_id = (int)t[6];
+        kp_out[pos] = kp;
+      }
+      __syncthreads();
+      if (tid == 0) base += total;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    counters[0].nkp = min(base, kp_cap);
+    if (base > kp_cap) atomicOr(&counters[0].overflow, 4);
+  }
+}
+
+// the one-lane walk: everything when `always`, else only the calls k_cs_admit handed over (a layer without admitted points)
 __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr, uint16_t* smap, const BriskKeyPoint* in, int n_in,
                                                        int suppress, BriskFrameCounters* counters, unsigned* det_scratch,
-                                                       int det_cap, BriskKeyPoint* kp_out, int kp_cap) {
+                                                       int det_cap, BriskKeyPoint* kp_out, int kp_cap, int always) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!always && !counters[0].pad[0]) return;
   counters[0].full_clear = 1;
   BriskOrderedOut out;
   out.kp = kp_out; out.cap = kp_cap; out.n = 0; out.mask = nullptr; out.mask_row_pitch = 0;
@@ -1835,8 +1961,24 @@ void brisk_launch_compute_scale(const BriskGeom& G, const BriskDetectBuffers& B,
                                 const BriskKeyPoint* d_in, int n_in, int suppress, hipStream_t s) {
   (void)hipMemsetAsync(B.counters, 0, sizeof(BriskFrameCounters), s);
   launch_pyramid(G, B, 1, frame, 0, row_pitch, s);
+  // one lane per (layer, point) where the scratch buffers hold the lists - adm: nlayers x n_in ints in B.keys (2 x cand_cap
+  // words), tmp: 32 bytes per entry in B.blocks (64 x cand_cap bytes) -, the one-lane walk otherwise and for the calls in
+  // which a layer admits no point (decided on the device: counters[0].pad[0])
+  static const int seq_knob = env_knob("BRISK_CS_SEQUENTIAL", 0);  // tests / A-B runs: 1 = always the one-lane walk
+  const bool parallel = !seq_knob && (long)G.nlayers * n_in <= 2L * B.cand_cap;
+  if (parallel) {
+    int* adm = reinterpret_cast<int*>(B.keys);
+    unsigned* tmp = reinterpret_cast<unsigned*>(B.blocks);
+    hipLaunchKernelGGL(k_cs_admit, dim3(G.nlayers), dim3(CS_THREADS), 0, s, G, B.pyr, B.smap, d_in, n_in, B.counters, adm);
+    hipLaunchKernelGGL(k_cs_scores, dim3((n_in + CS_THREADS - 1) / CS_THREADS, G.nlayers), dim3(CS_THREADS), 0, s, G, B.pyr, B.smap, d_in,
+                       n_in, B.counters, adm);
+    hipLaunchKernelGGL(k_cs_refine, dim3((n_in + 63) / 64, G.nlayers), dim3(64), 0, s, G, B.pyr, B.smap, d_in, n_in, suppress, B.counters,
+                       adm, tmp);
+    hipLaunchKernelGGL(k_cs_emit, dim3(1), dim3(1024), 0, s, G, B.counters, tmp, n_in, B.kp_out, B.kp_cap);
+  }
+  // (the walk's detection scratch is B.keys as well: it only runs where the lists above are not used any more)
   hipLaunchKernelGGL(k_compute_scale, dim3(1), dim3(64), 0, s, G, B.pyr, B.smap, d_in, n_in, suppress, B.counters, B.keys,
-                     2 * B.cand_cap, B.kp_out, B.kp_cap);
+                     2 * B.cand_cap, B.kp_out, B.kp_cap, parallel ? 0 : 1);
 }
 
 void brisk_launch_layer0_only(const BriskGeom& G, const BriskDetectBuffers& B, int nframes, const uint8_t* frames,

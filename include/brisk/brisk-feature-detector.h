@@ -59,7 +59,8 @@ class BriskFeatureDetector {
   }
 
   // brisk-feature-detector.cc:87-92: scores and scales for provided keypoints (`keypoints` is replaced by the result,
-  // up to one entry per layer that admits a point).  Runs the reference's sequential algorithm on the device; throws
+  // up to one entry per layer that admits a point).  One lane per (layer, point) on the device (the walk's phases are
+  // order-free among themselves; a call in which a layer admits no point runs the reference's sequential walk); throws
   // where the reference has no defined result (a point within a few rows of a layer's bottom border makes it read
   // beyond the image, brisk-layer.cc:110-115; see brisk_hip_compute_scale).
   void ComputeScale(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints) const {

@@ -162,3 +162,60 @@ def test_describe_runs_of_eight_and_provided_angles(B):
         assert same_kps(kg, kw), explain(kg, kw)
         assert np.array_equal(dg, dw), mode
     ctx.close()
+
+
+def test_compute_scale_one_lane_per_layer_and_point(B):
+    """BriskFeatureDetector::ComputeScale (brisk-feature-detector.cc:87-92) off the one-lane walk: the provided points are
+    touched, scored and refined one lane per (layer, point) and emitted in (layer, provided) order (k_cs_*).  3 000 and 16 000
+    random points on a 1080p frame in all three branches (scale NMS, several layers without it, one layer), class ids kept;
+    a list whose points sit in the outer 30 pixels only, so that the small layers admit none of them and DETECT instead (the
+    call then stays on the one-lane walk, decided on the device); and the undefined input - each against the oracle, and the
+    3 000-point call against the clock (0.45 s on the one-lane walk; the review asked for 5 ms)."""
+    import time
+    img = synth.frame_1080p(5)
+    rng = np.random.default_rng(3)
+    ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+
+    def points(n, lo_x, hi_x, lo_y, hi_y):
+        k = np.zeros(n, B.KEYPOINT)
+        k["x"] = rng.uniform(lo_x, hi_x, n).astype(np.float32)
+        k["y"] = rng.uniform(lo_y, hi_y, n).astype(np.float32)
+        k["x"][::7] = np.floor(k["x"][::7])          # some integral coordinates
+        k["size"], k["angle"], k["class_id"] = 12, -1, np.arange(n) * 3 + 1
+        return k
+
+    for n, octaves, suppress in ((3000, 4, True), (16000, 4, True), (3000, 3, False), (3000, 0, True), (700, 2, True)):
+        k = points(n, 60, 1860, 60, 1020)
+        want = O.compute_scale(img, k, 60, octaves, suppress)
+        det = B.BriskFeatureDetector(60, octaves, suppress, context=ctx)
+        got = det.ComputeScale(img, k)
+        if want is None:   # (the no-scale-NMS branch indexes layer i with layer 0's list: undefined on most inputs)
+            continue
+        assert len(want) > n // 2 and same_kps(got, want), (n, octaves, suppress, explain(got, want))
+    k = points(3000, 60, 1860, 60, 1020)
+    det = B.BriskFeatureDetector(60, 4, context=ctx)
+    det.ComputeScale(img, k)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        det.ComputeScale(img, k)
+    dt = (time.perf_counter() - t0) / 3
+    assert dt < 0.02, "ComputeScale of 3 000 points took %.1f ms" % (dt * 1e3)
+    # points in the outer frame only: layers of scale >= 6 admit none (x / scale - offset < 3) and detect instead
+    edge = points(400, 4, 30, 4, 1076)
+    want = O.compute_scale(img, edge, 60, 4)
+    if want is not None:
+        assert same_kps(det.ComputeScale(img, edge), want)
+    else:
+        with pytest.raises(B.BriskHipError) as ei:
+            det.ComputeScale(img, edge)
+        assert ei.value.code == 7
+    small = synth.gen(320, 240, 9, 30)
+    edge2 = points(60, 3.5, 12, 3.5, 200)
+    want = O.compute_scale(small, edge2, 40, 3)
+    d2 = B.BriskFeatureDetector(40, 3, context=ctx)
+    if want is not None:
+        assert len(want) > 20 and same_kps(d2.ComputeScale(small, edge2), want), explain(d2.ComputeScale(small, edge2), want)
+    else:
+        with pytest.raises(B.BriskHipError):
+            d2.ComputeScale(small, edge2)
+    ctx.close()

@@ -376,6 +376,89 @@ int emul_compute_scale(const uint8_t* img, int w, int h, int threshold, int octa
   return (int)E.kps.size();
 }
 
+// The same call in the pieces the k_cs_* kernels run one lane per (layer, provided point), with the items of every phase
+// taken in a pseudo-random order (seed): the claim behind those kernels is that the phases are order-free among themselves.
+// Returns -1 where the reference has no defined result, -2 where a layer admits no provided point (the engine then runs the
+// one-lane walk instead).
+int emul_compute_scale_phased(const uint8_t* img, int w, int h, int threshold, int octaves, int suppress, const BriskKeyPoint* in,
+                              int n_in, unsigned seed, BriskKeyPoint** out) {
+  Emul E;
+  make_geometry(w, h, threshold, octaves, &E.G);
+  E.G.lower_threshold = 0;
+  const BriskGeom& G = E.G;
+  E.pyr.assign((size_t)G.pyr_elems + 256, 0);
+  E.smap.assign((size_t)G.pyr_elems + 256, 0);
+  for (int y = 0; y < h; ++y) memcpy(E.pyr.data() + G.L[0].off + (size_t)y * G.L[0].stride, img + (size_t)y * w, w);
+  for (int l = 1; l < G.nlayers; ++l) {
+    const int sl = (l == 1) ? 0 : l - 2;
+    const uint8_t* src = E.pyr.data() + G.L[sl].off;
+    uint8_t* dst = E.pyr.data() + G.L[l].off;
+    for (int y = 0; y < G.L[l].h; ++y)
+      for (int x = 0; x < G.L[l].w; ++x)
+        dst[(size_t)y * G.L[l].stride + x] = (l == 1) ? brisk_twothird_px(src, G.L[sl].stride, G.L[sl].w, x, y)
+                                                      : brisk_half_px(src, G.L[sl].stride, G.L[sl].w, x, y);
+  }
+  struct Item { int l, j, k; };
+  std::vector<Item> items;
+  std::vector<std::vector<int> > adm((size_t)G.nlayers);
+  for (int l = 0; l < G.nlayers; ++l) {
+    for (int k = 0; k < n_in; ++k) {
+      float kx, ky;
+      if (brisk_provided_on_layer(G, l, in[k], &kx, &ky)) { items.push_back({l, (int)adm[(size_t)l].size(), k}); adm[(size_t)l].push_back(k); }
+    }
+    if (adm[(size_t)l].empty()) return -2;
+  }
+  unsigned st = seed * 2654435761u + 99u;
+  auto shuffle = [&]() {
+    for (size_t i = items.size(); i > 1; --i) {
+      st = st * 1664525u + 1013904223u;
+      std::swap(items[i - 1], items[(st >> 8) % i]);
+    }
+  };
+  shuffle();
+  for (const Item& it : items) {
+    float kx, ky;
+    brisk_provided_on_layer(G, it.l, in[it.k], &kx, &ky);
+    brisk_cs_touch(G, E.pyr.data(), E.smap.data(), it.l, kx, ky);
+  }
+  shuffle();
+  for (const Item& it : items) {
+    float kx, ky;
+    brisk_provided_on_layer(G, it.l, in[it.k], &kx, &ky);
+    if (brisk_cs_score(G, E.pyr.data(), E.smap.data(), it.l, kx, ky)) return -1;
+  }
+  const bool flat = !suppress && !G.single_layer;
+  std::vector<std::vector<BriskKeyPoint> > res((size_t)G.nlayers);
+  std::vector<std::vector<char> > ok((size_t)G.nlayers);
+  for (int l = 0; l < G.nlayers; ++l) {
+    if (flat && adm[(size_t)l].size() > adm[0].size()) return -1;
+    res[(size_t)l].resize(adm[(size_t)l].size());
+    ok[(size_t)l].assign(adm[(size_t)l].size(), 0);
+  }
+  shuffle();
+  for (const Item& it : items) {
+    float kx, ky;
+    BriskKeyPoint kp;
+    if (flat) {
+      const BriskKeyPoint& src0 = in[adm[0][(size_t)it.j]];
+      brisk_provided_on_layer(G, 0, src0, &kx, &ky);
+      brisk_cs_flat(G, E.pyr.data(), E.smap.data(), it.l, src0, kx, ky, &kp);
+      ok[(size_t)it.l][(size_t)it.j] = 1;
+    } else {
+      brisk_provided_on_layer(G, it.l, in[it.k], &kx, &ky);
+      ok[(size_t)it.l][(size_t)it.j] = brisk_cs_refine(G, E.pyr.data(), E.smap.data(), it.l, in[it.k], kx, ky, &kp) ? 1 : 0;
+    }
+    res[(size_t)it.l][(size_t)it.j] = kp;
+  }
+  std::vector<BriskKeyPoint> all;
+  for (int l = 0; l < G.nlayers; ++l)
+    for (size_t j = 0; j < res[(size_t)l].size(); ++j)
+      if (ok[(size_t)l][j]) all.push_back(res[(size_t)l][j]);
+  *out = (BriskKeyPoint*)malloc(sizeof(BriskKeyPoint) * (all.size() + 1));
+  memcpy(*out, all.data(), sizeof(BriskKeyPoint) * all.size());
+  return (int)all.size();
+}
+
 void emul_free(void* p) { free(p); }
 
 // the kernel evaluates the tie list on 8 lanes (brisk_tie_neighbour_ok); must equal the serial brisk_tie_decide

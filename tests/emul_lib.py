@@ -25,6 +25,7 @@ def lib():
         L.emul_detect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(vp), vp]
         L.emul_free.argtypes = [vp]
         L.emul_compute_scale.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
+        L.emul_compute_scale_phased.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_uint, C.POINTER(vp)]
         L.emul_oast_Kp.argtypes = [vp, C.c_int]
         L.emul_agast58_Kp.argtypes = [vp, C.c_int]
         L.emul_detect_px.argtypes = [vp, C.c_int, C.c_int]
@@ -71,6 +72,24 @@ def compute_scale(img, keypoints, threshold, octaves, suppress_scale_nonmaxima=T
     out = C.c_void_p()
     n = lib().emul_compute_scale(_p(img), w, h, threshold, octaves, int(bool(suppress_scale_nonmaxima)),
                                  _p(k) if len(k) else None, len(k), C.byref(out))
+    if n < 0:
+        return None
+    kps = np.frombuffer(C.string_at(out.value, n * KP.itemsize), dtype=KP).copy() if n else np.zeros(0, KP)
+    lib().emul_free(out)
+    return kps
+
+
+def compute_scale_phased(img, keypoints, threshold, octaves, suppress_scale_nonmaxima=True, seed=1):
+    """the same call in the pieces the k_cs_* kernels run in parallel, every phase's items in a shuffled order; None = no
+    defined result in the reference, 'walk' = a layer admits no provided point (the engine runs the one-lane walk)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    k = np.ascontiguousarray(keypoints, KP)
+    out = C.c_void_p()
+    n = lib().emul_compute_scale_phased(_p(img), w, h, threshold, octaves, int(bool(suppress_scale_nonmaxima)), _p(k), len(k),
+                                        seed, C.byref(out))
+    if n == -2:
+        return "walk"
     if n < 0:
         return None
     kps = np.frombuffer(C.string_at(out.value, n * KP.itemsize), dtype=KP).copy() if n else np.zeros(0, KP)

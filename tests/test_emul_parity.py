@@ -348,6 +348,36 @@ def test_compute_scale_walk_equals_oracle():
     assert O.compute_scale(img, bad, 60, 3) is None and E.compute_scale(img, bad, 60, 3) is None
 
 
+def test_compute_scale_phases_are_order_free():
+    """What lets k_cs_admit / _scores / _refine run ComputeScale one lane per (layer, provided point): the walk's three phases -
+    threshold-0 touches, the provided lists' scores, the per-point refinement - executed as separate passes with the items of
+    every pass in a SHUFFLED order (three seeds) give the oracle's result: same keypoints, same order, same bits; the inputs
+    without a defined result are recognised, a layer without admitted points is handed to the walk."""
+    img = synth.gen(320, 240, 9, 30)
+    rng = np.random.default_rng(12)
+    for thr, octaves, suppress in ((60, 3, True), (60, 0, True), (60, 2, False), (25, 2, True), (8, 1, True), (40, 3, True)):
+        k = provided_keypoints(img, max(thr, 30), 3, 70, seed=thr)
+        # many points on few pixels: touches and refinements of different points meet on the same cache entries
+        extra = np.zeros(300, O.KP)
+        extra["x"] = rng.uniform(60, 110, 300).astype(np.float32)
+        extra["y"] = rng.uniform(60, 100, 300).astype(np.float32)
+        extra["size"], extra["angle"], extra["class_id"] = 12, -1, 5
+        k = np.concatenate([k, extra])
+        ko = O.compute_scale(img, k, thr, octaves, suppress)
+        for seed in (1, 2, 3):
+            ke = E.compute_scale_phased(img, k, thr, octaves, suppress, seed)
+            if ko is None:
+                assert ke is None, (thr, octaves, suppress, seed)
+            else:
+                assert not isinstance(ke, str) and same_kps(ke, ko), (thr, octaves, suppress, seed, None if ke is None else len(ke), len(ko))
+    few = np.zeros(3, O.KP)
+    few["x"], few["y"], few["size"] = [4, 6.5, 5], [4, 5, 7.25], 12
+    assert E.compute_scale_phased(img, few, 60, 3) == "walk"
+    bad = np.zeros(1, O.KP)   # one layer, a point in its last admitted row: the ring of the linear offset leaves the image
+    bad["x"], bad["y"] = 100, 237
+    assert O.compute_scale(img, bad, 60, 0) is None and E.compute_scale_phased(img, bad, 60, 0) is None
+
+
 def test_describe_box_that_ends_in_the_last_column():
     """SmoothedIntensity's displaced bottom corner (brisk-descriptor-extractor.cc:453) sits one column right of the box;
     for a keypoint on the border limit that is column `cols`, which the reference's linear address turns into the first

@@ -488,7 +488,6 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) / 4 * 1e3 * inner
         gather.verify_counts()   # outside every timed region: no frame had more rows than the slabs carry
-        gather.close()
 
     total_frames = frames_per_step_total * nsteps
     fps = total_frames / dt
@@ -570,6 +569,8 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if gather is not None and args.force_gather:
         gather_selftest(ctx, ext, frames, chunk, strings, stream, gather, rank)
+    if gather is not None:
+        gather.close()   # (the C-ABI communicator: brisk_hip_comm_destroy)
     if use_dist:
         dist.destroy_process_group()
 

@@ -62,7 +62,7 @@ def _compile_objects(hipcc, flags, objdir, verbose, force):
         fl = list(flags)
         if s == "brisk_capi.hip":
             fl.append('-DBRISK_KERNEL_REV="%s"' % kernel_revision())
-        cmd = [hipcc] + fl + ["-c", "-o", obj, src]
+        cmd = [hipcc] + fl + ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", obj, src]
         stamp = obj + ".cmd"
         sig = hashlib.sha1(" ".join(cmd).encode()).hexdigest()
         objs.append(obj)
@@ -71,12 +71,56 @@ def _compile_objects(hipcc, flags, objdir, verbose, force):
             continue
         if verbose:
             print(" ".join(cmd))
-        procs.append((s, stamp, sig, subprocess.Popen(cmd)))
-    for s, stamp, sig, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, "hipcc -c " + s)
+        # (stderr = warnings + the resource remarks of every kernel: kept beside the object for kernel_resources())
+        procs.append((s, stamp, sig, obj + ".log", subprocess.Popen(cmd, stderr=open(obj + ".log", "w"))))
+    for s, stamp, sig, log, p in procs:
+        rc = p.wait()
+        text = open(log).read()
+        diag = _strip_remarks(text)
+        if diag.strip():
+            sys.stderr.write(diag)
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, "hipcc -c " + s)
         open(stamp, "w").write(sig)
     return objs
+
+
+def _strip_remarks(text):
+    """compiler output without the resource remarks (each a header line + the source lines it points at)"""
+    import re
+    out, held, skipping = [], [], False
+    for ln in text.splitlines(True):
+        if ln.startswith("In file included from "):
+            held.append(ln)  # (belongs to the diagnostic that follows)
+            continue
+        if re.match(r"^(\S.*?: (remark|warning|error|note|fatal error): |\d+ (warning|error)s? generated)", ln):
+            skipping = ": remark: " in ln
+            if not skipping:
+                out += held
+            held = []
+        if not skipping:
+            out.append(ln)
+    return "".join(out)
+
+
+def kernel_resources(objdir=None):
+    """{kernel name (mangled): {"vgpr", "agpr", "sgpr", "scratch", "occupancy", "lds"}} of the last build(), from the
+    compiler's resource remarks kept beside the objects ({} if the objects were not built here)"""
+    import re
+    objdir = objdir or os.path.join(HERE, "..", "build", "obj")
+    out = {}
+    if not os.path.isdir(objdir):
+        return out
+    for f in sorted(os.listdir(objdir)):
+        if not f.endswith(".o.log"):
+            continue
+        t = open(os.path.join(objdir, f)).read()
+        for m in re.finditer(r"Function Name: (\S+).*?\n(.*?)LDS Size \[bytes/block\]: (\d+)", t, re.S):
+            body = m.group(2)
+            g = lambda k: int(re.search(k + r": (\d+)", body).group(1))
+            out[m.group(1)] = {"vgpr": g("VGPRs"), "agpr": g("AGPRs"), "sgpr": g("SGPRs"), "scratch": g(r"ScratchSize \[bytes/lane\]"),
+                               "occupancy": g(r"Occupancy \[waves/SIMD\]"), "lds": int(m.group(3))}
+    return out
 
 
 def build(force=False, verbose=False):

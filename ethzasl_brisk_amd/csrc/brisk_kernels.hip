@@ -1255,6 +1255,7 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 #define TR_KERNEL_NAME k_tie_resolve
 #define TR_SORT_NAME tie_sort_large
 #define TR_KERNEL_MASKS 0
+#define TR_KERNEL_PAIR 0
 #include "brisk_tie_kernel.inc"
 #undef TR_KERNEL_NAME
 #undef TR_KERNEL_MASKS
@@ -1264,6 +1265,15 @@ __global__ void __launch_bounds__(64) k_compute_scale(BriskGeom G, uint8_t* pyr,
 #define TR_KERNEL_MASKS 1
 #include "brisk_tie_kernel.inc"
 #undef TR_KERNEL_NAME
+#undef TR_SORT_NAME
+#undef TR_KERNEL_PAIR
+// k_tie_resolve_pair (round 5): the small form with TWO ties per wave, one per half wave (brisk_tie_kernel.inc)
+#define TR_KERNEL_NAME k_tie_resolve_pair
+#define TR_SORT_NAME tie_sort_large_pair
+#define TR_KERNEL_PAIR 1
+#include "brisk_tie_kernel.inc"
+#undef TR_KERNEL_NAME
+#undef TR_KERNEL_PAIR
 #undef TR_KERNEL_MASKS
 
 // ------------------------------------------------------------------------------------------------
@@ -1941,12 +1951,22 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     // kernel is what the window waits for).
     static const int waves_knob = env_knob("BRISK_TR_WAVES", 0);
     const int tr_waves = waves_knob ? min(max(waves_knob, 2), TR_WAVES) : ((!persist && lpw >= G.nlayers && nframes >= 192) ? 12 : TR_WAVES);
-    if (nframes < 32)
+    // two ties per wave (k_tie_resolve_pair) up to 64 frames per call: 64 dense frames 3.83 -> 4.15 k frames/s (threshold 30),
+    // 64 4K frames 15.45 -> 15.78 k, one 4K frame's tie stage 0.386 -> 0.32 ms; from 128 frames on its 107 VGPRs cost more
+    // beside the integral kernel than the pairs win (128: 68.1 -> 67.2 k frames/s, 512: 76.0 -> 74.6 k).
+    static const int pair_knob = env_knob("BRISK_TR_PAIR", 1);  // A / B runs: 0 = one tie per wave everywhere, 2 = pairs in all batches
+    static const int pair_min_knob = env_knob("BRISK_TR_PAIR_MIN", 0);
+    static const int pair_mode_knob = env_knob("BRISK_TR_PAIR_MODE", 1);
+    const int pair_min = (pair_min_knob ? pair_min_knob : 4 * (tr_waves - 1)) | (pair_mode_knob << 16);
+    if ((nframes <= 64 && pair_knob) || pair_knob == 2)
+      hipLaunchKernelGGL(k_tie_resolve_pair, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
+                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, pair_min);
+    else if (nframes < 32)
       hipLaunchKernelGGL(k_tie_resolve_small, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist);
+                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, 0);
     else
       hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist);
+                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, 0);
   }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,

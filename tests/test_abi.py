@@ -42,3 +42,23 @@ def test_product_does_not_reference_oracle():
     for d, _, files in os.walk(os.path.join(ROOT, "include")):
         for f in files:
             assert "oracle" not in open(os.path.join(d, f), errors="ignore").read(), f
+
+
+def test_kernel_resources_hold_their_bounds():
+    """Register bounds the launch code relies on (brisk_launch_detect: the large-batch tie kernel runs beside two integral
+    workgroups per SIMD only at 96 VGPRs or fewer), and no kernel of the hot path may touch scratch."""
+    from ethzasl_brisk_amd import build
+    build.build()
+    res = build.kernel_resources()
+    if not res:
+        pytest.skip("the objects were not compiled here (no resource remarks beside them)")
+    by = lambda frag: {k: v for k, v in res.items() if frag in k}
+    large = [v for k, v in by("k_tie_resolve").items() if "k_tie_resolve_small" not in k and "k_tie_resolve_pair" not in k]
+    assert len(large) == 1 and large[0]["vgpr"] <= 96, large
+    assert by("k_tie_resolve_pair") and all(v["vgpr"] <= 128 for v in by("k_tie_resolve_pair").values())
+    for frag in ("k_detect", "k_describe", "k_tie_resolve", "k_pyramid", "k_score_blocks", "k_classify_refine", "k_finalize",
+                 "k_integral_final", "k_desc_prepare"):
+        ks = by(frag)
+        assert ks, frag
+        for k, v in ks.items():
+            assert v["scratch"] == 0, (k, v)

@@ -12,9 +12,9 @@ import ethzasl_brisk_amd as B
 import synth
 
 which = sys.argv[1] if len(sys.argv) > 1 else "vga"
-img = {"vga": lambda: synth.frame_vga(1), "1080p": lambda: synth.frame_1080p(0)}[which]()
+img = {"vga": lambda: synth.frame_vga(1), "1080p": lambda: synth.frame_1080p(0), "4k": lambda: synth.frame_4k(2)}[which]()
 thr = 70 if which == "vga" else 80
-det = B.BriskFeatureDetector(thr, 4)
+det = B.BriskFeatureDetector(thr, 6 if which == "4k" else 4)
 for _ in range(5):
     k = det.detect(img)
 ctx = det._ctx

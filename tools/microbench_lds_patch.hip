@@ -53,6 +53,8 @@ struct MbArgs {
   const uint32_t* integ32;  // [NF] (h + 1) x (w + 1) u32
   const uint8_t* integ24;   // [NF] the same in 3-byte elements
   const uint8_t* pix;       // [NF] h x w u8
+  const uint8_t* integ_il2; // [NF] 3-byte elements, rows interleaved in pairs: (y, x) at ((y >> 1) * 2 iw + 2 x + (y & 1)) * 3
+  long il2_bytes;
   long f32_elems, f24_bytes, pix_bytes;
   int iw, ih, w, h;
   const int4* tab4;
@@ -78,18 +80,40 @@ struct Raw {
   u32x2 p00, p02, p10, p12, p30, p32, ql, qr;
   u32x3 p20, p22;
 };
-template <bool I24>
+// what-if forms (timing only, wrong results): 1 = without the two gathers of the displaced corners (8 gathers, 18 dwords),
+// 2 = every pair gather three dwords wide (10 gathers, 30 dwords, the same lines), 3 = every gather ONE dword (10 gathers, 10 dwords)
+template <bool I24, int WHATIF = 0>
 __device__ __forceinline__ void gather_load(Raw& r, const BriskBoxPrep& p, __amdgpu_buffer_rsrc_t rs, int istride) {
   constexpr int ES = I24 ? 3 : 4;
   const int rowb = istride * ES;
   const int o_t = p.y_top * rowb, o_b = p.y_bottom * rowb;
   const int o_tl = o_t + p.x_left * ES, o_tr = o_t + p.x_right * ES, o_bl = o_b + p.x_left * ES, o_br = o_b + p.x_right * ES;
+  if (WHATIF == 2) {
+    auto w = [&](int o, int so) { const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, o, so, 0); return u32x2{v.x + v.z, v.y}; };
+    r.p00 = w(o_tl, 0); r.p02 = w(o_tr, 0); r.p10 = w(o_tl, rowb); r.p12 = w(o_tr, rowb);
+    r.ql = w(o_bl - rowb + ES, 0); r.qr = w(o_br - rowb + ES, 0); r.p30 = w(o_bl, rowb); r.p32 = w(o_br, rowb);
+    r.p20 = __builtin_amdgcn_raw_buffer_load_b96(rs, o_bl, 0, 0);
+    r.p22 = __builtin_amdgcn_raw_buffer_load_b96(rs, o_br, 0, 0);
+    return;
+  }
+  if (WHATIF == 3) {
+    auto w = [&](int o, int so) { const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rs, o, so, 0); return u32x2{v, v >> 3}; };
+    r.p00 = w(o_tl, 0); r.p02 = w(o_tr, 0); r.p10 = w(o_tl, rowb); r.p12 = w(o_tr, rowb);
+    r.ql = w(o_bl - rowb + ES, 0); r.qr = w(o_br - rowb + ES, 0); r.p30 = w(o_bl, rowb); r.p32 = w(o_br, rowb);
+    const u32x2 a = w(o_bl, 0), b = w(o_br, 0);
+    r.p20 = u32x3{a.x, a.y, a.x ^ 1}; r.p22 = u32x3{b.x, b.y, b.x ^ 1};
+    return;
+  }
   r.p00 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_tl, 0, 0);
   r.p02 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_tr, 0, 0);
   r.p10 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_tl, rowb, 0);
   r.p12 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_tr, rowb, 0);
-  r.ql = __builtin_amdgcn_raw_buffer_load_b64(rs, o_bl - rowb + ES, 0, 0);
-  r.qr = __builtin_amdgcn_raw_buffer_load_b64(rs, o_br - rowb + ES, 0, 0);
+  if (WHATIF == 1) {
+    r.ql = r.p00; r.qr = r.p02;
+  } else {
+    r.ql = __builtin_amdgcn_raw_buffer_load_b64(rs, o_bl - rowb + ES, 0, 0);
+    r.qr = __builtin_amdgcn_raw_buffer_load_b64(rs, o_br - rowb + ES, 0, 0);
+  }
   r.p20 = __builtin_amdgcn_raw_buffer_load_b96(rs, o_bl, 0, 0);
   r.p22 = __builtin_amdgcn_raw_buffer_load_b96(rs, o_br, 0, 0);
   r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_bl, rowb, 0);
@@ -126,7 +150,7 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // ---- the shipped formulation -----------------------------------------------------------------------------------
-template <bool I24>
+template <bool I24, int WHATIF = 0>
 __global__ void __launch_bounds__(128) k_gather(MbArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -163,8 +187,113 @@ __global__ void __launch_bounds__(128) k_gather(MbArgs A) {
           const float xf = (float)(mm * uv.x) + __uint_as_float(rec.x), yf = (float)(mm * uv.y) + __uint_as_float(rec.y);
           const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
           Raw raw;
-          if (valid) gather_load<I24>(raw, pr, rs, A.iw);
+          if (valid) gather_load<I24, WHATIF>(raw, pr, rs, A.iw);
           const int value = gather_combine<I24>(pr, raw);
+          if (valid) { vals[sc] = value; ksum += value; }
+        }
+        wave_sync();
+      }
+      int f = vals[lane] + ksum;
+      { int f1 = f ^ 5, f2 = f + 7, f3 = f * 3; for (int k = 0; k < A.filler * cnt / 12; ++k) { f += (f >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; } f ^= f1 ^ f2 ^ f3; }
+      if (f == 0x12345678) ksum += 1;
+      sum += ksum;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
+  if (lane == 0) atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
+}
+
+
+// ---- round 5, second half: the 3-byte integral image with its rows interleaved in pairs --------------------------------
+// Element (y, x) at byte ((y >> 1) * 2 iw + 2 x + (y & 1)) * 3: a 128-byte line holds 21 columns of TWO rows.  The 2 x 2 top
+// block of a box side is one 12-byte gather when y_top is even, two when it is odd; the bottom rows y_bottom - 1 .. + 1 are
+// always two gathers (16 + 12 bytes): 8 gather instructions per sample instead of 10 (one of them disabled - out-of-range
+// offset, no access - in half of the lanes), 7 lines instead of 10 where nothing is shared.
+struct RawIl2 {
+  u32x3 a[2], b[2], d[2];
+  u32x4 c[2];
+};
+__device__ __forceinline__ void il2_side(RawIl2& r, int s, __amdgpu_buffer_rsrc_t rs, int rowb2, int x, int yt, int yb) {
+  const int xo = x * 6;
+  const int kt = yt >> 1, kb = (yb - 1) >> 1;
+  const bool todd = yt & 1, bodd = (yb - 1) & 1;
+  const int ot = kt * rowb2 + xo, ob = kb * rowb2 + xo;
+  r.a[s] = __builtin_amdgcn_raw_buffer_load_b96(rs, ot + (todd ? 3 : 0), 0, 0);
+  r.b[s] = __builtin_amdgcn_raw_buffer_load_b96(rs, todd ? ot + rowb2 : 0x7FFF0000, 0, 0);
+  r.c[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, bodd ? ob + rowb2 : ob + 3, 0, 0);
+  r.d[s] = __builtin_amdgcn_raw_buffer_load_b96(rs, bodd ? ob + 9 : ob + rowb2, 0, 0);
+}
+__device__ __forceinline__ void il2_unpack(const RawIl2& r, int s, bool todd, bool bodd, uint32_t& v00, uint32_t& v01, uint32_t& v10,
+                                           uint32_t& v11, uint32_t& i20, uint32_t& i21, uint32_t& i22, uint32_t& i30, uint32_t& i31,
+                                           uint32_t& q0, uint32_t& q1) {
+  const u32x3 a = r.a[s], b = r.b[s], d = r.d[s];
+  const u32x4 c = r.c[s];
+  v00 = a.x;
+  v01 = __builtin_amdgcn_alignbit(a.z, a.y, 16);
+  const uint32_t a3 = __builtin_amdgcn_alignbit(a.y, a.x, 24), a9 = a.z >> 8;
+  const uint32_t b6 = __builtin_amdgcn_alignbit(b.z, b.y, 16);
+  v10 = todd ? b.x : a3;
+  v11 = todd ? b6 : a9;
+  i20 = c.x;
+  i21 = __builtin_amdgcn_alignbit(c.z, c.y, 16);
+  i22 = c.w;
+  const uint32_t c3 = __builtin_amdgcn_alignbit(c.y, c.x, 24), c9 = __builtin_amdgcn_alignbit(c.w, c.z, 8);
+  const uint32_t d0 = d.x, d6 = __builtin_amdgcn_alignbit(d.z, d.y, 16);
+  q0 = bodd ? d0 : c3;
+  q1 = bodd ? d6 : c9;
+  i30 = bodd ? c3 : d0;
+  i31 = bodd ? c9 : d6;
+}
+__global__ void __launch_bounds__(128) k_gather_il2(MbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* vals = reinterpret_cast<int*>(lds + wave * 1024);
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 7);
+  const int np = A.np;
+  const int rowb2 = A.iw * 6;
+  long long sum = 0;
+  for (int gi = 0; gi < 8; ++gi) {
+    const int g = (xcc + gi) & 7;
+    const int nt = A.ntasks[g];
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&A.tickets[g * 32], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nt) break;
+      const uint4 task = A.tasks[(long)g * A.max_tasks + t];
+      const int cnt = (int)task.z >= 0 ? 2 : 1, total = cnt * np;
+      const uint4 rec0 = A.kps[task.y], rec1 = A.kps[cnt == 2 ? task.z : task.y];
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.integ_il2 + (long)task.x * A.il2_bytes), 0, (int)A.il2_bytes, 0x00020000);
+      int ksum = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int s0 = 0; s0 < total; s0 += 64) {
+          const int s = s0 + lane;
+          const bool valid = s < total;
+          const int sc = min(s, total - 1);
+          const int kq = sc >= np ? 1 : 0, pt = sc - kq * np;
+          const uint4 rec = kq ? rec1 : rec0;
+          const int theta = pass ? (int)rec.w : 0;
+          const int4 tab = A.tab4[(int)rec.z * np + pt];
+          const double2 uv = A.uv2[theta * np + pt];
+          const double mm = (double)__int_as_float(tab.x);
+          const float xf = (float)(mm * uv.x) + __uint_as_float(rec.x), yf = (float)(mm * uv.y) + __uint_as_float(rec.y);
+          const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
+          RawIl2 raw;
+          if (valid) {
+            il2_side(raw, 0, rs, rowb2, pr.x_left, pr.y_top, pr.y_bottom);
+            il2_side(raw, 1, rs, rowb2, pr.x_right, pr.y_top, pr.y_bottom);
+          }
+          const bool todd = pr.y_top & 1, bodd = (pr.y_bottom - 1) & 1;
+          uint32_t i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i2x, i22, i23, i2y, i30, i31, i32, i33, ql0, ql1, qr0, qr1;
+          il2_unpack(raw, 0, todd, bodd, i00, i01, i10, i11, i20, i21, i2x, i30, i31, ql0, ql1);
+          il2_unpack(raw, 1, todd, bodd, i02, i03, i12, i13, i22, i23, i2y, i32, i33, qr0, qr1);
+          constexpr uint32_t mask = 0xFFFFFFu;
+          const unsigned qbr = (i2y - i23 - qr1 + qr0) & mask;
+          const unsigned qbl = (i2x - i21 - ql1 + ql0) & mask;
+          const uint32_t acc = brisk_box_acc(pr, i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i22, i23, i30, i31, i32, i33, qbr, qbl, mask);
+          const int value = brisk_div_by_magic((int)acc, pr.magic, pr.shift);
           if (valid) { vals[sc] = value; ksum += value; }
         }
         wave_sync();
@@ -658,13 +787,16 @@ int main(int argc, char** argv) {
   const int NF = 256;
   const int iw = w + 1, ih = h + 1;
   const long f32_elems = (long)iw * ih, f24_bytes = ((f32_elems * 3 + 15) & ~15L) + 16, pix_bytes = (long)w * h;
-  uint32_t* d_i32; uint8_t* d_i24; uint8_t* d_pix;
+  uint32_t* d_i32; uint8_t* d_i24; uint8_t* d_pix; uint8_t* d_il2;
+  const long il2_bytes = (((long)((ih + 1) / 2) * iw * 6 + 15) & ~15L) + 32;
+  CHECK(hipMalloc(&d_il2, NF * il2_bytes));
   CHECK(hipMalloc(&d_i32, NF * f32_elems * 4));
   CHECK(hipMalloc(&d_i24, NF * f24_bytes));
   CHECK(hipMalloc(&d_pix, NF * pix_bytes + 64));
   {
     std::vector<uint32_t> I(f32_elems);
     std::vector<uint8_t> I3(f24_bytes);
+    std::vector<uint8_t> I2(il2_bytes);
     for (int f = 0; f < nd; ++f) {
       std::fill(I.begin(), I.end(), 0u);
       for (int y = 0; y < h; ++y) {
@@ -675,7 +807,14 @@ int main(int argc, char** argv) {
         }
       }
       for (long i = 0; i < f32_elems; ++i) { I3[3 * i] = I[i] & 0xFF; I3[3 * i + 1] = (I[i] >> 8) & 0xFF; I3[3 * i + 2] = (I[i] >> 16) & 0xFF; }
+      for (int y = 0; y < ih; ++y)
+        for (int x = 0; x < iw; ++x) {
+          const uint32_t v = I[(size_t)y * iw + x];
+          uint8_t* q = &I2[((size_t)(y >> 1) * iw * 2 + 2 * x + (y & 1)) * 3];
+          q[0] = v & 0xFF; q[1] = (v >> 8) & 0xFF; q[2] = (v >> 16) & 0xFF;
+        }
       for (int s = f; s < NF; s += nd) {
+        CHECK(hipMemcpy(d_il2 + s * il2_bytes, I2.data(), il2_bytes, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(d_i32 + s * f32_elems, I.data(), f32_elems * 4, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(d_i24 + s * f24_bytes, I3.data(), f24_bytes, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(d_pix + s * pix_bytes, img[f].data(), pix_bytes, hipMemcpyHostToDevice));
@@ -726,6 +865,7 @@ int main(int argc, char** argv) {
   CHECK(hipEventCreate(&e1));
 
   MbArgs A;
+  A.integ_il2 = d_il2; A.il2_bytes = il2_bytes;
   A.integ32 = d_i32; A.integ24 = d_i24; A.pix = d_pix; A.f32_elems = f32_elems; A.f24_bytes = f24_bytes; A.pix_bytes = pix_bytes;
   A.iw = iw; A.ih = ih; A.w = w; A.h = h; A.tab4 = d_tab; A.uv2 = d_uv; A.size_list = d_size; A.np = np; A.kps = d_kps;
   A.tasks = d_tasks; A.ntasks = d_ntasks; A.max_tasks = max_tasks; A.tickets = d_tickets; A.checksum = d_sum; A.filler = filler; A.phase = d_phase;
@@ -734,7 +874,8 @@ int main(int argc, char** argv) {
   const Cls classes[] = {{"side<=67", 0, 67}, {"67<side<=101", 67, 101}, {"side<=101", 0, 101}, {"101<side<=151", 101, 151},
                          {"151<side<=201", 151, 201}, {"side>201", 201, 100000}, {"all", 0, 100000}};
   struct Var { const char* name; int kind; int src; bool u16; int max_side; };
-  const Var vars[] = {{"gather_i24", 0, 1, false, 100000},    {"gather_u32", 0, 0, false, 100000},   {"lds_u16_from_i24", 1, 1, true, 101},
+  const Var vars[] = {{"gather_il2", 9, 1, false, 100000}, {"gather_i24_whatif_8gathers", 0, 11, false, 100000},
+                      {"gather_i24_whatif_30dwords", 0, 12, false, 100000}, {"gather_i24_whatif_10dwords", 0, 13, false, 100000}, {"gather_i24", 0, 1, false, 100000},    {"gather_u32", 0, 0, false, 100000},   {"lds_u16_from_i24", 1, 1, true, 101},
                       {"lds_u16_from_u32", 1, 0, true, 101}, {"lds_u32_from_u32", 1, 0, false, 201}, {"lds_u32_from_i24", 1, 1, false, 201},
                       {"lds_u16_from_pix", 1, 2, true, 101}, {"lds_u32_from_pix", 1, 2, false, 101},
                       {"lds2_i24_nb13", 2, 1, true, 101}, {"lds2_i24_nb26", 3, 1, true, 101}, {"lds2_u32_nb13", 4, 0, true, 101},
@@ -763,7 +904,7 @@ int main(int argc, char** argv) {
             bmax = std::max(bmax, b);
           }
           nkp += (long)sel.size();
-          if (V.kind == 0) {
+          if (V.kind == 0 || V.kind == 9) {
             for (size_t i = 0; i < sel.size(); i += 2)
               tq[g].push_back(make_uint4((unsigned)s, (unsigned)(base[f] + sel[i]), i + 1 < sel.size() ? (unsigned)(base[f] + sel[i + 1]) : 0xFFFFFFFFu, 0));
           } else {
@@ -780,7 +921,7 @@ int main(int argc, char** argv) {
       if (!nkp) continue;
       std::vector<int> wpcs;
       size_t lds = 0;
-      if (V.kind == 0) {
+      if (V.kind == 0 || V.kind == 9) {
         wpcs = {3};
       } else {
         lds = 512 + (size_t)patch_pw(bmax) * patch_ph(bmax) * (V.u16 ? 2 : 4);
@@ -797,9 +938,10 @@ int main(int argc, char** argv) {
           CHECK(hipMemsetAsync(d_sum, 0, 8, 0));
           CHECK(hipMemsetAsync(d_phase, 0, 64, 0));
           CHECK(hipEventRecord(e0, 0));
-          if (V.kind == 0) {
+          if (V.kind == 0 || V.kind == 9) {
             const size_t l = 160 * 1024 / 4 + 512;
-            auto fn = V.src == 1 ? k_gather<true> : k_gather<false>;
+            auto fn = V.kind == 9 ? k_gather_il2 : V.src == 11 ? k_gather<true, 1> : V.src == 12 ? k_gather<true, 2> : V.src == 13 ? k_gather<true, 3> :
+                      V.src == 1 ? k_gather<true> : k_gather<false>;
             CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
             hipLaunchKernelGGL(fn, dim3(ncu * wpc), dim3(128), l, 0, A);
           } else {
@@ -838,7 +980,7 @@ int main(int argc, char** argv) {
         printf("%s{\"class\": \"%s\", \"variant\": \"%s\", \"keypoints\": %ld, \"max_border\": %d, \"lds_bytes\": %zu, \"waves_per_cu\": %d, "
                "\"ms\": %.4f, \"samples_per_ns_chip\": %.2f, \"us_per_keypoint_cu\": %.3f, \"checksum\": %llu, "
                "\"wave_us_per_keypoint\": {\"ticket_params\": %.2f, \"staging\": %.2f, \"pass0\": %.2f, \"pass1\": %.2f, \"other\": %.2f}}",
-               first ? "" : ",\n", C.name, V.name, nkp, bmax, lds, V.kind == 0 ? wpc * 2 : wpc, best_ms, samples / (best_ms * 1e6),
+               first ? "" : ",\n", C.name, V.name, nkp, bmax, lds, (V.kind == 0 || V.kind == 9) ? wpc * 2 : wpc, best_ms, samples / (best_ms * 1e6),
                best_ms * 1e3 * ncu / (double)nkp, sum, php[0] * 0.01 / nkp, php[1] * 0.01 / nkp, php[2] * 0.01 / nkp, php[3] * 0.01 / nkp,
                php[4] * 0.01 / nkp);
         first = false;

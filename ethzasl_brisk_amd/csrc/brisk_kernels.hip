@@ -1911,7 +1911,10 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
   // blocks per frame: few for large batches (every block then walks several rounds of its frame's candidates on one
   // XCD), many for small ones (a single frame must spread over the chip)
   static const int sb_knob = env_knob("BRISK_SB_BLOCKS", 0), cr_knob = env_knob("BRISK_CR_BLOCKS", 0);
-  const int sb_blocks = sb_knob ? sb_knob : (nframes >= 64 ? 32 : 256), cr_blocks = cr_knob ? cr_knob : (nframes >= 64 ? 24 : 64);
+  // (round 5, tools/sweep_cr_sb.sh: 64 frames per call with 256 score blocks per frame instead of 32 - 64 dense frames at threshold
+  // 30 4.23 -> 4.33 k frames/s, threshold 50 14.65 -> 14.9 k, 64 4K frames 16.04 -> 16.23 k; 128 frames with 64: 68.07 -> 68.55 k;
+  // more classification blocks per frame lose everywhere: 48 / 96 / 192 at 64 dense frames 4.22 / 4.12 / 3.95 k)
+  const int sb_blocks = sb_knob ? sb_knob : (nframes > 64 ? (nframes >= 256 ? 32 : 64) : 256), cr_blocks = cr_knob ? cr_knob : (nframes >= 64 ? 24 : 64);
   {
     const int sb_bpf = grid_for(B.cand_cap, SB_WAVES * SB_PER_WAVE, sb_blocks), cr_bpf = grid_for(B.cand_cap, 64, cr_blocks);
     hipLaunchKernelGGL(k_score_blocks, dim3(xcd_grid(nframes, sb_bpf)), dim3(SB_WAVES * 64), 0, s, G, B.pyr, B.smap, B.cand,

@@ -219,3 +219,42 @@ def test_compute_scale_one_lane_per_layer_and_point(B):
         with pytest.raises(B.BriskHipError):
             d2.ComputeScale(small, edge2)
     ctx.close()
+
+
+@pytest.mark.parametrize("n,thr", [(33, 80), (64, 80), (40, 30)])
+def test_two_ties_per_wave_batches_up_to_64_frames(B, n, thr):
+    """k_tie_resolve_pair (two raster-adjacent ties per wave, round 5) serves every call of up to 64 frames: 33 and 64
+    frames at BASELINE config-2 content (64 x 8 layers = 512 tickets on 256 persistent workgroups), 40 dense frames at
+    threshold 30 (~30 k ties per frame: layers beyond the on-chip chunk of 3 072 ranks, so pairs straddle chunk ends and the
+    last pair of a chunk has one member) - every slot against the oracle, on a fresh and on a dirty workspace."""
+    distinct = [synth.frame_1080p(900 + s) for s in range(3)]
+    total = _run_batch_and_compare(B, distinct, n, thr, 4, 1920, 1080, every_slot=(thr != 30))
+    assert total > (30000 if thr == 30 else 3000)
+
+
+def test_two_ties_per_wave_agrees_with_one_tie_per_wave(B):
+    """the A / B knob of the tie kernel's forms (BRISK_TR_PAIR is read once per process: both forms run in child processes):
+    one 4K frame with 6 octaves (layers of 23 ... 1 026 ties) and an all-tie image give the same bytes either way."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import ethzasl_brisk_amd as B, synth
+h = hashlib.sha256()
+det = B.BriskFeatureDetector(80, 6)
+k = det.detect(synth.frame_4k(2)); h.update(k.tobytes())
+flat = np.full((240, 320), 90, np.uint8); flat[::7, ::5] = 200
+det2 = B.BriskFeatureDetector(30, 3)
+k2 = det2.detect(flat, capacity=65536); h.update(k2.tobytes())
+print(len(k), len(k2), h.hexdigest())
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for knob in ("1", "0"):
+        env = dict(os.environ, BRISK_TR_PAIR=knob)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1], outs
+    assert int(outs[0].split()[0]) > 3000

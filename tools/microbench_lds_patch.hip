@@ -96,6 +96,23 @@ __device__ __forceinline__ void gather_load(Raw& r, const BriskBoxPrep& p, __amd
     r.p22 = __builtin_amdgcn_raw_buffer_load_b96(rs, o_br, 0, 0);
     return;
   }
+  if (WHATIF == 4) {  // no gathers at all: the address stage's values stand in for the data
+    const uint32_t a = (uint32_t)o_tl, b = (uint32_t)o_br;
+    r.p00 = u32x2{a, b}; r.p02 = u32x2{b, a}; r.p10 = u32x2{a + 1, b}; r.p12 = u32x2{b + 1, a}; r.ql = u32x2{a, b + 2}; r.qr = u32x2{b, a + 2};
+    r.p30 = u32x2{a + 3, b}; r.p32 = u32x2{b + 3, a}; r.p20 = u32x3{a, b, a}; r.p22 = u32x3{b, a, b};
+    return;
+  }
+  if (WHATIF >= 5) {  // the ten gathers at their real widths from ONE line per lane (always L1 hits after the first round);
+    // 6 / 7 / 8: two / four / sixteen adjacent lanes share their line
+    const int ln = (int)(threadIdx.x & 63);
+    const int o = WHATIF == 5 ? ln * 128 : WHATIF == 6 ? (ln >> 1) * 128 + (ln & 1) * 3 : WHATIF == 7 ? (ln >> 2) * 128 + (ln & 3) * 3 : (ln >> 4) * 128 + (ln & 15);
+    r.p00 = __builtin_amdgcn_raw_buffer_load_b64(rs, o, 0, 0); r.p02 = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 9, 0, 0);
+    r.p10 = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 18, 0, 0); r.p12 = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 27, 0, 0);
+    r.ql = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 36, 0, 0); r.qr = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 45, 0, 0);
+    r.p20 = __builtin_amdgcn_raw_buffer_load_b96(rs, o + 54, 0, 0); r.p22 = __builtin_amdgcn_raw_buffer_load_b96(rs, o + 69, 0, 0);
+    r.p30 = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 84, 0, 0); r.p32 = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 96, 0, 0);
+    return;
+  }
   if (WHATIF == 3) {
     auto w = [&](int o, int so) { const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rs, o, so, 0); return u32x2{v, v >> 3}; };
     r.p00 = w(o_tl, 0); r.p02 = w(o_tr, 0); r.p10 = w(o_tl, rowb); r.p12 = w(o_tr, rowb);
@@ -875,7 +892,9 @@ int main(int argc, char** argv) {
                          {"151<side<=201", 151, 201}, {"side>201", 201, 100000}, {"all", 0, 100000}};
   struct Var { const char* name; int kind; int src; bool u16; int max_side; };
   const Var vars[] = {{"gather_il2", 9, 1, false, 100000}, {"gather_i24_whatif_8gathers", 0, 11, false, 100000},
-                      {"gather_i24_whatif_30dwords", 0, 12, false, 100000}, {"gather_i24_whatif_10dwords", 0, 13, false, 100000}, {"gather_i24", 0, 1, false, 100000},    {"gather_u32", 0, 0, false, 100000},   {"lds_u16_from_i24", 1, 1, true, 101},
+                      {"gather_i24_whatif_30dwords", 0, 12, false, 100000}, {"gather_i24_whatif_10dwords", 0, 13, false, 100000}, {"gather_i24_whatif_nogathers", 0, 14, false, 100000},
+                      {"gather_i24_whatif_l1hits", 0, 15, false, 100000}, {"gather_i24_whatif_l1hits_pairs", 0, 16, false, 100000},
+                      {"gather_i24_whatif_l1hits_quads", 0, 17, false, 100000}, {"gather_i24_whatif_l1hits_16", 0, 18, false, 100000}, {"gather_i24", 0, 1, false, 100000},    {"gather_u32", 0, 0, false, 100000},   {"lds_u16_from_i24", 1, 1, true, 101},
                       {"lds_u16_from_u32", 1, 0, true, 101}, {"lds_u32_from_u32", 1, 0, false, 201}, {"lds_u32_from_i24", 1, 1, false, 201},
                       {"lds_u16_from_pix", 1, 2, true, 101}, {"lds_u32_from_pix", 1, 2, false, 101},
                       {"lds2_i24_nb13", 2, 1, true, 101}, {"lds2_i24_nb26", 3, 1, true, 101}, {"lds2_u32_nb13", 4, 0, true, 101},
@@ -940,7 +959,7 @@ int main(int argc, char** argv) {
           CHECK(hipEventRecord(e0, 0));
           if (V.kind == 0 || V.kind == 9) {
             const size_t l = 160 * 1024 / 4 + 512;
-            auto fn = V.kind == 9 ? k_gather_il2 : V.src == 11 ? k_gather<true, 1> : V.src == 12 ? k_gather<true, 2> : V.src == 13 ? k_gather<true, 3> :
+            auto fn = V.kind == 9 ? k_gather_il2 : V.src == 11 ? k_gather<true, 1> : V.src == 12 ? k_gather<true, 2> : V.src == 13 ? k_gather<true, 3> : V.src == 14 ? k_gather<true, 4> : V.src == 15 ? k_gather<true, 5> : V.src == 16 ? k_gather<true, 6> : V.src == 17 ? k_gather<true, 7> : V.src == 18 ? k_gather<true, 8> :
                       V.src == 1 ? k_gather<true> : k_gather<false>;
             CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
             hipLaunchKernelGGL(fn, dim3(ncu * wpc), dim3(128), l, 0, A);

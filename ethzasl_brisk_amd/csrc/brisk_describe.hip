@@ -432,6 +432,88 @@ __device__ __forceinline__ int ds_combine(const DsPrep& p, const DsRaw& r) {
   if (__any(p.shift < 0)) return brisk_box_divide(p, acc);  // (a pattern with degenerate boxes: the plain division is compiled in but skipped)
   return brisk_div_by_magic((int)acc, p.magic, p.shift);
 }
+// ---- round 5: the same ten gathers, dealt so that the two lanes of a lane pair read the SAME row ------------------------------
+// What the vector L1 charges a gather for is one tag look-up per lane whose line no neighbouring lane shares
+// (profiles/r05_microbench_il2.txt: ten gathers that all hit cost 0.63 ms with a line per lane, 0.29 with a line per lane pair).
+// A lane is still a pattern point, but of the lane pair (2 k, 2 k + 1) = samples (a, b) five gathers serve a - the even lane
+// reads a's left column pairs, the odd lane a's right ones: the same rows, one line for narrow boxes - and five serve b the same
+// way.  Every lane reduces its side of both samples to six numbers (brisk_box_side), hands the partner's six over by DPP and
+// finishes its own sample (brisk_box_acc_pair).  Microbenchmark: 1.416 -> 1.280 ms on BASELINE config 2's keypoints.
+__device__ __forceinline__ int ds_dpp_even(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xA0, 0xf, 0xf, false); }     // quad_perm(0,0,2,2)
+__device__ __forceinline__ int ds_dpp_odd(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xF5, 0xf, 0xf, false); }      // quad_perm(1,1,3,3)
+__device__ __forceinline__ int ds_dpp_partner(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }  // quad_perm(1,0,3,2)
+struct DsRawPair {
+  ds_u32x2 at0, at1, aq, ab1, bt0, bt1, bq, bb1;  // a*: the gathers that serve the even lane's sample, b*: the odd lane's
+  ds_u32x3 ab0, bb0;
+  unsigned br, bl;                                // the lane's OWN sample: displaced corner pixels from the frame (last column)
+  bool a_quirk, b_quirk;
+};
+template <bool I24>
+__device__ __forceinline__ void ds_load_pair(DsRawPair& r, const DsPrep& p, bool odd, bool pair_valid, bool valid, __amdgpu_buffer_rsrc_t rs_img,
+                                             int stride, int cols, __amdgpu_buffer_rsrc_t rs_int, int istride) {
+  constexpr int ES = I24 ? 3 : 4;
+  const int rowb = istride * ES;
+  const int o_t = p.y_top * rowb, o_b = p.y_bottom * rowb;
+  const int o_tl = o_t + p.x_left * ES, o_tr = o_t + p.x_right * ES, o_bl = o_b + p.x_left * ES, o_br = o_b + p.x_right * ES;
+  // (DPP reads are statements of their own: inside a conditional expression they would run with half of the lanes switched
+  // off and read nothing from them)
+  const int e_tr = ds_dpp_even(o_tr), o_tl_ = ds_dpp_odd(o_tl), e_br = ds_dpp_even(o_br), o_bl_ = ds_dpp_odd(o_bl);
+  const int qk = p.quirk ? 1 : 0;
+  const int e_qk = ds_dpp_even(qk), o_qk = ds_dpp_odd(qk);
+  r.a_quirk = e_qk != 0; r.b_quirk = o_qk != 0;
+  const int a_top = odd ? e_tr : o_tl, b_top = odd ? o_tr : o_tl_;
+  const int a_bot = odd ? e_br : o_bl, b_bot = odd ? o_br : o_bl_;
+  if (pair_valid) {
+    r.at0 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, a_top, 0, 0);
+    r.bt0 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, b_top, 0, 0);
+    r.at1 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, a_top, rowb, 0);
+    r.bt1 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, b_top, rowb, 0);
+    r.aq = __builtin_amdgcn_raw_buffer_load_b64(rs_int, a_bot - rowb + ES, 0, 0);  // row y_bottom - 1, columns c + 1, c + 2
+    r.bq = __builtin_amdgcn_raw_buffer_load_b64(rs_int, b_bot - rowb + ES, 0, 0);
+    r.ab0 = __builtin_amdgcn_raw_buffer_load_b96(rs_int, a_bot, 0, 0);
+    r.bb0 = __builtin_amdgcn_raw_buffer_load_b96(rs_int, b_bot, 0, 0);
+    r.ab1 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, a_bot, rowb, 0);
+    r.bb1 = __builtin_amdgcn_raw_buffer_load_b64(rs_int, b_bot, rowb, 0);
+  }
+  r.br = 0; r.bl = 0;
+  const bool wrap = valid && p.quirk && (p.x_right + 1 >= cols || p.x_left + 1 >= cols);
+  if (__builtin_expect(wrap, 0)) {  // (as ds_load: a box that ends in the image's last column reads the frame)
+    const int qy = max(p.y_bottom - 1, 0), xr = p.x_right + 1, xl = p.x_left + 1, o_q = qy * stride, wr = stride - cols;
+    r.br = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xr + (xr >= cols ? wr : 0), 0, 0);
+    r.bl = __builtin_amdgcn_raw_buffer_load_b8(rs_img, o_q + xl + (xl >= cols ? wr : 0), 0, 0);
+    r.br |= 0x100u; r.bl |= 0x100u;
+  }
+}
+template <bool I24>
+__device__ __forceinline__ BriskBoxSide ds_side(ds_u32x2 t0, ds_u32x2 t1, ds_u32x2 q, ds_u32x3 b0, ds_u32x2 b1, bool quirk, bool right) {
+  uint32_t t0x, t0y, t1x, t1y, qx, qy, b0x, b0y, b0z, b1x, b1y;
+  if (I24) {
+    ds_unpack2(t0, t0x, t0y); ds_unpack2(t1, t1x, t1y); ds_unpack2(q, qx, qy); ds_unpack2(ds_u32x2{b0.x, b0.y}, b0x, b0y); ds_unpack2(b1, b1x, b1y);
+    b0z = __builtin_amdgcn_alignbit(b0.z, b0.y, 16);
+  } else {
+    t0x = t0.x; t0y = t0.y; t1x = t1.x; t1y = t1.y; qx = q.x; qy = q.y; b0x = b0.x; b0y = b0.y; b0z = b0.z; b1x = b1.x; b1y = b1.y;
+  }
+  return brisk_box_side(t0x, t0y, t1x, t1y, qx, qy, b0x, b0y, b0z, b1x, b1y, quirk, right, I24 ? 0xFFFFFFu : 0xFFFFFFFFu);
+}
+template <bool I24>
+__device__ __forceinline__ int ds_combine_pair(const DsPrep& p, const DsRawPair& r, bool odd) {
+  constexpr uint32_t mask = I24 ? 0xFFFFFFu : 0xFFFFFFFFu;
+  const BriskBoxSide sa = ds_side<I24>(r.at0, r.at1, r.aq, r.ab0, r.ab1, r.a_quirk, odd);
+  const BriskBoxSide sb = ds_side<I24>(r.bt0, r.bt1, r.bq, r.bb0, r.bb1, r.b_quirk, odd);
+  // own: my side of my sample; par: the other side of my sample, which the partner lane computed in ITS other set
+  BriskBoxSide own, par;
+#define DS_X(f) own.f = odd ? sb.f : sa.f; par.f = (uint32_t)ds_dpp_partner((int)(odd ? sa.f : sb.f));
+  DS_X(ct) DS_X(cb) DS_X(st) DS_X(dt) DS_X(db) DS_X(dm)
+#undef DS_X
+  if (r.br & 0x100u) {  // displaced corner pixels from the frame: bl belongs to the left side, br to the right one
+    const unsigned pbl = r.bl & 0xFFu, pbr = r.br & 0xFFu;
+    own.cb = odd ? pbr : pbl;
+    par.cb = odd ? pbl : pbr;
+  }
+  const uint32_t acc = brisk_box_acc_pair(p, own, par, odd, mask);
+  if (__any(p.shift < 0)) return brisk_box_divide(p, acc);
+  return brisk_div_by_magic((int)acc, p.magic, p.shift);
+}
 // one sample: address stage + gathers (issue), and its combine stage
 // GENERIC: the pattern has points on the bilinear branch of SmoothedIntensity (sigma < 0.5, :391-408; only with a small
 // patternScale): every sample through the generic function of brisk_device_describe.h
@@ -576,15 +658,31 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
         value = valid ? brisk_smoothed_intensity(F.img, stride, cols, F.integ, istride, Lc.kx, Lc.ky, sp) : 0;
       } else {
         const DsPrep pr = ds_prep(xf, yf, sigma, Lc.tab.z, Lc.tab.w);
-        DsRaw raw;
         if (side && s0 == 0) {
           out.t = take_fn();
           if (lane < ncnt) out.rec = nsrc[lane];
         }
-        __builtin_amdgcn_s_setprio(1);  // a wave that has its gathers to issue goes first (1 % of the kernel)
-        if (valid) ds_load<I24>(raw, pr, F.rs_img, stride, cols, F.rs_int, istride);
-        __builtin_amdgcn_s_setprio(0);
-        value = ds_combine<I24>(pr, raw);
+#ifdef DS_NO_PAIRS  // (A / B builds: one sample's ten gathers per lane everywhere)
+        constexpr bool pairs = false;
+#else
+        // (the 3-byte image only: with 4-byte elements - dense frames - the two column pairs of a row share a line less often and
+        // the exchange costs more than it saves: 64 frames at threshold 30 4.36 -> 4.34 k frames/s, 100 000 keypoints 0.263 -> 0.269 ms)
+        constexpr bool pairs = I24;
+#endif
+        if (!pairs) {
+          DsRaw raw;
+          __builtin_amdgcn_s_setprio(1);  // a wave that has its gathers to issue goes first (1 % of the kernel)
+          if (valid) ds_load<I24>(raw, pr, F.rs_img, stride, cols, F.rs_int, istride);
+          __builtin_amdgcn_s_setprio(0);
+          value = ds_combine<I24>(pr, raw);
+        } else {
+          DsRawPair raw;
+          const bool odd = lane & 1;
+          __builtin_amdgcn_s_setprio(1);
+          ds_load_pair<I24>(raw, pr, odd, s0 + (lane & ~1) < total, valid, F.rs_img, stride, cols, F.rs_int, istride);
+          __builtin_amdgcn_s_setprio(0);
+          value = ds_combine_pair<I24>(pr, raw, odd);
+        }
       }
       if (valid) vals[Lc.slot] = value;
       Lc = Ln;

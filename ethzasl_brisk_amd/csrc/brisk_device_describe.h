@@ -249,6 +249,36 @@ BRISK_HD uint32_t brisk_box_acc(const BriskBoxPrep& p, uint32_t i00, uint32_t i0
   return p.A * tl + p.B * tr + p.C * br + p.D * bl + p.r_y_1_i * top + p.r_y1_i * bottom + p.r_x_1_i * left + p.r_x1_i * right +
          (unsigned)p.scaling * middle;
 }
+// The same sum from the two SIDES of the box (round 5: k_describe reads a box's left and right column pairs on the two lanes
+// of a lane pair, brisk_describe.hip).  A side = the integral samples of one column pair: t0 / t1 = rows y_top, y_top + 1 at
+// columns (c, c + 1); q = row y_bottom - 1 at (c + 1, c + 2); b0 = row y_bottom at (c, c + 1, c + 2); b1 = row y_bottom + 1 at
+// (c, c + 1), with c = x_left or x_right.  It reduces to six numbers: its corner pixels (top; bottom - the displaced one of the
+// reference quirk when p.quirk), its column strip, and three differences down its INNER column (c + 1 on the left, c on the
+// right), from which top / bottom / middle of brisk_box_acc follow as right minus left.  brisk_box_acc_pair(own, partner) is
+// brisk_box_acc for the lane that holds `own` (odd: the right side); tests/test_emul_parity.py checks the identity.
+struct BriskBoxSide {
+  uint32_t ct, cb, st, dt, db, dm;
+};
+BRISK_HD BriskBoxSide brisk_box_side(uint32_t t0x, uint32_t t0y, uint32_t t1x, uint32_t t1y, uint32_t qx, uint32_t qy, uint32_t b0x,
+                                     uint32_t b0y, uint32_t b0z, uint32_t b1x, uint32_t b1y, bool quirk, bool right, uint32_t mask) {
+  BriskBoxSide r;
+  r.ct = (t1y - t0y - t1x + t0x) & mask;
+  r.cb = (quirk ? (b0z - b0y - qy + qx) : (b1y - b0y - b1x + b0x)) & mask;
+  r.st = (b0y - b0x - t1y + t1x) & mask;
+  const uint32_t t0i = right ? t0x : t0y, t1i = right ? t1x : t1y, b0i = right ? b0x : b0y, b1i = right ? b1x : b1y;
+  r.dt = t1i - t0i;
+  r.db = b1i - b0i;
+  r.dm = b0i - t1i;
+  return r;
+}
+BRISK_HD uint32_t brisk_box_acc_pair(const BriskBoxPrep& p, const BriskBoxSide& own, const BriskBoxSide& par, bool odd, uint32_t mask) {
+  const uint32_t tt = par.dt - own.dt, tb = par.db - own.db, tm = par.dm - own.dm;  // right minus left on the even lane
+  const uint32_t top = (odd ? 0u - tt : tt) & mask, bottom = (odd ? 0u - tb : tb) & mask, middle = (odd ? 0u - tm : tm) & mask;
+  const unsigned w_own_t = odd ? p.B : p.A, w_par_t = odd ? p.A : p.B, w_own_b = odd ? p.C : p.D, w_par_b = odd ? p.D : p.C;
+  const unsigned w_own_s = odd ? p.r_x1_i : p.r_x_1_i, w_par_s = odd ? p.r_x_1_i : p.r_x1_i;
+  return w_own_t * own.ct + w_par_t * par.ct + w_own_b * own.cb + w_par_b * par.cb + p.r_y_1_i * top + p.r_y1_i * bottom +
+         w_own_s * own.st + w_par_s * par.st + (unsigned)p.scaling * middle;
+}
 BRISK_HD int brisk_box_divide(const BriskBoxPrep& p, uint32_t acc) {
   return p.shift < 0 ? (int)acc / p.magic : brisk_div_by_magic((int)acc, p.magic, p.shift);
 }

@@ -787,6 +787,10 @@ long emul_div_magic_mismatches_d(int d, const int* numerators, int n) {
 // offset, box corners / weights (brisk_box_prep), the 4 x 4 integral samples + the two displaced corner pixels, the
 // weighted sum (brisk_box_acc), the division by multiplication (brisk_box_divide); points on the bilinear branch through
 // the generic function (the kernel's GENERIC variant)
+// every sample of emul_describe also goes through the two-sided form of the box sum (brisk_box_side / brisk_box_acc_pair:
+// what k_describe's lane pairs compute since round 5), as the even and as the odd lane, on 32-bit and on 24-bit samples
+static long g_pair_checked = 0, g_pair_mismatch = 0;
+extern "C" void emul_box_pair_stats(long* checked, long* mismatches) { *checked = g_pair_checked; *mismatches = g_pair_mismatch; }
 static int emul_sample(const BriskPatternDev& P, const uint8_t* img, int stride, int cols, const uint32_t* integ, int istride, float kx,
                        float ky, int scale, int theta, int i) {
   const int ti = scale * P.npoints + i;
@@ -807,6 +811,28 @@ static int emul_sample(const BriskPatternDev& P, const uint8_t* img, int stride,
   const uint32_t acc = brisk_box_acc(p, r0[p.x_left], r0[p.x_left + 1], r0[p.x_right], r0[p.x_right + 1], r1[p.x_left], r1[p.x_left + 1],
                                      r1[p.x_right], r1[p.x_right + 1], r2[p.x_left], r2[p.x_left + 1], r2[p.x_right], r2[p.x_right + 1],
                                      r3[p.x_left], r3[p.x_left + 1], r3[p.x_right], r3[p.x_right + 1], qbr, qbl);
+  {
+    const bool wrap = p.quirk && (p.x_right + 1 >= cols || p.x_left + 1 >= cols);  // (there the kernel reads the frame)
+    const uint32_t* rq = integ + (long)qy * istride;
+    for (int m24 = 0; m24 < 2; ++m24) {
+      const uint32_t mask = m24 ? 0xFFFFFFu : 0xFFFFFFFFu;
+      auto V = [&](const uint32_t* r, int x) { return r[x] & mask; };
+      BriskBoxSide Ls = brisk_box_side(V(r0, p.x_left), V(r0, p.x_left + 1), V(r1, p.x_left), V(r1, p.x_left + 1), V(rq, p.x_left + 1),
+                                       V(rq, p.x_left + 2), V(r2, p.x_left), V(r2, p.x_left + 1), V(r2, p.x_left + 2), V(r3, p.x_left),
+                                       V(r3, p.x_left + 1), p.quirk, false, mask);
+      BriskBoxSide Rs = brisk_box_side(V(r0, p.x_right), V(r0, p.x_right + 1), V(r1, p.x_right), V(r1, p.x_right + 1), V(rq, p.x_right + 1),
+                                       V(rq, p.x_right + 2), V(r2, p.x_right), V(r2, p.x_right + 1), V(r2, p.x_right + 2), V(r3, p.x_right),
+                                       V(r3, p.x_right + 1), p.quirk, true, mask);
+      if (wrap) { Ls.cb = qbl; Rs.cb = qbr; }
+      const uint32_t want = brisk_box_acc(p, V(r0, p.x_left), V(r0, p.x_left + 1), V(r0, p.x_right), V(r0, p.x_right + 1), V(r1, p.x_left),
+                                          V(r1, p.x_left + 1), V(r1, p.x_right), V(r1, p.x_right + 1), V(r2, p.x_left), V(r2, p.x_left + 1),
+                                          V(r2, p.x_right), V(r2, p.x_right + 1), V(r3, p.x_left), V(r3, p.x_left + 1), V(r3, p.x_right),
+                                          V(r3, p.x_right + 1), qbr, qbl, mask);
+      g_pair_checked += 2;
+      if (brisk_box_acc_pair(p, Ls, Rs, false, mask) != want) ++g_pair_mismatch;
+      if (brisk_box_acc_pair(p, Rs, Ls, true, mask) != want) ++g_pair_mismatch;
+    }
+  }
   return brisk_box_divide(p, acc);
 }
 

@@ -413,3 +413,36 @@ def test_division_by_multiplication_is_exact():
         assert L.emul_div_magic_mismatches(p._h, nums.ctypes.data_as(C.c_void_p), len(nums)) == 0, (version, scale)
     for d in (2, 3, 7, 4095, 4096, 4097, 65535, 65536, 1 << 30, (1 << 30) + 1, 2**31 - 1, 12345677):
         assert L.emul_div_magic_mismatches_d(d, nums.ctypes.data_as(C.c_void_p), len(nums)) == 0, d
+
+
+def test_two_sided_box_sum_equals_the_one_sided_one(golden_ast):
+    """k_describe's lane pairs (round 5) compute a sample's weighted box sum from its two sides - six numbers each
+    (brisk_box_side), combined on the lane that owns the sample (brisk_box_acc_pair, as the even and as the odd lane).  Every
+    sample the emulator describes goes through both forms, on 32-bit and on 24-bit integral samples: a golden image, a
+    1080p frame, and frames whose boxes end in the last column (displaced corner pixels from the frame)."""
+    L = E.lib()
+    L.emul_box_pair_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.emul_box_pair_stats.restype = None
+    c0, m0 = C.c_long(), C.c_long()
+    L.emul_box_pair_stats(C.byref(c0), C.byref(m0))
+    pat = E.Pattern()
+    for img in (golden_ast[0]["image"], synth.frame_1080p(11)):
+        k = O.detect(img, 60, 4)
+        assert len(k) > 50
+        pat.describe(img, k)
+    _, size_list, _ = pat.tables()
+    for w, h in ((426, 320), (333, 201)):
+        img = synth.gen(w, h, 12, 50)
+        k = np.zeros(400, O.KP)
+        rng = np.random.default_rng(w)
+        k["size"] = rng.uniform(8.0, 14.0, len(k)).astype(np.float32)
+        k["y"] = rng.uniform(40, h - 40, len(k)).astype(np.float32)
+        k["angle"] = -1
+        for i in range(len(k)):
+            border = size_list[pat.scale_index(k["size"][i])]
+            k["x"][i] = np.float32(w - border) - np.float32(rng.uniform(0.0, 1.2))
+        pat.describe(img, k)
+    c1, m1 = C.c_long(), C.c_long()
+    L.emul_box_pair_stats(C.byref(c1), C.byref(m1))
+    assert c1.value - c0.value > 500000, c1.value - c0.value
+    assert m1.value == 0 and m0.value == 0

@@ -222,6 +222,203 @@ __global__ void __launch_bounds__(128) k_gather(MbArgs A) {
 }
 
 
+
+// ---- round 5: two lanes per sample, one per box side --------------------------------------------------------------------
+// What the vector L1 charges a gather for is one tag look-up per lane whose line no neighbouring lane shares (the what-if
+// rows above): here lane 2 k reads the left column pairs of sample k's five rows and lane 2 k + 1 the right ones - the same row,
+// the same line when the box is narrow.  Each side reduces its eleven values to six (corner pixel top / bottom, column strip, three
+// inner-column differences), the right lane's six cross to the left lane by DPP, which finishes the sample.
+__device__ __forceinline__ int dpp_partner(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }  // quad_perm(1,0,3,2)
+__global__ void __launch_bounds__(128) k_gather_lr(MbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* vals = reinterpret_cast<int*>(lds + wave * 1024);
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 7);
+  const int np = A.np;
+  const bool right = lane & 1;
+  const int rowb = A.iw * 3;
+  long long sum = 0;
+  for (int gi = 0; gi < 8; ++gi) {
+    const int g = (xcc + gi) & 7;
+    const int nt = A.ntasks[g];
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&A.tickets[g * 32], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nt) break;
+      const uint4 task = A.tasks[(long)g * A.max_tasks + t];
+      const int cnt = (int)task.z >= 0 ? 2 : 1, total = cnt * np;
+      const uint4 rec0 = A.kps[task.y], rec1 = A.kps[cnt == 2 ? task.z : task.y];
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.integ24 + (long)task.x * A.f24_bytes), 0, (int)A.f24_bytes, 0x00020000);
+      int ksum = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int s0 = 0; s0 < total; s0 += 32) {
+          const int s = s0 + (lane >> 1);
+          const bool valid = s < total;
+          const int sc = min(s, total - 1);
+          const int kq = sc >= np ? 1 : 0, pt = sc - kq * np;
+          const uint4 rec = kq ? rec1 : rec0;
+          const int theta = pass ? (int)rec.w : 0;
+          const int4 tab = A.tab4[(int)rec.z * np + pt];
+          const double2 uv = A.uv2[theta * np + pt];
+          const double mm = (double)__int_as_float(tab.x);
+          const float xf = (float)(mm * uv.x) + __uint_as_float(rec.x), yf = (float)(mm * uv.y) + __uint_as_float(rec.y);
+          const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
+          const int xo = (right ? pr.x_right : pr.x_left) * 3;
+          const int o_t = pr.y_top * rowb + xo, o_b = pr.y_bottom * rowb + xo;
+          u32x2 t0 = {0, 0}, t1 = {0, 0}, q = {0, 0}, b1 = {0, 0};
+          u32x3 b0 = {0, 0, 0};
+          if (valid) {
+            t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_t, 0, 0);
+            t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_t, rowb, 0);
+            q = __builtin_amdgcn_raw_buffer_load_b64(rs, o_b - rowb + 3, 0, 0);
+            b0 = __builtin_amdgcn_raw_buffer_load_b96(rs, o_b, 0, 0);
+            b1 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_b, rowb, 0);
+          }
+          constexpr uint32_t m = 0xFFFFFFu;
+          uint32_t t0x, t0y, t1x, t1y, qx, qy, b0x, b0y, b1x, b1y;
+          unpack2(t0, t0x, t0y); unpack2(t1, t1x, t1y); unpack2(q, qx, qy); unpack2(u32x2{b0.x, b0.y}, b0x, b0y); unpack2(b1, b1x, b1y);
+          const uint32_t b0z = __builtin_amdgcn_alignbit(b0.z, b0.y, 16);
+          // the side's six numbers
+          const uint32_t corner_t = (t1y - t0y - t1x + t0x) & m;
+          const uint32_t corner_b = (pr.quirk ? (b0z - b0y - qy + qx) : (b1y - b0y - b1x + b0x)) & m;
+          const uint32_t strip = (b0y - b0x - t1y + t1x) & m;
+          const uint32_t t0i = right ? t0x : t0y, t1i = right ? t1x : t1y, b0i = right ? b0x : b0y, b1i = right ? b1x : b1y;  // the inner column
+          const uint32_t d_top = t1i - t0i, d_bot = b1i - b0i, d_mid = b0i - t1i;
+          // the right lane's numbers cross to the left lane
+          const uint32_t Rct = (uint32_t)dpp_partner((int)corner_t), Rcb = (uint32_t)dpp_partner((int)corner_b), Rst = (uint32_t)dpp_partner((int)strip);
+          const uint32_t Rdt = (uint32_t)dpp_partner((int)d_top), Rdb = (uint32_t)dpp_partner((int)d_bot), Rdm = (uint32_t)dpp_partner((int)d_mid);
+          const uint32_t top = (Rdt - d_top) & m, bottom = (Rdb - d_bot) & m, middle = (Rdm - d_mid) & m;
+          const uint32_t acc = pr.A * corner_t + pr.B * Rct + pr.C * Rcb + pr.D * corner_b + pr.r_y_1_i * top + pr.r_y1_i * bottom +
+                               pr.r_x_1_i * strip + pr.r_x1_i * Rst + (unsigned)pr.scaling * middle;
+          const int value = brisk_div_by_magic((int)acc, pr.magic, pr.shift);
+          if (valid && !right) { vals[sc] = value; ksum += value; }
+        }
+        wave_sync();
+      }
+      int f = vals[lane] + ksum;
+      { int f1 = f ^ 5, f2 = f + 7, f3 = f * 3; for (int k = 0; k < A.filler * cnt / 12; ++k) { f += (f >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; } f ^= f1 ^ f2 ^ f3; }
+      if (f == 0x12345678) ksum += 1;
+      sum += ksum;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
+  if (lane == 0) atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
+}
+
+
+// ---- round 5: one lane per sample, but every gather instruction reads the SAME row on the two lanes of a pair -----------------
+// Lane pair (2 k, 2 k + 1) = samples (a, b).  Five gathers serve a: the even lane reads a's left column pairs, the odd lane a's
+// right ones; five serve b the same way.  Every lane reduces its side of both samples to six numbers, hands the partner's six over
+// (one DPP each) and finishes its own sample: the ALU work of the shipped form plus the exchange, the tag look-ups of gather_lr.
+__device__ __forceinline__ int dpp_even(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xA0, 0xf, 0xf, false); }  // quad_perm(0,0,2,2)
+__device__ __forceinline__ int dpp_odd(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xF5, 0xf, 0xf, false); }   // quad_perm(1,1,3,3)
+struct SideSix { uint32_t ct, cb, st, dt, db, dm; };
+__device__ __forceinline__ SideSix side_six(u32x2 t0, u32x2 t1, u32x2 q, u32x3 b0, u32x2 b1, bool quirk, bool right) {
+  constexpr uint32_t m = 0xFFFFFFu;
+  uint32_t t0x, t0y, t1x, t1y, qx, qy, b0x, b0y, b1x, b1y;
+  unpack2(t0, t0x, t0y); unpack2(t1, t1x, t1y); unpack2(q, qx, qy); unpack2(u32x2{b0.x, b0.y}, b0x, b0y); unpack2(b1, b1x, b1y);
+  const uint32_t b0z = __builtin_amdgcn_alignbit(b0.z, b0.y, 16);
+  SideSix r;
+  r.ct = (t1y - t0y - t1x + t0x) & m;
+  r.cb = (quirk ? (b0z - b0y - qy + qx) : (b1y - b0y - b1x + b0x)) & m;
+  r.st = (b0y - b0x - t1y + t1x) & m;
+  const uint32_t t0i = right ? t0x : t0y, t1i = right ? t1x : t1y, b0i = right ? b0x : b0y, b1i = right ? b1x : b1y;
+  r.dt = t1i - t0i; r.db = b1i - b0i; r.dm = b0i - t1i;
+  return r;
+}
+__global__ void __launch_bounds__(128) k_gather_sw(MbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* vals = reinterpret_cast<int*>(lds + wave * 1024);
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 7);
+  const int np = A.np;
+  const bool odd = lane & 1;
+  const int rowb = A.iw * 3;
+  long long sum = 0;
+  for (int gi = 0; gi < 8; ++gi) {
+    const int g = (xcc + gi) & 7;
+    const int nt = A.ntasks[g];
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&A.tickets[g * 32], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nt) break;
+      const uint4 task = A.tasks[(long)g * A.max_tasks + t];
+      const int cnt = (int)task.z >= 0 ? 2 : 1, total = cnt * np;
+      const uint4 rec0 = A.kps[task.y], rec1 = A.kps[cnt == 2 ? task.z : task.y];
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.integ24 + (long)task.x * A.f24_bytes), 0, (int)A.f24_bytes, 0x00020000);
+      int ksum = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int s0 = 0; s0 < total; s0 += 64) {
+          const int s = s0 + lane;
+          const bool valid = s < total;
+          const bool pair_valid = s0 + (lane & ~1) < total;
+          const int sc = min(s, total - 1);
+          const int kq = sc >= np ? 1 : 0, pt = sc - kq * np;
+          const uint4 rec = kq ? rec1 : rec0;
+          const int theta = pass ? (int)rec.w : 0;
+          const int4 tab = A.tab4[(int)rec.z * np + pt];
+          const double2 uv = A.uv2[theta * np + pt];
+          const double mm = (double)__int_as_float(tab.x);
+          const float xf = (float)(mm * uv.x) + __uint_as_float(rec.x), yf = (float)(mm * uv.y) + __uint_as_float(rec.y);
+          const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
+          const int o_t = pr.y_top * rowb, o_b = pr.y_bottom * rowb;
+          const int o_tl = o_t + pr.x_left * 3, o_tr = o_t + pr.x_right * 3, o_bl = o_b + pr.x_left * 3, o_br = o_b + pr.x_right * 3;
+          // set A serves the even lane's sample, set B the odd lane's; a lane reads its side (even: left, odd: right) of both
+          // (the DPP reads are statements of their own: inside a conditional expression they would run with half of the lanes
+          // switched off and read nothing from them)
+          const int e_tr = dpp_even(o_tr), o_tl_ = dpp_odd(o_tl), e_br = dpp_even(o_br), o_bl_ = dpp_odd(o_bl);
+          const int a_top = odd ? e_tr : o_tl, b_top = odd ? o_tr : o_tl_;
+          const int a_bot = odd ? e_br : o_bl, b_bot = odd ? o_br : o_bl_;
+          const int qk = pr.quirk ? 1 : 0;
+          const bool a_quirk = dpp_even(qk) != 0, b_quirk = dpp_odd(qk) != 0;
+          u32x2 at0 = {0, 0}, at1 = {0, 0}, aq = {0, 0}, ab1 = {0, 0}, bt0 = {0, 0}, bt1 = {0, 0}, bq = {0, 0}, bb1 = {0, 0};
+          u32x3 ab0 = {0, 0, 0}, bb0 = {0, 0, 0};
+          if (pair_valid) {
+            at0 = __builtin_amdgcn_raw_buffer_load_b64(rs, a_top, 0, 0);
+            bt0 = __builtin_amdgcn_raw_buffer_load_b64(rs, b_top, 0, 0);
+            at1 = __builtin_amdgcn_raw_buffer_load_b64(rs, a_top, rowb, 0);
+            bt1 = __builtin_amdgcn_raw_buffer_load_b64(rs, b_top, rowb, 0);
+            aq = __builtin_amdgcn_raw_buffer_load_b64(rs, a_bot - rowb + 3, 0, 0);
+            bq = __builtin_amdgcn_raw_buffer_load_b64(rs, b_bot - rowb + 3, 0, 0);
+            ab0 = __builtin_amdgcn_raw_buffer_load_b96(rs, a_bot, 0, 0);
+            bb0 = __builtin_amdgcn_raw_buffer_load_b96(rs, b_bot, 0, 0);
+            ab1 = __builtin_amdgcn_raw_buffer_load_b64(rs, a_bot, rowb, 0);
+            bb1 = __builtin_amdgcn_raw_buffer_load_b64(rs, b_bot, rowb, 0);
+          }
+          const SideSix sa = side_six(at0, at1, aq, ab0, ab1, a_quirk, odd), sb = side_six(bt0, bt1, bq, bb0, bb1, b_quirk, odd);
+          // mine: my side of my sample; theirs: the partner's side of my sample (the partner computed it in the other set)
+#define SW_X(f) const uint32_t own_##f = odd ? sb.f : sa.f, par_##f = (uint32_t)dpp_partner((int)(odd ? sa.f : sb.f));
+          SW_X(ct) SW_X(cb) SW_X(st) SW_X(dt) SW_X(db) SW_X(dm)
+#undef SW_X
+          constexpr uint32_t m = 0xFFFFFFu;
+          // right minus left: the even lane's own side is the left one
+          const uint32_t tt = par_dt - own_dt, tb = par_db - own_db, tm = par_dm - own_dm;
+          const uint32_t top = (odd ? 0u - tt : tt) & m, bottom = (odd ? 0u - tb : tb) & m, middle = (odd ? 0u - tm : tm) & m;
+          const unsigned w_own_t = odd ? pr.B : pr.A, w_par_t = odd ? pr.A : pr.B, w_own_b = odd ? pr.C : pr.D, w_par_b = odd ? pr.D : pr.C;
+          const unsigned w_own_s = odd ? pr.r_x1_i : pr.r_x_1_i, w_par_s = odd ? pr.r_x_1_i : pr.r_x1_i;
+          const uint32_t acc = w_own_t * own_ct + w_par_t * par_ct + w_own_b * own_cb + w_par_b * par_cb + pr.r_y_1_i * top + pr.r_y1_i * bottom +
+                               w_own_s * own_st + w_par_s * par_st + (unsigned)pr.scaling * middle;
+          const int value = brisk_div_by_magic((int)acc, pr.magic, pr.shift);
+          if (valid) { vals[sc] = value; ksum += value; }
+        }
+        wave_sync();
+      }
+      int f = vals[lane] + ksum;
+      { int f1 = f ^ 5, f2 = f + 7, f3 = f * 3; for (int k = 0; k < A.filler * cnt / 12; ++k) { f += (f >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; } f ^= f1 ^ f2 ^ f3; }
+      if (f == 0x12345678) ksum += 1;
+      sum += ksum;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
+  if (lane == 0) atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
+}
+
 // ---- round 5, second half: the 3-byte integral image with its rows interleaved in pairs --------------------------------
 // Element (y, x) at byte ((y >> 1) * 2 iw + 2 x + (y & 1)) * 3: a 128-byte line holds 21 columns of TWO rows.  The 2 x 2 top
 // block of a box side is one 12-byte gather when y_top is even, two when it is odd; the bottom rows y_bottom - 1 .. + 1 are
@@ -891,7 +1088,7 @@ int main(int argc, char** argv) {
   const Cls classes[] = {{"side<=67", 0, 67}, {"67<side<=101", 67, 101}, {"side<=101", 0, 101}, {"101<side<=151", 101, 151},
                          {"151<side<=201", 151, 201}, {"side>201", 201, 100000}, {"all", 0, 100000}};
   struct Var { const char* name; int kind; int src; bool u16; int max_side; };
-  const Var vars[] = {{"gather_il2", 9, 1, false, 100000}, {"gather_i24_whatif_8gathers", 0, 11, false, 100000},
+  const Var vars[] = {{"gather_sw", 11, 1, false, 100000}, {"gather_lr", 10, 1, false, 100000}, {"gather_il2", 9, 1, false, 100000}, {"gather_i24_whatif_8gathers", 0, 11, false, 100000},
                       {"gather_i24_whatif_30dwords", 0, 12, false, 100000}, {"gather_i24_whatif_10dwords", 0, 13, false, 100000}, {"gather_i24_whatif_nogathers", 0, 14, false, 100000},
                       {"gather_i24_whatif_l1hits", 0, 15, false, 100000}, {"gather_i24_whatif_l1hits_pairs", 0, 16, false, 100000},
                       {"gather_i24_whatif_l1hits_quads", 0, 17, false, 100000}, {"gather_i24_whatif_l1hits_16", 0, 18, false, 100000}, {"gather_i24", 0, 1, false, 100000},    {"gather_u32", 0, 0, false, 100000},   {"lds_u16_from_i24", 1, 1, true, 101},
@@ -923,7 +1120,7 @@ int main(int argc, char** argv) {
             bmax = std::max(bmax, b);
           }
           nkp += (long)sel.size();
-          if (V.kind == 0 || V.kind == 9) {
+          if (V.kind == 0 || V.kind == 9 || V.kind == 10 || V.kind == 11) {
             for (size_t i = 0; i < sel.size(); i += 2)
               tq[g].push_back(make_uint4((unsigned)s, (unsigned)(base[f] + sel[i]), i + 1 < sel.size() ? (unsigned)(base[f] + sel[i + 1]) : 0xFFFFFFFFu, 0));
           } else {
@@ -940,7 +1137,7 @@ int main(int argc, char** argv) {
       if (!nkp) continue;
       std::vector<int> wpcs;
       size_t lds = 0;
-      if (V.kind == 0 || V.kind == 9) {
+      if (V.kind == 0 || V.kind == 9 || V.kind == 10 || V.kind == 11) {
         wpcs = {3};
       } else {
         lds = 512 + (size_t)patch_pw(bmax) * patch_ph(bmax) * (V.u16 ? 2 : 4);
@@ -957,9 +1154,9 @@ int main(int argc, char** argv) {
           CHECK(hipMemsetAsync(d_sum, 0, 8, 0));
           CHECK(hipMemsetAsync(d_phase, 0, 64, 0));
           CHECK(hipEventRecord(e0, 0));
-          if (V.kind == 0 || V.kind == 9) {
+          if (V.kind == 0 || V.kind == 9 || V.kind == 10 || V.kind == 11) {
             const size_t l = 160 * 1024 / 4 + 512;
-            auto fn = V.kind == 9 ? k_gather_il2 : V.src == 11 ? k_gather<true, 1> : V.src == 12 ? k_gather<true, 2> : V.src == 13 ? k_gather<true, 3> : V.src == 14 ? k_gather<true, 4> : V.src == 15 ? k_gather<true, 5> : V.src == 16 ? k_gather<true, 6> : V.src == 17 ? k_gather<true, 7> : V.src == 18 ? k_gather<true, 8> :
+            auto fn = V.kind == 11 ? k_gather_sw : V.kind == 10 ? k_gather_lr : V.kind == 9 ? k_gather_il2 : V.src == 11 ? k_gather<true, 1> : V.src == 12 ? k_gather<true, 2> : V.src == 13 ? k_gather<true, 3> : V.src == 14 ? k_gather<true, 4> : V.src == 15 ? k_gather<true, 5> : V.src == 16 ? k_gather<true, 6> : V.src == 17 ? k_gather<true, 7> : V.src == 18 ? k_gather<true, 8> :
                       V.src == 1 ? k_gather<true> : k_gather<false>;
             CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
             hipLaunchKernelGGL(fn, dim3(ncu * wpc), dim3(128), l, 0, A);
@@ -999,7 +1196,7 @@ int main(int argc, char** argv) {
         printf("%s{\"class\": \"%s\", \"variant\": \"%s\", \"keypoints\": %ld, \"max_border\": %d, \"lds_bytes\": %zu, \"waves_per_cu\": %d, "
                "\"ms\": %.4f, \"samples_per_ns_chip\": %.2f, \"us_per_keypoint_cu\": %.3f, \"checksum\": %llu, "
                "\"wave_us_per_keypoint\": {\"ticket_params\": %.2f, \"staging\": %.2f, \"pass0\": %.2f, \"pass1\": %.2f, \"other\": %.2f}}",
-               first ? "" : ",\n", C.name, V.name, nkp, bmax, lds, (V.kind == 0 || V.kind == 9) ? wpc * 2 : wpc, best_ms, samples / (best_ms * 1e6),
+               first ? "" : ",\n", C.name, V.name, nkp, bmax, lds, (V.kind == 0 || V.kind == 9 || V.kind == 10 || V.kind == 11) ? wpc * 2 : wpc, best_ms, samples / (best_ms * 1e6),
                best_ms * 1e3 * ncu / (double)nkp, sum, php[0] * 0.01 / nkp, php[1] * 0.01 / nkp, php[2] * 0.01 / nkp, php[3] * 0.01 / nkp,
                php[4] * 0.01 / nkp);
         first = false;

@@ -544,10 +544,11 @@ def main():
                      # revision; null when they belong to another revision)
                      "hbm_frac": None if not dom_traffic or dom_ms <= 0 else round(dom_traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "algorithmic_bytes_per_launch": dom_alg, "avg_launch_ms": round(dom_ms, 4), "launches_timed": ncalls,
-                     "note": ("k_describe is bound by the vector L1's line fills for its gathers (ten 128-byte lines moved per sample "
-                              "for 88 bytes used: 47 of the 64 bytes per clock and CU the L1 can take from L2), not by HBM bandwidth, "
-                              "occupancy or instruction issue: DESIGN.md 5, profiles/r05_describe_phases.txt, "
-                              "profiles/r05_microbench_lds_patch.json; " if dom_stage == "k_describe" else "")
+                     "note": ("k_describe is bound by the vector L1's tag look-up rate for its gathers (ten per sample, 88 bytes used; one "
+                              "look-up per lane whose line no neighbouring lane shares, 2 lanes per clock and CU - which is why the two "
+                              "lanes of a lane pair read the same row since round 5), not by HBM bandwidth, occupancy or instruction "
+                              "issue: DESIGN.md 5, profiles/r05_microbench_il2.txt, profiles/r05_describe_phases.txt; "
+                              if dom_stage == "k_describe" else "")
                              + "every kernel group: config.kernel_groups"},
     }
     if rank == 0:

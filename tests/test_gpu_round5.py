@@ -258,3 +258,28 @@ print(len(k), len(k2), h.hexdigest())
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1], outs
     assert int(outs[0].split()[0]) > 3000
+
+
+@pytest.mark.parametrize("drop", [1, 7])
+def test_pair_dealt_gathers_with_odd_pattern_sizes_and_both_image_formats(B, drop):
+    """k_describe deals a sample's gathers to lane pairs (round 5): custom patterns of 65 and 59 points make the run's sample
+    count odd (the last pair has one member, keypoint boundaries fall on odd lanes), few and many keypoints give runs of 1 ... 8,
+    and the integral format is forced to 24 bits (pair form) and to 32 bits (one sample per lane) - the host compute() call on a
+    1080p frame, descriptors and kept keypoints bit-equal to the oracle."""
+    import ptn
+    text = ptn.custom_pattern(3, sigma_factor=1.0, drop_points=drop)
+    img = synth.frame_1080p(17)
+    kall = O.detect(img, 60, 4)
+    assert len(kall) > 1500
+    oext = O.Extractor(True, True, pattern_text=text, pattern_scale=1.0)
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(True, True, pattern_text=text, patternScale=1.0, context=ctx)
+    for fmt in (24, 32):
+        ctx.set_integral_format(fmt)
+        for n in (1, 2, 3, 5, 64, 777, len(kall)):
+            k = np.ascontiguousarray(kall[:n])
+            ko, do = oext.compute(img, k)
+            kg, dg = ext.compute(img, k)
+            assert same_kps(kg, ko), (drop, fmt, n, explain(kg, ko))
+            assert np.array_equal(dg, do), (drop, fmt, n)
+    ctx.close()

@@ -1961,15 +1961,19 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     static const int pair_min_knob = env_knob("BRISK_TR_PAIR_MIN", 0);
     static const int pair_mode_knob = env_knob("BRISK_TR_PAIR_MODE", 1);
     const int pair_min = (pair_min_knob ? pair_min_knob : 4 * (tr_waves - 1)) | (pair_mode_knob << 16);
+    // calls of one or two frames: every layer's ties dealt to `bands` workgroups by image row (brisk_tie_kernel.inc): one 4K frame's tie
+    // stage 0.267 -> 0.210 ms with four, one 1080p frame 121 -> 105 us (two: 0.249 / 118, three: 0.219 / 114); VGA unchanged
+    static const int bands_knob = env_knob("BRISK_TR_BANDS", 0);
+    const int bands = (lpw == 1 && !persist) ? (bands_knob ? min(max(bands_knob, 1), 4) : (nframes <= 2 ? 4 : 1)) : 1;
     if ((nframes <= 64 && pair_knob) || pair_knob == 2)
-      hipLaunchKernelGGL(k_tie_resolve_pair, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, pair_min);
+      hipLaunchKernelGGL(k_tie_resolve_pair, dim3(tr_grid * bands), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
+                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, pair_min, bands);
     else if (nframes < 32)
       hipLaunchKernelGGL(k_tie_resolve_small, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, 0);
+                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, 0, 1);
     else
       hipLaunchKernelGGL(k_tie_resolve, dim3(tr_grid), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
-                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, 0);
+                         B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, 0, 1);
   }
   brisk_prof_mark(prof, BRISK_STG_FINALIZE, s);
   hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(FN_THREADS), 0, s, G, B.cand, B.counters, B.keys, B.kp_out, B.cand_cap,

@@ -1961,10 +1961,15 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     static const int pair_min_knob = env_knob("BRISK_TR_PAIR_MIN", 0);
     static const int pair_mode_knob = env_knob("BRISK_TR_PAIR_MODE", 1);
     const int pair_min = (pair_min_knob ? pair_min_knob : 4 * (tr_waves - 1)) | (pair_mode_knob << 16);
-    // calls of one or two frames: every layer's ties dealt to `bands` workgroups by image row (brisk_tie_kernel.inc): one 4K frame's tie
-    // stage 0.267 -> 0.210 ms with four, one 1080p frame 121 -> 105 us (two: 0.249 / 118, three: 0.219 / 114); VGA unchanged
+    // small calls: every layer's ties dealt to `bands` workgroups by image row (brisk_tie_kernel.inc), as many as leave one
+    // workgroup per CU: one 4K frame's tie stage 0.267 -> 0.210 ms with four, one 1080p frame 121 -> 105 us (two: 0.249 / 118, three:
+    // 0.219 / 114), VGA unchanged; 3 / 4 / 8 frames per call + 7 / 6 / 2.5 %
     static const int bands_knob = env_knob("BRISK_TR_BANDS", 0);
-    const int bands = (lpw == 1 && !persist) ? (bands_knob ? min(max(bands_knob, 1), 4) : (nframes <= 2 ? 4 : 1)) : 1;
+    int bands = 1;
+    if (lpw == 1 && !persist) {
+      bands = bands_knob ? min(max(bands_knob, 1), 4) : (tr_grid * 4 <= pgrid_knob ? 4 : tr_grid * 2 <= pgrid_knob ? 2 : 1);
+      if (tr_grid * bands > pgrid_knob) bands = 1;  // (every ticket needs a resident workgroup: a band waits for the band above)
+    }
     if ((nframes <= 64 && pair_knob) || pair_knob == 2)
       hipLaunchKernelGGL(k_tie_resolve_pair, dim3(tr_grid * bands), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,
                          B.blocks, B.keys, B.cand_cap, B.tie_cap, nframes, lpw, persist, pair_min, bands);

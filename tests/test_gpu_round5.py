@@ -288,8 +288,8 @@ def test_pair_dealt_gathers_with_odd_pattern_sizes_and_both_image_formats(B, dro
 def test_tie_layers_cut_into_row_bands_agree_with_one_workgroup_per_layer(B):
     """One- and two-frame calls deal every layer's ties to up to four workgroups by image row (BRISK_TR_BANDS, read once per
     process: child processes).  A band's first rows wait for pending ties of the band above through the score-state map: an
-    image of nothing but ties (every boundary is crossed by chains), a 4K frame with six octaves, a VGA frame and a batch of two
-    different frames give the same bytes with 1, 2, 3 and 4 bands - and the suite's oracle comparisons run at the default, 4."""
+    image of nothing but ties (every boundary is crossed by chains), a 4K frame with six octaves, a VGA frame, a 1080p frame at
+    threshold 60 and one at threshold 30 (layers beyond the on-chip chunk are not cut, the ones above them are) give the same bytes with 1, 2, 3 and 4 bands - and the suite's oracle comparisons run at the default, 4."""
     import os
     import subprocess
     import sys
@@ -303,7 +303,10 @@ k0 = B.BriskFeatureDetector(30, 3).detect(flat, capacity=65536); h.update(k0.tob
 k1 = B.BriskFeatureDetector(80, 6).detect(synth.frame_4k(2)); h.update(k1.tobytes())
 k2 = B.BriskFeatureDetector(70, 4).detect(synth.frame_vga(1)); h.update(k2.tobytes())
 k3 = B.BriskFeatureDetector(60, 4).detect(synth.frame_1080p(3), capacity=65536); h.update(k3.tobytes())
-print(len(k0), len(k1), len(k2), len(k3), h.hexdigest())
+# threshold 30: the lower layers hold more ties than the on-chip chunk (one workgroup takes all of them), the upper ones are cut
+big = B.Context(0, max_candidates=262144, max_keypoints=65536)
+k4 = B.BriskFeatureDetector(30, 4, context=big).detect(synth.frame_1080p(4), capacity=65536); h.update(k4.tobytes())
+print(len(k0), len(k1), len(k2), len(k3), len(k4), h.hexdigest())
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for bands in ("1", "2", "3", "4"):
@@ -312,5 +315,5 @@ print(len(k0), len(k1), len(k2), len(k3), h.hexdigest())
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert len(set(outs)) == 1, outs
-    counts = [int(v) for v in outs[0].split()[:4]]
-    assert counts[1] > 3000 and counts[3] > 2500, counts
+    counts = [int(v) for v in outs[0].split()[:5]]
+    assert counts[1] > 3000 and counts[3] > 2500 and counts[4] > 20000, counts

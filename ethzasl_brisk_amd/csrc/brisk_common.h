@@ -94,6 +94,7 @@ struct BriskCand {
   uint32_t key;                     // (layer << 26) | (y << 13) | x : output order
 };
 
+#define BRISK_TIE_MAX_BANDS 8
 // per-frame counters (device)
 struct BriskFrameCounters {
   int ncand;                        // appended candidates (may exceed cap -> overflow)
@@ -130,9 +131,9 @@ struct BriskFrameCounters {
 #ifdef TR_TIMELINE  // experiments (build variant): wall-clock stamps of k_tie_resolve per layer (tools/tie_timeline.py)
   int tl[BRISK_MAX_LAYERS * 8];
 #endif
-  // k_tie_resolve_pair with a layer cut into row bands (calls of one or two frames): progress of band b = 1 .. 3 of layer l at
-  // [l * 3 + b - 1] (band 0 uses tie_prog[l]); at the end of the struct: the experiment arrays above keep their offsets
-  int tie_prog_b[BRISK_MAX_LAYERS * 3];
+  // k_tie_resolve_pair with a layer cut into row bands (small calls): progress of band b = 1 .. BRISK_TIE_MAX_BANDS - 1 of layer l at
+  // [l * (BRISK_TIE_MAX_BANDS - 1) + b - 1] (band 0 uses tie_prog[l]); at the end of the struct: the experiment arrays above keep their offsets
+  int tie_prog_b[BRISK_MAX_LAYERS * (BRISK_TIE_MAX_BANDS - 1)];
 };
 
 // descriptor pattern tables (device pointers or host pointers, same layout)

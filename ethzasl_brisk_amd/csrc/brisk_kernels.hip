@@ -1962,12 +1962,12 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     static const int pair_mode_knob = env_knob("BRISK_TR_PAIR_MODE", 1);
     const int pair_min = (pair_min_knob ? pair_min_knob : 4 * (tr_waves - 1)) | (pair_mode_knob << 16);
     // small calls: every layer's ties dealt to `bands` workgroups by image row (brisk_tie_kernel.inc), as many as leave one
-    // workgroup per CU: one 4K frame's tie stage 0.267 -> 0.210 ms with four, one 1080p frame 121 -> 105 us (two: 0.249 / 118, three:
-    // 0.219 / 114), VGA unchanged; 3 / 4 / 8 frames per call + 7 / 6 / 2.5 %
+    // workgroup per CU (8, 4 or 2): one 4K frame's tie stage 0.267 -> 0.179 ms with eight (four: 0.209, two: 0.249), one 1080p frame
+    // 121 -> 99 us (four: 104), VGA 92 -> 82 us; 3 / 4 / 8 frames per call + 7 / 6 / 2.5 % with four (six bands lose: 115 us at 1080p)
     static const int bands_knob = env_knob("BRISK_TR_BANDS", 0);
     int bands = 1;
     if (lpw == 1 && !persist) {
-      bands = bands_knob ? min(max(bands_knob, 1), 4) : (tr_grid * 4 <= pgrid_knob ? 4 : tr_grid * 2 <= pgrid_knob ? 2 : 1);
+      bands = bands_knob ? min(max(bands_knob, 1), BRISK_TIE_MAX_BANDS) : (tr_grid * 8 <= pgrid_knob ? 8 : tr_grid * 4 <= pgrid_knob ? 4 : tr_grid * 2 <= pgrid_knob ? 2 : 1);
       if (tr_grid * bands > pgrid_knob) bands = 1;  // (every ticket needs a resident workgroup: a band waits for the band above)
     }
     if ((nframes <= 64 && pair_knob) || pair_knob == 2)

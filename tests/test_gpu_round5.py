@@ -286,10 +286,10 @@ def test_pair_dealt_gathers_with_odd_pattern_sizes_and_both_image_formats(B, dro
 
 
 def test_tie_layers_cut_into_row_bands_agree_with_one_workgroup_per_layer(B):
-    """One- and two-frame calls deal every layer's ties to up to four workgroups by image row (BRISK_TR_BANDS, read once per
+    """One- and two-frame calls deal every layer's ties to up to eight workgroups by image row (BRISK_TR_BANDS, read once per
     process: child processes).  A band's first rows wait for pending ties of the band above through the score-state map: an
     image of nothing but ties (every boundary is crossed by chains), a 4K frame with six octaves, a VGA frame, a 1080p frame at
-    threshold 60 and one at threshold 30 (layers beyond the on-chip chunk are not cut, the ones above them are) give the same bytes with 1, 2, 3 and 4 bands - and the suite's oracle comparisons run at the default, 4."""
+    threshold 60 and one at threshold 30 (layers beyond the on-chip chunk are not cut, the ones above them are) give the same bytes with 1, 2, 3, 4 and 8 bands - and the suite's oracle comparisons run at the default (8 for one frame)."""
     import os
     import subprocess
     import sys
@@ -309,7 +309,7 @@ k4 = B.BriskFeatureDetector(30, 4, context=big).detect(synth.frame_1080p(4), cap
 print(len(k0), len(k1), len(k2), len(k3), len(k4), h.hexdigest())
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for bands in ("1", "2", "3", "4"):
+    for bands in ("1", "2", "3", "4", "8"):
         env = dict(os.environ, BRISK_TR_BANDS=bands)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -754,7 +754,35 @@ def _other_configs(device, only="", seconds=0.4):
                                   "intervals only; python_wrapper: the same through ethzasl_brisk_amd.BriskDescriptorExtractor.compute "
                                   "(fresh numpy arrays per call)"})
         ctx.close()
+    if want("threads"):
+        res["threads"] = guarded(threads_table, seconds)
     return res
+
+
+def threads_table(seconds):
+    """The drop-in C++ classes (include/brisk/*.h: one thread_local context per host thread) under 1 ... 16 host threads:
+    tests/cpp/test_threads --time, a child process per row; distinct 1080p frames per thread, detect() + compute() per
+    frame, every result compared with the serial run inside the child."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_cpp_classes as tc
+    exe = tc.build_binary("test_threads")
+    rows = []
+    for n in (1, 2, 4, 8, 16):
+        r = subprocess.run([exe, "--time", str(n), str(max(1.0, 3 * seconds))], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            rows.append({"threads": n, "failed": (r.stdout + r.stderr)[-300:]})
+            continue
+        rows.append(json.loads(line[-1]))
+    ok = [r for r in rows if "frames_per_s" in r]
+    base = ok[0]["frames_per_s"] if ok and ok[0]["threads"] == 1 else None
+    return {"workload": "drop-in classes brisk::BriskFeatureDetector::detect + BriskDescriptorExtractor::compute, one 1080p frame per "
+                        "call pair, threshold 80, 4 octaves, N host threads with their own contexts (hip-context.h), pageable cv::Mat-like "
+                        "buffers; aggregate over threads",
+            "unit": "frames/s", "rows": rows,
+            "speedup_vs_1_thread": None if not base else {str(r["threads"]): round(r["frames_per_s"] / base, 2) for r in ok},
+            "host_cpus": len(os.sched_getaffinity(0))}
 
 
 def kernel_groups(stage_ms, groups, fpl, traffic):
@@ -796,10 +824,15 @@ def load_traffic(ctx):
 
 
 def host_fed(ctx, ext, host, chunk, strings, seconds=1.5):
-    """PCIe-fed rate: frames start in pinned HOST memory, the engine's host-batch entry moves them in
-    chunks over a copy stream while the previous chunk computes.  Never `value`: reported next to it."""
+    """PCIe-fed rates: frames start in pinned HOST memory, the engine's host-batch entry moves them in
+    slices over a copy stream while the previous slice computes.  `fps`: results left in HBM (the H2D-only rate);
+    `host_to_host_fps`: keypoints + descriptors of every frame back in pinned host memory as well
+    (brisk_hip_detect_describe_batch_host_results: exact prefix-summed rows, written by the device on the egress stream
+    beside the next batch), two destination sets alternating, every batch waited for before its set is reused.  Never
+    `value`: reported next to it."""
     import numpy as np
     import torch
+    import ethzasl_brisk_amd as B
     n = min(chunk, 256)
     src = torch.from_numpy(np.ascontiguousarray(host[np.arange(n) % len(host)])).pin_memory()
     ctx.detect_describe_batch_host(ext, src.data_ptr(), n, W, H, W * H, W, THRESHOLD, OCTAVES)
@@ -811,8 +844,46 @@ def host_fed(ctx, ext, host, chunk, strings, seconds=1.5):
         reps += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"fps": round(reps * n / dt, 1), "frames_per_call": n,
-            "note": "frames in pinned host memory, H2D on a copy stream overlapped with compute; results stay in HBM"}
+    out = {"fps": round(reps * n / dt, 1), "frames_per_call": n,
+           "note": "fps: frames in pinned host memory, H2D on a copy stream overlapped with compute, results left in HBM; "
+                   "host_to_host_fps: the same with every frame's keypoints + descriptors back in pinned host memory "
+                   "(brisk_hip_detect_describe_batch_host_results, transfer of batch n beside batch n + 1)"}
+    if not hasattr(ctx, "detect_describe_batch_host_results"):
+        return out
+    # rows of one batch (results are still in HBM from the loop above), with room to spare
+    rows = int(1.25 * sum(len(ctx.batch_download(f, True, strings)[0]) for f in range(0, n, max(1, n // 8))) * max(1, n // 8)) + 4096
+    dsts = [B.HostResults(n, rows, strings, pinned=True) for _ in range(2)]
+    tk = [0, 0]
+
+    def issue(i):
+        if tk[i & 1]:
+            assert ctx.batch_download_wait(tk[i & 1]) == 0
+        tk[i & 1] = ctx.detect_describe_batch_host_results(ext, src.data_ptr(), n, W, H, W * H, W, THRESHOLD, OCTAVES, dsts[i & 1])
+    issue(0)
+    issue(1)
+    issue(2)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        issue(reps + 3)
+        reps += 1
+    for i in (0, 1):
+        if tk[i]:
+            assert ctx.batch_download_wait(tk[i]) == 0
+    dt = time.perf_counter() - t0
+    out["host_to_host_fps"] = round(reps * n / dt, 1)
+    out["host_to_host_vs_h2d_only"] = round(out["host_to_host_fps"] / out["fps"], 4)
+    # outside the timed region: the rows the last transfer delivered against the per-frame download of the same batch
+    last = dsts[(reps + 2) & 1]
+    checked = []
+    for f in (0, n // 2, n - 1):
+        k0, d0 = ctx.batch_download(f, True, strings)
+        k1, d1 = last.frame(f, strings)
+        assert len(k0) == len(k1) and np.array_equal(k0.view(np.uint8), np.ascontiguousarray(k1).view(np.uint8)) and np.array_equal(d0, d1), f
+        checked.append(f)
+    out["host_to_host_checked_frames"] = checked
+    out["host_to_host_MB_per_batch"] = round(int(last.offsets[n]) * (28 + strings) / 1e6, 2)
+    return out
 
 
 def gather_selftest(ctx, ext, frames, chunk, strings, stream, gather, rank):

@@ -26,16 +26,24 @@ ABI_SYMBOLS = [
     "brisk_hip_pattern_destroy", "brisk_hip_pattern_descriptor_size", "brisk_hip_pattern_points",
     "brisk_hip_pattern_tables", "brisk_hip_detect", "brisk_hip_describe", "brisk_hip_detect_describe_batch",
     "brisk_hip_detect_batch", "brisk_hip_batch_results", "brisk_hip_batch_download", "brisk_hip_batch_status",
-    "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_debug_counters", "brisk_hip_debug_counters_raw", "brisk_hip_profile_enable", "brisk_hip_profile_stages",
-    "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_debug_set_flags", "brisk_hip_debug_image_reuse", "brisk_hip_set_bucketing", "brisk_hip_halfsample16", "brisk_hip_twothirdsample16",
+    "brisk_hip_profile_enable", "brisk_hip_profile_stages",
+    "brisk_hip_profile_stage_name", "brisk_hip_profile_read", "brisk_hip_set_bucketing", "brisk_hip_halfsample16", "brisk_hip_twothirdsample16",
     "brisk_hip_integral_image16",
     "brisk_hip_set_streams", "brisk_hip_profile_frames_per_launch",
     "brisk_hip_match_knn", "brisk_hip_match_radius", "brisk_hip_match_knn_device", "brisk_hip_set_uniformity",
     "brisk_hip_reserve", "brisk_hip_detect_uniform", "brisk_hip_detect_describe_batch_host", "brisk_hip_stream_ceiling",
     "brisk_hip_kernel_revision", "brisk_hip_compute_scale", "brisk_hip_describe_same_image", "brisk_hip_detect_filtered",
     "brisk_hip_comm_unique_id", "brisk_hip_comm_create", "brisk_hip_comm_destroy", "brisk_hip_comm_rank", "brisk_hip_comm_world",
-    "brisk_hip_comm_gather_results", "brisk_hip_comm_wait", "brisk_hip_debug_filter_keypoints", "brisk_hip_debug_integral_bits",
-    "brisk_hip_set_integral_format", "brisk_hip_debug_forge_pattern_device",
+    "brisk_hip_comm_gather_results", "brisk_hip_comm_wait",
+    "brisk_hip_set_integral_format",
+    "brisk_hip_host_register", "brisk_hip_host_unregister",
+    "brisk_hip_batch_download_all", "brisk_hip_batch_download_wait", "brisk_hip_detect_describe_batch_host_results",
+]
+# every symbol include/brisk_hip_debug.h declares: test / tuning builds (BRISK_HIP_TUNING) only
+DEBUG_SYMBOLS = [
+    "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_debug_counters", "brisk_hip_debug_counters_raw",
+    "brisk_hip_debug_set_flags", "brisk_hip_debug_image_reuse", "brisk_hip_debug_filter_keypoints", "brisk_hip_debug_integral_bits",
+    "brisk_hip_debug_forge_pattern_device",
 ]
 
 
@@ -43,6 +51,48 @@ class PostFilter(C.Structure):
     """brisk_hip_postfilter: the optional post-filters of one detect call"""
     _fields_ = [("uniformity_radius", C.c_double), ("uniformity_max_keypoints", C.c_int), ("num_buckets_u", C.c_int),
                 ("num_buckets_v", C.c_int), ("bucket_max_keypoints", C.c_int)]
+
+
+class BatchHostResults(C.Structure):
+    """brisk_hip_batch_host_results: capacities + the five destination arrays of a whole batch in host memory"""
+    _fields_ = [("frames_cap", C.c_int), ("desc_stride", C.c_int), ("rows_cap", C.c_longlong), ("counts", C.c_void_p),
+                ("flags", C.c_void_p), ("offsets", C.c_void_p), ("kps", C.c_void_p), ("desc", C.c_void_p)]
+
+
+ROWS_CUT = 0x100
+
+
+class HostResults:
+    """Destination arrays of brisk_hip_batch_download_all: `frames` frames, `rows` rows in total, descriptor rows of
+    `desc_stride` bytes (0 = keypoints only).  pinned=True takes them from torch's pinned allocator (the device then writes
+    them directly); otherwise plain NumPy arrays (pageable: the engine goes through its own pinned bounce buffer)."""
+
+    def __init__(self, frames, rows, desc_stride=48, pinned=True):
+        self.frames, self.rows, self.desc_stride = int(frames), int(rows), int(desc_stride)
+        self._keep = []
+
+        def arr(n, dtype):
+            n = max(int(n), 1)
+            if pinned:
+                import torch
+                t = torch.empty(n * np.dtype(dtype).itemsize, dtype=torch.uint8).pin_memory()
+                self._keep.append(t)
+                return t.numpy().view(dtype)
+            return np.empty(n, dtype)
+        self.counts = arr(frames, np.int32)
+        self.flags = arr(frames, np.int32)
+        self.offsets = arr(frames + 1, np.int64)
+        self.kps = arr(rows, KEYPOINT)
+        self.desc = arr(rows * max(desc_stride, 1), np.uint8).reshape(max(rows, 1), max(desc_stride, 1)) if desc_stride else None
+        self.struct = BatchHostResults(self.frames, self.desc_stride or 4, self.rows, self.counts.ctypes.data, self.flags.ctypes.data,
+                                       self.offsets.ctypes.data, self.kps.ctypes.data,
+                                       self.desc.ctypes.data if self.desc is not None else None)
+
+    def frame(self, f, strings=None):
+        """(keypoints, descriptors) of frame f: views of the rows [offsets[f], offsets[f + 1])"""
+        a, b = int(self.offsets[f]), int(self.offsets[f + 1])
+        d = None if self.desc is None else self.desc[a:b, :strings or self.desc_stride]
+        return self.kps[a:b], d
 
 
 class BriskHipError(RuntimeError):
@@ -95,16 +145,24 @@ def load_library():
                                           C.POINTER(vp), ip, ip]
     L.brisk_hip_batch_download.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip, vp, C.c_int]
     L.brisk_hip_batch_status.argtypes = [vp, C.c_int, ip]
-    L.brisk_hip_debug_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, ip]
-    L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
-    L.brisk_hip_debug_integral_bits.argtypes = [vp, C.c_int]
-    L.brisk_hip_debug_counters.argtypes = [vp, C.c_int, vp, ip]
-    L.brisk_hip_debug_counters_raw.argtypes = [vp, C.c_int, vp, C.c_int]
+    if hasattr(L, "brisk_hip_debug_layer"):
+        L.brisk_hip_debug_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, ip]
+    if hasattr(L, "brisk_hip_debug_integral"):
+        L.brisk_hip_debug_integral.argtypes = [vp, C.c_int, vp]
+    if hasattr(L, "brisk_hip_debug_integral_bits"):
+        L.brisk_hip_debug_integral_bits.argtypes = [vp, C.c_int]
+    if hasattr(L, "brisk_hip_debug_counters"):
+        L.brisk_hip_debug_counters.argtypes = [vp, C.c_int, vp, ip]
+    if hasattr(L, "brisk_hip_debug_counters_raw"):
+        L.brisk_hip_debug_counters_raw.argtypes = [vp, C.c_int, vp, C.c_int]
     L.brisk_hip_profile_enable.argtypes = [vp, C.c_int]
-    L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
+    if hasattr(L, "brisk_hip_debug_set_flags"):
+        L.brisk_hip_debug_set_flags.argtypes = [vp, C.c_int]
     L.brisk_hip_set_integral_format.argtypes = [vp, C.c_int]
-    L.brisk_hip_debug_forge_pattern_device.argtypes = [vp, C.c_int]
-    L.brisk_hip_debug_image_reuse.argtypes = [vp]
+    if hasattr(L, "brisk_hip_debug_forge_pattern_device"):
+        L.brisk_hip_debug_forge_pattern_device.argtypes = [vp, C.c_int]
+    if hasattr(L, "brisk_hip_debug_image_reuse"):
+        L.brisk_hip_debug_image_reuse.argtypes = [vp]
     L.brisk_hip_set_bucketing.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     for f in (L.brisk_hip_halfsample16, L.brisk_hip_twothirdsample16, L.brisk_hip_integral_image16):
         f.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
@@ -123,7 +181,8 @@ def load_library():
                                            C.c_double, C.c_int, vp, C.c_int, ip]
     L.brisk_hip_detect_filtered.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                             C.POINTER(PostFilter), vp, C.c_int, ip]
-    L.brisk_hip_debug_filter_keypoints.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, ip]
+    if hasattr(L, "brisk_hip_debug_filter_keypoints"):
+        L.brisk_hip_debug_filter_keypoints.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, ip]
     L.brisk_hip_comm_unique_id.argtypes = [vp]
     L.brisk_hip_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.brisk_hip_comm_destroy.argtypes = [vp]
@@ -136,6 +195,12 @@ def load_library():
                                           C.c_int, ip]
     L.brisk_hip_detect_describe_batch_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
                                                        C.c_int]
+    L.brisk_hip_host_register.argtypes = [vp, C.c_size_t]
+    L.brisk_hip_host_unregister.argtypes = [vp]
+    L.brisk_hip_batch_download_all.argtypes = [vp, C.c_int, C.POINTER(BatchHostResults), vp, C.POINTER(C.c_uint)]
+    L.brisk_hip_batch_download_wait.argtypes = [vp, C.c_uint, ip]
+    L.brisk_hip_detect_describe_batch_host_results.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
+                                                               C.c_int, C.POINTER(BatchHostResults), C.POINTER(C.c_uint)]
     L.brisk_hip_stream_ceiling.argtypes = [vp, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.brisk_hip_kernel_revision.argtypes = []
     L.brisk_hip_kernel_revision.restype = C.c_char_p
@@ -287,6 +352,31 @@ class Context:
         """frames in (pinned) HOST memory: sliced H2D copies on a copy stream overlapped with compute"""
         self.check(self._L.brisk_hip_detect_describe_batch_host(self._h, pattern._h, C.c_void_p(h_frames_ptr), nframes, w,
                                                                 h, frame_pitch, row_pitch, threshold, octaves))
+
+    def batch_download_all(self, dst, described=True, stream=None):
+        """queues the transfer of the last batch's results into `dst` (HostResults); returns the ticket"""
+        t = C.c_uint()
+        self.check(self._L.brisk_hip_batch_download_all(self._h, int(described), C.byref(dst.struct),
+                                                        C.c_void_p(stream) if stream else None, C.byref(t)))
+        return t.value
+
+    def batch_download_wait(self, ticket, check=True):
+        """completes transfer `ticket`; returns the number of flagged frames (check=False: (rc, flagged) instead of raising)"""
+        n = C.c_int()
+        rc = self._L.brisk_hip_batch_download_wait(self._h, ticket, C.byref(n))
+        if not check:
+            return rc, n.value
+        self.check(rc)
+        return n.value
+
+    def detect_describe_batch_host_results(self, pattern, h_frames_ptr, nframes, w, h, frame_pitch, row_pitch, threshold, octaves,
+                                           dst):
+        """host frames in, host results out (everything queued on return); returns the ticket"""
+        t = C.c_uint()
+        self.check(self._L.brisk_hip_detect_describe_batch_host_results(self._h, pattern._h, C.c_void_p(h_frames_ptr), nframes, w, h,
+                                                                        frame_pitch, row_pitch, threshold, octaves,
+                                                                        C.byref(dst.struct), C.byref(t)))
+        return t.value
 
     def reserve(self, min_candidates, min_keypoints):
         self.check(self._L.brisk_hip_reserve(self._h, int(min_candidates), int(min_keypoints)))

@@ -5,8 +5,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libbrisk_hip.so")
-SOURCES = ["brisk_kernels.hip", "brisk_describe.hip", "brisk_image16.hip", "brisk_match.hip", "brisk_uniformity.hip", "brisk_comm.hip", "brisk_capi.hip", "brisk_pattern.cpp"]
+LIB = os.path.join(HERE, "libbrisk_hip.so")                  # tests / tools / bench.py: built with -DBRISK_HIP_TUNING
+LIB_RELEASE = os.path.join(HERE, "libbrisk_hip_release.so")  # what a maintainer links: no env knobs, no debug bits, no brisk_hip_debug_*
+TUNING = ["-DBRISK_HIP_TUNING"]
+SOURCES = ["brisk_kernels.hip", "brisk_describe.hip", "brisk_export.hip", "brisk_image16.hip", "brisk_match.hip", "brisk_uniformity.hip", "brisk_comm.hip", "brisk_capi.hip", "brisk_pattern.cpp"]
 # -ffp-contract=off: the reference binary has no FMA contraction (built with -mssse3 only); the
 # sub-pixel / sub-scale float expressions must round after every operation to stay bit-exact.
 # -simplifycfg-sink-common=false: sinking the common tails of the per-layer-class branches of the refinement code
@@ -19,11 +21,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 LINK_LIBS = ["-ldl"]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "brisk_hip.h")]
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", f) for f in ("brisk_hip.h", "brisk_hip_debug.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
@@ -38,10 +41,11 @@ def kernel_revision():
 
 
 def build_variant(name, defines):
-    """tuning experiments: the same sources with extra -D knobs into ethzasl_brisk_amd/<name>.so (load with BRISK_HIP_LIB)"""
+    """tuning experiments: the same sources with extra -D knobs into ethzasl_brisk_amd/<name>.so (load with BRISK_HIP_LIB);
+    kernel_resources() does not see these builds (it describes the objects of build() / build_release())"""
     out = os.path.join(HERE, name + ".so")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ['-DBRISK_KERNEL_REV="%s"' % kernel_revision(), "-o", out] + \
+    cmd = [hipcc] + FLAGS + TUNING + ["-D" + d for d in defines] + ['-DBRISK_KERNEL_REV="%s"' % kernel_revision(), "-o", out] + \
           [os.path.join(CSRC, s) for s in SOURCES]
     subprocess.check_call(cmd)
     return out
@@ -53,7 +57,7 @@ def _compile_objects(hipcc, flags, objdir, verbose, force):
     import hashlib
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
-    hdrs.append(os.path.join(HERE, "..", "include", "brisk_hip.h"))
+    hdrs += [os.path.join(HERE, "..", "include", f) for f in ("brisk_hip.h", "brisk_hip_debug.h")]
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
     procs, objs = [], []
     for s in SOURCES:
@@ -72,9 +76,11 @@ def _compile_objects(hipcc, flags, objdir, verbose, force):
         if verbose:
             print(" ".join(cmd))
         # (stderr = warnings + the resource remarks of every kernel: kept beside the object for kernel_resources())
-        procs.append((s, stamp, sig, obj + ".log", subprocess.Popen(cmd, stderr=open(obj + ".log", "w"))))
-    for s, stamp, sig, log, p in procs:
+        lf = open(obj + ".log", "w")
+        procs.append((s, stamp, sig, obj + ".log", subprocess.Popen(cmd, stderr=lf), lf))
+    for s, stamp, sig, log, p, lf in procs:
         rc = p.wait()
+        lf.close()
         text = open(log).read()
         diag = _strip_remarks(text)
         if diag.strip():
@@ -117,27 +123,42 @@ def kernel_resources(objdir=None):
         t = open(os.path.join(objdir, f)).read()
         for m in re.finditer(r"Function Name: (\S+).*?\n(.*?)LDS Size \[bytes/block\]: (\d+)", t, re.S):
             body = m.group(2)
-            g = lambda k: int(re.search(k + r": (\d+)", body).group(1))
-            out[m.group(1)] = {"vgpr": g("VGPRs"), "agpr": g("AGPRs"), "sgpr": g("SGPRs"), "scratch": g(r"ScratchSize \[bytes/lane\]"),
-                               "occupancy": g(r"Occupancy \[waves/SIMD\]"), "lds": int(m.group(3))}
+            def g(k):  # (a field the compiler's remark format lacks is left out, not an error)
+                mm = re.search(k + r": (\d+)", body)
+                return int(mm.group(1)) if mm else None
+            rec = {"vgpr": g("VGPRs"), "agpr": g("AGPRs"), "sgpr": g("SGPRs"), "scratch": g(r"ScratchSize \[bytes/lane\]"),
+                   "occupancy": g(r"Occupancy \[waves/SIMD\]"), "lds": int(m.group(3))}
+            out[m.group(1)] = {k: v for k, v in rec.items() if v is not None}
     return out
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+def _build(lib, objdir, extra_flags, force, verbose):
+    if not force and not needs_build(lib):
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    extra = os.environ.get("BRISK_HIPCC_EXTRA", "").split()  # tuning experiments only (e.g. -DBRISK_DETECT_ROWS_PER_THREAD=2)
-    cflags = [f for f in FLAGS if f != "-shared"] + extra
-    objs = _compile_objects(hipcc, cflags, os.path.join(HERE, "..", "build", "obj"), verbose, force)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + LINK_LIBS
+    cflags = [f for f in FLAGS if f != "-shared"] + extra_flags
+    objs = _compile_objects(hipcc, cflags, objdir, verbose, force)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + LINK_LIBS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
+
+
+def build(force=False, verbose=False):
+    """libbrisk_hip.so: the engine with its test / tuning scaffolding (-DBRISK_HIP_TUNING: environment knobs, debug bits,
+    the brisk_hip_debug_* entry points of include/brisk_hip_debug.h) - what the test suite, tools/ and bench.py load"""
+    extra = os.environ.get("BRISK_HIPCC_EXTRA", "").split()  # tuning experiments only (e.g. -DBRISK_DETECT_ROWS_PER_THREAD=2)
+    return _build(LIB, os.path.join(HERE, "..", "build", "obj"), TUNING + extra, force, verbose)
+
+
+def build_release(force=False, verbose=False):
+    """libbrisk_hip_release.so: the same sources without the scaffolding - the library INTEGRATION.md links"""
+    return _build(LIB_RELEASE, os.path.join(HERE, "..", "build", "obj_release"), [], force, verbose)
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_release(force="--force" in sys.argv, verbose=True)

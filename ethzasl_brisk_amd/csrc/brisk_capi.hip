@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/brisk_hip.h"
+#include "../../include/brisk_hip_debug.h"
 #include "brisk_common.h"
 #include "brisk_kernels.h"
 #include "brisk_pattern.h"
@@ -117,7 +118,36 @@ struct brisk_hip_ctx {
     const uint8_t* l0_ext = nullptr;  // layer 0 was read in place from the staging buffer (width a multiple of 64)
     int hits = 0;                     // describe calls that reused the device copy (brisk_hip_debug_image_reuse)
   } img_cache;
+  // brisk_hip_batch_download_all: two slots of {device slab, pinned bounce buffer, events, the transfer in flight}
+  struct ExportSlot {
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+    uint8_t* bounce = nullptr;  // pinned staging for destinations the device cannot write (pageable memory)
+    size_t bounce_bytes = 0;
+    hipEvent_t packed = nullptr, done = nullptr;
+    bool done_valid = false;  // `done` has been recorded: the slab is in use until it fires
+    bool pending = false;     // the transfer has not been completed by a wait yet
+    bool use_bounce = false;
+    unsigned ticket = 0;
+    int nframes = 0;
+    brisk_hip_batch_host_results dst{};  // the caller's destinations
+    brisk_hip_batch_host_results wr{};   // where k_export_egress writes (the caller's arrays, or the bounce buffer)
+    int rc = BRISK_HIP_OK, flagged = 0;
+    std::string msg;
+  } ex[2];
+  hipStream_t egress = nullptr;
+  unsigned ex_seq = 0;
+  int last_strings = 0;  // descriptor bytes of the pattern the last describing call used
 };
+
+// debug bits / environment knobs exist in BRISK_HIP_TUNING builds only (brisk_common.h); the release library sees none
+#ifdef BRISK_HIP_TUNING
+static inline int dbg_flags(const brisk_hip_ctx* c) { return c->debug_flags; }
+static inline const char* tuning_env(const char* name) { return getenv(name); }
+#else
+static inline int dbg_flags(const brisk_hip_ctx*) { return 0; }
+static inline const char* tuning_env(const char*) { return nullptr; }
+#endif
 
 // 64-bit hash over one 8-byte word of every 128 bytes of every row (row-dependent phase): ~130 KB of a 1080p frame, a few
 // microseconds.  A caller that changes the image between detect() and compute() is noticed unless the change avoids all
@@ -335,11 +365,11 @@ static int ensure_stage(brisk_hip_ctx* c, size_t bytes) {
 // 195 - than the smaller image saves.)  Debug bit 18 forces 32, bit 24 forces 24 (stage parity tests of both forms);
 // BRISK_INTEGRAL_BITS=32 / 24 for A / B runs.
 static void integral_format(const brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, bool batch_with_detect, int* ibits) {
-  static const int env = getenv("BRISK_INTEGRAL_BITS") ? atoi(getenv("BRISK_INTEGRAL_BITS")) : 0;
+  static const int env = tuning_env("BRISK_INTEGRAL_BITS") ? atoi(tuning_env("BRISK_INTEGRAL_BITS")) : 0;
   *ibits = 32;
   if (!pat || !pat->dev.int24_ok) return;
-  if (env == 32 || (ctx->debug_flags & (1 << 18))) return;
-  if (env == 24 || (ctx->debug_flags & (1 << 24))) { *ibits = 24; return; }
+  if (env == 32 || (dbg_flags(ctx) & (1 << 18))) return;
+  if (env == 24 || (dbg_flags(ctx) & (1 << 24))) { *ibits = 24; return; }
   if (ctx->integral_fmt == BRISK_HIP_INTEGRAL_U32) return;                     // brisk_hip_set_integral_format
   if (ctx->integral_fmt == BRISK_HIP_INTEGRAL_U24) { *ibits = 24; return; }
   if (!batch_with_detect) return;
@@ -386,6 +416,23 @@ int brisk_hip_device_count(void) {
   return n;
 }
 
+int brisk_hip_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return BRISK_HIP_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BRISK_HIP_ERR_NO_DEVICE;
+  const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (e == hipSuccess) return BRISK_HIP_OK;
+  (void)hipGetLastError();
+  return e == hipErrorHostMemoryAlreadyRegistered ? BRISK_HIP_ERR_ARG : BRISK_HIP_ERR_HIP;
+}
+
+int brisk_hip_host_unregister(void* ptr) {
+  if (!ptr) return BRISK_HIP_ERR_ARG;
+  if (hipHostUnregister(ptr) == hipSuccess) return BRISK_HIP_OK;
+  (void)hipGetLastError();
+  return BRISK_HIP_ERR_ARG;
+}
+
 int brisk_hip_create(int device, brisk_hip_ctx** out) {
   if (!out) return BRISK_HIP_ERR_ARG;
   *out = nullptr;
@@ -421,6 +468,13 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
     if (c->consumed_ev[i]) hipEventDestroy(c->consumed_ev[i]);
   }
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  for (auto& E : c->ex) {
+    if (E.slab) hipFree(E.slab);
+    if (E.bounce) hipHostFree(E.bounce);
+    if (E.packed) hipEventDestroy(E.packed);
+    if (E.done) hipEventDestroy(E.done);
+  }
+  if (c->egress) hipStreamDestroy(c->egress);
   if (c->d_occ) hipFree(c->d_occ);
   if (c->d_uni_tmp) hipFree(c->d_uni_tmp);
   if (c->d_uni_order) hipFree(c->d_uni_order);
@@ -552,7 +606,7 @@ int brisk_hip_pattern_create_from_text(brisk_hip_ctx* ctx, const char* ptn_text,
 
 void brisk_hip_pattern_destroy(brisk_hip_pattern* p) {
   if (!p) return;
-  hipSetDevice(p->device);
+  hipSetDevice(p->true_device);  // (p->device may be forged by a test: only the guard comparison reads it)
   if (p->blob) hipFree(p->blob);
   delete p;
 }
@@ -623,7 +677,7 @@ static int batch_begin(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipS
   if (rc) return rc;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   make_geometry(A.w, A.h, A.threshold, A.octaves, &ctx->G, &ctx->T);
-  ctx->G.debug_flags = ctx->debug_flags;
+  ctx->G.debug_flags = dbg_flags(ctx);
   ctx->G.no_scale_nms = (A.no_scale_nms && A.octaves != 0) ? 1 : 0;
   ctx->G.lower_threshold = A.lower_threshold;
   if (A.do_describe && A.pat && A.pat->host.strings > ctx->desc_pitch) ctx->desc_pitch = brisk_align_up(A.pat->host.strings, 16);
@@ -674,13 +728,13 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
   Di.desc += f0 * Bi.kp_cap * Di.desc_pitch;
   BriskOverlap ov{};
   const BriskOverlap* ovp = nullptr;
-  if (A.do_detect && A.do_describe && overlap_integral && ctx->overlap && !(ctx->debug_flags & 0x10000)) {
+  if (A.do_detect && A.do_describe && overlap_integral && ctx->overlap && !(dbg_flags(ctx) & 0x10000)) {
     if (!ctx->side) {
       // lowest priority: the detector's latency-bound kernels get their workgroups placed first, the
       // bandwidth-bound integral kernel fills what they leave
       int least = 0, greatest = 0;
       HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-      const char* pe = getenv("BRISK_SIDE_PRIO");  // tuning experiments: 0 = default priority for the side stream
+      const char* pe = tuning_env("BRISK_SIDE_PRIO");  // tuning experiments: 0 = default priority for the side stream
       HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, (pe && atoi(pe) == 0) ? 0 : least));
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
@@ -692,7 +746,7 @@ static int batch_slice(brisk_hip_ctx* ctx, const BatchArgs& A, const uint8_t* d_
   // the ordered path and ComputeScale keep their private copy)
   BriskGeom Gs = ctx->G;
   {
-    static const bool inplace_on = !(getenv("BRISK_L0_INPLACE") && atoi(getenv("BRISK_L0_INPLACE")) == 0);
+    static const bool inplace_on = !(tuning_env("BRISK_L0_INPLACE") && atoi(tuning_env("BRISK_L0_INPLACE")) == 0);
     const bool ordered = Gs.threshold < BRISK_FAST_PATH_MIN_THRESHOLD || Gs.no_scale_nms || Gs.lower_threshold != BRISK_LOWER_THRESHOLD;
     // (width == stride: the caller's rows have no pad columns, so nothing is read that the argument check did not
     // cover - a pitch of align_up(width, 64) with width % 64 != 0 would make the clamped 16-byte loads read the caller's
@@ -745,6 +799,7 @@ static int batch_end(brisk_hip_ctx* ctx, const BatchArgs& A, int nframes, hipStr
   ctx->last_nframes = nframes;
   ctx->last_has_desc = A.do_describe;
   ctx->last_desc_pitch = ctx->D.desc_pitch;
+  if (A.do_describe && A.pat) ctx->last_strings = A.pat->host.strings;
   const int rc = workspace_release(ctx, s);
   if (rc) return fail(ctx, rc, "hipEventRecord failed");
   return BRISK_HIP_OK;
@@ -760,7 +815,7 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
   if (int rcp = check_pattern_device(ctx, pat)) return rcp;
   // timing experiments only (debug bit 27): the descriptor half of a batch alone, on the keypoints the previous batch left
   const bool full_batch = do_detect && do_describe;
-  if (do_detect && do_describe && (ctx->debug_flags & (1 << 27)) && ctx->last_nframes >= nframes) do_detect = false;
+  if (do_detect && do_describe && (dbg_flags(ctx) & (1 << 27)) && ctx->last_nframes >= nframes) do_detect = false;
   BatchArgs A{pat, w, h, threshold, octaves, frame_pitch, row_pitch, d_mask, mask_frame_pitch, mask_row_pitch, do_detect,
               do_describe, uni_radius < 0.0 ? ctx->uni_radius : uni_radius, uni_radius < 0.0 ? ctx->uni_max : uni_max};
   A.no_scale_nms = no_scale_nms;
@@ -786,9 +841,9 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
   // timing experiments only (debug bits 20-23 = g with bit 27): the descriptor half in groups of 8 g frames, one after the
   // other on `s` (integral image of a group -> its descriptors: is the integral still in the Infinity Cache?); bit 19: the
   // integral images of all frames first, then the groups (the same launches with a stale cache)
-  const int grp = 8 * ((ctx->debug_flags >> 20) & 0xF);
+  const int grp = 8 * ((dbg_flags(ctx) >> 20) & 0xF);
   if (grp > 0 && !do_detect && do_describe) {
-    if (ctx->debug_flags & (1 << 19))
+    if (dbg_flags(ctx) & (1 << 19))
       brisk_launch_integral(ctx->G, ctx->B.pyr, ctx->B.bandsum, ctx->D.integral, ctx->D.istride, ctx->D.iframe_elems, ctx->B.band_h, nframes, s);
     for (long f0 = 0; f0 < nframes; f0 += grp) {
       const int nf = (int)((nframes - f0) < grp ? (nframes - f0) : grp);
@@ -823,15 +878,12 @@ static int run_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uin
 
 // ---- host-fed batch: frames in (pinned) host memory, H2D on a copy stream overlapped with compute ---------------
 static int host_slice_frames() {
-  static const int v = [] { const char* e = getenv("BRISK_HOST_SLICE"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 64; }();
+  static const int v = [] { const char* e = tuning_env("BRISK_HOST_SLICE"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 64; }();
   return v;
 }
 
-int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames,
-                                         int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
-                                         int octaves) {
-  if (!ctx || !pat) return BRISK_HIP_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames, int nframes, int w, int h,
+                             long frame_pitch, int row_pitch, int threshold, int octaves) {
   if (!h_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   if (int rcp = check_pattern_device(ctx, pat)) return rcp;
@@ -897,6 +949,14 @@ int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pat
   }
   guard.armed = false;  // batch_end records the event itself
   return batch_end(ctx, A, nframes, s);
+}
+
+int brisk_hip_detect_describe_batch_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames,
+                                         int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
+                                         int octaves) {
+  if (!ctx || !pat) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return batch_host_locked(ctx, pat, h_frames, nframes, w, h, frame_pitch, row_pitch, threshold, octaves);
 }
 
 int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes,
@@ -1016,7 +1076,7 @@ static int download_single(brisk_hip_ctx* ctx, int which, brisk_hip_keypoint* kp
   const unsigned o_cnt = 64, o_kp = (unsigned)((o_cnt + sizeof(BriskFrameCounters) + 255) & ~(size_t)255);
   const size_t row = sizeof(BriskKeyPoint) + (want_desc ? (size_t)dev_pitch : 0);
   // (debug bit 25: a 16 KB limit, so that tests reach the staged-copy path with a few hundred keypoints)
-  const size_t limit = (ctx->debug_flags & (1 << 25)) ? (size_t)o_kp + 256 + 16384 : (size_t)BRISK_SINGLE_BYTES;
+  const size_t limit = (dbg_flags(ctx) & (1 << 25)) ? (size_t)o_kp + 256 + 16384 : (size_t)BRISK_SINGLE_BYTES;
   long max_kp = kps ? (long)((limit - o_kp - 256) / row) : 0;
   if (max_kp > cap) max_kp = cap;
   if (max_kp > ctx->B.kp_cap) max_kp = ctx->B.kp_cap;
@@ -1073,6 +1133,212 @@ int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which, brisk_hip
   // descriptor width of the last describe is not stored per call: copy the full pitch-limited row
   const int pitch = ctx->last_desc_pitch ? ctx->last_desc_pitch : ctx->D.desc_pitch;
   return download_locked(ctx, frame, which, kps, cap, n, desc, desc_stride, desc_stride < pitch ? desc_stride : pitch, pitch);
+}
+
+// ---- the batch path's exit to host memory (brisk_hip_batch_download_all; kernels: brisk_export.hip) ------------------
+// Can the device write to this address?  Pinned / registered host memory, managed and device memory: yes (through the
+// device-side alias the runtime reports); pageable host memory: no - the transfer then lands in the context's pinned bounce
+// buffer and brisk_hip_batch_download_wait copies it out.
+static bool device_can_write(const void* p, void** dev) {
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // (an unregistered pointer is an error on older runtimes, hipMemoryTypeUnregistered on newer ones)
+    return false;
+  }
+  if (a.type != hipMemoryTypeHost && a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged && a.type != hipMemoryTypeUnified)
+    return false;
+  *dev = a.devicePointer ? a.devicePointer : const_cast<void*>(p);
+  return true;
+}
+
+// byte offsets of the five arrays inside a slab / bounce buffer holding `frames` frames and `rows` rows
+struct ExportLayout {
+  size_t counts, flags, offsets, kps, desc, bytes;
+  ExportLayout(int frames, long long rows, int desc_stride) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    counts = 0;
+    flags = up(counts + sizeof(int) * (size_t)frames);
+    offsets = up(flags + sizeof(int) * (size_t)frames);
+    kps = up(offsets + sizeof(long long) * ((size_t)frames + 1));
+    desc = up(kps + sizeof(BriskKeyPoint) * (size_t)rows);
+    bytes = up(desc + (size_t)rows * (size_t)desc_stride) + 256;
+  }
+};
+
+// the egress kernel of slot E has finished (ctx->mu held): status of the transfer, and - for a pageable destination - the
+// copy out of the bounce buffer
+static void export_finish(brisk_hip_ctx* ctx, brisk_hip_ctx::ExportSlot& E) {
+  const brisk_hip_batch_host_results& W = E.wr;
+  int flagged = 0, orf = 0;
+  for (int f = 0; f < E.nframes; ++f)
+    if (W.flags[f]) { ++flagged; orf |= W.flags[f]; }
+  if (E.use_bounce) {
+    const long long rows = W.offsets[E.nframes];
+    memcpy(E.dst.counts, W.counts, sizeof(int) * (size_t)E.nframes);
+    memcpy(E.dst.flags, W.flags, sizeof(int) * (size_t)E.nframes);
+    memcpy(E.dst.offsets, W.offsets, sizeof(long long) * ((size_t)E.nframes + 1));
+    if (rows > 0) memcpy(E.dst.kps, W.kps, sizeof(BriskKeyPoint) * (size_t)rows);
+    if (rows > 0 && E.dst.desc) memcpy(E.dst.desc, W.desc, (size_t)rows * (size_t)E.dst.desc_stride);
+  }
+  E.pending = false;
+  E.flagged = flagged;
+  E.rc = BRISK_HIP_OK;
+  E.msg.clear();
+  if (flagged) {
+    char msg[200];
+    if (orf & 7) {
+      E.rc = overflow_to_rc(ctx, orf);
+      E.msg = ctx->err;
+    } else if (orf & BRISK_HIP_ROWS_CUT) {
+      snprintf(msg, sizeof msg, "%d frame(s) did not fit the destination's rows_cap (flags[f] & BRISK_HIP_ROWS_CUT); their counts are reported",
+               flagged);
+      E.rc = BRISK_HIP_ERR_CAPACITY;
+      E.msg = msg;
+    } else {
+      E.rc = overflow_to_rc(ctx, orf);
+      E.msg = ctx->err;
+    }
+  }
+}
+
+static int download_all_locked(brisk_hip_ctx* ctx, int which, const brisk_hip_batch_host_results* dst, hipStream_t s, unsigned* ticket) {
+  if (!dst || !ticket || (which != 0 && which != 1)) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: null destination / ticket, or which not 0 / 1");
+  *ticket = 0;
+  const int nframes = ctx->last_nframes;
+  if (nframes <= 0 || !ctx->B.counters) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: no batch has run on this context");
+  if (which && !ctx->last_has_desc) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: the last batch described nothing (which = 1)");
+  const int strings = which ? ctx->last_strings : 0;
+  const bool want_desc = which && dst->desc;
+  if (dst->frames_cap < nframes || dst->rows_cap < 0 || !dst->counts || !dst->flags || !dst->offsets || (dst->rows_cap > 0 && !dst->kps))
+    return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: frames_cap below the batch's frames, or a null counts / flags / offsets / kps array");
+  if (want_desc && (dst->desc_stride < strings || dst->desc_stride % 4 || strings % 4 || strings <= 0))
+    return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: desc_stride must be a multiple of 4 and at least the descriptor size");
+  if ((((uintptr_t)dst->counts | (uintptr_t)dst->flags | (uintptr_t)dst->kps | (uintptr_t)dst->desc) & 3) || ((uintptr_t)dst->offsets & 7))
+    return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: destination arrays must be 4-byte aligned (offsets: 8)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int dstride = want_desc ? dst->desc_stride : 4;
+  brisk_hip_ctx::ExportSlot& E = ctx->ex[(ctx->ex_seq + 1) & 1];
+  if (!ctx->egress) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->egress, hipStreamNonBlocking));
+  if (!E.packed) {
+    HIPCHK(ctx, hipEventCreateWithFlags(&E.packed, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&E.done, hipEventDisableTiming));
+  }
+  if (E.pending) {  // a third transfer in flight: complete the oldest first
+    HIPCHK(ctx, hipEventSynchronize(E.done));
+    export_finish(ctx, E);
+  }
+  const ExportLayout LY(dst->frames_cap, dst->rows_cap, dstride);
+  if (LY.bytes > E.slab_bytes) {
+    if (E.done_valid) HIPCHK(ctx, hipEventSynchronize(E.done));
+    if (E.slab) (void)hipFree(E.slab);
+    E.slab = nullptr; E.slab_bytes = 0;
+    HIPCHK(ctx, hipMalloc(&E.slab, LY.bytes));
+    E.slab_bytes = LY.bytes;
+  }
+  // where the egress kernel writes: the caller's arrays when the device can reach all of them, else the bounce buffer
+  brisk_hip_batch_host_results W = *dst;
+  void* dv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const bool direct = device_can_write(dst->counts, &dv[0]) && device_can_write(dst->flags, &dv[1]) && device_can_write(dst->offsets, &dv[2]) &&
+                (dst->rows_cap == 0 || device_can_write(dst->kps, &dv[3])) && (!want_desc || device_can_write(dst->desc, &dv[4]));
+  if (direct) {
+    W.counts = static_cast<int*>(dv[0]); W.flags = static_cast<int*>(dv[1]); W.offsets = static_cast<long long*>(dv[2]);
+    W.kps = static_cast<brisk_hip_keypoint*>(dv[3]); W.desc = want_desc ? static_cast<uint8_t*>(dv[4]) : nullptr;
+  } else {
+    if (LY.bytes > E.bounce_bytes) {
+      if (E.bounce) (void)hipHostFree(E.bounce);
+      E.bounce = nullptr; E.bounce_bytes = 0;
+      HIPCHK(ctx, hipHostMalloc((void**)&E.bounce, LY.bytes, hipHostMallocDefault));
+      E.bounce_bytes = LY.bytes;
+    }
+    W.counts = reinterpret_cast<int*>(E.bounce + LY.counts); W.flags = reinterpret_cast<int*>(E.bounce + LY.flags);
+    W.offsets = reinterpret_cast<long long*>(E.bounce + LY.offsets); W.kps = reinterpret_cast<brisk_hip_keypoint*>(E.bounce + LY.kps);
+    W.desc = want_desc ? E.bounce + LY.desc : nullptr;
+  }
+  uint8_t* sl = static_cast<uint8_t*>(E.slab);
+  const BriskExportSlab S{reinterpret_cast<int*>(sl + LY.counts), reinterpret_cast<int*>(sl + LY.flags),
+                          reinterpret_cast<long long*>(sl + LY.offsets), reinterpret_cast<uint32_t*>(sl + LY.kps),
+                          reinterpret_cast<uint32_t*>(sl + LY.desc)};
+  if (workspace_acquire(ctx, s)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
+  WorkspaceGuard guard(ctx, s);
+  if (E.done_valid) HIPCHK(ctx, hipStreamWaitEvent(s, E.done, 0));  // the slab's previous transfer
+  const int dev_pitch = ctx->last_desc_pitch ? ctx->last_desc_pitch : ctx->D.desc_pitch;
+  brisk_launch_export_pack(ctx->B.counters, which ? ctx->D.dkp : ctx->B.kp_out, want_desc ? ctx->D.desc : nullptr, ctx->B.kp_cap, dev_pitch,
+                           want_desc ? strings : 4, nframes, which, dst->rows_cap, dstride, BRISK_HIP_ROWS_CUT, S, s);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(E.packed, s));
+  if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->egress, E.packed, 0));
+  static const bool egress_off = tuning_env("BRISK_EXPORT_EGRESS") && atoi(tuning_env("BRISK_EXPORT_EGRESS")) == 0;  // timing experiments: pack only (the destination stays unwritten)
+  if (!egress_off) brisk_launch_export_egress(S, nframes, dstride, W.counts, W.flags, W.offsets, W.kps, W.desc, ctx->egress);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(E.done, ctx->egress));
+  E.done_valid = true;
+  E.pending = true;
+  E.use_bounce = !direct;
+  E.nframes = nframes;
+  E.dst = *dst;
+  if (!want_desc) E.dst.desc = nullptr;
+  if (direct) {  // the host reads the caller's own arrays
+    W = *dst;
+    if (!want_desc) W.desc = nullptr;
+  }
+  E.wr = W;
+  E.ticket = ++ctx->ex_seq;
+  if (!E.ticket) E.ticket = ++ctx->ex_seq;  // (0 is never a ticket)
+  *ticket = E.ticket;
+  return BRISK_HIP_OK;
+}
+
+int brisk_hip_batch_download_all(brisk_hip_ctx* ctx, int which, const brisk_hip_batch_host_results* dst, void* stream,
+                                 unsigned* ticket) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return download_all_locked(ctx, which, dst, stream ? (hipStream_t)stream : ctx->stream, ticket);
+}
+
+int brisk_hip_batch_download_wait(brisk_hip_ctx* ctx, unsigned ticket, int* frames_flagged) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  if (frames_flagged) *frames_flagged = 0;
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BRISK_HIP_ERR_HIP, "hipSetDevice failed");
+  // the transfers up to `ticket`, oldest first; the lock is released while the host waits for the device
+  for (int pass = 0; pass < 2; ++pass) {
+    brisk_hip_ctx::ExportSlot* E = nullptr;
+    for (auto& X : ctx->ex)
+      if (X.pending && (int)(X.ticket - ticket) <= 0 && (!E || (int)(X.ticket - E->ticket) < 0)) E = &X;
+    if (!E) break;
+    const unsigned t = E->ticket;
+    hipEvent_t ev = E->done;
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(ev);
+    lk.lock();
+    if (e != hipSuccess) {
+      ctx->err = std::string("brisk_hip_batch_download_wait: ") + hipGetErrorString(e);
+      return BRISK_HIP_ERR_HIP;
+    }
+    if (E->pending && E->ticket == t) export_finish(ctx, *E);  // (unless another thread completed it meanwhile)
+  }
+  for (auto& X : ctx->ex)
+    if (X.ticket == ticket && ticket != 0 && !X.pending) {
+      if (frames_flagged) *frames_flagged = X.flagged;
+      if (X.rc) ctx->err = X.msg;
+      return X.rc;
+    }
+  return fail(ctx, BRISK_HIP_ERR_ARG, "download_wait: unknown ticket (never issued on this context, or two later transfers have replaced it)");
+}
+
+int brisk_hip_detect_describe_batch_host_results(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames,
+                                                 int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
+                                                 int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket) {
+  if (!ctx || !pat) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!dst || !ticket) return fail(ctx, BRISK_HIP_ERR_ARG, "null destination / ticket");
+  *ticket = 0;
+  if (dst->frames_cap < nframes) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: frames_cap below the batch's frames");
+  const int rc = batch_host_locked(ctx, pat, h_frames, nframes, w, h, frame_pitch, row_pitch, threshold, octaves);
+  if (rc) return rc;
+  return download_all_locked(ctx, 1, dst, ctx->stream, ticket);
 }
 
 // ---- host-buffer calls ---------------------------------------------------------------------------
@@ -1170,7 +1436,7 @@ int brisk_hip_compute_scale(brisk_hip_ctx* ctx, const uint8_t* img, int w, int h
     return download_single(ctx, 0, out, cap, n, nullptr, 0, 0, 0, ctx->spec_nkp < cap ? ctx->spec_nkp : cap);
   }
   make_geometry(w, h, threshold, octaves, &ctx->G, &ctx->T);
-  ctx->G.debug_flags = ctx->debug_flags;
+  ctx->G.debug_flags = dbg_flags(ctx);
   ctx->G.lower_threshold = 0;
   rc = ensure_buffers(ctx, 1, ctx->G);
   if (rc) return rc;
@@ -1254,6 +1520,7 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
   ctx->last_nframes = 1;
   ctx->last_has_desc = true;
   ctx->last_desc_pitch = Dd.desc_pitch;
+  ctx->last_strings = pat->host.strings;
   if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
   return download_single(ctx, 1, kps, n_in, n, desc, desc_stride, pat->host.strings, Dd.desc_pitch, n_in);
 }
@@ -1353,7 +1620,7 @@ static int match_host(brisk_hip_ctx* ctx, const uint8_t* query, int nq, int q_pi
                                      hipMemcpyHostToDevice, s));
   }
   bool fused = false;
-  if (mode == 0 && !d_mask && !(ctx->debug_flags & 0x20000)) {
+  if (mode == 0 && !d_mask && !(dbg_flags(ctx) & 0x20000)) {
     int nonempty = 0, first = -1;
     for (int i = 0; i < nimg; ++i)
       if (ntrain[i] > 0) { ++nonempty; if (first < 0) first = i; }
@@ -1419,7 +1686,7 @@ int brisk_hip_match_knn_device(brisk_hip_ctx* ctx, const uint8_t* d_query, int n
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int dim16 = (dim_bytes / 16) * 16;
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-  if (!(ctx->debug_flags & 0x20000) &&
+  if (!(dbg_flags(ctx) & 0x20000) &&
       brisk_launch_match_knn_fused(d_query, q_pitch, nq, d_train, t_pitch, nt, dim16 / 4, k,
                                    reinterpret_cast<BriskDMatch*>(d_out), d_out_count, st)) {
     HIPCHK(ctx, hipGetLastError());
@@ -1621,6 +1888,8 @@ int brisk_hip_set_integral_format(brisk_hip_ctx* ctx, int format) {
   return BRISK_HIP_OK;
 }
 
+// ---- test / tuning entry points (include/brisk_hip_debug.h): BRISK_HIP_TUNING builds only -------------------------------
+#ifdef BRISK_HIP_TUNING
 int brisk_hip_debug_forge_pattern_device(brisk_hip_pattern* p, int device) {
   if (!p) return BRISK_HIP_ERR_ARG;
   p->device = device < 0 ? p->true_device : device;
@@ -1759,5 +2028,7 @@ int brisk_hip_debug_counters_raw(brisk_hip_ctx* ctx, int frame, void* out, int b
   if (hipMemcpy(out, ctx->B.counters + frame, sizeof(BriskFrameCounters), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int)sizeof(BriskFrameCounters);
 }
+
+#endif  // BRISK_HIP_TUNING
 
 }  // extern "C"

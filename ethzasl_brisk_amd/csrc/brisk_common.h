@@ -19,6 +19,15 @@
 #define BRISK_HD inline
 #endif
 
+// BRISK_HIP_TUNING (the build the tests, tools and bench.py load): environment knobs, debug bits and the brisk_hip_debug_*
+// entry points (include/brisk_hip_debug.h) exist.  Without it - the release library a maintainer links,
+// libbrisk_hip_release.so - every knob is its default at compile time: no getenv, no debug bit read by any kernel.
+#ifdef BRISK_HIP_TUNING
+#define BRISK_DBG_FLAGS(G) ((G).debug_flags)
+#else
+#define BRISK_DBG_FLAGS(G) 0
+#endif
+
 #define BRISK_MAX_LAYERS 16
 // Below this AGAST threshold a detection may store a score <= 2, which the reference's lazy cache treats as "not cached"
 // (brisk-layer.cc:118-132): a FRAME in which k_detect stores such a score runs the ordered path (k_ordered_keypoints); all

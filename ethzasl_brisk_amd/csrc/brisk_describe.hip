@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
     if (keep) {
       const int j = base + wbase + before;
       dkp[(long)frame * kp_cap + j] = kp;
-      if (j < DP_MAXSORT) pkey[j] = dp_order_key((int)kp.x, (int)kp.y, sc, j, (G.debug_flags >> 4) & 0xF);
+      if (j < DP_MAXSORT) pkey[j] = dp_order_key((int)kp.x, (int)kp.y, sc, j, (BRISK_DBG_FLAGS(G) >> 4) & 0xF);
       srec[j] = make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), __float_as_uint(kp.angle), (unsigned)sc | ((unsigned)j << 8));
     }
     __syncthreads();
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
   __syncthreads();
   // the keypoints again, in processing order, as one 16-byte record each: k_describe reads them with a single
   // (prefetchable) load instead of the dependent chain order -> keypoint -> scale
-  if (((G.debug_flags >> 4) & 0xF) != 0) {  // the experimental orders (debug bits 4-7): rank by counting all smaller keys
+  if (((BRISK_DBG_FLAGS(G) >> 4) & 0xF) != 0) {  // the experimental orders (debug bits 4-7): rank by counting all smaller keys
     for (int j = tid; j < m; j += DP_THREADS) {
       const unsigned kj = pkey[j];
       int r = 0;
@@ -699,8 +699,8 @@ __global__ void __launch_bounds__(DS_WAVES * 64) k_describe(BriskGeom G, BriskPa
     F.img = brisk_layer_img(G, pyr, frame, 0);
     F.integ = integral + (long)frame * iframe_elems;
     // timing experiments (debug bits 29 / 30): a descriptor without records drops every gather through it
-    F.rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(F.img), 0, (G.debug_flags & (1 << 30)) ? 0 : img_bytes, 0x00020000);
-    F.rs_int = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(F.integ), 0, (G.debug_flags & (1 << 29)) ? 0 : (int)(iframe_elems * 4), 0x00020000);
+    F.rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(F.img), 0, (BRISK_DBG_FLAGS(G) & (1 << 30)) ? 0 : img_bytes, 0x00020000);
+    F.rs_int = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(F.integ), 0, (BRISK_DBG_FLAGS(G) & (1 << 29)) ? 0 : (int)(iframe_elems * 4), 0x00020000);
     return F;
   };
 
@@ -939,7 +939,7 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
                            const BriskDescribeBuffers& Dd, int nframes, const BriskKeyPoint* kp_in, const int* n_in,
                            long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov, int n_in_max) {
   brisk_prof_mark(prof, BRISK_STG_INTEGRAL, s);
-  if (!ov && !((G.debug_flags & (1 << 19)) && (G.debug_flags & (1 << 27))))  // (bits 19 + 27: brisk_capi.hip, timing experiments)
+  if (!ov && !((BRISK_DBG_FLAGS(G) & (1 << 19)) && (BRISK_DBG_FLAGS(G) & (1 << 27))))  // (bits 19 + 27: brisk_capi.hip, timing experiments)
     brisk_launch_integral(G, B.pyr, B.bandsum, Dd.integral, Dd.istride, Dd.iframe_elems, B.band_h, nframes, s, Dd.ibits, B.counters);
   brisk_prof_mark(prof, BRISK_STG_DESC_PREPARE, s);
   hipLaunchKernelGGL(k_desc_prepare, dim3(nframes), dim3(DP_THREADS), 0, s, G, P, kp_in, n_in, n_in_stride, B.counters, Dd.dkp,
@@ -978,16 +978,16 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
     }
     // keypoints per ticket: chosen per frame inside the kernel (from the frame's keypoint density) up to DS_MAXRUN;
     // debug bits 8-11 fix it (tuning experiments)
-    int run_fixed = (G.debug_flags >> 8) & 0xF;
+    int run_fixed = (BRISK_DBG_FLAGS(G) >> 8) & 0xF;
     if (P.has_bilinear) run_fixed = 1;
     if (run_fixed > DS_MAXRUN) run_fixed = DS_MAXRUN;
-    int bpc = (G.debug_flags >> 12) & 0xF;
+    int bpc = (BRISK_DBG_FLAGS(G) >> 12) & 0xF;
     if (!bpc) bpc = DS_BLOCKS_PER_CU;
     const bool regtab = P.reg_tables && !P.has_bilinear;
     const int run_max = P.has_bilinear ? 1 : DS_MAXRUN;
     size_t lds = describe_lds_bytes(P, run_max, regtab);
     const size_t lds_limit = 160 * 1024 / (size_t)(bpc + 1) + 512;  // bpc + 1 workgroups of this size do not fit a CU
-    if (lds < lds_limit && !(G.debug_flags & (1 << 28))) lds = lds_limit;  // bit 28: no padding (other kernels share the CUs)
+    if (lds < lds_limit && !(BRISK_DBG_FLAGS(G) & (1 << 28))) lds = lds_limit;  // bit 28: no padding (other kernels share the CUs)
     const bool i24 = Dd.ibits == 24;  // (decided by the caller from BriskPatternDev::int24_ok: never with the bilinear branch)
     ds_kernel_t fn = regtab ? (i24 ? k_describe<DS_MAXRUN, false, true, true> : k_describe<DS_MAXRUN, false, true, false>)
                             : (i24 ? k_describe<DS_MAXRUN, false, false, true> : k_describe<DS_MAXRUN, false, false, false>);

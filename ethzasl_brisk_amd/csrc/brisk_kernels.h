@@ -108,6 +108,23 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
                            long n_in_stride, hipStream_t s, BriskProfiler* prof, const BriskOverlap* ov = nullptr,
                            int n_in_max = -1 /* largest per-frame count if the host knows it, else -1 */);
 
+// ---- the batch path's exit to host memory (brisk_export.hip) ----
+struct BriskExportSlab {  // device memory: what k_export_egress writes to the host, in the host's layout
+  int* counts;            // [frames]
+  int* flags;             // [frames]
+  long long* offsets;     // [frames + 1]
+  uint32_t* kps;          // [rows_cap][7]
+  uint32_t* desc;         // [rows_cap][desc_stride / 4]
+};
+// counts / flags / exact prefix sums of the last batch's rows (which: 0 detected, 1 described) and the rows themselves
+// -> slab, on the batch's stream
+void brisk_launch_export_pack(const BriskFrameCounters* counters, const BriskKeyPoint* kps, const uint8_t* desc, int kp_cap, int dev_pitch,
+                              int strings, int nframes, int which, long long rows_cap, int desc_stride, int cut_flag,
+                              const BriskExportSlab& S, hipStream_t s);
+// slab -> host memory the device can write (pinned / registered): the stored rows only
+void brisk_launch_export_egress(const BriskExportSlab& S, int nframes, int desc_stride, int* h_counts, int* h_flags, long long* h_offsets,
+                                void* h_kps, void* h_desc, hipStream_t s);
+
 // streaming probe (brisk_hip_stream_ceiling): mode 0 copies `bytes` from a to b with 16-byte loads/stores, mode 1 only reads a
 void brisk_launch_stream_probe(const void* a, void* b, size_t bytes, int mode, hipStream_t s);
 

@@ -22,11 +22,16 @@
 #include "brisk_device_detect.h"
 #include "brisk_kernels.h"
 
-// tuning experiments only: integer knob from the environment (read once)
+// tuning experiments only (BRISK_HIP_TUNING builds): integer knob from the environment; the release library has no
+// environment knobs - every one of them is its default
+#ifdef BRISK_HIP_TUNING
 static int env_knob(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+#else
+#define env_knob(name, dflt) (dflt)
+#endif
 
 
 // ------------------------------------------------------------------------------------------------
@@ -885,7 +890,7 @@ __global__ void __launch_bounds__(64) k_classify_refine(BriskGeom G, uint8_t* py
 #ifdef CR_TIMING
     { const long long now_ = (long long)wall_clock64(); atomicAdd(&counters[frame].cphase[7], (int)(now_ - touch.tlast)); touch.tlast = now_; }  // (lanes that ended early: waiting for the others)
 #endif
-    if ((Lo.miss | La.miss | Lb.miss) || (G.debug_flags & 1)) {  // leave the candidate to k_classify_refine_direct
+    if ((Lo.miss | La.miss | Lb.miss) || (BRISK_DBG_FLAGS(G) & 1)) {  // leave the candidate to k_classify_refine_direct
       c->status = 0xFF;
       atomicAdd(&counters[frame].nredo, 1);
       continue;

@@ -55,6 +55,14 @@ int brisk_hip_device_count(void);
 /* raises the capacities to at least these values; never lowers them (no reallocation for smaller requests) */
 int brisk_hip_reserve(brisk_hip_ctx* ctx, int min_candidates, int min_keypoints);
 
+/* Page-locks a caller's host buffer (an image, a frame ring, result arrays) so that the device reads / writes it directly:
+ * hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves.  A registered image is
+ * uploaded by DMA straight from the buffer (a pageable one goes through the runtime's staging copies, on the calling
+ * thread); registered result arrays make brisk_hip_batch_download_all write them without a bounce buffer.  The buffer must
+ * be unregistered before it is freed.  Registration costs ~0.1 ms per MB: register buffers that are reused. */
+int brisk_hip_host_register(void* ptr, size_t bytes);
+int brisk_hip_host_unregister(void* ptr);
+
 /* ---- pattern: replaces the BriskDescriptorExtractor constructors ---------------------------- */
 /* brisk-descriptor-extractor.cc:293-343: version 2 = built-in 66-point pattern (InitFromStream :180-291),
  * version 1 = generated 60-point BRISK 1.0 kernel (generateKernel :65-178, 512 bits). */
@@ -149,8 +157,9 @@ int brisk_hip_detect_describe_batch(brisk_hip_ctx* ctx, const brisk_hip_pattern*
  *        choice of a call therefore depends on the call before it - a benchmark that wants one form says so:
  *   BRISK_HIP_INTEGRAL_U24 / _U32      that form for every call of the context (U24 only where it is exact: patterns
  *        whose boxes cover fewer than 2^24 / 255 pixels - every built-in one; other patterns use u32).
- * (BRISK_INTEGRAL_BITS=24 / 32 in the environment and debug bits 18 / 24 do the same for A / B runs and tests and
- * take precedence.)  brisk_hip_debug_integral_bits reports what the last call used. */
+ * (Test / tuning builds - libbrisk_hip.so with BRISK_HIP_TUNING, include/brisk_hip_debug.h - also know BRISK_INTEGRAL_BITS=24 / 32
+ * in the environment and debug bits 18 / 24, which take precedence, and report the format of the last call with
+ * brisk_hip_debug_integral_bits; the release library has neither.) */
 enum { BRISK_HIP_INTEGRAL_AUTO = 0, BRISK_HIP_INTEGRAL_U24 = 24, BRISK_HIP_INTEGRAL_U32 = 32 };
 int brisk_hip_set_integral_format(brisk_hip_ctx* ctx, int format);
 /* Host-fed form of the batch (the PCIe-fed stream): h_frames is HOST memory (pinned with hipHostMalloc /
@@ -181,6 +190,50 @@ int brisk_hip_batch_download(brisk_hip_ctx* ctx, int frame, int which /*0 detect
                              brisk_hip_keypoint* kps, int cap, int* n, uint8_t* desc, int desc_stride);
 /* error / overflow flags of the last batch, OR-ed over frames (0 = clean); synchronises */
 int brisk_hip_batch_status(brisk_hip_ctx* ctx, int nframes, int* overflow_flags);
+
+/* ---- the batch path's exit to HOST memory: every frame's results in one asynchronous transfer ------------------------
+ * The reference hands a call's results to the caller's std::vector<cv::KeyPoint> and descriptor cv::Mat
+ * (brisk-feature-detector.cc:77-85, brisk-descriptor-extractor.cc:601-604); for a batch that is, per frame f, the rows
+ * [offsets[f], offsets[f + 1]) of ONE keypoint array and ONE descriptor matrix in the caller's memory - exact prefix sums,
+ * no padding rows.  The caller fills in the capacities and the five destination pointers:
+ *   counts  [frames]      rows frame f HAS (detected or described keypoints)
+ *   flags   [frames]      0 = clean, else the frame's rows are NOT stored: the engine's capacity flags of the frame (bit 0
+ *                         candidates, bit 1 ties, bit 2 keypoints: brisk_hip_set_capacity), bit 3 / 4 as brisk_hip_batch_status,
+ *                         BRISK_HIP_ROWS_CUT = the frame (and every frame behind it) did not fit rows_cap
+ *   offsets [frames + 1]  first row of frame f; offsets[frames] = rows stored
+ *   kps     [rows_cap]    desc [rows_cap][desc_stride] (NULL: no descriptors; bytes of a stored row behind the descriptor: 0)
+ * Destinations in pinned / registered host memory (hipHostMalloc, hipHostRegister, torch pin_memory) are written by the
+ * device directly, the stored rows only; pageable destinations go through a pinned buffer of the context and a host copy
+ * inside brisk_hip_batch_download_wait.  4-byte aligned pointers, desc_stride a multiple of 4 and >= the descriptor size. */
+#define BRISK_HIP_ROWS_CUT 0x100
+typedef struct brisk_hip_batch_host_results {
+  int frames_cap;          /* frames the arrays hold: >= the frames of the batch */
+  int desc_stride;         /* bytes between descriptor rows */
+  long long rows_cap;      /* rows kps / desc hold */
+  int* counts;
+  int* flags;
+  long long* offsets;
+  brisk_hip_keypoint* kps;
+  uint8_t* desc;
+} brisk_hip_batch_host_results;
+/* Queues the transfer of the context's LAST batch (which: 0 detected keypoints, 1 described keypoints + descriptors) behind
+ * that batch and returns: two small kernels on `stream` (hipStream_t the batch ran on; NULL = the context's stream) pack the
+ * rows into a device slab, the transfer itself runs on the context's egress stream beside whatever the context does next -
+ * the next batch may be issued at once.  *ticket names the transfer.  At most two transfers are in flight per context: a
+ * third call first completes the oldest (as brisk_hip_batch_download_wait would).  `dst` (the struct) is copied; the arrays
+ * it points to must stay valid until the ticket has been waited for. */
+int brisk_hip_batch_download_all(brisk_hip_ctx* ctx, int which, const brisk_hip_batch_host_results* dst, void* stream,
+                                 unsigned* ticket);
+/* Blocks until transfer `ticket` (and every earlier one) is complete; the context's lock is not held while waiting.
+ * *frames_flagged = frames whose flags[] entry is non-zero.  BRISK_HIP_OK, or - with the rows of all clean frames in place -
+ * BRISK_HIP_ERR_CAPACITY (some frame hit an engine capacity or was cut) / the code brisk_hip_batch_status would give. */
+int brisk_hip_batch_download_wait(brisk_hip_ctx* ctx, unsigned ticket, int* frames_flagged);
+/* brisk_hip_detect_describe_batch_host followed by brisk_hip_batch_download_all(which = 1) in one call: frames from host
+ * memory in, keypoints + descriptors back in host memory, everything queued when the call returns.  The transfer of
+ * batch n overlaps the H2D copies and kernels of batch n + 1 (alternate two destination sets). */
+int brisk_hip_detect_describe_batch_host_results(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames,
+                                                 int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
+                                                 int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket);
 
 /* Number of internal streams a batch is sliced over (1..8, default 1: measured no gain from slicing).  The slices fork from / join into the
  * caller's stream with events, so the call stays asynchronous and ordered on that stream. */
@@ -295,37 +348,6 @@ int brisk_hip_stream_ceiling(brisk_hip_ctx* ctx, size_t bytes, double* copy_GBps
 /* identifies the kernel sources this library was built from (hash); committed PMC traffic data names the revision
  * it was measured on */
 const char* brisk_hip_kernel_revision(void);
-
-/* ---- per-stage device entry points (parity tests of individual kernels) ---------------------- */
-/* which: 0 pyramid image, 1 score-state map low byte (D), after the last detect on frame slot 0.
- * Copies layer `layer` (w x h, tightly packed u8) to the host buffer. */
-int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, uint8_t* out, int* w, int* h);
-/* test knobs: bit0 = route every AGAST candidate through the direct-evaluation safety-net kernel; bit 25 = the pinned
- * result buffer of the one-frame host calls holds 16 KB only (results beyond it take the staged copies) */
-int brisk_hip_debug_set_flags(brisk_hip_ctx* ctx, int flags);
-/* integral image of frame slot `frame` after the last describe: (h+1) x (w+1) u32, tightly packed.  The engine keeps it
- * modulo 2^24 in 3-byte elements where the pattern's boxes are small enough for that (every built-in pattern; the values
- * come back zero-extended) and as u32 otherwise - brisk_hip_debug_integral_bits tells which (24 / 32); debug flag bit 18
- * forces the 32-bit form. */
-int brisk_hip_debug_integral(brisk_hip_ctx* ctx, int frame, uint32_t* out);
-int brisk_hip_debug_integral_bits(brisk_hip_ctx* ctx, int frame);
-/* test knob: overwrites the device a pattern handle believes its tables live on (the engine refuses a pattern / context
- * pair of different devices with BRISK_HIP_ERR_ARG; a one-GPU box can only test the refusal by forging the field).
- * device < 0 restores the true one. */
-int brisk_hip_debug_forge_pattern_device(brisk_hip_pattern* p, int device);
-/* number of describe calls that reused the image a detect call had left on the device (brisk_hip_describe_same_image, or
- * brisk_hip_describe under BRISK_HIP_IMAGE_CACHE=1) and skipped the upload and the layer-0 pass */
-int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx);
-/* the uniformity filter of brisk_hip_set_uniformity alone, on a GIVEN keypoint list of a rows x cols image (tests of the
- * filter kernels on lists no detector produces: tight clusters, the smallest radii); out holds n_in keypoints */
-int brisk_hip_debug_filter_keypoints(brisk_hip_ctx* ctx, const brisk_hip_keypoint* in, int n_in, int rows, int cols, double radius,
-                                     int max_keypoints, brisk_hip_keypoint* out, int* n);
-/* per-frame work counts of the last batch (tools only): out[0] candidates, out[1] keypoints, out[2] described
- * keypoints, out[3] overflow flags, out[4 + l] tie candidates of layer l, out[20 .. 27] experiment words; out holds 28 ints. */
-int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlayers);
-/* the raw counter record of a frame (tools only; instrumented build variants append fields): returns its size in bytes,
- * -1 on error; `bytes` = size of out */
-int brisk_hip_debug_counters_raw(brisk_hip_ctx* ctx, int frame, void* out, int bytes);
 
 #ifdef __cplusplus
 }

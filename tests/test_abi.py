@@ -22,6 +22,34 @@ def test_header_symbols_exported(lib):
     assert declared == set(B.ABI_SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
+    dbg = open(os.path.join(ROOT, "include", "brisk_hip_debug.h")).read()
+    declared_dbg = set(re.findall(r"\b(brisk_hip_debug_[a-z_0-9]+)\s*\(", dbg))
+    assert declared_dbg == set(B.DEBUG_SYMBOLS)
+    for s in declared_dbg:
+        assert hasattr(lib, s), s          # (libbrisk_hip.so is the test / tuning build)
+
+
+def test_release_library_has_no_scaffolding():
+    """libbrisk_hip_release.so - what INTEGRATION.md links - exports the boundary and nothing of the test / tuning
+    scaffolding: no brisk_hip_debug_* symbol, no tuning variable name in its strings (the three documented BRISK_HIP_*
+    variables - RCCL library, image cache opt-in - remain)."""
+    import ctypes
+    import subprocess
+    from ethzasl_brisk_amd import build
+    rel = build.build_release()
+    L = ctypes.CDLL(rel)
+    for s in B.ABI_SYMBOLS:
+        assert hasattr(L, s), s
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", rel], text=True)
+    assert "brisk_hip_debug_" not in syms
+    exported = set(re.findall(r" T (brisk_hip_[a-z_0-9]+)", syms))
+    assert exported == set(B.ABI_SYMBOLS), exported ^ set(B.ABI_SYMBOLS)
+    txt = subprocess.check_output(["strings", "-n", "6", rel], text=True)
+    for frag in ("BRISK_TR_", "BRISK_II_", "BRISK_INTEGRAL_", "BRISK_SB_", "BRISK_CR_", "BRISK_CS_", "BRISK_DETECT_PROBE", "BRISK_SIDE_PRIO",
+                 "BRISK_L0_INPLACE", "BRISK_HOST_SLICE"):
+        assert frag not in txt, frag
+    tun = subprocess.check_output(["strings", "-n", "6", build.build()], text=True)
+    assert "BRISK_TR_BANDS" in tun        # (the check above can find what it looks for)
 
 
 def test_no_cpu_fallback(lib):

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "brisk_hip_comm_gather_results", "brisk_hip_comm_wait",
     "brisk_hip_set_integral_format",
     "brisk_hip_host_register", "brisk_hip_host_unregister",
+    "brisk_hip_pool_create", "brisk_hip_pool_destroy", "brisk_hip_pool_last_error", "brisk_hip_pool_detect", "brisk_hip_pool_describe",
     "brisk_hip_batch_download_all", "brisk_hip_batch_download_wait", "brisk_hip_detect_describe_batch_host_results",
 ]
 # every symbol include/brisk_hip_debug.h declares: test / tuning builds (BRISK_HIP_TUNING) only
@@ -195,6 +196,13 @@ def load_library():
                                           C.c_int, ip]
     L.brisk_hip_detect_describe_batch_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
                                                        C.c_int]
+    L.brisk_hip_pool_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.brisk_hip_pool_destroy.argtypes = [vp]
+    L.brisk_hip_pool_destroy.restype = None
+    L.brisk_hip_pool_last_error.argtypes = [vp]
+    L.brisk_hip_pool_last_error.restype = C.c_char_p
+    L.brisk_hip_pool_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, ip, C.POINTER(C.c_ulonglong)]
+    L.brisk_hip_pool_describe.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, C.c_int, C.c_int, C.c_int, C.c_ulonglong]
     L.brisk_hip_host_register.argtypes = [vp, C.c_size_t]
     L.brisk_hip_host_unregister.argtypes = [vp]
     L.brisk_hip_batch_download_all.argtypes = [vp, C.c_int, C.POINTER(BatchHostResults), vp, C.POINTER(C.c_uint)]
@@ -407,6 +415,55 @@ class Context:
         self.check(self._L.brisk_hip_batch_download(self._h, frame, int(described), _ptr(kps), len(kps), C.byref(n),
                                                     _ptr(desc) if described else None, strings))
         return _kcopy(kps, n.value), (desc[:n.value].copy() if described else None)
+
+
+class Pool:
+    """brisk_hip_pool: the one-frame calls of many threads combined into batches (thread-safe, blocking calls)"""
+
+    def __init__(self, device=0, max_batch=16, max_keypoints=16384):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.brisk_hip_pool_create(device, max_batch, max_keypoints, C.byref(h))
+        if rc:
+            raise BriskHipError(rc, "brisk_hip_pool_create failed")
+        self._h = h
+
+    def _check(self, rc):
+        if rc:
+            raise BriskHipError(rc, self._L.brisk_hip_pool_last_error(self._h).decode())
+
+    def detect(self, image, threshold, octaves, capacity=16384):
+        """-> (keypoints, token of the frame's device copy)"""
+        img = np.ascontiguousarray(image, np.uint8)
+        h, w = img.shape
+        out = np.empty(capacity, KEYPOINT)
+        n, tok = C.c_int(), C.c_ulonglong()
+        self._check(self._L.brisk_hip_pool_detect(self._h, _ptr(img), w, h, w, threshold, octaves, _ptr(out), capacity, C.byref(n), C.byref(tok)))
+        return _kcopy(out, n.value), tok.value
+
+    def describe(self, pattern, image, keypoints, token=0, rotation_invariant=True, scale_invariant=True):
+        img = np.ascontiguousarray(image, np.uint8)
+        h, w = img.shape
+        k = _kcopy(np.ascontiguousarray(keypoints, KEYPOINT))
+        n = C.c_int(len(k))
+        s = pattern.descriptorSize()
+        desc = np.empty((max(len(k), 1), s), np.uint8)
+        if len(k) == 0:
+            k = np.zeros(1, KEYPOINT)
+        self._check(self._L.brisk_hip_pool_describe(self._h, pattern._h, _ptr(img), w, h, w, _ptr(k), C.byref(n), _ptr(desc), s,
+                                                    int(rotation_invariant), int(scale_invariant), token))
+        return k[:n.value], desc[:n.value]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.brisk_hip_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default_ctx = {}

@@ -2032,3 +2032,5 @@ int brisk_hip_debug_counters_raw(brisk_hip_ctx* ctx, int frame, void* out, int b
 #endif  // BRISK_HIP_TUNING
 
 }  // extern "C"
+
+#include "brisk_pool.inc"

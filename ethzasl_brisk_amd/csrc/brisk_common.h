@@ -25,7 +25,8 @@
 #ifdef BRISK_HIP_TUNING
 #define BRISK_DBG_FLAGS(G) ((G).debug_flags)
 #else
-#define BRISK_DBG_FLAGS(G) 0
+BRISK_HD int brisk_no_debug_flags() { return 0; }  // (a call, not a literal: no constant-operand warnings; folded all the same)
+#define BRISK_DBG_FLAGS(G) brisk_no_debug_flags()
 #endif
 
 #define BRISK_MAX_LAYERS 16

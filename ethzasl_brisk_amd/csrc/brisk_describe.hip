@@ -969,13 +969,7 @@ void brisk_launch_describe(const BriskGeom& G, const BriskPatternDev& P, const B
     // Persistent grid: `wpc` waves per CU (the dynamic LDS request keeps the hardware from placing more workgroups on a
     // CU than that), runs of `run` keypoints per ticket.  Test / tuning knobs: debug bits 8-11 = run, 12-15 = workgroups
     // per CU.  Few frames: single keypoints per ticket (latency), many: runs of 4 (fewer, fuller sampling rounds).
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      (void)hipGetDevice(&dev);
-      ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = brisk_device_cus();
     // keypoints per ticket: chosen per frame inside the kernel (from the frame's keypoint density) up to DS_MAXRUN;
     // debug bits 8-11 fix it (tuning experiments)
     int run_fixed = (BRISK_DBG_FLAGS(G) >> 8) & 0xF;

@@ -80,6 +80,7 @@ struct BriskOverlap {
   hipEvent_t fork, join;
   const BriskDescribeBuffers* Dd;
 };
+int brisk_device_cus();  // compute units of the current device (cached)
 // frames: u8 images, frame f at frames + f*frame_pitch, row pitch row_pitch (device memory)
 void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const BriskDetectBuffers& B, int nframes,
                          const uint8_t* frames, long frame_pitch, int row_pitch, const uint8_t* mask,

@@ -1069,6 +1069,12 @@ __global__ void __launch_bounds__(64) k_ordered_keypoints(BriskGeom G, uint8_t* 
 //                the reference reads beyond the image)
 //   k_cs_refine  the per-point refinement of GetKeypoints -> tmp[layer][j] = keypoint, valid
 //   k_cs_emit    the valid ones in (layer, provided) order
+// Benign race, stated: k_cs_admit and k_cs_refine let many lanes read-modify-write the same 16-bit cells of the score-state map
+// (brisk_S_literal) without atomics.  Every such access is a threshold-1 access of the literal cache, and what a lane stores in
+// a cell is a pure function of the IMAGE around the cell (the AGAST score of that pixel), never of the order of accesses: all
+// racing writers store the same value, and a reader sees either "not cached" (and computes that same value itself) or the
+// value.  Provided lists whose points share cells and neighbourhoods across layers - duplicates, a dense grid - are compared
+// with the sequential algorithm (the oracle) in tests/test_gpu_round6.py.
 // A layer that admits no provided point DETECTS instead (brisk-layer.cc:99-105) and its raster-ordered list feeds the same
 // loop: that case - and a point count beyond the scratch buffers - stays on the one-lane walk (k_compute_scale runs when
 // counters[0].pad[0] is set; the touches k_cs_admit already made are the ones the walk makes first, and are idempotent).
@@ -1773,6 +1779,20 @@ void brisk_launch_publish_single(const BriskFrameCounters* counters, const Brisk
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from the C ABI implementation)
 // ------------------------------------------------------------------------------------------------
+// compute units of the current device (cached per device ordinal): what the "one workgroup per CU" launch shapes go by
+int brisk_device_cus() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+  if (!v) {
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    __atomic_store_n(&cus[dev], v, __ATOMIC_RELAXED);
+  }
+  return v;
+}
+
 static inline int grid_for(long items, int per_block, int cap) {
   long b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -1949,7 +1969,8 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
       if (nframes * ((G.nlayers + c - 1) / c) <= per_wg) { lpw_auto = c; break; }
     const int lpw = lpw_knob ? min(lpw_knob, G.nlayers) : (nframes * G.nlayers <= 512 ? 1 : lpw_auto);
     int tr_grid = (nframes >= 8 ? (nframes + 7) / 8 * 8 : nframes) * ((G.nlayers + lpw - 1) / lpw);
-    static const int persist_knob = env_knob("BRISK_TR_PERSIST", -1), pgrid_knob = env_knob("BRISK_TR_PGRID", 256);
+    static const int persist_knob = env_knob("BRISK_TR_PERSIST", -1), pgrid_env = env_knob("BRISK_TR_PGRID", 0);
+    const int pgrid_knob = pgrid_env > 0 ? pgrid_env : brisk_device_cus();  // one workgroup per CU of THIS device (256 on an MI355X)
     const int persist = persist_knob >= 0 ? persist_knob : (tr_grid > pgrid_knob ? 1 : 0);
     if (persist && tr_grid > pgrid_knob) tr_grid = pgrid_knob;
     // waves per workgroup: 16 (15 deciding).  Where a workgroup owns a whole frame of a large batch (one workgroup per CU,
@@ -1973,7 +1994,9 @@ void brisk_launch_detect(const BriskGeom& G, const BriskTileTable& T, const Bris
     int bands = 1;
     if (lpw == 1 && !persist) {
       bands = bands_knob ? min(max(bands_knob, 1), BRISK_TIE_MAX_BANDS) : (tr_grid * 8 <= pgrid_knob ? 8 : tr_grid * 4 <= pgrid_knob ? 4 : tr_grid * 2 <= pgrid_knob ? 2 : 1);
-      if (tr_grid * bands > pgrid_knob) bands = 1;  // (every ticket needs a resident workgroup: a band waits for the band above)
+      // (a performance choice, not a residency requirement: tickets are drawn at run time and a ticket only waits for tickets
+      // drawn before it, so forward progress holds with any number of resident workgroups - more bands than CUs only queue)
+      if (tr_grid * bands > pgrid_knob) bands = 1;
     }
     if ((nframes <= 64 && pair_knob) || pair_knob == 2)
       hipLaunchKernelGGL(k_tie_resolve_pair, dim3(tr_grid * bands), dim3(tr_waves * 64), 0, s, G, B.pyr, B.smap, B.cand, B.counters, B.tie_idx,

@@ -94,6 +94,28 @@ class BriskDescriptorExtractor {
     const int strings = descriptorSize();
     int n = (int)keypoints.size();
     agast::Mat tmp = agast::Mat::zeros(n > 0 ? n : 1, strings, CV_8UC1);
+    // several threads inside the classes right now: the call joins the batch the device's shared pool is forming
+    const hip::CallScope scope;
+    if (hip::PoolThreshold() > 0 && scope.n >= hip::PoolThreshold() && n <= 16384) {
+      if (brisk_hip_pool* pool = hip::SharedPool(hip::ThisThread().device)) {
+        const hip::PooledImage& li = hip::LastPooledImage();
+        const unsigned long long token =
+            (hip::SameImageHint() && li.token && li.data == image.data && li.rows == image.rows && li.cols == image.cols) ? li.token : 0ull;
+        std::vector<agast::KeyPoint> kin = keypoints;  // (filtered in place: the thread's own context gets the original list if the pool declines)
+        int np = n;
+        const int rc = brisk_hip_pool_describe(pool, pattern_, image.data, image.cols, image.rows, (int)image.step,
+                                               reinterpret_cast<brisk_hip_keypoint*>(kin.data()), &np, tmp.data, (int)tmp.step,
+                                               rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0, token);
+        if (rc == BRISK_HIP_OK) {
+          kin.resize((size_t)np);
+          keypoints.swap(kin);
+          descriptors = agast::Mat::zeros(np, strings, CV_8UC1);
+          for (int i = 0; i < np; ++i) memcpy(descriptors.data + (size_t)i * descriptors.step, tmp.data + (size_t)i * tmp.step, strings);
+          return;
+        }
+        if (rc != BRISK_HIP_ERR_CAPACITY) throw std::runtime_error(std::string("brisk_hip_pool_describe failed (code ") + std::to_string(rc) + "): " + brisk_hip_pool_last_error(pool));
+      }
+    }
     brisk_hip_ctx* ctx = hip::DefaultContext();
     brisk_hip_reserve(ctx, 4 * n, n);  // grows the workspace when needed, never shrinks it
     // (hip::ScopedSameImage: the caller's word that this is the unchanged buffer of the thread's last detect() call)

@@ -9,6 +9,7 @@
 #include <agast/wrap-opencv.h>
 #include <brisk/hip-context.h>
 
+#include <string>
 #include <vector>
 
 namespace brisk {
@@ -95,6 +96,28 @@ class BriskFeatureDetector {
     keypoints.clear();
     if (image.empty()) throw std::runtime_error("BriskFeatureDetector: empty image");
     if (image.type() != CV_8UC1) throw std::runtime_error("BriskFeatureDetector: image must be CV_8UC1");
+    // several threads inside the classes right now: the call joins the batch the device's shared pool is forming (plain
+    // detection only; whatever the pool cannot serve - a capacity it does not have - takes the thread's own context below)
+    const hip::CallScope scope;
+    hip::LastPooledImage().token = 0;
+    if (hip::PoolThreshold() > 0 && scope.n >= hip::PoolThreshold() && mask.empty() && m_suppressScaleNonmaxima && m_uniformityRadius == 0.0 &&
+        m_bucketsU == 0 && m_bucketsV == 0) {
+      if (brisk_hip_pool* pool = hip::SharedPool(hip::ThisThread().device)) {
+        keypoints.resize(16384);
+        int n = 0;
+        unsigned long long token = 0;
+        const int rc = brisk_hip_pool_detect(pool, image.data, image.cols, image.rows, (int)image.step, threshold, octaves,
+                                             reinterpret_cast<brisk_hip_keypoint*>(keypoints.data()), (int)keypoints.size(), &n, &token);
+        if (rc == BRISK_HIP_OK) {
+          keypoints.resize((size_t)n);
+          hip::PooledImage& li = hip::LastPooledImage();
+          li.data = image.data; li.rows = image.rows; li.cols = image.cols; li.token = token;
+          return;
+        }
+        keypoints.clear();
+        if (rc != BRISK_HIP_ERR_CAPACITY) throw std::runtime_error(std::string("brisk_hip_pool_detect failed (code ") + std::to_string(rc) + "): " + brisk_hip_pool_last_error(pool));
+      }
+    }
     brisk_hip_ctx* ctx = hip::DefaultContext();  // this thread's workspace
     // the object's post-filter settings travel with the call: the thread's context keeps whatever a user set on it
     brisk_hip_postfilter pf;

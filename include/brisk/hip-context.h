@@ -4,7 +4,9 @@
 
 #include <brisk_hip.h>
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -89,6 +91,55 @@ struct ScopedSameImage {
   ScopedSameImage() : prev(SameImageHint()) { SameImageHint() = true; }
   ~ScopedSameImage() { SameImageHint() = prev; }
 };
+
+// ---- many threads at once: call combining (brisk_hip_pool, include/brisk_hip.h) -----------------------------------------
+// A thread's own context is the fastest way to serve ONE caller; from a few concurrent callers on, the calls that are in
+// the engine at the same time are cheaper as one batch (the HIP runtime serialises the API calls of a process: 16 threads
+// with their own contexts reach 3.6 x one thread).  The classes count the threads that are inside detect() / compute() right
+// now and hand a call to the device's shared pool when that count has reached PoolThreshold() (default 4; 0 = never;
+// BRISK_HIP_POOL_THREADS in the environment or SetPoolThreshold() change it).  Results are bit-identical either way.
+inline std::atomic<int>& ActiveCalls() {
+  static std::atomic<int> n{0};
+  return n;
+}
+struct CallScope {
+  int n;
+  CallScope() : n(ActiveCalls().fetch_add(1, std::memory_order_relaxed) + 1) {}
+  ~CallScope() { ActiveCalls().fetch_sub(1, std::memory_order_relaxed); }
+  CallScope(const CallScope&) = delete;
+  CallScope& operator=(const CallScope&) = delete;
+};
+inline std::atomic<int>& PoolThresholdRef() {
+  static std::atomic<int> t{[] { const char* e = std::getenv("BRISK_HIP_POOL_THREADS"); return e ? std::atoi(e) : 4; }()};
+  return t;
+}
+inline int PoolThreshold() { return PoolThresholdRef().load(std::memory_order_relaxed); }
+inline void SetPoolThreshold(int concurrent_callers) { PoolThresholdRef().store(concurrent_callers, std::memory_order_relaxed); }
+// the shared pool of a device: created by the first call that needs it, lives as long as the process (null: creation failed,
+// the caller uses its own context)
+inline brisk_hip_pool* SharedPool(int device) {
+  static std::mutex mu;
+  static brisk_hip_pool* pools[16] = {};
+  static bool tried[16] = {};
+  if (device < 0 || device >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tried[device]) {
+    tried[device] = true;
+    if (brisk_hip_pool_create(device, 32, 16384, &pools[device]) != BRISK_HIP_OK) pools[device] = nullptr;
+  }
+  return pools[device];
+}
+// the thread's last pooled detect(): the buffer it was given and the token of its device copy (compute() presents the token
+// only under ScopedSameImage - the caller's word that the pixels are unchanged - and for that very buffer)
+struct PooledImage {
+  const void* data = nullptr;
+  int rows = 0, cols = 0;
+  unsigned long long token = 0;
+};
+inline PooledImage& LastPooledImage() {
+  static thread_local PooledImage p;
+  return p;
+}
 
 }  // namespace hip
 }  // namespace brisk

@@ -235,6 +235,31 @@ int brisk_hip_detect_describe_batch_host_results(brisk_hip_ctx* ctx, const brisk
                                                  int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
                                                  int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket);
 
+/* ---- call combining: the one-frame host calls of MANY threads as batches ------------------------------------------------
+ * The reference's classes are re-entrant (detectImpl is const and builds its state per call, brisk-feature-detector.cc:77-85);
+ * with a context per thread every call is ~15 kernel launches and 2 - 4 copies of its own, and the HIP runtime serialises the
+ * API calls of a process - 16 threads get 3.6 x one thread.  A pool runs the calls that are inside it at the same
+ * time as ONE batch: every caller copies its frame into a pinned staging slot (a CPU copy on its own thread), the first
+ * caller of a group submits the group - one H2D copy, the batch kernels, one result transfer - and every caller takes its
+ * own rows.  Groups close when the device can take them (two are in flight at most): batches grow with the load, a lone
+ * caller is a batch of one (slower than brisk_hip_detect by the staging copy - use the pool from about four threads on, as
+ * include/brisk/hip-context.h does).  All calls of a pool are thread-safe and blocking; results are bit-identical to
+ * brisk_hip_detect / brisk_hip_describe.  max_batch <= 64 frames per group, max_keypoints per frame as brisk_hip_set_capacity. */
+typedef struct brisk_hip_pool brisk_hip_pool;
+int brisk_hip_pool_create(int device, int max_batch, int max_keypoints, brisk_hip_pool** out);
+void brisk_hip_pool_destroy(brisk_hip_pool* pool);
+const char* brisk_hip_pool_last_error(const brisk_hip_pool* pool); /* of the calling thread's last failed call */
+/* brisk_hip_detect (suppressScaleNonmaxima = true, no mask, no post-filter) through the pool.  *image_token (may be NULL)
+ * names the device copy of this frame for a following brisk_hip_pool_describe. */
+int brisk_hip_pool_detect(brisk_hip_pool* pool, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,
+                          brisk_hip_keypoint* out, int cap, int* n, unsigned long long* image_token);
+/* brisk_hip_describe through the pool.  image_token: 0, or the token of the brisk_hip_pool_detect call that was given the
+ * SAME, unchanged pixels (the caller's word, as brisk_hip_describe_same_image): the frame is then taken from its device
+ * copy while the pool still holds it (a stale token is harmless: the frame is uploaded). */
+int brisk_hip_pool_describe(brisk_hip_pool* pool, const brisk_hip_pattern* pat, const uint8_t* img, int w, int h, int stride,
+                            brisk_hip_keypoint* kps, int* n, uint8_t* desc, int desc_stride, int rotation_invariant,
+                            int scale_invariant, unsigned long long image_token);
+
 /* Number of internal streams a batch is sliced over (1..8, default 1: measured no gain from slicing).  The slices fork from / join into the
  * caller's stream with events, so the call stays asynchronous and ordered on that stream. */
 int brisk_hip_set_streams(brisk_hip_ctx* ctx, int n);

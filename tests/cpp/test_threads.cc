@@ -9,7 +9,10 @@
 //        every result is compared with the serial run's.  Prints one JSON line (aggregate frames/s, per-call latency, host
 //        CPU time per call) that bench.py collects into config.other_configs["threads"].  --pinned: the frames are registered
 //        with brisk_hip_host_register first (DMA straight from the caller's buffer); --same-image: compute() runs under
-//        brisk::hip::ScopedSameImage (the caller's word that it is detect()'s unchanged buffer: no second upload).
+//        brisk::hip::ScopedSameImage (the caller's word that it is detect()'s unchanged buffer: no second upload);
+//        --pool-threshold K: concurrent callers from which the classes hand calls to the device's shared pool (0 = never,
+//        default 4: brisk::hip::SetPoolThreshold).
+//        test_threads <golden dir> [threads] [iterations] --pool-threshold 1: the bit-equality run with EVERY eligible call pooled.
 #include <brisk/brisk.h>
 
 #include "set_serialization.h"
@@ -164,10 +167,10 @@ static int time_mode(int nthreads, double seconds, int w, int h, bool pinned, bo
   for (int t = 0; t < nthreads; ++t) { total += calls[t]; cpu_sum += cpu[t]; lat_sum += lat[t]; if (lat_max[t] > lmax) lmax = lat_max[t]; }
   if (pinned)
     for (auto& v : pix) (void)brisk_hip_host_unregister(v.data());
-  printf("{\"threads\": %d, \"pinned\": %d, \"same_image\": %d, \"width\": %d, \"height\": %d, \"frames_per_s\": %.1f, \"calls\": %ld, \"seconds\": %.3f, "
+  printf("{\"threads\": %d, \"pool_threshold\": %d, \"pinned\": %d, \"same_image\": %d, \"width\": %d, \"height\": %d, \"frames_per_s\": %.1f, \"calls\": %ld, \"seconds\": %.3f, "
          "\"latency_ms_mean\": %.4f, \"latency_ms_max\": %.3f, \"host_cpu_ms_per_call\": %.4f, \"mean_keypoints\": %.1f, "
          "\"mismatches\": %d}\n",
-         nthreads, (int)pinned, (int)same_image, w, h, total / dt, total, dt, total ? lat_sum / total : 0.0, lmax, total ? 1e3 * cpu_sum / total : 0.0,
+         nthreads, brisk::hip::PoolThreshold(), (int)pinned, (int)same_image, w, h, total / dt, total, dt, total ? lat_sum / total : 0.0, lmax, total ? 1e3 * cpu_sum / total : 0.0,
          (double)kp_total / pix.size(), (int)bad);
   return bad ? 1 : 0;
 }
@@ -179,6 +182,7 @@ int main(int argc, char** argv) {
       std::vector<std::string> pos;
       for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
+        if (a == "--pool-threshold" && i + 1 < argc) { brisk::hip::SetPoolThreshold(atoi(argv[++i])); continue; }
         if (a == "--pinned") pinned = true;
         else if (a == "--same-image") same_image = true;
         else pos.push_back(a);
@@ -190,9 +194,14 @@ int main(int argc, char** argv) {
       return 2;
     }
   }
-  const std::string dir = argc > 1 ? argv[1] : ".";
-  const int nthreads = argc > 2 ? atoi(argv[2]) : 4;
-  const int iters = argc > 3 ? atoi(argv[3]) : 12;
+  std::vector<std::string> pos;
+  for (int i = 1; i < argc; ++i) {
+    if (std::string(argv[i]) == "--pool-threshold" && i + 1 < argc) { brisk::hip::SetPoolThreshold(atoi(argv[++i])); continue; }
+    pos.push_back(argv[i]);
+  }
+  const std::string dir = pos.size() > 0 ? pos[0] : ".";
+  const int nthreads = pos.size() > 1 ? atoi(pos[1].c_str()) : 4;
+  const int iters = pos.size() > 2 ? atoi(pos[2].c_str()) : 12;
   try {
     const agast::Mat img = first_image(dir + "/brisk_verification_ast.set");
     brisk::BriskDescriptorExtractor ext;  // shared by all threads

@@ -201,3 +201,153 @@ def test_download_all_argument_errors(B, frames65):
         assert e.value.code == 1
     assert ctx.batch_download_wait(ctx.batch_download_all(res, stream=stream)) == 0
     ctx.close()
+
+
+def test_eight_contexts_at_once_against_the_oracle():
+    """tools/soak.py threads, 32 iterations per thread = 256 cases: eight host threads with their own contexts - a one-frame 4K call
+    (eight tie bands per layer), a 64-frame pair-form batch, dense frames at threshold 30, odd sizes, a single-layer pyramid, the
+    host-to-host batch entry - on the chip together, every result of every iteration bit-equal to the oracle; a hang (a tie band
+    waiting for a workgroup that never runs) kills the child process and fails the test."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "threads", "32", "600"], capture_output=True, text=True)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "256 cases" in r.stdout and ", 0 mismatches, 0 errors" in r.stdout
+
+
+def test_compute_scale_points_that_share_cells(B):
+    """ComputeScale's parallel form lets lanes race on cells of the score-state map (every writer stores the same value: a
+    function of the image).  Lists built to collide - a 2.5-pixel grid over a textured region (neighbouring points share most
+    of their 3 x 3 / 4 x 4 reads on every layer), every point four times (exact duplicates and sub-pixel neighbours), shuffled -
+    against the oracle, i.e. the sequential algorithm; with and without scale NMS."""
+    img = synth.frame_1080p(6)
+    rng = np.random.default_rng(11)
+    gx, gy = np.meshgrid(700 + 2.5 * np.arange(40), 400 + 2.5 * np.arange(40))
+    base = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    pts = np.concatenate([base, base, base + np.float32(0.25), base + rng.uniform(-0.5, 0.5, base.shape).astype(np.float32)])
+    pts = pts[rng.permutation(len(pts))]
+    k = np.zeros(len(pts), B.KEYPOINT)
+    k["x"], k["y"], k["size"], k["angle"], k["class_id"] = pts[:, 0], pts[:, 1], 12, -1, np.arange(len(pts))
+    ctx = B.Context(0, max_candidates=262144, max_keypoints=65536)
+    checked = 0
+    for octaves, suppress in ((4, True), (2, True), (0, True)):
+        want = O.compute_scale(img, k, 60, octaves, suppress)
+        if want is None:
+            continue
+        got = B.BriskFeatureDetector(60, octaves, suppress, context=ctx).ComputeScale(img, k)
+        assert len(want) > 1000 and same_kps(got, want), (octaves, suppress, explain(got, want))
+        checked += 1
+    assert checked >= 2
+    ctx.close()
+
+
+def test_reference_goldens_on_the_release_library():
+    """libbrisk_hip_release.so (no BRISK_HIP_TUNING: no environment knobs, no debug bits, no brisk_hip_debug_* exports - the
+    library INTEGRATION.md links) in a child process: both reference goldens bit-exact through the host calls, the batch path
+    and brisk_hip_batch_download_all (tests/release_golden.py)."""
+    import os
+    import subprocess
+    import sys
+    from ethzasl_brisk_amd import build
+    rel = build.build_release()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "release_golden.py")], env=dict(os.environ, BRISK_HIP_LIB=rel),
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "goldens OK" in r.stdout
+
+
+def test_pool_combines_concurrent_calls_bit_exactly(B, frames65, oracle65):
+    """brisk_hip_pool: twelve host threads call detect() then describe() on their own frames at once - two image sizes and two
+    thresholds (calls of different kinds must not mix in a group), describe() with the detect call's token (device copy of the
+    frame), with a stale token and without one; every result equals the oracle, and a lone caller (a group of one) does too."""
+    import threading
+    pool = B.Pool(0, max_batch=8)
+    ext = B.BriskDescriptorExtractor()
+    small = [synth.gen(333, 201, 7700 + i, 40) for i in range(4)]
+    X = O.Extractor()
+    want_small = []
+    for img in small:
+        ko = O.detect(img, 60, 2)
+        want_small.append((ko,) + tuple(X.compute(img, ko)))
+    k, tok = pool.detect(frames65[0], THR, OCT)                          # alone: a group of one
+    k2, d = pool.describe(ext, frames65[0], k, tok)
+    assert same_kps(k, oracle65[0][0]) and same_kps(k2, oracle65[0][1]) and np.array_equal(d, oracle65[0][2])
+    errors = []
+
+    def worker(t):
+        try:
+            stale = 0
+            for it in range(12):
+                if t % 3 == 2:                                           # another size / threshold / octave count
+                    j = (t + it) % len(small)
+                    img, (wk, wk2, wd), thr, octv = small[j], want_small[j], 60, 2
+                else:
+                    j = (5 * t + it) % 65
+                    img, (wk, wk2, wd), thr, octv = frames65[j], oracle65[j], THR, OCT
+                k, tok = pool.detect(img, thr, octv)
+                use = tok if it % 3 == 0 else (stale if it % 3 == 1 else 0)
+                k2, d = pool.describe(ext, img, k, use)
+                if not (same_kps(k, wk) and same_kps(k2, wk2) and np.array_equal(d, wd)):
+                    errors.append((t, it, "mismatch"))
+                stale = tok
+        except Exception as e:
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:5]
+    pool.close()
+    ext.close()
+
+
+def test_pool_reports_capacity_per_caller(B, frames65, oracle65):
+    """a pool whose per-frame keypoint capacity some frames exceed: exactly those callers get BRISK_HIP_ERR_CAPACITY (the
+    classes then use the thread's own context), the other members of the same groups get their results"""
+    import threading
+    nk = [len(o[0]) for o in oracle65[:16]]
+    cap = sorted(nk)[8]
+    pool = B.Pool(0, max_batch=16, max_keypoints=cap)
+    out = {}
+
+    def worker(t):
+        try:
+            out[t] = ("ok", pool.detect(frames65[t], THR, OCT)[0])
+        except B.BriskHipError as e:
+            out[t] = ("err", e.code)
+
+    for rep in range(3):
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        for t in range(16):
+            if nk[t] > cap:
+                assert out[t] == ("err", 4), (t, out[t])
+            else:
+                assert out[t][0] == "ok" and same_kps(out[t][1], oracle65[t][0]), t
+    pool.close()
+
+
+def test_drop_in_classes_through_the_pool():
+    """tests/cpp/test_threads with every eligible call pooled (--pool-threshold 1): eight threads with different thresholds,
+    octaves and post-filters (those with a uniformity radius stay on their own contexts), bit-equal to the serial run; and the
+    timed mode with ScopedSameImage, which presents the detect call's token to compute()."""
+    import os
+    import subprocess
+    from test_cpp_classes import build_binary
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = build_binary("test_threads")
+    r = subprocess.run([b, os.path.join(root, "tests", "golden"), "8", "12", "--pool-threshold", "1"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and "threads OK" in r.stdout
+    r = subprocess.run([b, "--time", "8", "1", "640", "480", "--same-image", "--pool-threshold", "2"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and '"mismatches": 0' in r.stdout

@@ -419,6 +419,137 @@ __global__ void __launch_bounds__(128) k_gather_sw(MbArgs A) {
   if (lane == 0) atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
 }
 
+// ---- round 6: gather_sw with a TWO-DEEP round pipeline ---------------------------------------------------------------
+// The shipped loop runs a round's phases one after the other (addresses -> ten gathers -> wait -> combine -> LDS); at 1.5 waves per
+// SIMD nothing covers a wave's combine stage while its gathers are out, and the kernel sits at 38 % of its VALU and of its L1
+// look-up rate at the same time.  Here round r + 1's addresses and gathers are issued BEFORE round r's combine: one wave's VALU work
+// overlaps its own vector memory traffic, and the keypoints in flight per XCD stay what they are (what killed "more waves").
+// CROSS = false: the pipeline drains at the end of a pass (the rotated pass needs the orientation of the unrotated one);
+// CROSS = true: it runs on into the task's second pass (an upper bound for a form that overlaps run k's rotated pass with run k + 1's
+// unrotated one).
+struct SwRound {
+  unsigned A, B, C, D, r_x_1_i, r_y_1_i, r_x1_i, r_y1_i;
+  int scaling, magic, shift, sc;
+  bool valid, a_quirk, b_quirk;
+  u32x2 at0, at1, aq, ab1, bt0, bt1, bq, bb1;
+  u32x3 ab0, bb0;
+};
+template <bool CROSS>
+__global__ void __launch_bounds__(128) k_gather_sw2(MbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* vals = reinterpret_cast<int*>(lds + wave * 1024);
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 7);
+  const int np = A.np;
+  const bool odd = lane & 1;
+  const int rowb = A.iw * 3;
+  long long sum = 0;
+  for (int gi = 0; gi < 8; ++gi) {
+    const int g = (xcc + gi) & 7;
+    const int nt = A.ntasks[g];
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&A.tickets[g * 32], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nt) break;
+      const uint4 task = A.tasks[(long)g * A.max_tasks + t];
+      const int cnt = (int)task.z >= 0 ? 2 : 1, total = cnt * np;
+      const uint4 rec0 = A.kps[task.y], rec1 = A.kps[cnt == 2 ? task.z : task.y];
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.integ24 + (long)task.x * A.f24_bytes), 0, (int)A.f24_bytes, 0x00020000);
+      int ksum = 0;
+      const int nr = (total + 63) >> 6;  // rounds per pass (wave-uniform): 2 or 3
+      auto issue = [&](int pass, int r) {
+        SwRound R;
+        const int s0 = r * 64, s = s0 + lane;
+        R.valid = s < total;
+        const bool pair_valid = s0 + (lane & ~1) < total;
+        const int sc = min(s, total - 1);
+        R.sc = sc;
+        const int kq = sc >= np ? 1 : 0, pt = sc - kq * np;
+        const uint4 rec = kq ? rec1 : rec0;
+        const int theta = pass ? (int)rec.w : 0;
+        const int4 tab = A.tab4[(int)rec.z * np + pt];
+        const double2 uv = A.uv2[theta * np + pt];
+        const double mm = (double)__int_as_float(tab.x);
+        const float xf = (float)(mm * uv.x) + __uint_as_float(rec.x), yf = (float)(mm * uv.y) + __uint_as_float(rec.y);
+        const BriskBoxPrep pr = brisk_box_prep(xf, yf, __int_as_float(tab.y), tab.z, tab.w);
+        R.A = pr.A; R.B = pr.B; R.C = pr.C; R.D = pr.D; R.r_x_1_i = pr.r_x_1_i; R.r_y_1_i = pr.r_y_1_i; R.r_x1_i = pr.r_x1_i; R.r_y1_i = pr.r_y1_i;
+        R.scaling = pr.scaling; R.magic = pr.magic; R.shift = pr.shift;
+        const int o_t = pr.y_top * rowb, o_b = pr.y_bottom * rowb;
+        const int o_tl = o_t + pr.x_left * 3, o_tr = o_t + pr.x_right * 3, o_bl = o_b + pr.x_left * 3, o_br = o_b + pr.x_right * 3;
+        const int e_tr = dpp_even(o_tr), o_tl_ = dpp_odd(o_tl), e_br = dpp_even(o_br), o_bl_ = dpp_odd(o_bl);
+        // (lanes beyond the run: an offset beyond the buffer - the load returns 0 without an access, and no branch splits the burst)
+        const int oob = pair_valid ? 0 : 0x40000000;
+        const int a_top = (odd ? e_tr : o_tl) | oob, b_top = (odd ? o_tr : o_tl_) | oob;
+        const int a_bot = (odd ? e_br : o_bl) | oob, b_bot = (odd ? o_br : o_bl_) | oob;
+        const int qk = pr.quirk ? 1 : 0;
+        R.a_quirk = dpp_even(qk) != 0; R.b_quirk = dpp_odd(qk) != 0;
+        R.at0 = __builtin_amdgcn_raw_buffer_load_b64(rs, a_top, 0, 0);
+        R.bt0 = __builtin_amdgcn_raw_buffer_load_b64(rs, b_top, 0, 0);
+        R.at1 = __builtin_amdgcn_raw_buffer_load_b64(rs, a_top, rowb, 0);
+        R.bt1 = __builtin_amdgcn_raw_buffer_load_b64(rs, b_top, rowb, 0);
+        R.aq = __builtin_amdgcn_raw_buffer_load_b64(rs, a_bot - rowb + 3, 0, 0);
+        R.bq = __builtin_amdgcn_raw_buffer_load_b64(rs, b_bot - rowb + 3, 0, 0);
+        R.ab0 = __builtin_amdgcn_raw_buffer_load_b96(rs, a_bot, 0, 0);
+        R.bb0 = __builtin_amdgcn_raw_buffer_load_b96(rs, b_bot, 0, 0);
+        R.ab1 = __builtin_amdgcn_raw_buffer_load_b64(rs, a_bot, rowb, 0);
+        R.bb1 = __builtin_amdgcn_raw_buffer_load_b64(rs, b_bot, rowb, 0);
+        return R;
+      };
+      auto finish = [&](const SwRound& R) {
+        const SideSix sa = side_six(R.at0, R.at1, R.aq, R.ab0, R.ab1, R.a_quirk, odd), sb = side_six(R.bt0, R.bt1, R.bq, R.bb0, R.bb1, R.b_quirk, odd);
+#define SW_X(f) const uint32_t own_##f = odd ? sb.f : sa.f, par_##f = (uint32_t)dpp_partner((int)(odd ? sa.f : sb.f));
+        SW_X(ct) SW_X(cb) SW_X(st) SW_X(dt) SW_X(db) SW_X(dm)
+#undef SW_X
+        constexpr uint32_t m = 0xFFFFFFu;
+        const uint32_t tt = par_dt - own_dt, tb = par_db - own_db, tm = par_dm - own_dm;
+        const uint32_t top = (odd ? 0u - tt : tt) & m, bottom = (odd ? 0u - tb : tb) & m, middle = (odd ? 0u - tm : tm) & m;
+        const unsigned w_own_t = odd ? R.B : R.A, w_par_t = odd ? R.A : R.B, w_own_b = odd ? R.C : R.D, w_par_b = odd ? R.D : R.C;
+        const unsigned w_own_s = odd ? R.r_x1_i : R.r_x_1_i, w_par_s = odd ? R.r_x_1_i : R.r_x1_i;
+        const uint32_t acc = w_own_t * own_ct + w_par_t * par_ct + w_own_b * own_cb + w_par_b * par_cb + R.r_y_1_i * top + R.r_y1_i * bottom +
+                             w_own_s * own_st + w_par_s * par_st + (unsigned)R.scaling * middle;
+        const int value = brisk_div_by_magic((int)acc, R.magic, R.shift);
+        if (R.valid) { vals[R.sc] = value; ksum += value; }
+      };
+      if (!CROSS) {
+        for (int pass = 0; pass < 2; ++pass) {
+          const SwRound R0 = issue(pass, 0);
+          const SwRound R1 = issue(pass, 1);
+          finish(R0);
+          if (nr == 3) {
+            const SwRound R2 = issue(pass, 2);
+            finish(R1);
+            finish(R2);
+          } else {
+            finish(R1);
+          }
+          wave_sync();
+        }
+      } else {
+        // the task's 2 nr rounds as one sequence, two in flight
+        SwRound Ra = issue(0, 0);
+        const int nseq = 2 * nr;
+        for (int q = 1; q < nseq; q += 2) {
+          const SwRound Rb = issue(q >= nr ? 1 : 0, q >= nr ? q - nr : q);
+          finish(Ra);
+          if (q + 1 < nseq) Ra = issue(q + 1 >= nr ? 1 : 0, q + 1 >= nr ? q + 1 - nr : q + 1);
+          finish(Rb);
+        }
+        if (nseq & 1) finish(Ra);  // (never: nseq is even)
+        wave_sync();
+      }
+      int f = vals[lane] + ksum;
+      { int f1 = f ^ 5, f2 = f + 7, f3 = f * 3; for (int k = 0; k < A.filler * cnt / 12; ++k) { f += (f >> 3) ^ k; f1 += (f1 >> 3) ^ k; f2 += (f2 >> 3) ^ k; f3 += (f3 >> 3) ^ k; } f ^= f1 ^ f2 ^ f3; }
+      if (f == 0x12345678) ksum += 1;
+      sum += ksum;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const int tot_lo = wave_sum_i((int)(sum & 0xFFFFFF)), tot_hi = wave_sum_i((int)(sum >> 24));
+  if (lane == 0) atomicAdd(A.checksum, (unsigned long long)tot_lo + ((unsigned long long)tot_hi << 24));
+}
+
 // ---- round 5, second half: the 3-byte integral image with its rows interleaved in pairs --------------------------------
 // Element (y, x) at byte ((y >> 1) * 2 iw + 2 x + (y & 1)) * 3: a 128-byte line holds 21 columns of TWO rows.  The 2 x 2 top
 // block of a box side is one 12-byte gather when y_top is even, two when it is odd; the bottom rows y_bottom - 1 .. + 1 are
@@ -1088,7 +1219,7 @@ int main(int argc, char** argv) {
   const Cls classes[] = {{"side<=67", 0, 67}, {"67<side<=101", 67, 101}, {"side<=101", 0, 101}, {"101<side<=151", 101, 151},
                          {"151<side<=201", 151, 201}, {"side>201", 201, 100000}, {"all", 0, 100000}};
   struct Var { const char* name; int kind; int src; bool u16; int max_side; };
-  const Var vars[] = {{"gather_sw", 11, 1, false, 100000}, {"gather_lr", 10, 1, false, 100000}, {"gather_il2", 9, 1, false, 100000}, {"gather_i24_whatif_8gathers", 0, 11, false, 100000},
+  const Var vars[] = {{"gather_sw2_drain", 12, 1, false, 100000}, {"gather_sw2_cross", 13, 1, false, 100000}, {"gather_sw", 11, 1, false, 100000}, {"gather_lr", 10, 1, false, 100000}, {"gather_il2", 9, 1, false, 100000}, {"gather_i24_whatif_8gathers", 0, 11, false, 100000},
                       {"gather_i24_whatif_30dwords", 0, 12, false, 100000}, {"gather_i24_whatif_10dwords", 0, 13, false, 100000}, {"gather_i24_whatif_nogathers", 0, 14, false, 100000},
                       {"gather_i24_whatif_l1hits", 0, 15, false, 100000}, {"gather_i24_whatif_l1hits_pairs", 0, 16, false, 100000},
                       {"gather_i24_whatif_l1hits_quads", 0, 17, false, 100000}, {"gather_i24_whatif_l1hits_16", 0, 18, false, 100000}, {"gather_i24", 0, 1, false, 100000},    {"gather_u32", 0, 0, false, 100000},   {"lds_u16_from_i24", 1, 1, true, 101},
@@ -1120,7 +1251,7 @@ int main(int argc, char** argv) {
             bmax = std::max(bmax, b);
           }
           nkp += (long)sel.size();
-          if (V.kind == 0 || V.kind == 9 || V.kind == 10 || V.kind == 11) {
+          if (V.kind == 0 || (V.kind >= 9 && V.kind <= 13)) {
             for (size_t i = 0; i < sel.size(); i += 2)
               tq[g].push_back(make_uint4((unsigned)s, (unsigned)(base[f] + sel[i]), i + 1 < sel.size() ? (unsigned)(base[f] + sel[i + 1]) : 0xFFFFFFFFu, 0));
           } else {
@@ -1137,7 +1268,7 @@ int main(int argc, char** argv) {
       if (!nkp) continue;
       std::vector<int> wpcs;
       size_t lds = 0;
-      if (V.kind == 0 || V.kind == 9 || V.kind == 10 || V.kind == 11) {
+      if (V.kind == 0 || (V.kind >= 9 && V.kind <= 13)) {
         wpcs = {3};
       } else {
         lds = 512 + (size_t)patch_pw(bmax) * patch_ph(bmax) * (V.u16 ? 2 : 4);
@@ -1154,9 +1285,9 @@ int main(int argc, char** argv) {
           CHECK(hipMemsetAsync(d_sum, 0, 8, 0));
           CHECK(hipMemsetAsync(d_phase, 0, 64, 0));
           CHECK(hipEventRecord(e0, 0));
-          if (V.kind == 0 || V.kind == 9 || V.kind == 10 || V.kind == 11) {
+          if (V.kind == 0 || (V.kind >= 9 && V.kind <= 13)) {
             const size_t l = 160 * 1024 / 4 + 512;
-            auto fn = V.kind == 11 ? k_gather_sw : V.kind == 10 ? k_gather_lr : V.kind == 9 ? k_gather_il2 : V.src == 11 ? k_gather<true, 1> : V.src == 12 ? k_gather<true, 2> : V.src == 13 ? k_gather<true, 3> : V.src == 14 ? k_gather<true, 4> : V.src == 15 ? k_gather<true, 5> : V.src == 16 ? k_gather<true, 6> : V.src == 17 ? k_gather<true, 7> : V.src == 18 ? k_gather<true, 8> :
+            auto fn = V.kind == 12 ? k_gather_sw2<false> : V.kind == 13 ? k_gather_sw2<true> : V.kind == 11 ? k_gather_sw : V.kind == 10 ? k_gather_lr : V.kind == 9 ? k_gather_il2 : V.src == 11 ? k_gather<true, 1> : V.src == 12 ? k_gather<true, 2> : V.src == 13 ? k_gather<true, 3> : V.src == 14 ? k_gather<true, 4> : V.src == 15 ? k_gather<true, 5> : V.src == 16 ? k_gather<true, 6> : V.src == 17 ? k_gather<true, 7> : V.src == 18 ? k_gather<true, 8> :
                       V.src == 1 ? k_gather<true> : k_gather<false>;
             CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
             hipLaunchKernelGGL(fn, dim3(ncu * wpc), dim3(128), l, 0, A);
@@ -1196,7 +1327,7 @@ int main(int argc, char** argv) {
         printf("%s{\"class\": \"%s\", \"variant\": \"%s\", \"keypoints\": %ld, \"max_border\": %d, \"lds_bytes\": %zu, \"waves_per_cu\": %d, "
                "\"ms\": %.4f, \"samples_per_ns_chip\": %.2f, \"us_per_keypoint_cu\": %.3f, \"checksum\": %llu, "
                "\"wave_us_per_keypoint\": {\"ticket_params\": %.2f, \"staging\": %.2f, \"pass0\": %.2f, \"pass1\": %.2f, \"other\": %.2f}}",
-               first ? "" : ",\n", C.name, V.name, nkp, bmax, lds, (V.kind == 0 || V.kind == 9 || V.kind == 10 || V.kind == 11) ? wpc * 2 : wpc, best_ms, samples / (best_ms * 1e6),
+               first ? "" : ",\n", C.name, V.name, nkp, bmax, lds, (V.kind == 0 || (V.kind >= 9 && V.kind <= 13)) ? wpc * 2 : wpc, best_ms, samples / (best_ms * 1e6),
                best_ms * 1e3 * ncu / (double)nkp, sum, php[0] * 0.01 / nkp, php[1] * 0.01 / nkp, php[2] * 0.01 / nkp, php[3] * 0.01 / nkp,
                php[4] * 0.01 / nkp);
         first = false;

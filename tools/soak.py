@@ -9,6 +9,8 @@ tests/test_gpu_round3.py runs a few hundred cases of three of them).  One entry 
   python3 tools/soak.py options   [cases] [seed]               masks, suppressScaleNonmaxima=false, post-filters, invariance flags, pattern versions / scales
   python3 tools/soak.py matcher   [cases] [seed]               Hamming matcher: set sizes, 1..6 train images, descriptor lengths 16..224, masks, k, radii
   python3 tools/soak.py large     [cases] [seed]               16-bit image functions, frames of 2000..4600 px, ComputeScale lists
+  python3 tools/soak.py threads   [iterations] [watchdog s]    eight host threads with their own contexts and kinds of work at once (one-frame 4K, 64-frame
+                                                               batch, dense, odd sizes, host-to-host), every iteration against the oracle; a hang kills the child
   python3 tools/soak.py all                                    every suite with its defaults
 
 Every case is compared bit-exactly with the oracle (or both sides must agree that the reference has no defined result).
@@ -17,7 +19,7 @@ import os
 import subprocess
 import sys
 
-SUITES = ["frames", "describe", "ordered", "callspace", "options", "matcher", "large"]
+SUITES = ["frames", "describe", "ordered", "callspace", "options", "matcher", "large", "threads"]
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "soak_cases")
 
 

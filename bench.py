@@ -760,28 +760,38 @@ def _other_configs(device, only="", seconds=0.4):
 
 
 def threads_table(seconds):
-    """The drop-in C++ classes (include/brisk/*.h: one thread_local context per host thread) under 1 ... 16 host threads:
-    tests/cpp/test_threads --time, a child process per row; distinct 1080p frames per thread, detect() + compute() per
-    frame, every result compared with the serial run inside the child."""
+    """The drop-in C++ classes (include/brisk/*.h) under 1 ... 32 host threads: tests/cpp/test_threads --time, a child process per
+    row; distinct 1080p frames per thread, detect() + compute() per frame, every result compared with the serial run inside the
+    child.  Rows: the classes' default policy (a context per thread; the device's shared call-combining pool from more concurrent
+    callers than CPUs on), then the same thread counts with the policy forced one way or the other and with ScopedSameImage (the
+    caller's word that compute() gets detect()'s unchanged buffer)."""
     import subprocess
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_cpp_classes as tc
     exe = tc.build_binary("test_threads")
-    rows = []
-    for n in (1, 2, 4, 8, 16):
-        r = subprocess.run([exe, "--time", str(n), str(max(1.0, 3 * seconds))], capture_output=True, text=True, timeout=300)
+    secs = str(max(1.0, 3 * seconds))
+
+    def run(n, *flags):
+        r = subprocess.run([exe, "--time", str(n), secs] + list(flags), capture_output=True, text=True, timeout=300)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
-            rows.append({"threads": n, "failed": (r.stdout + r.stderr)[-300:]})
-            continue
-        rows.append(json.loads(line[-1]))
+            return {"threads": n, "flags": list(flags), "failed": (r.stdout + r.stderr)[-300:]}
+        d = json.loads(line[-1])
+        d["flags"] = list(flags)
+        return d
+    rows = [run(n) for n in (1, 2, 4, 8, 16, 32)]
+    extra = [run(16, "--pool-threshold", "1"), run(32, "--pool-threshold", "0"), run(16, "--same-image"), run(32, "--same-image"),
+             run(32, "--same-image", "--pool-threshold", "1")]
     ok = [r for r in rows if "frames_per_s" in r]
     base = ok[0]["frames_per_s"] if ok and ok[0]["threads"] == 1 else None
     return {"workload": "drop-in classes brisk::BriskFeatureDetector::detect + BriskDescriptorExtractor::compute, one 1080p frame per "
-                        "call pair, threshold 80, 4 octaves, N host threads with their own contexts (hip-context.h), pageable cv::Mat-like "
-                        "buffers; aggregate over threads",
-            "unit": "frames/s", "rows": rows,
+                        "call pair, threshold 80, 4 octaves, N host threads, pageable cv::Mat-like buffers; aggregate over threads. "
+                        "rows: default policy (own context per thread; shared pool from more callers than CPUs on); "
+                        "forced: --pool-threshold 1 = every call through the pool, 0 = never; --same-image = ScopedSameImage",
+            "unit": "frames/s", "rows": rows, "forced": extra,
             "speedup_vs_1_thread": None if not base else {str(r["threads"]): round(r["frames_per_s"] / base, 2) for r in ok},
+            "limiter": "the HIP runtime serialises the API calls of a process (hipLaunchKernel 4.6 -> 26 us from 1 to 8 threads): "
+                       "profiles/r06_threads_limiter.txt",
             "host_cpus": len(os.sched_getaffinity(0))}
 
 

@@ -36,15 +36,15 @@ ABI_SYMBOLS = [
     "brisk_hip_comm_unique_id", "brisk_hip_comm_create", "brisk_hip_comm_destroy", "brisk_hip_comm_rank", "brisk_hip_comm_world",
     "brisk_hip_comm_gather_results", "brisk_hip_comm_wait",
     "brisk_hip_set_integral_format",
-    "brisk_hip_host_register", "brisk_hip_host_unregister",
-    "brisk_hip_pool_create", "brisk_hip_pool_destroy", "brisk_hip_pool_last_error", "brisk_hip_pool_detect", "brisk_hip_pool_describe",
+    "brisk_hip_host_register", "brisk_hip_host_unregister", "brisk_hip_usable_cpus",
+    "brisk_hip_pool_create", "brisk_hip_pool_destroy", "brisk_hip_pool_last_error", "brisk_hip_pool_detect", "brisk_hip_pool_describe", "brisk_hip_pool_stats",
     "brisk_hip_batch_download_all", "brisk_hip_batch_download_wait", "brisk_hip_detect_describe_batch_host_results",
 ]
 # every symbol include/brisk_hip_debug.h declares: test / tuning builds (BRISK_HIP_TUNING) only
 DEBUG_SYMBOLS = [
     "brisk_hip_debug_layer", "brisk_hip_debug_integral", "brisk_hip_debug_counters", "brisk_hip_debug_counters_raw",
     "brisk_hip_debug_set_flags", "brisk_hip_debug_image_reuse", "brisk_hip_debug_filter_keypoints", "brisk_hip_debug_integral_bits",
-    "brisk_hip_debug_forge_pattern_device",
+    "brisk_hip_debug_forge_pattern_device", "brisk_hip_debug_pool_phases",
 ]
 
 
@@ -201,6 +201,7 @@ def load_library():
     L.brisk_hip_pool_destroy.restype = None
     L.brisk_hip_pool_last_error.argtypes = [vp]
     L.brisk_hip_pool_last_error.restype = C.c_char_p
+    L.brisk_hip_pool_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.brisk_hip_pool_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, ip, C.POINTER(C.c_ulonglong)]
     L.brisk_hip_pool_describe.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, C.c_int, C.c_int, C.c_int, C.c_ulonglong]
     L.brisk_hip_host_register.argtypes = [vp, C.c_size_t]
@@ -453,6 +454,12 @@ class Pool:
         self._check(self._L.brisk_hip_pool_describe(self._h, pattern._h, _ptr(img), w, h, w, _ptr(k), C.byref(n), _ptr(desc), s,
                                                     int(rotation_invariant), int(scale_invariant), token))
         return k[:n.value], desc[:n.value]
+
+    def stats(self):
+        """(groups run, calls they carried)"""
+        g, c = C.c_ulonglong(), C.c_ulonglong()
+        self._L.brisk_hip_pool_stats(self._h, C.byref(g), C.byref(c))
+        return g.value, c.value
 
     def close(self):
         if getattr(self, "_h", None):

@@ -6,6 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -98,6 +102,7 @@ struct brisk_hip_ctx {
   // its stream wait for the end of the previous one (event recorded at the end of each call).
   hipEvent_t done_ev = nullptr;
   bool done_valid = false;
+  hipEvent_t block_ev = nullptr;  // blocking-sync event of the one-frame calls (download_single: when polling would starve other threads)
   // host-fed batches: two device staging buffers filled over a copy stream while the previous slice computes
   uint8_t* d_hstage[2] = {nullptr, nullptr};
   size_t hstage_bytes = 0;
@@ -408,6 +413,8 @@ static int check_detect_args(brisk_hip_ctx* ctx, int w, int h, int threshold, in
   return BRISK_HIP_OK;
 }
 
+static int usable_cpus();
+
 extern "C" {
 
 int brisk_hip_device_count(void) {
@@ -415,6 +422,8 @@ int brisk_hip_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+int brisk_hip_usable_cpus(void) { return usable_cpus(); }
 
 int brisk_hip_host_register(void* ptr, size_t bytes) {
   if (!ptr || !bytes) return BRISK_HIP_ERR_ARG;
@@ -462,6 +471,7 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
   if (c->h_res) hipHostFree(c->h_res);
   if (c->d_pub_done) hipFree(c->d_pub_done);
   if (c->done_ev) hipEventDestroy(c->done_ev);
+  if (c->block_ev) hipEventDestroy(c->block_ev);
   for (int i = 0; i < 2; ++i) {
     if (c->d_hstage[i]) hipFree(c->d_hstage[i]);
     if (c->copied_ev[i]) hipEventDestroy(c->copied_ev[i]);
@@ -1057,6 +1067,39 @@ static int download_locked(brisk_hip_ctx* ctx, int frame, int which, brisk_hip_k
   return BRISK_HIP_OK;
 }
 
+// CPUs this process may use: the affinity mask, cut by a cgroup CPU quota (containers) - what decides whether a thread that
+// waits for its results may poll or has to sleep
+static int usable_cpus() {
+  static const int n = [] {
+    int c = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) c = CPU_COUNT(&set);
+    if (c <= 0) c = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    long quota = -1, period = -1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota | max> <period>"
+      char q[64];
+      if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+      fclose(f);
+    } else {
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota > 0 && period > 0) {
+      const int lim = (int)((quota + period - 1) / period);
+      if (lim > 0 && lim < c) c = lim;
+    }
+    return c > 0 ? c : 1;
+  }();
+  return n;
+}
+// host threads that are polling for a one-frame call's results right now (all contexts of the process)
+static std::atomic<int> g_pollers{0};
+struct PollerScope {
+  int n;
+  PollerScope() : n(g_pollers.fetch_add(1, std::memory_order_relaxed) + 1) {}
+  ~PollerScope() { g_pollers.fetch_sub(1, std::memory_order_relaxed); }
+};
+
 // Results of a ONE-frame host-buffer call (frame slot 0).  download_locked costs three blocking copies - the count, then
 // the keypoints, then the descriptor rows: 20 us each, a third of such a call on a 640 x 480 frame.  Here a small kernel
 // behind the call's kernels (k_publish_single) writes the counter record and the rows it announces straight into pinned
@@ -1094,6 +1137,15 @@ static int download_single(brisk_hip_ctx* ctx, int which, brisk_hip_keypoint* kp
   // no deadline.)
   volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(ctx->h_res);
   unsigned v = 0;
+  // Polling needs a core per waiting thread: with more callers than the process has CPUs (round 6: 32 threads on 16 CPUs fell from
+  // 9 k to 4 k frames/s, every thread burning its time slice on the flag while the threads that had work waited for a core) the
+  // thread sleeps on a blocking event instead - an interrupt and ~20 us of wake-up, but the core goes to someone who needs it.
+  const PollerScope poller;
+  if (poller.n >= usable_cpus()) {
+    if (!ctx->block_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->block_ev, hipEventBlockingSync | hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->block_ev, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->block_ev));
+  }
   const auto t_poll = std::chrono::steady_clock::now();
   for (unsigned spin = 1;; ++spin) {
     v = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
@@ -1202,7 +1254,8 @@ static void export_finish(brisk_hip_ctx* ctx, brisk_hip_ctx::ExportSlot& E) {
   }
 }
 
-static int download_all_locked(brisk_hip_ctx* ctx, int which, const brisk_hip_batch_host_results* dst, hipStream_t s, unsigned* ticket) {
+static int download_all_locked(brisk_hip_ctx* ctx, int which, const brisk_hip_batch_host_results* dst, hipStream_t s, unsigned* ticket,
+                               bool known_pinned = false /* the arrays come from hipHostMalloc (the pool's own): no pointer queries */) {
   if (!dst || !ticket || (which != 0 && which != 1)) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: null destination / ticket, or which not 0 / 1");
   *ticket = 0;
   const int nframes = ctx->last_nframes;
@@ -1239,8 +1292,9 @@ static int download_all_locked(brisk_hip_ctx* ctx, int which, const brisk_hip_ba
   // where the egress kernel writes: the caller's arrays when the device can reach all of them, else the bounce buffer
   brisk_hip_batch_host_results W = *dst;
   void* dv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  const bool direct = device_can_write(dst->counts, &dv[0]) && device_can_write(dst->flags, &dv[1]) && device_can_write(dst->offsets, &dv[2]) &&
-                (dst->rows_cap == 0 || device_can_write(dst->kps, &dv[3])) && (!want_desc || device_can_write(dst->desc, &dv[4]));
+  if (known_pinned) { dv[0] = dst->counts; dv[1] = dst->flags; dv[2] = dst->offsets; dv[3] = dst->kps; dv[4] = dst->desc; }
+  const bool direct = known_pinned || (device_can_write(dst->counts, &dv[0]) && device_can_write(dst->flags, &dv[1]) && device_can_write(dst->offsets, &dv[2]) &&
+                (dst->rows_cap == 0 || device_can_write(dst->kps, &dv[3])) && (!want_desc || device_can_write(dst->desc, &dv[4])));
   if (direct) {
     W.counts = static_cast<int*>(dv[0]); W.flags = static_cast<int*>(dv[1]); W.offsets = static_cast<long long*>(dv[2]);
     W.kps = static_cast<brisk_hip_keypoint*>(dv[3]); W.desc = want_desc ? static_cast<uint8_t*>(dv[4]) : nullptr;

@@ -29,6 +29,14 @@ BRISK_HD int brisk_no_debug_flags() { return 0; }  // (a call, not a literal: no
 #define BRISK_DBG_FLAGS(G) brisk_no_debug_flags()
 #endif
 
+// experiment (build variant -DBRISK_CHAIN_PRIO=n, tools/r06_chainprio.sh): the latency-bound kernels that run beside the integral kernel -
+// tie resolution, k_finalize, k_desc_prepare - raise their waves' priority
+#ifdef BRISK_CHAIN_PRIO
+#define BRISK_CHAIN_SETPRIO() __builtin_amdgcn_s_setprio(BRISK_CHAIN_PRIO)
+#else
+#define BRISK_CHAIN_SETPRIO() do { } while (0)
+#endif
+
 #define BRISK_MAX_LAYERS 16
 // Below this AGAST threshold a detection may store a score <= 2, which the reference's lazy cache treats as "not cached"
 // (brisk-layer.cc:118-132): a FRAME in which k_detect stores such a score runs the ordered path (k_ordered_keypoints); all

@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(DP_THREADS) k_desc_prepare(BriskGeom G, BriskP
   __shared__ int wtot[DP_THREADS / 64];
   __shared__ int base, nest;
   __shared__ __attribute__((aligned(16))) unsigned pkey[DP_MAXSORT + 4];
+  BRISK_CHAIN_SETPRIO();
   const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = min(*(const int*)((const char*)n_in_ptr + (long)frame * n_in_stride), kp_cap);
   const BriskKeyPoint* K = kp_in + (long)frame * kp_cap;

@@ -1304,6 +1304,7 @@ __global__ void __launch_bounds__(FN_THREADS) k_finalize(BriskGeom G, const Bris
   __shared__ int nvalid;
   __shared__ unsigned skey[FN_SMALL];
   __shared__ unsigned sidx[FN_SMALL];
+  BRISK_CHAIN_SETPRIO();
   const int frame = blockIdx.x, tid = threadIdx.x;
   if (counters[frame].low_score) return;  // (the frame runs the ordered path, which writes its keypoints itself)
   const int n = min(counters[frame].ncand, cand_cap);

@@ -93,11 +93,14 @@ struct ScopedSameImage {
 };
 
 // ---- many threads at once: call combining (brisk_hip_pool, include/brisk_hip.h) -----------------------------------------
-// A thread's own context is the fastest way to serve ONE caller; from a few concurrent callers on, the calls that are in
-// the engine at the same time are cheaper as one batch (the HIP runtime serialises the API calls of a process: 16 threads
-// with their own contexts reach 3.6 x one thread).  The classes count the threads that are inside detect() / compute() right
-// now and hand a call to the device's shared pool when that count has reached PoolThreshold() (default 4; 0 = never;
-// BRISK_HIP_POOL_THREADS in the environment or SetPoolThreshold() change it).  Results are bit-identical either way.
+// A thread's own context is the fastest way to serve one caller, or a few; with many, every call's ~15 launches and 2 - 4 copies
+// queue behind each other in the HIP runtime (it serialises the API calls of a process: 16 threads with their own contexts reach
+// 3.6 x one thread) and the calls that are in the engine at the same time are better off as one batch.  The classes count the threads that are inside detect() / compute() right
+// now and hand a call to the device's shared pool when that count has reached PoolThreshold().  Default: one more than the
+// CPUs the process may use - measured: up to 16 threads on 16 CPUs a context per thread is as fast or faster
+// (9 - 10 k against 8 k 1080p frames/s), with more threads than CPUs the pool keeps its rate (10 - 12 k at 32 threads) where the
+// per-thread contexts lose theirs.  0 = never; BRISK_HIP_POOL_THREADS in the environment or SetPoolThreshold() change it.
+// Results are bit-identical either way.
 inline std::atomic<int>& ActiveCalls() {
   static std::atomic<int> n{0};
   return n;
@@ -110,7 +113,7 @@ struct CallScope {
   CallScope& operator=(const CallScope&) = delete;
 };
 inline std::atomic<int>& PoolThresholdRef() {
-  static std::atomic<int> t{[] { const char* e = std::getenv("BRISK_HIP_POOL_THREADS"); return e ? std::atoi(e) : 4; }()};
+  static std::atomic<int> t{[] { const char* e = std::getenv("BRISK_HIP_POOL_THREADS"); return e ? std::atoi(e) : brisk_hip_usable_cpus() + 1; }()};
   return t;
 }
 inline int PoolThreshold() { return PoolThresholdRef().load(std::memory_order_relaxed); }

@@ -52,6 +52,10 @@ const char* brisk_hip_last_error(const brisk_hip_ctx* ctx);
 /* per-frame capacities: AGAST candidates (default 65536) and keypoints (default 16384; below 2^23) */
 int brisk_hip_set_capacity(brisk_hip_ctx* ctx, int max_candidates, int max_keypoints);
 int brisk_hip_device_count(void);
+/* CPUs the process may use (affinity mask, cut by a cgroup quota).  A one-frame call POLLS for its results while fewer threads
+ * than that are polling (a wake-up costs more than the call's tail) and sleeps on a blocking event otherwise; the classes of
+ * include/brisk/ hand calls to the device's shared pool from more concurrent callers than CPUs on. */
+int brisk_hip_usable_cpus(void);
 /* raises the capacities to at least these values; never lowers them (no reallocation for smaller requests) */
 int brisk_hip_reserve(brisk_hip_ctx* ctx, int min_candidates, int min_keypoints);
 
@@ -249,6 +253,8 @@ typedef struct brisk_hip_pool brisk_hip_pool;
 int brisk_hip_pool_create(int device, int max_batch, int max_keypoints, brisk_hip_pool** out);
 void brisk_hip_pool_destroy(brisk_hip_pool* pool);
 const char* brisk_hip_pool_last_error(const brisk_hip_pool* pool); /* of the calling thread's last failed call */
+/* groups run so far and the calls they carried (calls / groups = mean batch size) */
+int brisk_hip_pool_stats(brisk_hip_pool* pool, unsigned long long* groups, unsigned long long* calls);
 /* brisk_hip_detect (suppressScaleNonmaxima = true, no mask, no post-filter) through the pool.  *image_token (may be NULL)
  * names the device copy of this frame for a following brisk_hip_pool_describe. */
 int brisk_hip_pool_detect(brisk_hip_pool* pool, const uint8_t* img, int w, int h, int stride, int threshold, int octaves,

@@ -38,6 +38,10 @@ int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx);
  * filter kernels on lists no detector produces: tight clusters, the smallest radii); out holds n_in keypoints */
 int brisk_hip_debug_filter_keypoints(brisk_hip_ctx* ctx, const brisk_hip_keypoint* in, int n_in, int rows, int cols, double radius,
                                      int max_keypoints, brisk_hip_keypoint* out, int* n);
+/* wall seconds per phase of the pool's calls, summed over all calls so far (tools): 0 until the call has joined a group, 1 its
+ * staging copies, 2 leader: until a context is free and all members have staged, 3 leader: copies queued, 4 leader: batch queued,
+ * 5 leader: until the results are in host memory, 6 member: until its group is done, 7 the whole call; out holds 8 doubles */
+int brisk_hip_debug_pool_phases(brisk_hip_pool* pool, double* out);
 /* per-frame work counts of the last batch (tools only): out[0] candidates, out[1] keypoints, out[2] described
  * keypoints, out[3] overflow flags, out[4 + l] tie candidates of layer l, out[20 .. 27] experiment words; out holds 28 ints. */
 int brisk_hip_debug_counters(brisk_hip_ctx* ctx, int frame, int* out, int* nlayers);

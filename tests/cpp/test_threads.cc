@@ -14,6 +14,7 @@
 //        default 4: brisk::hip::SetPoolThreshold).
 //        test_threads <golden dir> [threads] [iterations] --pool-threshold 1: the bit-equality run with EVERY eligible call pooled.
 #include <brisk/brisk.h>
+#include <brisk_hip_debug.h>
 
 #include "set_serialization.h"
 
@@ -167,10 +168,21 @@ static int time_mode(int nthreads, double seconds, int w, int h, bool pinned, bo
   for (int t = 0; t < nthreads; ++t) { total += calls[t]; cpu_sum += cpu[t]; lat_sum += lat[t]; if (lat_max[t] > lmax) lmax = lat_max[t]; }
   if (pinned)
     for (auto& v : pix) (void)brisk_hip_host_unregister(v.data());
-  printf("{\"threads\": %d, \"pool_threshold\": %d, \"pinned\": %d, \"same_image\": %d, \"width\": %d, \"height\": %d, \"frames_per_s\": %.1f, \"calls\": %ld, \"seconds\": %.3f, "
+  unsigned long long pg = 0, pc = 0;
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (brisk::hip::PoolThreshold() > 0 && nthreads >= brisk::hip::PoolThreshold())
+    if (brisk_hip_pool* pool = brisk::hip::SharedPool(brisk::hip::ThisThread().device)) {
+      (void)brisk_hip_pool_stats(pool, &pg, &pc);
+      (void)brisk_hip_debug_pool_phases(pool, ph);
+    }
+  if (pc)  // microseconds per pooled call (leader phases: per group)
+    printf("pool phases: join %.0f us, staging %.0f, whole call %.0f | per group: wait for context + members %.0f, queue copies %.0f, queue batch %.0f, "
+           "device + transfer %.0f | member wait %.0f per member\n", 1e6 * ph[0] / pc, 1e6 * ph[1] / pc, 1e6 * ph[7] / pc, 1e6 * ph[2] / pg, 1e6 * ph[3] / pg,
+           1e6 * ph[4] / pg, 1e6 * ph[5] / pg, pc > pg ? 1e6 * ph[6] / (pc - pg) : 0.0);
+  printf("{\"threads\": %d, \"pool_threshold\": %d, \"pool_groups\": %llu, \"pool_calls\": %llu, \"pinned\": %d, \"same_image\": %d, \"width\": %d, \"height\": %d, \"frames_per_s\": %.1f, \"calls\": %ld, \"seconds\": %.3f, "
          "\"latency_ms_mean\": %.4f, \"latency_ms_max\": %.3f, \"host_cpu_ms_per_call\": %.4f, \"mean_keypoints\": %.1f, "
          "\"mismatches\": %d}\n",
-         nthreads, brisk::hip::PoolThreshold(), (int)pinned, (int)same_image, w, h, total / dt, total, dt, total ? lat_sum / total : 0.0, lmax, total ? 1e3 * cpu_sum / total : 0.0,
+         nthreads, brisk::hip::PoolThreshold(), pg, pc, (int)pinned, (int)same_image, w, h, total / dt, total, dt, total ? lat_sum / total : 0.0, lmax, total ? 1e3 * cpu_sum / total : 0.0,
          (double)kp_total / pix.size(), (int)bad);
   return bad ? 1 : 0;
 }

@@ -263,7 +263,7 @@ def test_reference_goldens_on_the_release_library():
 def test_pool_combines_concurrent_calls_bit_exactly(B, frames65, oracle65):
     """brisk_hip_pool: twelve host threads call detect() then describe() on their own frames at once - two image sizes and two
     thresholds (calls of different kinds must not mix in a group), describe() with the detect call's token (device copy of the
-    frame), with a stale token and without one; every result equals the oracle, and a lone caller (a group of one) does too."""
+    frame), with a token that names no retained frame and without one; every result equals the oracle, and a lone caller (a group of one) does too."""
     import threading
     pool = B.Pool(0, max_batch=8)
     ext = B.BriskDescriptorExtractor()
@@ -280,7 +280,6 @@ def test_pool_combines_concurrent_calls_bit_exactly(B, frames65, oracle65):
 
     def worker(t):
         try:
-            stale = 0
             for it in range(12):
                 if t % 3 == 2:                                           # another size / threshold / octave count
                     j = (t + it) % len(small)
@@ -289,11 +288,11 @@ def test_pool_combines_concurrent_calls_bit_exactly(B, frames65, oracle65):
                     j = (5 * t + it) % 65
                     img, (wk, wk2, wd), thr, octv = frames65[j], oracle65[j], THR, OCT
                 k, tok = pool.detect(img, thr, octv)
-                use = tok if it % 3 == 0 else (stale if it % 3 == 1 else 0)
+                # the detect call's token / a token no detect call ever returned (the frame is then uploaded) / none
+                use = tok if it % 3 == 0 else ((tok ^ (0x5A5A << 16)) if it % 3 == 1 else 0)
                 k2, d = pool.describe(ext, img, k, use)
                 if not (same_kps(k, wk) and same_kps(k2, wk2) and np.array_equal(d, wd)):
-                    errors.append((t, it, "mismatch"))
-                stale = tok
+                    errors.append((t, it, img.shape, "detected %s" % same_kps(k, wk), "described %s" % same_kps(k2, wk2), hex(use)))
         except Exception as e:
             errors.append((t, repr(e)))
 
@@ -303,6 +302,8 @@ def test_pool_combines_concurrent_calls_bit_exactly(B, frames65, oracle65):
     for x in th:
         x.join()
     assert not errors, errors[:5]
+    groups, calls = pool.stats()
+    assert calls == 2 + 12 * 12 * 2 and groups <= calls
     pool.close()
     ext.close()
 
@@ -351,3 +352,4 @@ def test_drop_in_classes_through_the_pool():
     r = subprocess.run([b, "--time", "8", "1", "640", "480", "--same-image", "--pool-threshold", "2"], capture_output=True, text=True, timeout=600)
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0 and '"mismatches": 0' in r.stdout
+

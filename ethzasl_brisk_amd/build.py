@@ -35,7 +35,7 @@ def kernel_revision():
     import hashlib
     h = hashlib.sha1()
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".h", ".inc")) and f != "brisk_capi.hip":
+        if f.endswith((".hip", ".h", ".inc")) and f not in ("brisk_capi.hip", "brisk_pool.inc"):  # (host code only)
             h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:12]
 

@@ -1255,7 +1255,8 @@ static void export_finish(brisk_hip_ctx* ctx, brisk_hip_ctx::ExportSlot& E) {
 }
 
 static int download_all_locked(brisk_hip_ctx* ctx, int which, const brisk_hip_batch_host_results* dst, hipStream_t s, unsigned* ticket,
-                               bool known_pinned = false /* the arrays come from hipHostMalloc (the pool's own): no pointer queries */) {
+                               bool known_pinned = false /* the arrays come from hipHostMalloc (the pool's own): no pointer queries */,
+                               bool egress_on_s = false /* the transfer on the batch's own stream (the pool: its contexts run one group at a time) */) {
   if (!dst || !ticket || (which != 0 && which != 1)) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: null destination / ticket, or which not 0 / 1");
   *ticket = 0;
   const int nframes = ctx->last_nframes;
@@ -1272,7 +1273,17 @@ static int download_all_locked(brisk_hip_ctx* ctx, int which, const brisk_hip_ba
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int dstride = want_desc ? dst->desc_stride : 4;
   brisk_hip_ctx::ExportSlot& E = ctx->ex[(ctx->ex_seq + 1) & 1];
-  if (!ctx->egress) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->egress, hipStreamNonBlocking));
+  // The transfer's stream.  A context that runs detect + describe batches already owns a second stream - `side`, where the integral
+  // kernel runs beside the detector's tail - and the transfer goes there: a process gets 4 hardware queues by default, and with the
+  // caller's own stream, the context's main, side and copy streams a FIFTH active stream shares a queue with one of them (measured:
+  // host-to-host 26.3 k -> 21.1 k frames/s after batches on a caller's stream).  Behind the transfer the next batch's integral kernel
+  // starts up to half a millisecond late, inside its window beside the tie chain.  Contexts without a side stream get an egress stream.
+  static const bool own_egress = tuning_env("BRISK_EXPORT_OWN_STREAM") && atoi(tuning_env("BRISK_EXPORT_OWN_STREAM")) == 1;  // A / B runs
+  hipStream_t es = egress_on_s ? s : ((ctx->side && !own_egress) ? ctx->side : ctx->egress);
+  if (!es) {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->egress, hipStreamNonBlocking));
+    es = ctx->egress;
+  }
   if (!E.packed) {
     HIPCHK(ctx, hipEventCreateWithFlags(&E.packed, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&E.done, hipEventDisableTiming));
@@ -1322,11 +1333,11 @@ static int download_all_locked(brisk_hip_ctx* ctx, int which, const brisk_hip_ba
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(E.packed, s));
   if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
-  HIPCHK(ctx, hipStreamWaitEvent(ctx->egress, E.packed, 0));
+  HIPCHK(ctx, hipStreamWaitEvent(es, E.packed, 0));
   static const bool egress_off = tuning_env("BRISK_EXPORT_EGRESS") && atoi(tuning_env("BRISK_EXPORT_EGRESS")) == 0;  // timing experiments: pack only (the destination stays unwritten)
-  if (!egress_off) brisk_launch_export_egress(S, nframes, dstride, W.counts, W.flags, W.offsets, W.kps, W.desc, ctx->egress);
+  if (!egress_off) brisk_launch_export_egress(S, nframes, dstride, W.counts, W.flags, W.offsets, W.kps, W.desc, es);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(E.done, ctx->egress));
+  HIPCHK(ctx, hipEventRecord(E.done, es));
   E.done_valid = true;
   E.pending = true;
   E.use_bounce = !direct;

@@ -544,10 +544,11 @@ def main():
                      # revision; null when they belong to another revision)
                      "hbm_frac": None if not dom_traffic or dom_ms <= 0 else round(dom_traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "algorithmic_bytes_per_launch": dom_alg, "avg_launch_ms": round(dom_ms, 4), "launches_timed": ncalls,
-                     "note": ("k_describe is bound by the vector L1's tag look-up rate for its gathers (ten per sample, 88 bytes used; one "
-                              "look-up per lane whose line no neighbouring lane shares, 2 lanes per clock and CU - which is why the two "
-                              "lanes of a lane pair read the same row since round 5), not by HBM bandwidth, occupancy or instruction "
-                              "issue: DESIGN.md 5, profiles/r05_microbench_il2.txt, profiles/r05_describe_phases.txt; "
+                     "note": ("k_describe is bound by the CU's texture path - the address unit is busy 86 %, the data-return unit 93 %, the L1 96 % of the "
+                              "kernel's clocks (round 6 counters: profiles/r06_describe_overlap.txt) - i.e. by the NUMBER of gather look-ups (ten "
+                              "gathers per sample, 88 bytes used; one look-up per lane whose line no neighbouring lane shares, which is why the two "
+                              "lanes of a lane pair read the same row since round 5), not by HBM bandwidth, occupancy, instruction issue or exposed "
+                              "latency (a two-deep gather pipeline gains 1.7 %): DESIGN.md 5, profiles/r05_microbench_il2.txt; "
                               if dom_stage == "k_describe" else "")
                              + "every kernel group: config.kernel_groups"},
     }

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "brisk_hip_comm_gather_results", "brisk_hip_comm_wait",
     "brisk_hip_set_integral_format",
     "brisk_hip_host_register", "brisk_hip_host_unregister", "brisk_hip_usable_cpus",
+    "brisk_hip_detect_images", "brisk_hip_describe_images",
     "brisk_hip_pool_create", "brisk_hip_pool_destroy", "brisk_hip_pool_last_error", "brisk_hip_pool_detect", "brisk_hip_pool_describe", "brisk_hip_pool_stats",
     "brisk_hip_batch_download_all", "brisk_hip_batch_download_wait", "brisk_hip_detect_describe_batch_host_results",
 ]
@@ -204,6 +205,10 @@ def load_library():
     L.brisk_hip_pool_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.brisk_hip_pool_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, ip, C.POINTER(C.c_ulonglong)]
     L.brisk_hip_pool_describe.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, C.c_int, C.c_int, C.c_int, C.c_ulonglong]
+    L.brisk_hip_detect_images.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BatchHostResults),
+                                          C.POINTER(C.c_uint)]
+    L.brisk_hip_describe_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int,
+                                            C.POINTER(BatchHostResults), C.POINTER(C.c_uint)]
     L.brisk_hip_host_register.argtypes = [vp, C.c_size_t]
     L.brisk_hip_host_unregister.argtypes = [vp]
     L.brisk_hip_batch_download_all.argtypes = [vp, C.c_int, C.POINTER(BatchHostResults), vp, C.POINTER(C.c_uint)]
@@ -385,6 +390,30 @@ class Context:
         self.check(self._L.brisk_hip_detect_describe_batch_host_results(self._h, pattern._h, C.c_void_p(h_frames_ptr), nframes, w, h,
                                                                         frame_pitch, row_pitch, threshold, octaves,
                                                                         C.byref(dst.struct), C.byref(t)))
+        return t.value
+
+    def detect_images(self, images, threshold, octaves, dst):
+        """cv::FeatureDetector::detect(vector<Mat>) as one batch: `images` = equally sized 2-D uint8 arrays; returns the ticket"""
+        imgs = [np.ascontiguousarray(a, np.uint8) for a in images]
+        h, w = imgs[0].shape
+        ptrs = (C.c_void_p * len(imgs))(*[a.ctypes.data for a in imgs])
+        t = C.c_uint()
+        self.check(self._L.brisk_hip_detect_images(self._h, ptrs, len(imgs), w, h, w, threshold, octaves, C.byref(dst.struct), C.byref(t)))
+        self._keep_images = imgs
+        return t.value
+
+    def describe_images(self, pattern, images, keypoints, dst, rotation_invariant=True, scale_invariant=True):
+        """cv::DescriptorExtractor::compute(vector<Mat>, vector<vector<KeyPoint>>) as one batch; returns the ticket"""
+        imgs = [np.ascontiguousarray(a, np.uint8) for a in images]
+        ks = [np.ascontiguousarray(k, KEYPOINT) for k in keypoints]
+        h, w = imgs[0].shape
+        ptrs = (C.c_void_p * len(imgs))(*[a.ctypes.data for a in imgs])
+        kptrs = (C.c_void_p * len(ks))(*[k.ctypes.data if len(k) else None for k in ks])
+        nk = np.array([len(k) for k in ks], np.int32)
+        t = C.c_uint()
+        self.check(self._L.brisk_hip_describe_images(self._h, pattern._h, ptrs, len(imgs), w, h, w, kptrs, _ptr(nk), int(rotation_invariant),
+                                                     int(scale_invariant), C.byref(dst.struct), C.byref(t)))
+        self._keep_images = (imgs, ks, nk)
         return t.value
 
     def reserve(self, min_candidates, min_keypoints):

@@ -106,6 +106,8 @@ struct brisk_hip_ctx {
   // host-fed batches: two device staging buffers filled over a copy stream while the previous slice computes
   uint8_t* d_hstage[2] = {nullptr, nullptr};
   size_t hstage_bytes = 0;
+  uint8_t* d_imgs = nullptr;  // brisk_hip_describe_images: all frames of a call
+  size_t imgs_bytes = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t copied_ev[2] = {nullptr, nullptr}, consumed_ev[2] = {nullptr, nullptr};
   // The image of the last host-buffer detect call is still on the device (staging buffer, layer 0 and the pyramid
@@ -477,6 +479,7 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
     if (c->copied_ev[i]) hipEventDestroy(c->copied_ev[i]);
     if (c->consumed_ev[i]) hipEventDestroy(c->consumed_ev[i]);
   }
+  if (c->d_imgs) hipFree(c->d_imgs);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   for (auto& E : c->ex) {
     if (E.slab) hipFree(E.slab);
@@ -892,12 +895,17 @@ static int host_slice_frames() {
   return v;
 }
 
+// frame_ptrs: null (the frames are h_frames + f * frame_pitch) or one host pointer per frame (the multi-image calls: separate
+// cv::Mat buffers); pat == null: detection only
 static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames, int nframes, int w, int h,
-                             long frame_pitch, int row_pitch, int threshold, int octaves) {
-  if (!h_frames || nframes <= 0 || row_pitch < w || frame_pitch < (long)row_pitch * (h - 1) + w)
+                             long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* const* frame_ptrs = nullptr) {
+  if ((!h_frames && !frame_ptrs) || nframes <= 0 || row_pitch < w || (!frame_ptrs && frame_pitch < (long)row_pitch * (h - 1) + w))
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
+  if (frame_ptrs)
+    for (int f = 0; f < nframes; ++f)
+      if (!frame_ptrs[f]) return fail(ctx, BRISK_HIP_ERR_ARG, "null image in the list");
   if (int rcp = check_pattern_device(ctx, pat)) return rcp;
-  BatchArgs A{pat, w, h, threshold, octaves, 0, 0, nullptr, 0, 0, true, true, ctx->uni_radius, ctx->uni_max};
+  BatchArgs A{pat, w, h, threshold, octaves, 0, 0, nullptr, 0, 0, true, pat != nullptr, ctx->uni_radius, ctx->uni_max};
   A.bk_u = ctx->bk_u; A.bk_v = ctx->bk_v; A.bk_max = ctx->bk_max;
   A.inplace_ok = false;  // the staging buffers are recycled slice after slice: the engine keeps its own layer-0 copy (the link, not the engine, bounds this path)
   hipStream_t s = ctx->stream;
@@ -941,8 +949,12 @@ static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, c
     const int nf = (int)((nframes - f0 < slice) ? nframes - f0 : slice);
     const int b = k & 1;
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->consumed_ev[b], 0));
-    const uint8_t* src = h_frames + f0 * frame_pitch;
-    if (frame_pitch == (long)row_pitch * h) {          // rows of consecutive frames at one pitch: a single 2-D copy
+    const uint8_t* src = frame_ptrs ? nullptr : h_frames + f0 * frame_pitch;
+    if (frame_ptrs) {
+      for (int f = 0; f < nf; ++f)
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_hstage[b] + (size_t)f * dframe, dpitch, frame_ptrs[f0 + f], row_pitch, w, h, hipMemcpyHostToDevice,
+                                     ctx->copy_stream));
+    } else if (frame_pitch == (long)row_pitch * h) {          // rows of consecutive frames at one pitch: a single 2-D copy
       HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_hstage[b], dpitch, src, row_pitch, w, (size_t)h * nf, hipMemcpyHostToDevice,
                                    ctx->copy_stream));
     } else {
@@ -1404,6 +1416,70 @@ int brisk_hip_detect_describe_batch_host_results(brisk_hip_ctx* ctx, const brisk
   const int rc = batch_host_locked(ctx, pat, h_frames, nframes, w, h, frame_pitch, row_pitch, threshold, octaves);
   if (rc) return rc;
   return download_all_locked(ctx, 1, dst, ctx->stream, ticket);
+}
+
+// ---- the multi-image overloads of the reference's base classes as batches -------------------------------------------------------
+int brisk_hip_detect_images(brisk_hip_ctx* ctx, const uint8_t* const* images, int nimages, int w, int h, int stride, int threshold,
+                            int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket) {
+  if (!ctx) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!images || !dst || !ticket) return fail(ctx, BRISK_HIP_ERR_ARG, "null image list / destination / ticket");
+  *ticket = 0;
+  if (dst->frames_cap < nimages) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: frames_cap below the batch's frames");
+  const int rc = batch_host_locked(ctx, nullptr, nullptr, nimages, w, h, 0, stride, threshold, octaves, images);
+  if (rc) return rc;
+  return download_all_locked(ctx, 0, dst, ctx->stream, ticket);
+}
+
+static int describe_batch_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* d_frames, int nframes, int w, int h,
+                                 long frame_pitch, int row_pitch, int rot, int scl, int n_in_max, hipStream_t s);
+
+int brisk_hip_describe_images(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* const* images, int nimages, int w, int h,
+                              int stride, const brisk_hip_keypoint* const* kps, const int* nkps, int rotation_invariant,
+                              int scale_invariant, const brisk_hip_batch_host_results* dst, unsigned* ticket) {
+  if (!ctx || !pat) return BRISK_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!images || !kps || !nkps || !dst || !ticket || nimages <= 0) return fail(ctx, BRISK_HIP_ERR_ARG, "null image / keypoint list, destination or ticket");
+  *ticket = 0;
+  if (w <= 0 || h <= 0 || w > 8191 || h > 8191 || stride < w) return fail(ctx, BRISK_HIP_ERR_ARG, "bad image description");
+  if (dst->frames_cap < nimages) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: frames_cap below the batch's frames");
+  if (int rcp = check_pattern_device(ctx, pat)) return rcp;
+  int nmax = 0;
+  for (int f = 0; f < nimages; ++f) {
+    if (!images[f] || nkps[f] < 0 || (nkps[f] > 0 && !kps[f])) return fail(ctx, BRISK_HIP_ERR_ARG, "null image or keypoint list in the batch");
+    nmax = nkps[f] > nmax ? nkps[f] : nmax;
+  }
+  if (nmax > ctx->kp_cap) return fail(ctx, BRISK_HIP_ERR_CAPACITY, "more keypoints than the configured capacity");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  BriskGeom Gd;
+  BriskTileTable Td;
+  make_geometry(w, h, 20, 0, &Gd, &Td);
+  if (pat->host.strings > ctx->desc_pitch) ctx->desc_pitch = brisk_align_up(pat->host.strings, 16);
+  int rc = ensure_buffers(ctx, nimages, Gd);
+  if (rc) return rc;
+  // all frames of the call resident at once (the descriptor-only batch is one launch sequence): a device buffer of the context
+  const int dpitch = brisk_align_up(w, 64);
+  const size_t dframe = (size_t)dpitch * h;
+  if (ctx->imgs_bytes < dframe * (size_t)nimages) {
+    HIPCHK(ctx, hipDeviceSynchronize());
+    if (ctx->d_imgs) (void)hipFree(ctx->d_imgs);
+    ctx->d_imgs = nullptr; ctx->imgs_bytes = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_imgs, dframe * (size_t)nimages + 256));
+    ctx->imgs_bytes = dframe * (size_t)nimages;
+  }
+  hipStream_t s = ctx->stream;
+  if (workspace_acquire(ctx, s)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
+  WorkspaceGuard guard(ctx, s);
+  for (int f = 0; f < nimages; ++f)
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_imgs + (size_t)f * dframe, dpitch, images[f], stride, w, h, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, nkps, sizeof(int) * (size_t)nimages, hipMemcpyHostToDevice, s));
+  for (int f = 0; f < nimages; ++f)
+    if (nkps[f] > 0)
+      HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in + (size_t)f * ctx->B.kp_cap, kps[f], sizeof(BriskKeyPoint) * (size_t)nkps[f], hipMemcpyHostToDevice, s));
+  rc = describe_batch_locked(ctx, pat, ctx->d_imgs, nimages, w, h, (long)dframe, dpitch, rotation_invariant, scale_invariant, nmax, s);
+  if (rc) return rc;
+  if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");
+  return download_all_locked(ctx, 1, dst, s, ticket);
 }
 
 // ---- host-buffer calls ---------------------------------------------------------------------------

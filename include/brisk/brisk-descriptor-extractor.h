@@ -74,7 +74,26 @@ class BriskDescriptorExtractor {
                        std::vector<std::bitset<kDescriptorLength> >& descriptors) const {
     computeImpl(image, keypoints, descriptors);
   }
+  // The multi-image overload the reference's class inherits from its OpenCV base (cv::DescriptorExtractor::compute(const vector<Mat>&,
+  // vector<vector<KeyPoint>>&, vector<Mat>& descriptors), whose default loops over computeImpl): images of one size and layout run as
+  // ONE batch on the device (brisk_hip_describe_images); differing sizes image by image.  Same results either way.
+#ifndef BRISK_HAVE_OPENCV
+  virtual void compute(const std::vector<agast::Mat>& images, std::vector<std::vector<agast::KeyPoint> >& keypoints,
+                       std::vector<agast::Mat>& descriptors) const {
+    computeBatch(images, keypoints, descriptors);
+  }
+#endif
 #ifdef BRISK_HAVE_OPENCV
+  virtual void compute(cv::InputArrayOfArrays images, std::vector<std::vector<cv::KeyPoint> >& keypoints, cv::OutputArrayOfArrays descriptors) {
+    std::vector<cv::Mat> imgs;
+    images.getMatVector(imgs);
+    if (descriptors.isMatVector()) {
+      computeBatch(imgs, keypoints, *static_cast<std::vector<cv::Mat>*>(descriptors.getObj()));
+    } else {
+      std::vector<cv::Mat> d;
+      computeBatch(imgs, keypoints, d);
+    }
+  }
   virtual void detectAndCompute(cv::InputArray image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& keypoints,
                                 cv::OutputArray descriptors, bool /*useProvidedKeypoints*/ = false) {
     computeImpl(image.getMat(), keypoints, descriptors.getMatRef());
@@ -87,6 +106,56 @@ class BriskDescriptorExtractor {
 #endif
 
  protected:
+  void computeBatch(const std::vector<agast::Mat>& images, std::vector<std::vector<agast::KeyPoint> >& keypoints,
+                    std::vector<agast::Mat>& descriptors) const {
+    const size_t n = images.size();
+    if (keypoints.size() != n) throw std::runtime_error("BriskDescriptorExtractor::compute: one keypoint list per image");
+    descriptors.assign(n, agast::Mat());
+    bool batch = n >= 2;
+    size_t total = 0, most = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (images[i].type() != CV_8UC1) throw std::runtime_error("Unsupported image format. Must be CV_16UC1 or CV_8UC1.");
+      batch = batch && !images[i].empty() && images[i].rows == images[0].rows && images[i].cols == images[0].cols && images[i].step == images[0].step;
+      total += keypoints[i].size();
+      most = keypoints[i].size() > most ? keypoints[i].size() : most;
+    }
+    if (!batch) {
+      for (size_t i = 0; i < n; ++i) computeImpl(images[i], keypoints[i], descriptors[i]);
+      return;
+    }
+    const int strings = descriptorSize();
+    brisk_hip_ctx* ctx = hip::DefaultContext();
+    brisk_hip_reserve(ctx, 4 * (int)most, (int)most);
+    std::vector<const uint8_t*> ptrs(n);
+    std::vector<const brisk_hip_keypoint*> kin(n);
+    std::vector<int> nin(n), counts(n), flags(n);
+    std::vector<long long> offsets(n + 1);
+    for (size_t i = 0; i < n; ++i) {
+      ptrs[i] = images[i].data;
+      kin[i] = reinterpret_cast<const brisk_hip_keypoint*>(keypoints[i].data());
+      nin[i] = (int)keypoints[i].size();
+    }
+    // (the border filter only removes keypoints: the provided ones bound the rows)
+    std::vector<agast::KeyPoint> rows(total ? total : 1);
+    std::vector<uint8_t> drows((total ? total : 1) * (size_t)strings);
+    brisk_hip_batch_host_results dst;
+    dst.frames_cap = (int)n; dst.desc_stride = strings; dst.rows_cap = (long long)total;
+    dst.counts = counts.data(); dst.flags = flags.data(); dst.offsets = offsets.data();
+    dst.kps = reinterpret_cast<brisk_hip_keypoint*>(rows.data()); dst.desc = drows.data();
+    unsigned ticket = 0;
+    int flagged = 0;
+    int rc = brisk_hip_describe_images(ctx, pattern_, ptrs.data(), (int)n, images[0].cols, images[0].rows, (int)images[0].step, kin.data(), nin.data(),
+                                       rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0, &dst, &ticket);
+    if (rc == BRISK_HIP_OK) rc = brisk_hip_batch_download_wait(ctx, ticket, &flagged);
+    if (rc != BRISK_HIP_OK && rc != BRISK_HIP_ERR_CAPACITY) hip::Check(ctx, rc, "brisk_hip_describe_images");
+    for (size_t i = 0; i < n; ++i) {
+      if (rc != BRISK_HIP_OK && flags[i]) { computeImpl(images[i], keypoints[i], descriptors[i]); continue; }  // (an engine capacity: the single-image call grows the workspace)
+      const long long a = offsets[i], cnt = offsets[i + 1] - a;
+      keypoints[i].assign(rows.begin() + a, rows.begin() + a + cnt);
+      descriptors[i] = agast::Mat::zeros((int)cnt, strings, CV_8UC1);
+      for (long long r = 0; r < cnt; ++r) memcpy(descriptors[i].data + (size_t)r * descriptors[i].step, drows.data() + (size_t)(a + r) * strings, (size_t)strings);
+    }
+  }
   virtual void computeImpl(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,
                            agast::Mat& descriptors) const {
     if (image.type() != CV_8UC1)  // the reference's 16-bit branch is broken; 8-bit only

@@ -26,7 +26,16 @@ class BriskFeatureDetector {
   int threshold;
   int octaves;
 
+  // The multi-image overload the reference's class inherits from its OpenCV base
+  // (cv::FeatureDetector::detect(const vector<Mat>&, vector<vector<KeyPoint>>&, const vector<Mat>& masks), whose default loops over
+  // detectImpl): images of one size and layout without masks run as ONE batch on the device (brisk_hip_detect_images); anything
+  // else - differing sizes, masks, post-filters, suppressScaleNonmaxima = false - image by image.  Same results either way.
+  // (with OpenCV: the override of cv::Feature2D::detect(InputArrayOfArrays, ...) below)
 #ifndef BRISK_HAVE_OPENCV
+  void detect(const std::vector<agast::Mat>& images, std::vector<std::vector<agast::KeyPoint> >& keypoints,
+              const std::vector<agast::Mat>& masks = std::vector<agast::Mat>()) const {
+    detectBatch(images, keypoints, masks);
+  }
   void detect(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,
               const agast::Mat& mask = agast::Mat()) const {
     detectImpl(image, keypoints, mask);
@@ -37,6 +46,14 @@ class BriskFeatureDetector {
     detectImpl(image, keypoints, mask);
   }
 #else
+  using cv::Feature2D::detect;  // (the single-image overloads of the base class stay visible)
+  virtual void detect(cv::InputArrayOfArrays images, std::vector<std::vector<cv::KeyPoint> >& keypoints,
+                      cv::InputArrayOfArrays masks = cv::noArray()) {
+    std::vector<cv::Mat> imgs, ms;
+    images.getMatVector(imgs);
+    if (!masks.empty()) masks.getMatVector(ms);
+    detectBatch(imgs, keypoints, ms);
+  }
   virtual void detectAndCompute(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints,
                                 cv::OutputArray /*descriptors*/, bool /*useProvidedKeypoints*/ = false) {
     detectImpl(image.getMat(), keypoints, mask.getMat());
@@ -90,6 +107,50 @@ class BriskFeatureDetector {
   }
 
  protected:
+  void detectBatch(const std::vector<agast::Mat>& images, std::vector<std::vector<agast::KeyPoint> >& keypoints,
+                   const std::vector<agast::Mat>& masks) const {
+    const size_t n = images.size();
+    keypoints.assign(n, std::vector<agast::KeyPoint>());
+    bool batch = n >= 2 && masks.empty() && m_suppressScaleNonmaxima && m_uniformityRadius == 0.0 && m_bucketsU == 0 && m_bucketsV == 0;
+    for (size_t i = 0; i < n && batch; ++i)
+      batch = !images[i].empty() && images[i].type() == CV_8UC1 && images[i].rows == images[0].rows && images[i].cols == images[0].cols &&
+              images[i].step == images[0].step;
+    if (!batch) {
+      for (size_t i = 0; i < n; ++i) detectImpl(images[i], keypoints[i], i < masks.size() ? masks[i] : agast::Mat());
+      return;
+    }
+    brisk_hip_ctx* ctx = hip::DefaultContext();
+    std::vector<const uint8_t*> ptrs(n);
+    for (size_t i = 0; i < n; ++i) ptrs[i] = images[i].data;
+    std::vector<int> counts(n), flags(n);
+    std::vector<long long> offsets(n + 1);
+    std::vector<agast::KeyPoint> rows;
+    long long rows_cap = (long long)n * 2048;
+    for (int attempt = 0;; ++attempt) {
+      rows.resize((size_t)rows_cap);
+      brisk_hip_batch_host_results dst;
+      dst.frames_cap = (int)n; dst.desc_stride = 4; dst.rows_cap = rows_cap;
+      dst.counts = counts.data(); dst.flags = flags.data(); dst.offsets = offsets.data();
+      dst.kps = reinterpret_cast<brisk_hip_keypoint*>(rows.data()); dst.desc = nullptr;
+      unsigned ticket = 0;
+      int flagged = 0;
+      int rc = brisk_hip_detect_images(ctx, ptrs.data(), (int)n, images[0].cols, images[0].rows, (int)images[0].step, threshold, octaves, &dst,
+                                       &ticket);
+      if (rc == BRISK_HIP_OK) rc = brisk_hip_batch_download_wait(ctx, ticket, &flagged);
+      if (rc != BRISK_HIP_OK && rc != BRISK_HIP_ERR_CAPACITY) hip::Check(ctx, rc, "brisk_hip_detect_images");
+      // frames cut for want of rows: once more with what they need (their counts came back); frames that hit an engine capacity
+      // go through the single-image call below, which grows the workspace
+      long long need = 0;
+      bool cut = false;
+      for (size_t i = 0; i < n; ++i) { need += counts[i]; cut = cut || (flags[i] & BRISK_HIP_ROWS_CUT); }
+      if (cut && attempt == 0) { rows_cap = need + 64; continue; }
+      for (size_t i = 0; i < n; ++i) {
+        if (flags[i]) { detectImpl(images[i], keypoints[i], agast::Mat()); continue; }
+        keypoints[i].assign(rows.begin() + offsets[i], rows.begin() + offsets[i + 1]);
+      }
+      return;
+    }
+  }
   // brisk-feature-detector.cc:77-85
   virtual void detectImpl(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,
                           const agast::Mat& mask = agast::Mat()) const {

@@ -239,6 +239,21 @@ int brisk_hip_detect_describe_batch_host_results(brisk_hip_ctx* ctx, const brisk
                                                  int nframes, int w, int h, long frame_pitch, int row_pitch, int threshold,
                                                  int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket);
 
+/* ---- the multi-image overloads of the reference's base classes, as ONE batch -------------------------------------------------
+ * cv::FeatureDetector::detect(const vector<Mat>& images, vector<vector<KeyPoint>>& keypoints, ...) and
+ * cv::DescriptorExtractor::compute(const vector<Mat>& images, vector<vector<KeyPoint>>& keypoints, vector<Mat>& descriptors), which the
+ * reference's classes inherit (brisk-feature-detector.h:51, brisk-descriptor-extractor.h:54), loop over detectImpl / computeImpl;
+ * here the images of a call - separate host buffers of ONE size, given as an array of pointers, row pitch `stride` - go through the
+ * batch path and come back through brisk_hip_batch_download_all's destination (`dst`, `ticket`: brisk_hip_batch_download_wait).
+ * _detect_images: plain detection (suppressScaleNonmaxima = true, no masks); frame f's keypoints = rows [offsets[f], offsets[f + 1]).
+ * _describe_images: kps[f] / nkps[f] = the provided keypoints of image f (not modified); the rows of frame f are its border-filtered
+ * keypoints with their angles and the descriptors.  The drop-in classes' vector overloads forward here (include/brisk/). */
+int brisk_hip_detect_images(brisk_hip_ctx* ctx, const uint8_t* const* images, int nimages, int w, int h, int stride, int threshold,
+                            int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket);
+int brisk_hip_describe_images(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* const* images, int nimages, int w, int h,
+                              int stride, const brisk_hip_keypoint* const* kps, const int* nkps, int rotation_invariant,
+                              int scale_invariant, const brisk_hip_batch_host_results* dst, unsigned* ticket);
+
 /* ---- call combining: the one-frame host calls of MANY threads as batches ------------------------------------------------
  * The reference's classes are re-entrant (detectImpl is const and builds its state per call, brisk-feature-detector.cc:77-85);
  * with a context per thread every call is ~15 kernel launches and 2 - 4 copies of its own, and the HIP runtime serialises the

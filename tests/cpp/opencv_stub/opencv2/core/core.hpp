@@ -128,6 +128,8 @@ class _InputArray {
     else if (m_ && !m_->empty()) mv.push_back(*m_);
   }
   bool empty() const { return m_ ? m_->empty() : (v_ ? v_->empty() : true); }
+  bool isMatVector() const { return v_ != nullptr; }
+  void* getObj() const { return v_ ? static_cast<void*>(v_) : static_cast<void*>(m_); }
 
  protected:
   Mat* m_;

@@ -19,6 +19,24 @@ class Feature2D : public virtual Algorithm {
   virtual void compute(InputArray image, std::vector<KeyPoint>& keypoints, OutputArray descriptors) {
     detectAndCompute(image, noArray(), keypoints, descriptors, true);
   }
+  virtual void detect(InputArrayOfArrays images, std::vector<std::vector<KeyPoint> >& keypoints, InputArrayOfArrays masks = noArray()) {
+    std::vector<Mat> imgs, ms;
+    images.getMatVector(imgs);
+    if (!masks.empty()) masks.getMatVector(ms);
+    keypoints.resize(imgs.size());
+    for (size_t i = 0; i < imgs.size(); ++i) {
+      if (i < ms.size()) detect(_InputArray(imgs[i]), keypoints[i], _InputArray(ms[i]));
+      else detect(_InputArray(imgs[i]), keypoints[i], noArray());
+    }
+  }
+  virtual void compute(InputArrayOfArrays images, std::vector<std::vector<KeyPoint> >& keypoints, OutputArrayOfArrays descriptors) {
+    std::vector<Mat> imgs;
+    images.getMatVector(imgs);
+    if (!descriptors.isMatVector()) return;
+    std::vector<Mat>& d = *static_cast<std::vector<Mat>*>(descriptors.getObj());
+    d.resize(imgs.size());
+    for (size_t i = 0; i < imgs.size(); ++i) compute(imgs[i], keypoints[i], d[i]);
+  }
   virtual void detectAndCompute(InputArray, InputArray, std::vector<KeyPoint>&, OutputArray, bool = false) {}
   virtual int descriptorSize() const { return 0; }
   virtual int descriptorType() const { return CV_32F; }

@@ -141,7 +141,7 @@ def build_opencv_binary(name):
     return out
 
 
-@pytest.mark.parametrize("name", ["test_binary_equal", "test_threads", "test_capacity", "test_image16"])
+@pytest.mark.parametrize("name", ["test_binary_equal", "test_threads", "test_capacity", "test_image16", "test_multi_image"])
 def test_opencv_branch_of_the_drop_in_headers_compiles(name):
     """include/brisk/*.h have a cv::Feature2D / cv::DescriptorMatcher branch (-DBRISK_HAVE_OPENCV: the classes derive from
     the OpenCV bases and take cv::InputArray / cv::OutputArray, brisk/include/brisk/brisk.h:56-59 of the reference) - the
@@ -177,6 +177,20 @@ def test_four_threads_through_the_opencv_branch():
 
 def test_thread_test_compiles():
     build_binary("test_threads")
+    build_binary("test_multi_image")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opencv", [False, True])
+def test_multi_image_overloads_equal_the_single_image_calls(opencv):
+    """detect(vector<Mat>, vector<vector<KeyPoint>>) / compute(vector<Mat>, ..., vector<Mat>) - the overloads the reference's classes
+    inherit from cv::FeatureDetector / cv::DescriptorExtractor - as one batch (brisk_hip_detect_images / _describe_images): seven
+    images of one size (the goldens, mirrored copies, a blank one), a list with a smaller image and a list with masks (both image
+    by image), every image bit-equal to its single-image call; plain headers and the cv::Feature2D branch (InputArrayOfArrays)"""
+    b = build_opencv_binary("test_multi_image") if opencv else build_binary("test_multi_image")
+    r = subprocess.run([b, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "multi-image OK" in r.stdout
 
 
 @pytest.mark.gpu

@@ -353,3 +353,27 @@ def test_drop_in_classes_through_the_pool():
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0 and '"mismatches": 0' in r.stdout
 
+
+
+def test_detect_images_and_describe_images_against_the_oracle(B, frames65, oracle65):
+    """brisk_hip_detect_images / brisk_hip_describe_images (what the classes' vector overloads forward to): 70 separately
+    allocated frames in one call each (two slices of the host-fed path for detection; one descriptor-only launch over all
+    frames with every frame's own provided keypoint list, one of them empty), pageable destinations, against the oracle"""
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    idx = [(7 * i) % 65 for i in range(70)]
+    imgs = [frames65[j].copy() for j in idx]
+    det = B.HostResults(len(imgs), sum(len(oracle65[j][0]) for j in idx), 0, pinned=False)
+    assert ctx.batch_download_wait(ctx.detect_images(imgs, THR, OCT, det)) == 0
+    for f, j in enumerate(idx):
+        _check_frame(det, f, oracle65[j][0], None)
+    lists = [oracle65[j][0] for j in idx]
+    lists[3] = lists[3][:0]                                          # an image without keypoints
+    res = B.HostResults(len(imgs), sum(len(k) for k in lists), 48, pinned=False)
+    assert ctx.batch_download_wait(ctx.describe_images(ext, imgs, lists, res)) == 0
+    for f, j in enumerate(idx):
+        if f == 3:
+            assert int(res.counts[f]) == 0 and res.offsets[f + 1] == res.offsets[f]
+        else:
+            _check_frame(res, f, oracle65[j][1], oracle65[j][2])
+    ctx.close()

@@ -275,7 +275,7 @@ def parse_args(argv):
     ap.add_argument("--min-region-s", type=float, default=2.0,
                     help="--frames mode: the step is repeated until the timed region is at least this long")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 1 / 4 / 5 and the dense regimes (config.other_configs)")
-    ap.add_argument("--config", default="", help="profiling: run ONLY this entry of config.other_configs (1, 4, 4_uniform, 5, dense30, dense50) "
+    ap.add_argument("--config", default="", help="profiling: run ONLY this entry of config.other_configs (1, 4, 4_uniform, 5, dense30, dense50, threads, multi_image) "
                                                  "for --config-seconds and print its object")
     ap.add_argument("--config-seconds", type=float, default=0.5)
     ap.add_argument("--fail-rank", type=int, default=-1, help="launcher self-test: this rank exits with code 7 at start-up")
@@ -757,7 +757,27 @@ def _other_configs(device, only="", seconds=0.4):
         ctx.close()
     if want("threads"):
         res["threads"] = guarded(threads_table, seconds)
+    if want("multi_image"):
+        res["multi_image"] = guarded(multi_image_table, seconds)
     return res
+
+
+def multi_image_table(seconds):
+    """The classes' multi-image overloads (cv::FeatureDetector::detect(vector<Mat>), cv::DescriptorExtractor::compute(vector<Mat>) of the
+    reference's OpenCV bases) on N separate pageable 1080p buffers per call: tests/cpp/test_multi_image --time, a child process per row"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_cpp_classes as tc
+    exe = tc.build_binary("test_multi_image")
+    rows = []
+    for n, flags in ((1, []), (8, []), (64, []), (256, []), (64, ["--same-image"]), (256, ["--same-image"])):
+        r = subprocess.run([exe, "--time", str(n), str(max(1.0, 3 * seconds))] + flags, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        rows.append(json.loads(line[-1]) if (r.returncode == 0 and line) else {"images_per_call": n, "failed": (r.stdout + r.stderr)[-300:]})
+    return {"workload": "brisk::BriskFeatureDetector::detect(vector<Mat>) + BriskDescriptorExtractor::compute(vector<Mat>, ...) on N separate "
+                        "pageable 1080p buffers per call, threshold 80, 4 octaves, one host thread; two uploads per frame (detect and compute "
+                        "are separate calls in the reference's API) unless same_image = 1 (compute() under ScopedSameImage: the caller's word "
+                        "that it gets detect()'s unchanged buffers)", "unit": "frames/s", "rows": rows}
 
 
 def threads_table(seconds):

@@ -207,7 +207,7 @@ def load_library():
     L.brisk_hip_pool_describe.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, C.c_int, C.c_int, C.c_int, C.c_ulonglong]
     L.brisk_hip_detect_images.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BatchHostResults),
                                           C.POINTER(C.c_uint)]
-    L.brisk_hip_describe_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int,
+    L.brisk_hip_describe_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(BatchHostResults), C.POINTER(C.c_uint)]
     L.brisk_hip_host_register.argtypes = [vp, C.c_size_t]
     L.brisk_hip_host_unregister.argtypes = [vp]
@@ -402,8 +402,9 @@ class Context:
         self._keep_images = imgs
         return t.value
 
-    def describe_images(self, pattern, images, keypoints, dst, rotation_invariant=True, scale_invariant=True):
-        """cv::DescriptorExtractor::compute(vector<Mat>, vector<vector<KeyPoint>>) as one batch; returns the ticket"""
+    def describe_images(self, pattern, images, keypoints, dst, rotation_invariant=True, scale_invariant=True, same_images=False):
+        """cv::DescriptorExtractor::compute(vector<Mat>, vector<vector<KeyPoint>>) as one batch; returns the ticket.
+        same_images: `images` are the arrays the last detect_images call was given, unchanged (no second upload)"""
         imgs = [np.ascontiguousarray(a, np.uint8) for a in images]
         ks = [np.ascontiguousarray(k, KEYPOINT) for k in keypoints]
         h, w = imgs[0].shape
@@ -412,7 +413,7 @@ class Context:
         nk = np.array([len(k) for k in ks], np.int32)
         t = C.c_uint()
         self.check(self._L.brisk_hip_describe_images(self._h, pattern._h, ptrs, len(imgs), w, h, w, kptrs, _ptr(nk), int(rotation_invariant),
-                                                     int(scale_invariant), C.byref(dst.struct), C.byref(t)))
+                                                     int(scale_invariant), int(same_images), C.byref(dst.struct), C.byref(t)))
         self._keep_images = (imgs, ks, nk)
         return t.value
 

@@ -106,8 +106,13 @@ struct brisk_hip_ctx {
   // host-fed batches: two device staging buffers filled over a copy stream while the previous slice computes
   uint8_t* d_hstage[2] = {nullptr, nullptr};
   size_t hstage_bytes = 0;
-  uint8_t* d_imgs = nullptr;  // brisk_hip_describe_images: all frames of a call
+  uint8_t* d_imgs = nullptr;  // brisk_hip_detect_images / _describe_images: all frames of a call, resident until the next such call
   size_t imgs_bytes = 0;
+  int image_reuse_multi = 0;  // describe_images calls that took the frames of the last multi-image call from the device
+  struct {                    // what d_imgs holds (a describe call that names the same buffers as unchanged skips its uploads)
+    int n = 0, w = 0, h = 0, stride = 0;
+    std::vector<const uint8_t*> ptrs;
+  } imgs;
   hipStream_t copy_stream = nullptr;
   hipEvent_t copied_ev[2] = {nullptr, nullptr}, consumed_ev[2] = {nullptr, nullptr};
   // The image of the last host-buffer detect call is still on the device (staging buffer, layer 0 and the pyramid
@@ -898,7 +903,8 @@ static int host_slice_frames() {
 // frame_ptrs: null (the frames are h_frames + f * frame_pitch) or one host pointer per frame (the multi-image calls: separate
 // cv::Mat buffers); pat == null: detection only
 static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames, int nframes, int w, int h,
-                             long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* const* frame_ptrs = nullptr) {
+                             long frame_pitch, int row_pitch, int threshold, int octaves, const uint8_t* const* frame_ptrs = nullptr,
+                             uint8_t* d_resident = nullptr /* the frames land here (f * dframe) and stay, instead of in the recycled staging */) {
   if ((!h_frames && !frame_ptrs) || nframes <= 0 || row_pitch < w || (!frame_ptrs && frame_pitch < (long)row_pitch * (h - 1) + w))
     return fail(ctx, BRISK_HIP_ERR_ARG, "bad frame buffer description");
   if (frame_ptrs)
@@ -907,7 +913,7 @@ static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, c
   if (int rcp = check_pattern_device(ctx, pat)) return rcp;
   BatchArgs A{pat, w, h, threshold, octaves, 0, 0, nullptr, 0, 0, true, pat != nullptr, ctx->uni_radius, ctx->uni_max};
   A.bk_u = ctx->bk_u; A.bk_v = ctx->bk_v; A.bk_max = ctx->bk_max;
-  A.inplace_ok = false;  // the staging buffers are recycled slice after slice: the engine keeps its own layer-0 copy (the link, not the engine, bounds this path)
+  A.inplace_ok = d_resident != nullptr;  // the staging buffers are recycled slice after slice: the engine keeps its own layer-0 copy (the link, not the engine, bounds this path)
   hipStream_t s = ctx->stream;
   int rc = batch_begin(ctx, A, nframes, s);
   if (rc) return rc;
@@ -924,7 +930,7 @@ static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, c
     }
     fresh = true;
   }
-  if (ctx->hstage_bytes < dframe * slice) {
+  if (!d_resident && ctx->hstage_bytes < dframe * slice) {
     HIPCHK(ctx, hipDeviceSynchronize());
     for (int i = 0; i < 2; ++i) {
       if (ctx->d_hstage[i]) (void)hipFree(ctx->d_hstage[i]);
@@ -948,26 +954,28 @@ static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, c
   for (long f0 = 0; f0 < nframes; f0 += slice, ++k) {
     const int nf = (int)((nframes - f0 < slice) ? nframes - f0 : slice);
     const int b = k & 1;
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->consumed_ev[b], 0));
+    uint8_t* const dslice = d_resident ? d_resident + (size_t)f0 * dframe : ctx->d_hstage[b];
+    if (!d_resident) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->consumed_ev[b], 0));
+    else if (k == 0 && ctx->done_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->done_ev, 0));  // (the previous call may still read the resident frames)
     const uint8_t* src = frame_ptrs ? nullptr : h_frames + f0 * frame_pitch;
     if (frame_ptrs) {
       for (int f = 0; f < nf; ++f)
-        HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_hstage[b] + (size_t)f * dframe, dpitch, frame_ptrs[f0 + f], row_pitch, w, h, hipMemcpyHostToDevice,
+        HIPCHK(ctx, hipMemcpy2DAsync(dslice + (size_t)f * dframe, dpitch, frame_ptrs[f0 + f], row_pitch, w, h, hipMemcpyHostToDevice,
                                      ctx->copy_stream));
     } else if (frame_pitch == (long)row_pitch * h) {          // rows of consecutive frames at one pitch: a single 2-D copy
-      HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_hstage[b], dpitch, src, row_pitch, w, (size_t)h * nf, hipMemcpyHostToDevice,
+      HIPCHK(ctx, hipMemcpy2DAsync(dslice, dpitch, src, row_pitch, w, (size_t)h * nf, hipMemcpyHostToDevice,
                                    ctx->copy_stream));
     } else {
       for (int f = 0; f < nf; ++f)
-        HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_hstage[b] + (size_t)f * dframe, dpitch, src + (long)f * frame_pitch, row_pitch, w,
+        HIPCHK(ctx, hipMemcpy2DAsync(dslice + (size_t)f * dframe, dpitch, src + (long)f * frame_pitch, row_pitch, w,
                                      h, hipMemcpyHostToDevice, ctx->copy_stream));
     }
     HIPCHK(ctx, hipEventRecord(ctx->copied_ev[b], ctx->copy_stream));
     HIPCHK(ctx, hipStreamWaitEvent(s, ctx->copied_ev[b], 0));
     if (k == 0) ctx->last_frames_per_launch = nf;
-    rc = batch_slice(ctx, A, ctx->d_hstage[b], f0, nf, s, (k == 0) ? &ctx->prof : nullptr, true);
+    rc = batch_slice(ctx, A, dslice, f0, nf, s, (k == 0) ? &ctx->prof : nullptr, true);
     if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[b], s));
+    if (!d_resident) HIPCHK(ctx, hipEventRecord(ctx->consumed_ev[b], s));
   }
   guard.armed = false;  // batch_end records the event itself
   return batch_end(ctx, A, nframes, s);
@@ -1419,6 +1427,23 @@ int brisk_hip_detect_describe_batch_host_results(brisk_hip_ctx* ctx, const brisk
 }
 
 // ---- the multi-image overloads of the reference's base classes as batches -------------------------------------------------------
+static int ensure_images(brisk_hip_ctx* ctx, int nimages, int w, int h) {
+  const size_t dframe = (size_t)brisk_align_up(w, 64) * h;
+  if (ctx->imgs_bytes < dframe * (size_t)nimages) {
+    HIPCHK(ctx, hipDeviceSynchronize());
+    if (ctx->d_imgs) (void)hipFree(ctx->d_imgs);
+    ctx->d_imgs = nullptr; ctx->imgs_bytes = 0;
+    ctx->imgs.n = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_imgs, dframe * (size_t)nimages + 256));
+    ctx->imgs_bytes = dframe * (size_t)nimages;
+  }
+  return BRISK_HIP_OK;
+}
+static void remember_images(brisk_hip_ctx* ctx, const uint8_t* const* images, int nimages, int w, int h, int stride) {
+  ctx->imgs.n = nimages; ctx->imgs.w = w; ctx->imgs.h = h; ctx->imgs.stride = stride;
+  ctx->imgs.ptrs.assign(images, images + nimages);
+}
+
 int brisk_hip_detect_images(brisk_hip_ctx* ctx, const uint8_t* const* images, int nimages, int w, int h, int stride, int threshold,
                             int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket) {
   if (!ctx) return BRISK_HIP_ERR_ARG;
@@ -1426,8 +1451,15 @@ int brisk_hip_detect_images(brisk_hip_ctx* ctx, const uint8_t* const* images, in
   if (!images || !dst || !ticket) return fail(ctx, BRISK_HIP_ERR_ARG, "null image list / destination / ticket");
   *ticket = 0;
   if (dst->frames_cap < nimages) return fail(ctx, BRISK_HIP_ERR_ARG, "download_all: frames_cap below the batch's frames");
-  const int rc = batch_host_locked(ctx, nullptr, nullptr, nimages, w, h, 0, stride, threshold, octaves, images);
+  if (nimages <= 0 || w <= 0 || h <= 0 || w > 8191 || h > 8191 || stride < w) return fail(ctx, BRISK_HIP_ERR_ARG, "bad image description");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // the frames stay on the device until the next multi-image call: a describe call on the same, unchanged buffers takes them from there
+  int rc = ensure_images(ctx, nimages, w, h);
   if (rc) return rc;
+  ctx->imgs.n = 0;
+  rc = batch_host_locked(ctx, nullptr, nullptr, nimages, w, h, 0, stride, threshold, octaves, images, ctx->d_imgs);
+  if (rc) return rc;
+  remember_images(ctx, images, nimages, w, h, stride);
   return download_all_locked(ctx, 0, dst, ctx->stream, ticket);
 }
 
@@ -1436,7 +1468,7 @@ static int describe_batch_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pa
 
 int brisk_hip_describe_images(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* const* images, int nimages, int w, int h,
                               int stride, const brisk_hip_keypoint* const* kps, const int* nkps, int rotation_invariant,
-                              int scale_invariant, const brisk_hip_batch_host_results* dst, unsigned* ticket) {
+                              int scale_invariant, int same_images, const brisk_hip_batch_host_results* dst, unsigned* ticket) {
   if (!ctx || !pat) return BRISK_HIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!images || !kps || !nkps || !dst || !ticket || nimages <= 0) return fail(ctx, BRISK_HIP_ERR_ARG, "null image / keypoint list, destination or ticket");
@@ -1460,18 +1492,25 @@ int brisk_hip_describe_images(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, 
   // all frames of the call resident at once (the descriptor-only batch is one launch sequence): a device buffer of the context
   const int dpitch = brisk_align_up(w, 64);
   const size_t dframe = (size_t)dpitch * h;
-  if (ctx->imgs_bytes < dframe * (size_t)nimages) {
-    HIPCHK(ctx, hipDeviceSynchronize());
-    if (ctx->d_imgs) (void)hipFree(ctx->d_imgs);
-    ctx->d_imgs = nullptr; ctx->imgs_bytes = 0;
-    HIPCHK(ctx, hipMalloc(&ctx->d_imgs, dframe * (size_t)nimages + 256));
-    ctx->imgs_bytes = dframe * (size_t)nimages;
+  // same_images: the caller's word (as brisk_hip_describe_same_image) that images[] are the very buffers of the context's last
+  // multi-image call, unchanged - honoured when the list is that list
+  bool resident = same_images && ctx->imgs.n == nimages && ctx->imgs.w == w && ctx->imgs.h == h && ctx->imgs.stride == stride;
+  for (int f = 0; f < nimages && resident; ++f) resident = ctx->imgs.ptrs[(size_t)f] == images[f];
+  if (!resident) {
+    rc = ensure_images(ctx, nimages, w, h);
+    if (rc) return rc;
   }
   hipStream_t s = ctx->stream;
   if (workspace_acquire(ctx, s)) return fail(ctx, BRISK_HIP_ERR_HIP, "hipStreamWaitEvent failed");
   WorkspaceGuard guard(ctx, s);
-  for (int f = 0; f < nimages; ++f)
-    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_imgs + (size_t)f * dframe, dpitch, images[f], stride, w, h, hipMemcpyHostToDevice, s));
+  if (!resident) {
+    ctx->imgs.n = 0;
+    for (int f = 0; f < nimages; ++f)
+      HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_imgs + (size_t)f * dframe, dpitch, images[f], stride, w, h, hipMemcpyHostToDevice, s));
+    remember_images(ctx, images, nimages, w, h, stride);
+  } else {
+    ctx->image_reuse_multi++;
+  }
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, nkps, sizeof(int) * (size_t)nimages, hipMemcpyHostToDevice, s));
   for (int f = 0; f < nimages; ++f)
     if (nkps[f] > 0)
@@ -2071,7 +2110,7 @@ int brisk_hip_debug_layer(brisk_hip_ctx* ctx, int frame, int layer, int which, u
   return BRISK_HIP_OK;
 }
 
-int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx) { return ctx ? ctx->img_cache.hits : 0; }
+int brisk_hip_debug_image_reuse(brisk_hip_ctx* ctx) { return ctx ? ctx->img_cache.hits + ctx->image_reuse_multi : 0; }
 
 // the uniformity filter alone on a given keypoint list (parity tests of the filter kernels on lists no detector produces)
 int brisk_hip_debug_filter_keypoints(brisk_hip_ctx* ctx, const brisk_hip_keypoint* in, int n_in, int rows, int cols, double radius,

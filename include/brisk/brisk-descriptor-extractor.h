@@ -145,7 +145,7 @@ class BriskDescriptorExtractor {
     unsigned ticket = 0;
     int flagged = 0;
     int rc = brisk_hip_describe_images(ctx, pattern_, ptrs.data(), (int)n, images[0].cols, images[0].rows, (int)images[0].step, kin.data(), nin.data(),
-                                       rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0, &dst, &ticket);
+                                       rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0, hip::SameImageHint() ? 1 : 0, &dst, &ticket);
     if (rc == BRISK_HIP_OK) rc = brisk_hip_batch_download_wait(ctx, ticket, &flagged);
     if (rc != BRISK_HIP_OK && rc != BRISK_HIP_ERR_CAPACITY) hip::Check(ctx, rc, "brisk_hip_describe_images");
     for (size_t i = 0; i < n; ++i) {

@@ -247,12 +247,15 @@ int brisk_hip_detect_describe_batch_host_results(brisk_hip_ctx* ctx, const brisk
  * batch path and come back through brisk_hip_batch_download_all's destination (`dst`, `ticket`: brisk_hip_batch_download_wait).
  * _detect_images: plain detection (suppressScaleNonmaxima = true, no masks); frame f's keypoints = rows [offsets[f], offsets[f + 1]).
  * _describe_images: kps[f] / nkps[f] = the provided keypoints of image f (not modified); the rows of frame f are its border-filtered
- * keypoints with their angles and the descriptors.  The drop-in classes' vector overloads forward here (include/brisk/). */
+ * keypoints with their angles and the descriptors; same_images != 0 is the caller's word (as brisk_hip_describe_same_image) that images[]
+ * are the very buffers of the context's last multi-image call, unchanged: the frames are then taken from their device copies (no second
+ * upload); a list that is not that list is uploaded.  images / kps / nkps must stay valid until the ticket has been waited for.
+ * The drop-in classes' vector overloads forward here (include/brisk/). */
 int brisk_hip_detect_images(brisk_hip_ctx* ctx, const uint8_t* const* images, int nimages, int w, int h, int stride, int threshold,
                             int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket);
 int brisk_hip_describe_images(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* const* images, int nimages, int w, int h,
                               int stride, const brisk_hip_keypoint* const* kps, const int* nkps, int rotation_invariant,
-                              int scale_invariant, const brisk_hip_batch_host_results* dst, unsigned* ticket);
+                              int scale_invariant, int same_images, const brisk_hip_batch_host_results* dst, unsigned* ticket);
 
 /* ---- call combining: the one-frame host calls of MANY threads as batches ------------------------------------------------
  * The reference's classes are re-entrant (detectImpl is const and builds its state per call, brisk-feature-detector.cc:77-85);

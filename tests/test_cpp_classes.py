@@ -16,6 +16,7 @@ def build_binary(name="test_binary_equal", hip_runtime=False, defines=(), extra_
     out = os.path.join(ROOT, "tests", "cpp", name)
     hdrs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs]
     hdrs.append(os.path.join(ROOT, "tests", "cpp", "set_serialization.h"))
+    hdrs.append(os.path.join(ROOT, "tests", "cpp", "synthetic_frame.h"))
     if not os.path.exists(out) or any(os.path.getmtime(p) > os.path.getmtime(out) for p in [src] + hdrs):
         # hip_runtime: the test itself allocates device memory (plain g++ against the HIP runtime's C API)
         hip = ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lamdhip64"] if hip_runtime else []

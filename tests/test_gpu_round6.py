@@ -376,4 +376,20 @@ def test_detect_images_and_describe_images_against_the_oracle(B, frames65, oracl
             assert int(res.counts[f]) == 0 and res.offsets[f + 1] == res.offsets[f]
         else:
             _check_frame(res, f, oracle65[j][1], oracle65[j][2])
+    # the same list right after detect_images, stated unchanged: the frames are taken from their device copies; a list that is
+    # not the detect call's list is uploaded whatever the caller says
+    assert ctx.batch_download_wait(ctx.detect_images(imgs, THR, OCT, det)) == 0
+    reuse0 = ctx.debug_image_reuse()
+    res.desc[:] = 0
+    assert ctx.batch_download_wait(ctx.describe_images(ext, imgs, lists, res, same_images=True)) == 0
+    assert ctx.debug_image_reuse() == reuse0 + 1
+    for f, j in enumerate(idx):
+        if f != 3:
+            _check_frame(res, f, oracle65[j][1], oracle65[j][2])
+    other = [frames65[(j + 1) % 65].copy() for j in idx]
+    lists2 = [oracle65[(j + 1) % 65][0] for j in idx]
+    assert ctx.batch_download_wait(ctx.describe_images(ext, other, lists2, res, same_images=True)) == 0
+    assert ctx.debug_image_reuse() == reuse0 + 1
+    for f, j in enumerate(idx):
+        _check_frame(res, f, oracle65[(j + 1) % 65][1], oracle65[(j + 1) % 65][2])
     ctx.close()

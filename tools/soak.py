@@ -11,6 +11,7 @@ tests/test_gpu_round3.py runs a few hundred cases of three of them).  One entry 
   python3 tools/soak.py large     [cases] [seed]               16-bit image functions, frames of 2000..4600 px, ComputeScale lists
   python3 tools/soak.py threads   [iterations] [watchdog s]    eight host threads with their own contexts and kinds of work at once (one-frame 4K, 64-frame
                                                                batch, dense, odd sizes, host-to-host), every iteration against the oracle; a hang kills the child
+  python3 tools/soak.py hostpaths [cases] [seed]               round 6's host-side paths: multi-image calls, host-to-host batches with exact / short row capacities, the pool from six threads
   python3 tools/soak.py all                                    every suite with its defaults
 
 Every case is compared bit-exactly with the oracle (or both sides must agree that the reference has no defined result).
@@ -19,7 +20,7 @@ import os
 import subprocess
 import sys
 
-SUITES = ["frames", "describe", "ordered", "callspace", "options", "matcher", "large", "threads"]
+SUITES = ["frames", "describe", "ordered", "callspace", "options", "matcher", "large", "threads", "hostpaths"]
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "soak_cases")
 
 

@@ -20,11 +20,13 @@ import numpy as np
 
 def make_case(i, seed):
     rng = np.random.default_rng(seed * 100003 + i)
-    w = int(rng.choice([rng.integers(40, 200), rng.integers(200, 700), 640, 333, 1281, 1920]))
-    h = int(rng.choice([rng.integers(40, 160), rng.integers(160, 500), 480, 201, 723, 1080]))
+    w = int(rng.choice([rng.integers(72, 200), rng.integers(200, 700), 640, 333, 1281, 1920]))
+    h = int(rng.choice([rng.integers(72, 160), rng.integers(160, 500), 480, 201, 723, 1080]))
     if w * h > 1281 * 723:
         w, h = 1920, 1080
     thr = int(rng.choice([25, 40, 60, 70, 90, 120]))
+    if w * h > 300000 and thr < 40:
+        thr = 40   # (threshold 25 on a large frame exceeds the 65 536 keypoints the contexts of this suite are sized for)
     octv = int(rng.integers(0, 5))
     n = int(rng.integers(2, 10)) if w * h < 700000 else int(rng.integers(2, 4))
     nrect = max(6, int(300 * w * h / (1920 * 1080)))
@@ -87,7 +89,7 @@ def main():
                             got.append((np.ascontiguousarray(det.frame(f)[0]).tobytes(), np.ascontiguousarray(k2).tobytes(), np.ascontiguousarray(d).tobytes()))
                 elif c["kind"] == "h2h":
                     src = torch.from_numpy(np.stack(imgs)).pin_memory()
-                    short = c["i"] % 7 == 1 and sum(nd) > 0
+                    short = c["i"] % 7 == 1 and sum(nd) > 1
                     res = B.HostResults(n, max(sum(nd) - (1 if short else 0), 1), 48, pinned=not (c["i"] & 8))
                     t = ctx.detect_describe_batch_host_results(ext, src.data_ptr(), n, w, h, w * h, w, c["thr"], c["oct"], res)
                     rc, flagged = ctx.batch_download_wait(t, check=False)
@@ -105,10 +107,13 @@ def main():
                     out = [None] * n
 
                     def worker(f):
-                        k, tok = pool.detect(imgs[f], c["thr"], c["oct"], capacity=65536)
-                        use = tok if (f + c["i"]) % 3 == 0 else ((tok ^ (0x5A5A << 16)) if (f + c["i"]) % 3 == 1 else 0)
-                        k2, d = pool.describe(ext, imgs[f], k, use)
-                        out[f] = (k.tobytes(), np.ascontiguousarray(k2).tobytes(), np.ascontiguousarray(d).tobytes())
+                        try:
+                            k, tok = pool.detect(imgs[f], c["thr"], c["oct"], capacity=65536)
+                            use = tok if (f + c["i"]) % 3 == 0 else ((tok ^ (0x5A5A << 16)) if (f + c["i"]) % 3 == 1 else 0)
+                            k2, d = pool.describe(ext, imgs[f], k, use)
+                            out[f] = (k.tobytes(), np.ascontiguousarray(k2).tobytes(), np.ascontiguousarray(d).tobytes())
+                        except Exception as e:
+                            out[f] = (repr(e)[:200], b"", b"")
                     th = [threading.Thread(target=worker, args=(f,)) for f in range(n)]
                     for x in th:
                         x.start()

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -108,6 +109,16 @@ struct brisk_hip_ctx {
   size_t hstage_bytes = 0;
   uint8_t* d_imgs = nullptr;  // brisk_hip_detect_images / _describe_images: all frames of a call, resident until the next such call
   size_t imgs_bytes = 0;
+  // pageable images of the multi-image calls: copied into these pinned buffers by a few host threads (a pageable hipMemcpy is a
+  // staging copy on the CALLING thread: 95 us per 2 MB image), then moved by one DMA per slice
+  uint8_t* h_pin[2] = {nullptr, nullptr};
+  size_t pin_bytes = 0;
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
+  bool pin_used[2] = {false, false};
+  uint8_t* h_kin_pin = nullptr;  // brisk_hip_describe_images: the provided keypoint lists, packed (pinned)
+  size_t kin_pin_bytes = 0;
+  hipEvent_t kin_pin_ev = nullptr;
+  bool kin_pin_used = false;
   int image_reuse_multi = 0;  // describe_images calls that took the frames of the last multi-image call from the device
   struct {                    // what d_imgs holds (a describe call that names the same buffers as unchanged skips its uploads)
     int n = 0, w = 0, h = 0, stride = 0;
@@ -485,6 +496,12 @@ void brisk_hip_destroy(brisk_hip_ctx* c) {
     if (c->consumed_ev[i]) hipEventDestroy(c->consumed_ev[i]);
   }
   if (c->d_imgs) hipFree(c->d_imgs);
+  if (c->h_kin_pin) hipHostFree(c->h_kin_pin);
+  if (c->kin_pin_ev) hipEventDestroy(c->kin_pin_ev);
+  for (int i = 0; i < 2; ++i) {
+    if (c->h_pin[i]) hipHostFree(c->h_pin[i]);
+    if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]);
+  }
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   for (auto& E : c->ex) {
     if (E.slab) hipFree(E.slab);
@@ -900,6 +917,74 @@ static int host_slice_frames() {
   return v;
 }
 
+static bool device_can_write(const void* p, void** dev);
+#define BRISK_STAGED_SLICE 32  // frames per pinned staging buffer of the multi-image calls
+// host threads that copy pageable images into the pinned staging buffers (the caller's thread is one of them)
+static int copy_threads() {
+  static const int n = [] {
+    const char* e = tuning_env("BRISK_COPY_THREADS");
+    int t = e ? atoi(e) : usable_cpus() / 2;
+    return t < 1 ? 1 : (t > 8 ? 8 : t);
+  }();
+  return n;
+}
+// Frames ptrs[0 .. nf) (host memory, row pitch `stride`) -> d_dst (rows at dpitch, frames dframe apart) on stream cs.
+// staged: the sources are pageable - `copy_threads()` host threads copy them into pinned buffer b of the context, one DMA moves
+// the slice (nf <= BRISK_STAGED_SLICE); otherwise one asynchronous 2-D copy per frame straight from the caller's pinned memory.
+static int upload_frames(brisk_hip_ctx* ctx, uint8_t* d_dst, size_t dframe, int dpitch, const uint8_t* const* ptrs, int nf, int w, int h, int stride,
+                         bool staged, int b, hipStream_t cs) {
+  if (!staged) {
+    for (int f = 0; f < nf; ++f)
+      HIPCHK(ctx, hipMemcpy2DAsync(d_dst + (size_t)f * dframe, dpitch, ptrs[f], stride, w, h, hipMemcpyHostToDevice, cs));
+    return BRISK_HIP_OK;
+  }
+  if (ctx->pin_bytes < dframe * BRISK_STAGED_SLICE) {
+    for (int i = 0; i < 2; ++i) {
+      if (ctx->pin_used[i]) HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[i]));
+      ctx->pin_used[i] = false;
+      if (ctx->h_pin[i]) (void)hipHostFree(ctx->h_pin[i]);
+      ctx->h_pin[i] = nullptr;
+    }
+    ctx->pin_bytes = 0;
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_pin[i], dframe * BRISK_STAGED_SLICE + 256, hipHostMallocDefault));
+      if (!ctx->pin_ev[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+    }
+    ctx->pin_bytes = dframe * BRISK_STAGED_SLICE;
+  }
+  if (ctx->pin_used[b]) HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[b]));  // the DMA that last read this buffer (two slices ago)
+  uint8_t* const pin = ctx->h_pin[b];
+  // work items = quarter frames (row bands): a few threads stay busy to the end of the slice
+  std::atomic<int> next{0};
+  const int items = nf * 4;
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= items) break;
+      const int f = i >> 2, part = i & 3;
+      const int y0 = (int)((long)h * part / 4), y1 = (int)((long)h * (part + 1) / 4);
+      uint8_t* d = pin + (size_t)f * dframe;
+      const uint8_t* sp = ptrs[f];
+      if (stride == dpitch) memcpy(d + (size_t)y0 * dpitch, sp + (size_t)y0 * stride, (size_t)(y1 - y0 - 1) * dpitch + (y1 > y0 ? w : 0));
+      else for (int y = y0; y < y1; ++y) memcpy(d + (size_t)y * dpitch, sp + (size_t)y * stride, (size_t)w);
+    }
+  };
+  const int T = copy_threads() < items ? copy_threads() : items;
+  std::vector<std::thread> helpers;
+  for (int t = 1; t < T; ++t) helpers.emplace_back(work);
+  work();
+  for (std::thread& t : helpers) t.join();
+  HIPCHK(ctx, hipMemcpyAsync(d_dst, pin, dframe * (size_t)nf, hipMemcpyHostToDevice, cs));
+  HIPCHK(ctx, hipEventRecord(ctx->pin_ev[b], cs));
+  ctx->pin_used[b] = true;
+  return BRISK_HIP_OK;
+}
+// pageable host memory?  (what a cv::Mat's buffer is unless the caller page-locked it)
+static bool is_pageable(const void* p) {
+  void* dev = nullptr;
+  return !device_can_write(p, &dev);
+}
+
 // frame_ptrs: null (the frames are h_frames + f * frame_pitch) or one host pointer per frame (the multi-image calls: separate
 // cv::Mat buffers); pat == null: detection only
 static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const uint8_t* h_frames, int nframes, int w, int h,
@@ -918,7 +1003,9 @@ static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, c
   int rc = batch_begin(ctx, A, nframes, s);
   if (rc) return rc;
   WorkspaceGuard guard(ctx, s);
-  const int slice = host_slice_frames() < nframes ? host_slice_frames() : nframes;
+  const bool staged = frame_ptrs && is_pageable(frame_ptrs[0]);
+  const int slice_max = staged ? BRISK_STAGED_SLICE : host_slice_frames();
+  const int slice = slice_max < nframes ? slice_max : nframes;
   const int dpitch = brisk_align_up(w, 64);           // device staging: rows at a 64-byte aligned pitch
   const size_t dframe = (size_t)dpitch * h;
   bool fresh = false;
@@ -959,9 +1046,8 @@ static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, c
     else if (k == 0 && ctx->done_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->done_ev, 0));  // (the previous call may still read the resident frames)
     const uint8_t* src = frame_ptrs ? nullptr : h_frames + f0 * frame_pitch;
     if (frame_ptrs) {
-      for (int f = 0; f < nf; ++f)
-        HIPCHK(ctx, hipMemcpy2DAsync(dslice + (size_t)f * dframe, dpitch, frame_ptrs[f0 + f], row_pitch, w, h, hipMemcpyHostToDevice,
-                                     ctx->copy_stream));
+      rc = upload_frames(ctx, dslice, dframe, dpitch, frame_ptrs + f0, nf, w, h, row_pitch, staged, b, ctx->copy_stream);
+      if (rc) return rc;
     } else if (frame_pitch == (long)row_pitch * h) {          // rows of consecutive frames at one pitch: a single 2-D copy
       HIPCHK(ctx, hipMemcpy2DAsync(dslice, dpitch, src, row_pitch, w, (size_t)h * nf, hipMemcpyHostToDevice,
                                    ctx->copy_stream));
@@ -1505,16 +1591,44 @@ int brisk_hip_describe_images(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, 
   WorkspaceGuard guard(ctx, s);
   if (!resident) {
     ctx->imgs.n = 0;
-    for (int f = 0; f < nimages; ++f)
-      HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_imgs + (size_t)f * dframe, dpitch, images[f], stride, w, h, hipMemcpyHostToDevice, s));
+    const bool staged = is_pageable(images[0]);
+    const int step = staged ? BRISK_STAGED_SLICE : nimages;
+    for (int f0 = 0, k = 0; f0 < nimages; f0 += step, ++k) {
+      const int nf = nimages - f0 < step ? nimages - f0 : step;
+      rc = upload_frames(ctx, ctx->d_imgs + (size_t)f0 * dframe, dframe, dpitch, images + f0, nf, w, h, stride, staged, k & 1, s);
+      if (rc) return rc;
+    }
     remember_images(ctx, images, nimages, w, h, stride);
   } else {
     ctx->image_reuse_multi++;
   }
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, nkps, sizeof(int) * (size_t)nimages, hipMemcpyHostToDevice, s));
-  for (int f = 0; f < nimages; ++f)
-    if (nkps[f] > 0)
-      HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in + (size_t)f * ctx->B.kp_cap, kps[f], sizeof(BriskKeyPoint) * (size_t)nkps[f], hipMemcpyHostToDevice, s));
+  // the provided lists: packed into one pinned block at a common pitch by this thread, moved by ONE 2-D copy (a small copy per image is
+  // 10 us of runtime call each: 2.5 ms of a 256-image call)
+  {
+    const size_t kpitch = sizeof(BriskKeyPoint) * (size_t)(nmax > 0 ? nmax : 1);
+    const size_t need = sizeof(int) * (size_t)nimages + 256 + kpitch * (size_t)nimages;
+    if (need > ctx->kin_pin_bytes) {
+      if (ctx->kin_pin_used) HIPCHK(ctx, hipEventSynchronize(ctx->kin_pin_ev));
+      ctx->kin_pin_used = false;
+      if (ctx->h_kin_pin) (void)hipHostFree(ctx->h_kin_pin);
+      ctx->h_kin_pin = nullptr; ctx->kin_pin_bytes = 0;
+      HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_kin_pin, need + need / 4, hipHostMallocDefault));
+      ctx->kin_pin_bytes = need + need / 4;
+      if (!ctx->kin_pin_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->kin_pin_ev, hipEventDisableTiming));
+    }
+    if (ctx->kin_pin_used) HIPCHK(ctx, hipEventSynchronize(ctx->kin_pin_ev));  // (the previous call's copy out of the block)
+    int* h_n = reinterpret_cast<int*>(ctx->h_kin_pin);
+    uint8_t* h_k = ctx->h_kin_pin + ((sizeof(int) * (size_t)nimages + 255) & ~(size_t)255);
+    for (int f = 0; f < nimages; ++f) {
+      h_n[f] = nkps[f];
+      if (nkps[f] > 0) memcpy(h_k + (size_t)f * kpitch, kps[f], sizeof(BriskKeyPoint) * (size_t)nkps[f]);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, h_n, sizeof(int) * (size_t)nimages, hipMemcpyHostToDevice, s));
+    if (nmax > 0)
+      HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_kp_in, sizeof(BriskKeyPoint) * (size_t)ctx->B.kp_cap, h_k, kpitch, kpitch, (size_t)nimages, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipEventRecord(ctx->kin_pin_ev, s));
+    ctx->kin_pin_used = true;
+  }
   rc = describe_batch_locked(ctx, pat, ctx->d_imgs, nimages, w, h, (long)dframe, dpitch, rotation_invariant, scale_invariant, nmax, s);
   if (rc) return rc;
   if (guard.release()) return fail(ctx, BRISK_HIP_ERR_HIP, "hipEventRecord failed");

@@ -128,32 +128,30 @@ class BriskDescriptorExtractor {
     brisk_hip_reserve(ctx, 4 * (int)most, (int)most);
     std::vector<const uint8_t*> ptrs(n);
     std::vector<const brisk_hip_keypoint*> kin(n);
-    std::vector<int> nin(n), counts(n), flags(n);
-    std::vector<long long> offsets(n + 1);
+    std::vector<int> nin(n);
     for (size_t i = 0; i < n; ++i) {
       ptrs[i] = images[i].data;
       kin[i] = reinterpret_cast<const brisk_hip_keypoint*>(keypoints[i].data());
       nin[i] = (int)keypoints[i].size();
     }
-    // (the border filter only removes keypoints: the provided ones bound the rows)
-    std::vector<agast::KeyPoint> rows(total ? total : 1);
-    std::vector<uint8_t> drows((total ? total : 1) * (size_t)strings);
-    brisk_hip_batch_host_results dst;
-    dst.frames_cap = (int)n; dst.desc_stride = strings; dst.rows_cap = (long long)total;
-    dst.counts = counts.data(); dst.flags = flags.data(); dst.offsets = offsets.data();
-    dst.kps = reinterpret_cast<brisk_hip_keypoint*>(rows.data()); dst.desc = drows.data();
+    // (the border filter only removes keypoints: the provided ones bound the rows; the thread's page-locked result arrays)
+    brisk_hip_batch_host_results* dst = hip::ThreadResultScratch().Prepare((int)n, (long long)(total ? total : 1), strings);
     unsigned ticket = 0;
     int flagged = 0;
     int rc = brisk_hip_describe_images(ctx, pattern_, ptrs.data(), (int)n, images[0].cols, images[0].rows, (int)images[0].step, kin.data(), nin.data(),
-                                       rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0, hip::SameImageHint() ? 1 : 0, &dst, &ticket);
+                                       rotationInvariance ? 1 : 0, scaleInvariance ? 1 : 0, hip::SameImageHint() ? 1 : 0, dst, &ticket);
     if (rc == BRISK_HIP_OK) rc = brisk_hip_batch_download_wait(ctx, ticket, &flagged);
     if (rc != BRISK_HIP_OK && rc != BRISK_HIP_ERR_CAPACITY) hip::Check(ctx, rc, "brisk_hip_describe_images");
+    const agast::KeyPoint* rows = reinterpret_cast<const agast::KeyPoint*>(dst->kps);
     for (size_t i = 0; i < n; ++i) {
-      if (rc != BRISK_HIP_OK && flags[i]) { computeImpl(images[i], keypoints[i], descriptors[i]); continue; }  // (an engine capacity: the single-image call grows the workspace)
-      const long long a = offsets[i], cnt = offsets[i + 1] - a;
-      keypoints[i].assign(rows.begin() + a, rows.begin() + a + cnt);
-      descriptors[i] = agast::Mat::zeros((int)cnt, strings, CV_8UC1);
-      for (long long r = 0; r < cnt; ++r) memcpy(descriptors[i].data + (size_t)r * descriptors[i].step, drows.data() + (size_t)(a + r) * strings, (size_t)strings);
+      if (rc != BRISK_HIP_OK && dst->flags[i]) { computeImpl(images[i], keypoints[i], descriptors[i]); continue; }  // (an engine capacity: the single-image call grows the workspace)
+      const long long a = dst->offsets[i], cnt = dst->offsets[i + 1] - a;
+      keypoints[i].assign(rows + a, rows + a + cnt);
+      descriptors[i] = agast::Mat((int)cnt, strings, CV_8UC1);
+      if (cnt > 0) {
+        if ((size_t)descriptors[i].step == (size_t)strings) memcpy(descriptors[i].data, dst->desc + (size_t)a * strings, (size_t)cnt * strings);
+        else for (long long r = 0; r < cnt; ++r) memcpy(descriptors[i].data + (size_t)r * descriptors[i].step, dst->desc + (size_t)(a + r) * strings, (size_t)strings);
+      }
     }
   }
   virtual void computeImpl(const agast::Mat& image, std::vector<agast::KeyPoint>& keypoints,

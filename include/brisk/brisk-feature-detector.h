@@ -122,19 +122,13 @@ class BriskFeatureDetector {
     brisk_hip_ctx* ctx = hip::DefaultContext();
     std::vector<const uint8_t*> ptrs(n);
     for (size_t i = 0; i < n; ++i) ptrs[i] = images[i].data;
-    std::vector<int> counts(n), flags(n);
-    std::vector<long long> offsets(n + 1);
-    std::vector<agast::KeyPoint> rows;
     long long rows_cap = (long long)n * 2048;
     for (int attempt = 0;; ++attempt) {
-      rows.resize((size_t)rows_cap);
-      brisk_hip_batch_host_results dst;
-      dst.frames_cap = (int)n; dst.desc_stride = 4; dst.rows_cap = rows_cap;
-      dst.counts = counts.data(); dst.flags = flags.data(); dst.offsets = offsets.data();
-      dst.kps = reinterpret_cast<brisk_hip_keypoint*>(rows.data()); dst.desc = nullptr;
+      // (the thread's page-locked result arrays: the device writes the rows straight into them)
+      brisk_hip_batch_host_results* dst = hip::ThreadResultScratch().Prepare((int)n, rows_cap, 0);
       unsigned ticket = 0;
       int flagged = 0;
-      int rc = brisk_hip_detect_images(ctx, ptrs.data(), (int)n, images[0].cols, images[0].rows, (int)images[0].step, threshold, octaves, &dst,
+      int rc = brisk_hip_detect_images(ctx, ptrs.data(), (int)n, images[0].cols, images[0].rows, (int)images[0].step, threshold, octaves, dst,
                                        &ticket);
       if (rc == BRISK_HIP_OK) rc = brisk_hip_batch_download_wait(ctx, ticket, &flagged);
       if (rc != BRISK_HIP_OK && rc != BRISK_HIP_ERR_CAPACITY) hip::Check(ctx, rc, "brisk_hip_detect_images");
@@ -142,11 +136,12 @@ class BriskFeatureDetector {
       // go through the single-image call below, which grows the workspace
       long long need = 0;
       bool cut = false;
-      for (size_t i = 0; i < n; ++i) { need += counts[i]; cut = cut || (flags[i] & BRISK_HIP_ROWS_CUT); }
+      for (size_t i = 0; i < n; ++i) { need += dst->counts[i]; cut = cut || (dst->flags[i] & BRISK_HIP_ROWS_CUT); }
       if (cut && attempt == 0) { rows_cap = need + 64; continue; }
+      const agast::KeyPoint* rows = reinterpret_cast<const agast::KeyPoint*>(dst->kps);
       for (size_t i = 0; i < n; ++i) {
-        if (flags[i]) { detectImpl(images[i], keypoints[i], agast::Mat()); continue; }
-        keypoints[i].assign(rows.begin() + offsets[i], rows.begin() + offsets[i + 1]);
+        if (dst->flags[i]) { detectImpl(images[i], keypoints[i], agast::Mat()); continue; }
+        keypoints[i].assign(rows + dst->offsets[i], rows + dst->offsets[i + 1]);
       }
       return;
     }

@@ -6,7 +6,9 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
+#include <new>
 #include <stdexcept>
 #include <string>
 
@@ -142,6 +144,51 @@ struct PooledImage {
 inline PooledImage& LastPooledImage() {
   static thread_local PooledImage p;
   return p;
+}
+
+// Destination of a multi-image call's results (brisk_hip_batch_host_results), one per thread, grown when a call needs more and
+// page-locked (brisk_hip_host_register): the device writes the rows straight into it, nothing is zero-filled or faulted in per
+// call, and the classes copy every image's rows out of it into the caller's vectors.
+struct ResultScratch {
+  void* mem = nullptr;
+  size_t bytes = 0;
+  bool locked = false;
+  brisk_hip_batch_host_results dst;
+  ResultScratch() { std::memset(&dst, 0, sizeof dst); }
+  ~ResultScratch() { Release(); }
+  ResultScratch(const ResultScratch&) = delete;
+  ResultScratch& operator=(const ResultScratch&) = delete;
+  void Release() {
+    if (mem && locked) (void)brisk_hip_host_unregister(mem);
+    std::free(mem);
+    mem = nullptr; bytes = 0; locked = false;
+  }
+  // arrays for `frames` frames and `rows` rows with descriptor rows of desc_stride bytes (0: keypoints only)
+  brisk_hip_batch_host_results* Prepare(int frames, long long rows, int desc_stride) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_flags = up(sizeof(int) * (size_t)frames), o_offs = up(o_flags + sizeof(int) * (size_t)frames);
+    const size_t o_kps = up(o_offs + sizeof(long long) * ((size_t)frames + 1));
+    const size_t o_desc = up(o_kps + sizeof(brisk_hip_keypoint) * (size_t)rows);
+    const size_t need = up(o_desc + (size_t)rows * (size_t)desc_stride) + 256;
+    if (need > bytes) {
+      Release();
+      const size_t want = need + need / 4;  // (room to grow: a registration costs ~0.1 ms per MB)
+      if (posix_memalign(&mem, 4096, want) != 0) { mem = nullptr; throw std::bad_alloc(); }
+      bytes = want;
+      locked = brisk_hip_host_register(mem, bytes) == BRISK_HIP_OK;  // (pageable still works: the engine goes through its bounce buffer)
+    }
+    unsigned char* b = static_cast<unsigned char*>(mem);
+    dst.frames_cap = frames; dst.desc_stride = desc_stride ? desc_stride : 4; dst.rows_cap = rows;
+    dst.counts = reinterpret_cast<int*>(b); dst.flags = reinterpret_cast<int*>(b + o_flags);
+    dst.offsets = reinterpret_cast<long long*>(b + o_offs);
+    dst.kps = reinterpret_cast<brisk_hip_keypoint*>(b + o_kps);
+    dst.desc = desc_stride ? b + o_desc : nullptr;
+    return &dst;
+  }
+};
+inline ResultScratch& ThreadResultScratch() {
+  static thread_local ResultScratch s;
+  return s;
 }
 
 }  // namespace hip

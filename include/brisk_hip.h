@@ -249,7 +249,8 @@ int brisk_hip_detect_describe_batch_host_results(brisk_hip_ctx* ctx, const brisk
  * _describe_images: kps[f] / nkps[f] = the provided keypoints of image f (not modified); the rows of frame f are its border-filtered
  * keypoints with their angles and the descriptors; same_images != 0 is the caller's word (as brisk_hip_describe_same_image) that images[]
  * are the very buffers of the context's last multi-image call, unchanged: the frames are then taken from their device copies (no second
- * upload); a list that is not that list is uploaded.  images / kps / nkps must stay valid until the ticket has been waited for.
+ * upload); a list that is not that list is uploaded.  images must stay valid until the ticket has been waited for (kps / nkps are
+ * copied before the call returns).
  * The drop-in classes' vector overloads forward here (include/brisk/). */
 int brisk_hip_detect_images(brisk_hip_ctx* ctx, const uint8_t* const* images, int nimages, int w, int h, int stride, int threshold,
                             int octaves, const brisk_hip_batch_host_results* dst, unsigned* ticket);

@@ -963,9 +963,10 @@ static int upload_frames(brisk_hip_ctx* ctx, uint8_t* d_dst, size_t dframe, int 
       if (i >= items) break;
       const int f = i >> 2, part = i & 3;
       const int y0 = (int)((long)h * part / 4), y1 = (int)((long)h * (part + 1) / 4);
+      if (y1 <= y0) continue;  // (images of fewer than four rows)
       uint8_t* d = pin + (size_t)f * dframe;
       const uint8_t* sp = ptrs[f];
-      if (stride == dpitch) memcpy(d + (size_t)y0 * dpitch, sp + (size_t)y0 * stride, (size_t)(y1 - y0 - 1) * dpitch + (y1 > y0 ? w : 0));
+      if (stride == dpitch) memcpy(d + (size_t)y0 * dpitch, sp + (size_t)y0 * stride, (size_t)(y1 - y0 - 1) * dpitch + (size_t)w);
       else for (int y = y0; y < y1; ++y) memcpy(d + (size_t)y * dpitch, sp + (size_t)y * stride, (size_t)w);
     }
   };

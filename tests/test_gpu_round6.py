@@ -393,3 +393,26 @@ def test_detect_images_and_describe_images_against_the_oracle(B, frames65, oracl
     for f, j in enumerate(idx):
         _check_frame(res, f, oracle65[(j + 1) % 65][1], oracle65[(j + 1) % 65][2])
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(17, 3), (9, 9), (70, 2), (333, 201)])
+def test_multi_image_calls_on_small_and_odd_sizes(B, w, h):
+    """brisk_hip_detect_images / _describe_images on images of a few rows (the staged copy deals quarter frames to its helper
+    threads) and on an odd size, against the oracle (tiny images have no keypoints: counts 0, no rows)"""
+    rng = np.random.default_rng(w * 1000 + h)
+    imgs = [synth.gen(w, h, 31 + i, 8) if (w >= 70 and h >= 70) else rng.integers(0, 255, (h, w), dtype=np.uint8) for i in range(5)]
+    ctx = B.Context(0)
+    ext = B.BriskDescriptorExtractor(context=ctx)
+    X = O.Extractor()
+    want = []
+    for img in imgs:
+        k = O.detect(img, 40, 2)
+        want.append((k,) + tuple(X.compute(img, k)))
+    det = B.HostResults(len(imgs), sum(len(x[0]) for x in want) + 1, 0, pinned=False)
+    assert ctx.batch_download_wait(ctx.detect_images(imgs, 40, 2, det)) == 0
+    res = B.HostResults(len(imgs), sum(len(x[0]) for x in want) + 1, 48, pinned=False)
+    assert ctx.batch_download_wait(ctx.describe_images(ext, imgs, [x[0] for x in want], res, same_images=True)) == 0
+    for f, x in enumerate(want):
+        _check_frame(det, f, x[0], None)
+        _check_frame(res, f, x[1], x[2])
+    ctx.close()

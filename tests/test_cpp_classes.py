@@ -65,6 +65,27 @@ def test_result_gather_through_the_c_abi_world_1():
     assert r.returncode == 0 and "gather OK" in r.stdout
 
 
+def test_host_results_test_compiles_and_fails_loudly_without_gpu():
+    """tests/cpp/test_host_results.cc: the batch path host memory -> host memory from C++ through the C ABI alone"""
+    import ethzasl_brisk_amd as B
+    b = build_binary("test_host_results")
+    if B.load_library().brisk_hip_device_count() > 0:
+        pytest.skip("GPU present")
+    r = subprocess.run([b], capture_output=True, text=True)
+    assert r.returncode == 2 and "brisk_hip_create failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_host_to_host_batches_through_the_c_abi():
+    """seven batches over a page-locked frame ring with two destination sets alternating (brisk_hip_host_register,
+    brisk_hip_detect_describe_batch_host_results, brisk_hip_batch_download_wait), every compared frame equal to its per-frame
+    download, a rerun of a batch's frames equal to the batch, a destination one row short reports the cut frame"""
+    b = build_binary("test_host_results")
+    r = subprocess.run([b], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "host results OK" in r.stdout
+
+
 def build_fake_rccl():
     """tests/cpp/fake_rccl.cc -> tests/cpp/libfake_rccl.so: the eight RCCL entry points brisk_comm.hip uses, over Unix sockets
     and staged hipMemcpy (a test double: several ranks on the one GPU of a test box)"""

@@ -102,7 +102,9 @@ struct brisk_hip_ctx {
   // Calls share one workspace but may be issued on different streams: every call that uses the workspace first makes
   // its stream wait for the end of the previous one (event recorded at the end of each call).
   hipEvent_t done_ev = nullptr;
-  bool done_valid = false;
+  bool done_valid = false;      // some call has queued work on the workspace (on last_stream)
+  bool done_recorded = false;   // done_ev has been recorded behind that work (ensure_done_event)
+  hipStream_t last_stream = nullptr;
   hipEvent_t block_ev = nullptr;  // blocking-sync event of the one-frame calls (download_single: when polling would starve other threads)
   // host-fed batches: two device staging buffers filled over a copy stream while the previous slice computes
   uint8_t* d_hstage[2] = {nullptr, nullptr};
@@ -195,16 +197,28 @@ static bool image_hash_reuse_enabled() {
   return on;
 }
 
-// the workspace is reused by every call: order this call's stream behind the previous call's work
+// The workspace is reused by every call: a call orders its stream behind the previous call's work.  The previous work is known by
+// the stream it was queued on; an event behind it is recorded only when somebody needs one - a call on ANOTHER stream, a copy
+// stream that must wait for it - and never for the usual case, call after call on the context's own stream (stream order does
+// it; round 6: three hipEventRecord + three hipStreamWaitEvent per detect() + compute() pair, each a serialised runtime call).
+// Work on a caller's stream gets its event at once: the stream may not exist any more when the next call comes.
+static int ensure_done_event(brisk_hip_ctx* c) {
+  if (!c->done_valid || c->done_recorded) return BRISK_HIP_OK;
+  if (!c->done_ev && hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) return BRISK_HIP_ERR_HIP;
+  if (hipEventRecord(c->done_ev, c->last_stream) != hipSuccess) return BRISK_HIP_ERR_HIP;
+  c->done_recorded = true;
+  return BRISK_HIP_OK;
+}
 static int workspace_acquire(brisk_hip_ctx* c, hipStream_t s) {
-  if (c->done_valid && hipStreamWaitEvent(s, c->done_ev, 0) != hipSuccess) return BRISK_HIP_ERR_HIP;
+  if (!c->done_valid || s == c->last_stream) return BRISK_HIP_OK;
+  if (ensure_done_event(c) || hipStreamWaitEvent(s, c->done_ev, 0) != hipSuccess) return BRISK_HIP_ERR_HIP;
   return BRISK_HIP_OK;
 }
 static int workspace_release(brisk_hip_ctx* c, hipStream_t s) {
-  if (!c->done_ev && hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) return BRISK_HIP_ERR_HIP;
-  if (hipEventRecord(c->done_ev, s) != hipSuccess) return BRISK_HIP_ERR_HIP;
+  c->last_stream = s;
   c->done_valid = true;
-  return BRISK_HIP_OK;
+  c->done_recorded = false;
+  return s == c->stream ? BRISK_HIP_OK : ensure_done_event(c);
 }
 
 // Every exit after the workspace was acquired must leave done_ev behind the work already queued (kernels of earlier
@@ -220,7 +234,8 @@ struct WorkspaceGuard {
 };
 // waits for THIS context's queued work only (other contexts - one per host thread in the C++ classes - keep running)
 static hipError_t wait_own_work(brisk_hip_ctx* c) {
-  return c->done_valid ? hipEventSynchronize(c->done_ev) : hipSuccess;
+  if (!c->done_valid) return hipSuccess;
+  return c->done_recorded ? hipEventSynchronize(c->done_ev) : hipStreamSynchronize(c->last_stream);
 }
 
 // ---- what brisk_comm.hip needs from a context (not part of the C ABI) -----------------------------------------------
@@ -1044,7 +1059,7 @@ static int batch_host_locked(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, c
     const int b = k & 1;
     uint8_t* const dslice = d_resident ? d_resident + (size_t)f0 * dframe : ctx->d_hstage[b];
     if (!d_resident) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->consumed_ev[b], 0));
-    else if (k == 0 && ctx->done_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->done_ev, 0));  // (the previous call may still read the resident frames)
+    else if (k == 0 && ctx->done_valid && !ensure_done_event(ctx)) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->done_ev, 0));  // (the previous call may still read the resident frames)
     const uint8_t* src = frame_ptrs ? nullptr : h_frames + f0 * frame_pitch;
     if (frame_ptrs) {
       rc = upload_frames(ctx, dslice, dframe, dpitch, frame_ptrs + f0, nf, w, h, row_pitch, staged, b, ctx->copy_stream);
@@ -1213,16 +1228,21 @@ struct PollerScope {
 // host memory and a sequence word behind them; the host polls that word (it changes a microsecond after the last store;
 // waking up from a stream wait takes ten) and copies out.  Results that do not fit the pinned buffer take download_locked.
 #define BRISK_SINGLE_BYTES (1u << 20)
+// the pinned block of the one-frame calls: [0] sequence word (device -> host), [16] the provided-keypoint count of a describe call
+// (host -> device: the kernels read it where it is - no copy, no runtime call), [64] counter record, then the rows
+static int ensure_single_buffer(brisk_hip_ctx* ctx) {
+  if (ctx->h_res) return BRISK_HIP_OK;
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_res, BRISK_SINGLE_BYTES, hipHostMallocCoherent));
+  memset(ctx->h_res, 0, 64);
+  HIPCHK(ctx, hipMalloc((void**)&ctx->d_pub_done, 64));
+  HIPCHK(ctx, hipMemset(ctx->d_pub_done, 0, 64));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  return BRISK_HIP_OK;
+}
 static int download_single(brisk_hip_ctx* ctx, int which, brisk_hip_keypoint* kps, int cap, int* n, uint8_t* desc,
                            int desc_stride, int strings, int dev_pitch, int expect) {
   const bool want_desc = desc && which;
-  if (!ctx->h_res) {
-    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_res, BRISK_SINGLE_BYTES, hipHostMallocCoherent));
-    memset(ctx->h_res, 0, 64);
-    HIPCHK(ctx, hipMalloc((void**)&ctx->d_pub_done, 64));
-    HIPCHK(ctx, hipMemset(ctx->d_pub_done, 0, 64));
-    HIPCHK(ctx, hipDeviceSynchronize());
-  }
+  if (int rcb = ensure_single_buffer(ctx)) return rcb;
   const unsigned o_cnt = 64, o_kp = (unsigned)((o_cnt + sizeof(BriskFrameCounters) + 255) & ~(size_t)255);
   const size_t row = sizeof(BriskKeyPoint) + (want_desc ? (size_t)dev_pitch : 0);
   // (debug bit 25: a 16 KB limit, so that tests reach the staged-copy path with a few hundred keypoints)
@@ -1778,7 +1798,11 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
   if (reuse) ctx->img_cache.hits++;
   if (!reuse) HIPCHK(ctx, upload_rows(ctx->d_stage, pitch, img, stride, w, h, ctx->stream));
   const int n_in = *n;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_n_in, &n_in, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  // (the count where the kernels read it: a word of the context's pinned block - the call is synchronous, nothing of an earlier
+  // call still reads it)
+  if (int rcb = ensure_single_buffer(ctx)) return rcb;
+  int* const h_n_in = reinterpret_cast<int*>(ctx->h_res + 16);
+  __atomic_store_n(h_n_in, n_in, __ATOMIC_RELEASE);
   if (n_in) HIPCHK(ctx, hipMemcpyAsync(ctx->d_kp_in, kps, sizeof(BriskKeyPoint) * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
   if (ctx->dirty_frames > 0) {  // the clear needs the last detect batch's counters, which are reset below
     brisk_launch_smap_clear(ctx->dirtyG, ctx->B, ctx->dirty_frames, ctx->stream);
@@ -1809,7 +1833,7 @@ static int describe_host(brisk_hip_ctx* ctx, const brisk_hip_pattern* pat, const
   BriskDescribeBuffers Dd = ctx->D;
   integral_format(ctx, pat, false, &Dd.ibits);
   if (desc_stride == pat->host.strings && pat->host.strings % 8 == 0 && pat->host.strings <= ctx->D.desc_pitch) Dd.desc_pitch = pat->host.strings;
-  brisk_launch_describe(ctx->G, P, Bd, Dd, 1, ctx->d_kp_in, ctx->d_n_in, sizeof(int), ctx->stream, &ctx->prof, nullptr, n_in);
+  brisk_launch_describe(ctx->G, P, Bd, Dd, 1, ctx->d_kp_in, h_n_in, sizeof(int), ctx->stream, &ctx->prof, nullptr, n_in);
   if (ctx->prof.on) ctx->prof.calls++;
   HIPCHK(ctx, hipGetLastError());
   ctx->last_nframes = 1;

@@ -222,7 +222,8 @@ typedef struct brisk_hip_batch_host_results {
 } brisk_hip_batch_host_results;
 /* Queues the transfer of the context's LAST batch (which: 0 detected keypoints, 1 described keypoints + descriptors) behind
  * that batch and returns: two small kernels on `stream` (hipStream_t the batch ran on; NULL = the context's stream) pack the
- * rows into a device slab, the transfer itself runs on the context's egress stream beside whatever the context does next -
+ * rows into a device slab, the transfer itself runs on the context's second stream (where the integral kernel runs beside the detector's
+ * tail; a process has four hardware queues: a stream of its own for the transfer would share one) beside whatever the context does next -
  * the next batch may be issued at once.  *ticket names the transfer.  At most two transfers are in flight per context: a
  * third call first completes the oldest (as brisk_hip_batch_download_wait would).  `dst` (the struct) is copied; the arrays
  * it points to must stay valid until the ticket has been waited for. */

@@ -16,3 +16,4 @@ run options 6000 12
 run matcher 3000 13
 run large 1500 14
 run threads 1500 1500
+run hostpaths 1500 29
